@@ -1,0 +1,130 @@
+/*
+ * ggml_oracle.h -- CPU oracle for the quantized mul_mat / quantize / dequantize path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ggmlsharp_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * What it is: a plain-C restatement of the reference's algorithm for the hot path
+ * (kant2002/GGMLSharp, GGMLSharp/Ggml.cs + GGMLSharp/TypeDefinitions.cs), written from the
+ * source text.  Every function cites the reference lines it follows.
+ *
+ * PARITY UNPINNED for the quantized functions: the reference is C# (net8.0); no .NET
+ * toolchain exists in the build image, so it cannot be compiled or run here, and the
+ * reference's own tests (Test0..Test3) hold no golden vector for any quantized type
+ * (SURVEY.md section 8(c)).  What IS pinned: tensor ne/nb layout (Test0/Program.cs:22-38),
+ * the Test3 LCG stream (Test3/Program.cs:98-107), hand-derived KAT1/KAT2,
+ * and an independent numpy restatement (tests/np_restatement.py) that must agree bit for bit.
+ *
+ * Semantics policy: "R" = replicate the C# as written,
+ * "I" = follow the intent (the upstream scalar ggml code the C# transcribes) where the C#
+ * as written is out-of-bounds, uninitialised or would crash.
+ *   D1 (R)  Math.Round(float) binds to Math.Round(double): round-half-to-EVEN.
+ *   D2 (I)  quantize_row_q8_0 writes all 32 quants (C# loop writes only even ones).
+ *   D3 (I)  quantize_row_q8_1 covers l<16 for both halves, signed sums.
+ *   D4 (I)  q8 quants are signed int8 (C# reads them through byte*).
+ *   D5 (I)  quantize_row_q4_0 == quantize_row_q4_0_reference (AVX packNibbles is broken).
+ *   D6 (I)  dequantize_row_q4_0 == its scalar branch.
+ *   D7 (I)  Q4_2 / Q5_1 half scales are IEEE bit patterns (C# does numeric casts).
+ *   D8      Q4_3 and Q8_1 are rejected as src0.
+ */
+#ifndef GGML_ORACLE_H
+#define GGML_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* TypeDefinitions.cs:153-169 */
+enum oracle_type {
+    ORACLE_TYPE_F32 = 0,
+    ORACLE_TYPE_F16 = 1,
+    ORACLE_TYPE_Q4_0 = 2,
+    ORACLE_TYPE_Q4_1 = 3,
+    ORACLE_TYPE_Q4_2 = 4,
+    ORACLE_TYPE_Q4_3 = 5,
+    ORACLE_TYPE_Q5_0 = 6,
+    ORACLE_TYPE_Q5_1 = 7,
+    ORACLE_TYPE_Q8_0 = 8,
+    ORACLE_TYPE_Q8_1 = 9,
+    ORACLE_TYPE_I8 = 10,
+    ORACLE_TYPE_I16 = 11,
+    ORACLE_TYPE_I32 = 12,
+    ORACLE_TYPE_COUNT = 13
+};
+
+/* Ggml.cs:55-87 */
+int    oracle_blck_size(int type);
+size_t oracle_type_size(int type);
+int    oracle_is_quantized(int type);       /* Ggml.cs:202-217 */
+int    oracle_vec_dot_type(int type);       /* Ggml.cs:219-290, -1 when the slot is null */
+
+/* IEEE binary16 <-> binary32, round-to-nearest-even (what (Half)f / (float)h do in .NET) */
+uint16_t oracle_f32_to_f16(float f);
+float    oracle_f16_to_f32(uint16_t h);
+
+/* Row functions: same signatures as the quantize_fns_t slots (TypeDefinitions.cs:334-342).
+ * k / n = element count, a multiple of the block size. */
+void oracle_quantize_row_q4_0(const float *x, void *y, int k);   /* Ggml.cs:334-377 */
+void oracle_quantize_row_q4_1(const float *x, void *y, int k);   /* Ggml.cs:487-528 */
+void oracle_quantize_row_q4_2(const float *x, void *y, int k);   /* Ggml.cs:547-590 (D7) */
+void oracle_quantize_row_q5_0(const float *x, void *y, int k);   /* Ggml.cs:609-653 */
+void oracle_quantize_row_q5_1(const float *x, void *y, int k);   /* Ggml.cs:672-714 (D7) */
+void oracle_quantize_row_q8_0(const float *x, void *y, int k);   /* Ggml.cs:733-762 (D2) */
+void oracle_quantize_row_q8_1(const float *x, void *y, int k);   /* Ggml.cs:781-823 (D3) */
+
+void oracle_dequantize_row_q4_0(const void *x, float *y, int k); /* Ggml.cs:886-910 */
+void oracle_dequantize_row_q4_1(const void *x, float *y, int k); /* Ggml.cs:962-987 */
+void oracle_dequantize_row_q4_2(const void *x, float *y, int k); /* Ggml.cs:992-1022 */
+void oracle_dequantize_row_q5_0(const void *x, float *y, int k); /* Ggml.cs:1025-1061 */
+void oracle_dequantize_row_q5_1(const void *x, float *y, int k); /* Ggml.cs:1064-1101 */
+void oracle_dequantize_row_q8_0(const void *x, float *y, int k); /* Ggml.cs:1104-1122 (D4) */
+
+void oracle_vec_dot_q4_0_q8_0(int n, float *s, const void *vx, const void *vy); /* Ggml.cs:1125-1162 */
+void oracle_vec_dot_q4_1_q8_1(int n, float *s, const void *vx, const void *vy); /* Ggml.cs:1165-1201 */
+void oracle_vec_dot_q4_2_q8_0(int n, float *s, const void *vx, const void *vy); /* Ggml.cs:1204-1255 */
+void oracle_vec_dot_q5_0_q8_0(int n, float *s, const void *vx, const void *vy); /* Ggml.cs:1258-1301 */
+void oracle_vec_dot_q5_1_q8_1(int n, float *s, const void *vx, const void *vy); /* Ggml.cs:1304-1348 */
+void oracle_vec_dot_q8_0_q8_0(int n, float *s, const void *vx, const void *vy); /* Ggml.cs:1351-1381 */
+
+void oracle_vec_dot_f32(int n, float *s, const float *x, const float *y);       /* Ggml.cs:2631-2640 */
+void oracle_vec_dot_f16(int n, float *s, const uint16_t *x, const uint16_t *y); /* Ggml.cs:2642-2651 */
+
+/* Type-indexed dispatch (the quantize_fns[] table, Ggml.cs:219-290). Return 0, or -1 for a null slot. */
+int oracle_quantize_row(int type, const float *x, void *y, int k);
+int oracle_dequantize_row(int type, const void *x, float *y, int k);
+int oracle_quantize_row_dot(int type, const float *x, void *y, int k);
+int oracle_vec_dot(int type, int n, float *s, const void *vx, const void *vy);
+
+/* Flattened tensor view: {type, ne[4], nb[4], data} of ggml_tensor (TypeDefinitions.cs:65-99). */
+typedef struct oracle_tensor {
+    int      type;
+    int64_t  ne[4];
+    uint64_t nb[4];
+    void    *data;
+} oracle_tensor;
+
+/* Work-buffer size the planner reserves for a MUL_MAT node (Ggml.cs:3329-3386). */
+size_t oracle_mul_mat_work_size(const oracle_tensor *src0, const oracle_tensor *src1);
+
+/*
+ * ggml_compute_forward_mul_mat (Ggml.cs:6714-6744) run through the three-phase protocol of
+ * ggml_graph_compute (Ggml.cs:3539-3704): INIT on thread 0 only, COMPUTE on nth threads with
+ * the contiguous row split of Ggml.cs:6129-6137 / 6392-6400 / 6664-6672, FINALIZE (no-op).
+ * wdata must hold oracle_mul_mat_work_size() bytes (may be NULL when that is 0).
+ * Returns 0; -1 unsupported src0 type (D8); -2 shape/stride precondition violated
+ * (the Debug.Asserts of Ggml.cs:6026-6046, 6222-6241, 6477-6504, 8228-8229).
+ */
+int oracle_mul_mat(const oracle_tensor *src0, const oracle_tensor *src1, const oracle_tensor *dst,
+                   void *wdata, size_t wsize, int nth);
+
+/* Test3's LCG (Test3/Program.cs:98-107): xsrand(seed); xrand() -> (next >> 16) & 0x7FFF. */
+void     oracle_xsrand(uint64_t seed);
+uint32_t oracle_xrand(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,125 @@
+"""ctypes loader for the CPU oracle (oracle/libggml_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "libggml_oracle.so")
+
+F32, F16, Q4_0, Q4_1, Q4_2, Q4_3, Q5_0, Q5_1, Q8_0, Q8_1, I8, I16, I32 = range(13)
+TYPE_NAMES = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q4_1: "q4_1", Q4_2: "q4_2", Q5_0: "q5_0",
+              Q5_1: "q5_1", Q8_0: "q8_0", Q8_1: "q8_1"}
+
+
+class OTensor(C.Structure):
+    _fields_ = [("type", C.c_int), ("ne", C.c_int64 * 4), ("nb", C.c_uint64 * 4), ("data", C.c_void_p)]
+
+
+def build():
+    src = [os.path.join(ORACLE_DIR, f) for f in ("ggml_oracle.c", "ggml_oracle.h", "Makefile")]
+    if (not os.path.exists(SO)) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(SO)
+        L.oracle_type_size.restype = C.c_size_t
+        L.oracle_mul_mat_work_size.restype = C.c_size_t
+        L.oracle_f16_to_f32.restype = C.c_float
+        L.oracle_f16_to_f32.argtypes = [C.c_uint16]
+        L.oracle_f32_to_f16.restype = C.c_uint16
+        L.oracle_f32_to_f16.argtypes = [C.c_float]
+        L.oracle_xsrand.argtypes = [C.c_uint64]
+        L.oracle_xrand.restype = C.c_uint32
+        L.oracle_mul_mat.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor), C.POINTER(OTensor),
+                                     C.c_void_p, C.c_size_t, C.c_int]
+        L.oracle_mul_mat_work_size.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor)]
+        _lib = L
+    return _lib
+
+
+def type_size(t):
+    return int(lib().oracle_type_size(t))
+
+
+def blck_size(t):
+    return int(lib().oracle_blck_size(t))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def quantize_row(t, x):
+    """x: f32 [..., k] -> uint8 [..., k/blck*type_size] of raw reference-format blocks."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    k = x.shape[-1]
+    rows = x.reshape(-1, k)
+    rb = k // blck_size(t) * type_size(t)
+    out = np.zeros((rows.shape[0], rb), dtype=np.uint8)
+    for i in range(rows.shape[0]):
+        rc = lib().oracle_quantize_row(t, _p(rows[i]), _p(out[i]), k)
+        assert rc == 0
+    return out.reshape(x.shape[:-1] + (rb,))
+
+
+def dequantize_row(t, q, k):
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    rows = q.reshape(-1, q.shape[-1])
+    out = np.zeros((rows.shape[0], k), dtype=np.float32)
+    for i in range(rows.shape[0]):
+        rc = lib().oracle_dequantize_row(t, _p(rows[i]), _p(out[i]), k)
+        assert rc == 0
+    return out.reshape(q.shape[:-1] + (k,))
+
+
+def vec_dot(t, n, xq, yq):
+    s = np.zeros(1, dtype=np.float32)
+    xq = np.ascontiguousarray(xq)
+    yq = np.ascontiguousarray(yq)
+    rc = lib().oracle_vec_dot(t, n, _p(s), _p(xq), _p(yq))
+    assert rc == 0
+    return s[0]
+
+
+def make_tensor(t, arr, ne, nb=None):
+    """Wrap a numpy buffer as an oracle_tensor with ggml's contiguous strides (Ggml.cs:7856-7861)."""
+    ne = list(ne) + [1] * (4 - len(ne))
+    if nb is None:
+        ts, bs = type_size(t), blck_size(t)
+        nb = [ts, ts * (ne[0] // bs), 0, 0]
+        nb[2] = nb[1] * ne[1]
+        nb[3] = nb[2] * ne[2]
+    ot = OTensor()
+    ot.type = t
+    for i in range(4):
+        ot.ne[i] = ne[i]
+        ot.nb[i] = nb[i]
+    ot.data = arr.ctypes.data
+    ot._keep = arr
+    return ot
+
+
+def mul_mat(t, w_raw, x, M, K, N, nth=1, ne2=1, ne3=1):
+    """w_raw: raw bytes/f32/f16 of src0 [ne3,ne2,M,K]; x: f32 [ne3,ne2,N,K] -> dst f32 [ne3,ne2,N,M]."""
+    w_raw = np.ascontiguousarray(w_raw)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    dst = np.zeros((ne3, ne2, N, M), dtype=np.float32)
+    s0 = make_tensor(t, w_raw, [K, M, ne2, ne3])
+    s1 = make_tensor(F32, x, [K, N, ne2, ne3])
+    d = make_tensor(F32, dst, [M, N, ne2, ne3])
+    ws = int(lib().oracle_mul_mat_work_size(C.byref(s0), C.byref(s1)))
+    work = np.zeros(max(ws, 1), dtype=np.uint8)
+    rc = lib().oracle_mul_mat(C.byref(s0), C.byref(s1), C.byref(d), _p(work), ws, nth)
+    assert rc == 0, rc
+    return dst
