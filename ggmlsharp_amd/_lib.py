@@ -1,0 +1,168 @@
+"""ctypes binding of libggml_hip.so (the C-ABI declared in include/ggml_hip.h and include/ggml.h).
+
+The library is built in-tree (ggmlsharp_amd/lib/libggml_hip.so) by `make -C ggmlsharp_amd/csrc`.
+Nothing here falls back to a CPU implementation: if the library is missing, loading raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libggml_hip.so")
+
+GGML_MAX_DIMS = 4
+GGML_MAX_OPT = 4
+GGML_MAX_NODES = 4096
+
+# ggml_type (TypeDefinitions.cs:153-169)
+F32, F16, Q4_0, Q4_1, Q4_2, Q4_3, Q5_0, Q5_1, Q8_0, Q8_1, I8, I16, I32 = range(13)
+TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q4_1: "q4_1", Q4_2: "q4_2", Q4_3: "q4_3", Q5_0: "q5_0",
+             Q5_1: "q5_1", Q8_0: "q8_0", Q8_1: "q8_1", I8: "i8", I16: "i16", I32: "i32"}
+BLCK_SIZE = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q4_2: 16, Q4_3: 16, Q5_0: 32, Q5_1: 32, Q8_0: 32, Q8_1: 32,
+             I8: 1, I16: 1, I32: 1}
+TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 20, Q4_1: 24, Q4_2: 10, Q4_3: 12, Q5_0: 22, Q5_1: 24, Q8_0: 36, Q8_1: 44,
+             I8: 1, I16: 2, I32: 4}
+
+GGML_OP_NONE, GGML_OP_MUL_MAT = 0, 20
+GGML_TASK_INIT, GGML_TASK_COMPUTE, GGML_TASK_FINALIZE = 0, 1, 2
+
+OK, ERR_NO_DEVICE, ERR_TYPE, ERR_SHAPE, ERR_ARG, ERR_RUNTIME = 0, -1, -2, -3, -4, -5
+
+
+class ggml_tensor(C.Structure):
+    pass
+
+
+ggml_tensor._fields_ = [
+    ("type", C.c_int32), ("n_dims", C.c_int32),
+    ("ne", C.c_int64 * GGML_MAX_DIMS), ("nb", C.c_uint64 * GGML_MAX_DIMS),
+    ("op", C.c_int32), ("is_param", C.c_uint8), ("_pad0", C.c_uint8 * 3),
+    ("grad", C.POINTER(ggml_tensor)), ("src0", C.POINTER(ggml_tensor)), ("src1", C.POINTER(ggml_tensor)),
+    ("opt", C.c_int64 * GGML_MAX_OPT),
+    ("n_tasks", C.c_int32), ("perf_runs", C.c_int32), ("perf_cycles", C.c_int64), ("perf_time_us", C.c_int64),
+    ("data", C.c_void_p), ("padding", C.c_uint8 * 8),
+]
+assert C.sizeof(ggml_tensor) == 176
+
+
+class ggml_compute_params(C.Structure):
+    _fields_ = [("type", C.c_int32), ("ith", C.c_int32), ("nth", C.c_int32), ("wsize", C.c_size_t),
+                ("wdata", C.c_void_p)]
+
+
+class ggml_init_params(C.Structure):
+    _fields_ = [("mem_size", C.c_uint64), ("mem_buffer", C.c_void_p), ("no_alloc", C.c_uint8)]
+
+
+class ggml_cgraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_leafs", C.c_int32), ("n_threads", C.c_int32), ("_pad0", C.c_int32),
+                ("work_size", C.c_size_t), ("work", C.POINTER(ggml_tensor)),
+                ("nodes", C.POINTER(ggml_tensor) * GGML_MAX_NODES),
+                ("grads", C.POINTER(ggml_tensor) * GGML_MAX_NODES),
+                ("leafs", C.POINTER(ggml_tensor) * GGML_MAX_NODES),
+                ("perf_runs", C.c_int32), ("_pad1", C.c_int32), ("perf_cycles", C.c_int64),
+                ("perf_time_us", C.c_int64)]
+
+
+assert C.sizeof(ggml_cgraph) == 98360
+
+# every symbol include/ggml_hip.h and include/ggml.h declare: name -> (restype, argtypes)
+_P = C.c_void_p
+_T = C.POINTER(ggml_tensor)
+SYMBOLS = {
+    # ggml_hip.h
+    "ggml_hip_blck_size": (C.c_int, [C.c_int]),
+    "ggml_hip_type_size": (C.c_size_t, [C.c_int]),
+    "ggml_hip_device_count": (C.c_int, []),
+    "ggml_hip_init": (C.c_int, [C.c_int]),
+    "ggml_hip_shutdown": (None, []),
+    "ggml_hip_last_error": (C.c_char_p, []),
+    "ggml_hip_arch": (C.c_char_p, []),
+    "ggml_hip_compute_forward_mul_mat": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
+    "ggml_hip_invalidate": (None, [_P]),
+    "ggml_hip_invalidate_all": (None, []),
+    "ggml_hip_weight_upload": (C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, _P,
+                                         C.POINTER(_P)]),
+    "ggml_hip_weight_from_device": (C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int64,
+                                              _P, C.POINTER(_P)]),
+    "ggml_hip_weight_download": (C.c_int, [_P, _P, _P]),
+    "ggml_hip_weight_free": (None, [_P]),
+    "ggml_hip_weight_rows": (C.c_int64, [_P]),
+    "ggml_hip_weight_cols": (C.c_int64, [_P]),
+    "ggml_hip_weight_type": (C.c_int, [_P]),
+    "ggml_hip_mul_mat_work_size": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64]),
+    "ggml_hip_mul_mat_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "ggml_hip_mul_mat_init_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_size_t, _P]),
+    "ggml_hip_mul_mat_compute_dev": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "ggml_hip_quantize_rows_dev": (C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, _P, _P]),
+    "ggml_hip_dequantize_rows_dev": (C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, _P, _P]),
+    "ggml_hip_quantize_row": (C.c_int, [C.c_int, _P, _P, C.c_int]),
+    "ggml_hip_dequantize_row": (C.c_int, [C.c_int, _P, _P, C.c_int]),
+    "ggml_hip_vec_dot": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
+    # ggml.h (host mirror)
+    "ggml_init": (_P, [C.POINTER(ggml_init_params)]),
+    "ggml_free": (None, [_P]),
+    "ggml_used_mem": (C.c_size_t, [_P]),
+    "ggml_new_tensor": (_T, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "ggml_new_tensor_1d": (_T, [_P, C.c_int, C.c_int64]),
+    "ggml_new_tensor_2d": (_T, [_P, C.c_int, C.c_int64, C.c_int64]),
+    "ggml_new_tensor_3d": (_T, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "ggml_new_tensor_4d": (_T, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "ggml_nelements": (C.c_int64, [_T]),
+    "ggml_nrows": (C.c_int64, [_T]),
+    "ggml_nbytes": (C.c_size_t, [_T]),
+    "ggml_blck_size": (C.c_int, [C.c_int]),
+    "ggml_type_size": (C.c_size_t, [C.c_int]),
+    "ggml_is_quantized": (C.c_int, [C.c_int]),
+    "ggml_is_contiguous": (C.c_int, [_T]),
+    "ggml_can_mul_mat": (C.c_int, [_T, _T]),
+    "ggml_set_f32": (_T, [_T, C.c_float]),
+    "ggml_get_f32_1d": (C.c_float, [_T, C.c_int]),
+    "ggml_set_f32_1d": (None, [_T, C.c_int, C.c_float]),
+    "ggml_mul_mat": (_T, [_P, _T, _T]),
+    "ggml_build_forward": (None, [C.POINTER(ggml_cgraph), _T]),
+    "ggml_build_forward_expand": (None, [C.POINTER(ggml_cgraph), _T]),
+    "ggml_graph_compute": (C.c_int, [_P, C.POINTER(ggml_cgraph)]),
+}
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into ggmlsharp_amd/lib/libggml_hip.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC_DIR, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            if os.path.exists("/opt/rocm/bin/hipcc"):
+                build()
+            else:
+                raise RuntimeError(f"{LIB_PATH} is missing and hipcc is not available; there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class GgmlHipError(RuntimeError):
+    def __init__(self, status, where):
+        msg = lib().ggml_hip_last_error().decode(errors="replace")
+        super().__init__(f"{where}: status {status}: {msg}")
+        self.status = status
+
+
+def check(status, where):
+    if status != OK:
+        raise GgmlHipError(status, where)

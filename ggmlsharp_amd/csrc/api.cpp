@@ -1,0 +1,461 @@
+// api.cpp -- the C-ABI of include/ggml_hip.h: lifecycle, resident weights, the two seams.
+// No CPU fallback anywhere: without a device every compute entry returns GGML_HIP_ERR_NO_DEVICE.
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+int g_device = -1;
+bool g_inited = false;
+std::string g_arch;
+hipStream_t g_stream = nullptr;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+const int BLCK[GGML_TYPE_COUNT] = {1, 1, 32, 32, 16, 16, 32, 32, 32, 32, 1, 1, 1};          // Ggml.cs:55-70
+const size_t TSIZE[GGML_TYPE_COUNT] = {4, 2, 20, 24, 10, 12, 22, 24, 36, 44, 1, 2, 4};      // Ggml.cs:72-87
+
+bool weight_type_ok(int t) {
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q8_0 ||
+           t == GGML_TYPE_F32 || t == GGML_TYPE_F16;
+}
+bool is_q(int t) { return t >= GGML_TYPE_Q4_0 && t <= GGML_TYPE_Q8_1; }
+int vec_dot_type(int t) {  // Ggml.cs:219-290
+    switch (t) {
+    case GGML_TYPE_Q4_0: case GGML_TYPE_Q5_0: case GGML_TYPE_Q8_0: return GGML_TYPE_Q8_0;
+    case GGML_TYPE_Q4_1: return GGML_TYPE_Q8_1;
+    default: return -1;
+    }
+}
+
+int ensure_init() {
+    if (g_inited) {
+        hipError_t e = hipSetDevice(g_device);  // calls arrive on arbitrary threads (SURVEY 8(b) "Threading")
+        if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "hipSetDevice: %s", hipGetErrorString(e));
+        return GGML_HIP_OK;
+    }
+    return ggml_hip_init(g_device < 0 ? 0 : g_device);
+}
+
+// ---- host-level scratch (Seam 1 / Seam 2 host forms) ----
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, n) != hipSuccess) return -1;
+        cap = n;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+Scratch g_src1, g_dst, g_work, g_stage;
+
+// ---- weight cache for Seam 1, keyed by the host pointer + shape ----
+using CacheKey = std::tuple<const void *, int, int64_t, int64_t, int64_t, int64_t, uint64_t, uint64_t, uint64_t>;
+std::map<CacheKey, std::vector<ggml_hip_weight *>> g_cache;
+
+int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
+    ggml_hip_weight *w = new ggml_hip_weight();
+    memset(w, 0, sizeof *w);
+    w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = g_device;
+    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, total = 0;
+    if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
+        total = (size_t)w->Mpad * K * (type == GGML_TYPE_F32 ? 4 : 2);
+    } else {
+        w->nbk = K / QK;
+        const size_t qs_bytes = (size_t)w->nbk * w->Mpad * (type == GGML_TYPE_Q8_0 ? 32 : 16);
+        const size_t plane = (size_t)w->nbk * w->Mpad * 4;
+        off_qs = 0; total = qs_bytes;
+        off_d = total; total += plane;
+        if (type == GGML_TYPE_Q4_1) { off_m = total; total += plane; }
+        if (type == GGML_TYPE_Q5_0) { off_qh = total; total += plane; }
+    }
+    if (total == 0) total = 16;
+    void *base = nullptr;
+    hipError_t e = hipMalloc(&base, total);
+    if (e != hipSuccess) { delete w; return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc(%zu): %s", total, hipGetErrorString(e)); }
+    w->bytes = total;
+    if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
+        w->dense = base;
+    } else {
+        w->qs = (uint8_t *)base + off_qs;
+        w->d = (float *)((uint8_t *)base + off_d);
+        if (type == GGML_TYPE_Q4_1) w->m = (float *)((uint8_t *)base + off_m);
+        if (type == GGML_TYPE_Q5_0) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
+    }
+    *out = w;
+    return GGML_HIP_OK;
+}
+
+void *weight_base(const ggml_hip_weight *w) { return w->dense ? w->dense : (void *)w->qs; }
+
+int make_weight(int type, const void *rows, bool rows_on_host, int64_t ne00, int64_t ne01, uint64_t nb01,
+                int64_t row_begin, int64_t row_end, hipStream_t st, ggml_hip_weight **out) {
+    if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (type < 0 || type >= GGML_TYPE_COUNT || !weight_type_ok(type))
+        return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type (Q4_3/Q8_1 have null slots, Ggml.cs:248,278-282)", type);
+    if (!rows || ne00 <= 0 || ne01 < 0 || row_begin < 0 || row_end < row_begin || row_end > ne01)
+        return fail(GGML_HIP_ERR_ARG, "bad weight arguments");
+    if (ne00 % BLCK[type] != 0) return fail(GGML_HIP_ERR_SHAPE, "ne00 %% %d != 0 (Ggml.cs:6694)", BLCK[type]);
+    const uint64_t row_bytes = (uint64_t)TSIZE[type] * (uint64_t)(ne00 / BLCK[type]);
+    if (nb01 < row_bytes) return fail(GGML_HIP_ERR_SHAPE, "nb01 smaller than a row (transposed src0, Ggml.cs:8229)");
+    int rc = ensure_init();
+    if (rc) return rc;
+    const int64_t rows_n = row_end - row_begin;
+    ggml_hip_weight *w = nullptr;
+    rc = alloc_weight(type, ne00, rows_n, &w);
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(weight_base(w), 0, w->bytes, st);
+    const uint8_t *dev_rows = (const uint8_t *)rows;
+    void *staging = nullptr;
+    if (e == hipSuccess && rows_on_host && rows_n > 0) {
+        e = hipMalloc(&staging, (size_t)rows_n * row_bytes);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(staging, row_bytes, (const uint8_t *)rows + (uint64_t)row_begin * nb01, nb01, row_bytes,
+                                 (size_t)rows_n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = launch_repack_to_planar(type, (const uint8_t *)staging, row_bytes, 0, rows_n, w, st);
+    } else if (e == hipSuccess) {
+        e = launch_repack_to_planar(type, dev_rows, nb01, row_begin, rows_n, w, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (staging) (void)hipFree(staging);
+    if (e != hipSuccess) {
+        (void)hipFree(weight_base(w));
+        delete w;
+        return fail(GGML_HIP_ERR_RUNTIME, "weight upload: %s", hipGetErrorString(e));
+    }
+    *out = w;
+    return GGML_HIP_OK;
+}
+
+void free_cache_locked() {
+    for (auto &kv : g_cache)
+        for (ggml_hip_weight *w : kv.second) ggml_hip_weight_free(w);
+    g_cache.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ggml_hip_blck_size(int type) { return (type >= 0 && type < GGML_TYPE_COUNT) ? BLCK[type] : 0; }
+size_t ggml_hip_type_size(int type) { return (type >= 0 && type < GGML_TYPE_COUNT) ? TSIZE[type] : 0; }
+
+int ggml_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ggml_hip_init(int device) {
+    int n = ggml_hip_device_count();
+    if (n <= 0) return fail(GGML_HIP_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU path");
+    if (device < 0 || device >= n) return fail(GGML_HIP_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited && g_device == device) return GGML_HIP_OK;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    g_arch = prop.gcnArchName;
+    if (g_stream == nullptr) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    g_inited = true;
+    return GGML_HIP_OK;
+}
+
+void ggml_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_inited) return;
+    (void)hipSetDevice(g_device);
+    free_cache_locked();
+    g_src1.release(); g_dst.release(); g_work.release(); g_stage.release();
+    if (g_stream) (void)hipStreamDestroy(g_stream);
+    g_stream = nullptr;
+    g_inited = false;
+}
+
+const char *ggml_hip_last_error(void) { return g_err.c_str(); }
+const char *ggml_hip_arch(void) { return g_arch.c_str(); }
+
+int ggml_hip_weight_upload(int type, const void *host_rows, int64_t ne00, int64_t ne01, uint64_t nb01,
+                           int64_t row_begin, int64_t row_end, void *stream, ggml_hip_weight **out) {
+    return make_weight(type, host_rows, true, ne00, ne01, nb01, row_begin, row_end, (hipStream_t)stream, out);
+}
+
+int ggml_hip_weight_from_device(int type, const void *dev_rows, int64_t ne00, int64_t ne01, uint64_t nb01,
+                                int64_t row_begin, int64_t row_end, void *stream, ggml_hip_weight **out) {
+    return make_weight(type, dev_rows, false, ne00, ne01, nb01, row_begin, row_end, (hipStream_t)stream, out);
+}
+
+int ggml_hip_weight_download(const ggml_hip_weight *w, void *host_rows, void *stream) {
+    if (!w || !host_rows) return fail(GGML_HIP_ERR_ARG, "null argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t row_bytes = TSIZE[w->type] * (size_t)(w->K / BLCK[w->type]);
+    const size_t total = row_bytes * (size_t)w->M;
+    if (total == 0) return GGML_HIP_OK;
+    void *staging = nullptr;
+    HIP_TRY(hipMalloc(&staging, total));
+    hipError_t e = launch_planar_to_aos(w, (uint8_t *)staging, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_rows, staging, total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "weight download: %s", hipGetErrorString(e));
+    return GGML_HIP_OK;
+}
+
+void ggml_hip_weight_free(ggml_hip_weight *w) {
+    if (!w) return;
+    (void)hipFree(weight_base(w));
+    delete w;
+}
+int64_t ggml_hip_weight_rows(const ggml_hip_weight *w) { return w ? w->M : 0; }
+int64_t ggml_hip_weight_cols(const ggml_hip_weight *w) { return w ? w->K : 0; }
+int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? w->type : -1; }
+
+size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
+    if (!is_q(type) || K <= 0 || N <= 0) return 0;
+    return act_bytes(K, pad_rows(N));
+}
+
+int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, void *d_work,
+                              size_t work_bytes, void *stream) {
+    if (!w || !d_src1) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (N <= 0) return GGML_HIP_OK;
+    if (!is_q(w->type)) return GGML_HIP_OK;  // dense: INIT is a no-op for f32 (Ggml.cs:6117-6120); f16 rounds in-kernel
+    if (ld1 < w->K) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K");
+    if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
+        return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", ggml_hip_mul_mat_work_size(w->type, w->K, N));
+    act_planes p = act_carve(d_work, w->K, pad_rows(N));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_dst, int64_t ldd, const void *d_work,
+                                 size_t work_bytes, void *stream) {
+    if (!w || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (N <= 0 || w->M <= 0) return GGML_HIP_OK;
+    if (!is_q(w->type)) return fail(GGML_HIP_ERR_TYPE, "compute_dev is the quantized COMPUTE phase; use ggml_hip_mul_mat_dev for dense");
+    if (ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ldd < M");
+    if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N)) return fail(GGML_HIP_ERR_ARG, "work buffer too small");
+    act_planes p = act_carve((void *)d_work, w->K, pad_rows(N));
+    if (N <= GEMV_MAX_N)
+        HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
+    else
+        HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *d_dst,
+                         int64_t ldd, void *d_work, size_t work_bytes, void *stream) {
+    if (!w || !d_src1 || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (N <= 0 || w->M <= 0) return GGML_HIP_OK;
+    if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
+    if (!is_q(w->type)) {
+        HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
+        return GGML_HIP_OK;
+    }
+    int rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
+    if (rc) return rc;
+    return ggml_hip_mul_mat_compute_dev(w, N, d_dst, ldd, d_work, work_bytes, stream);
+}
+
+int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {
+    if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q8_1))
+        return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
+    if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:336)");
+    HIP_TRY(launch_quantize_rows(type, d_x, nrows, k, d_blocks, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, int64_t k, float *d_y, void *stream) {
+    if (!d_y || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0))
+        return fail(GGML_HIP_ERR_TYPE, "dequantize: unsupported type %d (Q8_1 slot is null, Ggml.cs:278)", type);
+    if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:839)");
+    HIP_TRY(launch_dequantize_rows(type, d_blocks, nrows, k, d_y, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_quantize_row(int type, const float *x, void *y, int k) {
+    if (!x || !y || k <= 0) return fail(GGML_HIP_ERR_ARG, "bad argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (type < 0 || type >= GGML_TYPE_COUNT || !is_q(type)) return fail(GGML_HIP_ERR_TYPE, "not a quantized type");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t xb = (size_t)k * 4, yb = TSIZE[type] * (size_t)(k / BLCK[type]);
+    if (g_src1.ensure(xb) || g_dst.ensure(yb)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed");
+    HIP_TRY(hipMemcpyAsync(g_src1.p, x, xb, hipMemcpyHostToDevice, g_stream));
+    rc = ggml_hip_quantize_rows_dev(type, (const float *)g_src1.p, 1, k, g_dst.p, g_stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(y, g_dst.p, yb, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_dequantize_row(int type, const void *x, float *y, int k) {
+    if (!x || !y || k <= 0) return fail(GGML_HIP_ERR_ARG, "bad argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (type < 0 || type >= GGML_TYPE_COUNT || !is_q(type)) return fail(GGML_HIP_ERR_TYPE, "not a quantized type");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t yb = (size_t)k * 4, xb = TSIZE[type] * (size_t)(k / BLCK[type]);
+    if (g_src1.ensure(xb) || g_dst.ensure(yb)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed");
+    HIP_TRY(hipMemcpyAsync(g_src1.p, x, xb, hipMemcpyHostToDevice, g_stream));
+    rc = ggml_hip_dequantize_rows_dev(type, g_src1.p, 1, k, (float *)g_dst.p, g_stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(y, g_dst.p, yb, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_vec_dot(int type, int n, float *s, const void *vx, const void *vy) {
+    if (!s || !vx || !vy || n <= 0) return fail(GGML_HIP_ERR_ARG, "bad argument");
+    const int vt = (type >= 0 && type < GGML_TYPE_COUNT) ? vec_dot_type(type) : -1;
+    if (vt < 0) return fail(GGML_HIP_ERR_TYPE, "vec_dot: type %d has no usable slot (D7/D8)", type);
+    if (n % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "n %% 32 != 0 (Ggml.cs:1129)");
+    int rc = ensure_init();
+    if (rc) return rc;
+    ggml_hip_weight *w = nullptr;
+    const uint64_t xb = (uint64_t)TSIZE[type] * (uint64_t)(n / QK);
+    rc = ggml_hip_weight_upload(type, vx, n, 1, xb, 0, 1, g_stream, &w);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t yb = TSIZE[vt] * (size_t)(n / QK);
+    const size_t wb = ggml_hip_mul_mat_work_size(type, n, 1);
+    rc = GGML_HIP_OK;
+    if (g_src1.ensure(yb) || g_work.ensure(wb) || g_dst.ensure(4)) rc = fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed");
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(g_src1.p, vy, yb, hipMemcpyHostToDevice, g_stream);
+        if (e == hipSuccess) e = launch_q8_aos_to_planes(vt, g_src1.p, 1, n, act_carve(g_work.p, n, pad_rows(1)), g_stream);
+        if (e == hipSuccess) rc = ggml_hip_mul_mat_compute_dev(w, 1, (float *)g_dst.p, 1, g_work.p, wb, g_stream);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(s, g_dst.p, 4, hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(g_stream);
+    }
+    ggml_hip_weight_free(w);
+    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "vec_dot: %s", hipGetErrorString(e));
+    return rc;
+}
+
+int ggml_hip_relayout_gathered_dev(const float *d_gathered, int G, int64_t N, int64_t Ms, float *d_dst, int64_t M,
+                                   int64_t ldd, void *stream) {
+    if (!d_gathered || !d_dst || G <= 0 || Ms <= 0) return fail(GGML_HIP_ERR_ARG, "bad argument");
+    if (ldd < M) return fail(GGML_HIP_ERR_SHAPE, "ldd < M");
+    HIP_TRY(launch_relayout_gathered(d_gathered, G, N, Ms, d_dst, M, ldd, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+void ggml_hip_invalidate(const void *host_ptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_cache.begin(); it != g_cache.end();) {
+        if (std::get<0>(it->first) == host_ptr) {
+            for (ggml_hip_weight *w : it->second) ggml_hip_weight_free(w);
+            it = g_cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+void ggml_hip_invalidate_all(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    free_cache_locked();
+}
+
+/* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
+ * ggml_mul_mat_impl (Ggml.cs:8228-8229); the reference silently drops them in Release, here they are errors. */
+int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                     const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    // offload convention of the reference's own dead GPU blocks (Ggml.cs:6510-6521)
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const int type = src0->type;
+    if (type < 0 || type >= GGML_TYPE_COUNT || !weight_type_ok(type))
+        return fail(GGML_HIP_ERR_TYPE, "src0 type %d unsupported (Q4_3/Q8_1 null slots; Q4_2/Q5_1 broken storage, SURVEY D7/D8)", type);
+    if (src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "src1 and dst must be F32");
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t ne10 = src1->ne[0], ne11 = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
+    if (ne00 != ne10 || ne02 != ne12 || ne03 != ne13) return fail(GGML_HIP_ERR_SHAPE, "!ggml_can_mul_mat (Ggml.cs:8345-8353)");
+    if (dst->ne[0] != ne01 || dst->ne[1] != ne11 || dst->ne[2] != ne02 || dst->ne[3] != ne03)
+        return fail(GGML_HIP_ERR_SHAPE, "dst shape (Ggml.cs:6488-6491)");
+    if (src0->nb[0] != TSIZE[type]) return fail(GGML_HIP_ERR_SHAPE, "permuted src0 (Ggml.cs:6477)");
+    if (src0->nb[0] > src0->nb[1]) return fail(GGML_HIP_ERR_SHAPE, "transposed src0 (Ggml.cs:8229)");
+    if (src1->nb[0] != 4) return fail(GGML_HIP_ERR_SHAPE, "permuted src1 (Ggml.cs:6478)");
+    if (dst->nb[0] != 4 || dst->nb[0] > dst->nb[1] || dst->nb[1] > dst->nb[2] || dst->nb[2] > dst->nb[3])
+        return fail(GGML_HIP_ERR_SHAPE, "dst transposed or permuted (Ggml.cs:6481-6484)");
+    if (ne00 % BLCK[type] != 0) return fail(GGML_HIP_ERR_SHAPE, "ne00 %% 32 != 0 (Ggml.cs:6694)");
+    if (src1->nb[1] % 4 != 0 || dst->nb[1] % 4 != 0) return fail(GGML_HIP_ERR_SHAPE, "row strides must be multiples of 4");
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (ne01 == 0 || ne11 == 0 || ne02 * ne03 == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+
+    std::lock_guard<std::mutex> lk(g_mu);
+    const CacheKey key{src0->data, type, ne00, ne01, ne02, ne03, src0->nb[1], src0->nb[2], src0->nb[3]};
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) {
+        std::vector<ggml_hip_weight *> slices;
+        for (int64_t i03 = 0; i03 < ne03; ++i03)
+            for (int64_t i02 = 0; i02 < ne02; ++i02) {
+                ggml_hip_weight *w = nullptr;
+                const uint8_t *base = (const uint8_t *)src0->data + i02 * src0->nb[2] + i03 * src0->nb[3];
+                rc = ggml_hip_weight_upload(type, base, ne00, ne01, src0->nb[1], 0, ne01, g_stream, &w);
+                if (rc) {
+                    for (ggml_hip_weight *x : slices) ggml_hip_weight_free(x);
+                    return rc;
+                }
+                slices.push_back(w);
+            }
+        it = g_cache.emplace(key, std::move(slices)).first;
+    }
+    const size_t x_bytes = (size_t)ne11 * ne10 * 4, d_bytes = (size_t)ne11 * ne01 * 4;
+    const size_t w_bytes = ggml_hip_mul_mat_work_size(type, ne00, ne11);
+    if (g_src1.ensure(x_bytes) || g_dst.ensure(d_bytes) || g_work.ensure(w_bytes ? w_bytes : 16))
+        return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+    for (int64_t i03 = 0; i03 < ne03; ++i03)
+        for (int64_t i02 = 0; i02 < ne02; ++i02) {  // slice offsets as in Ggml.cs:6566-6570
+            const ggml_hip_weight *w = it->second[(size_t)(i03 * ne02 + i02)];
+            const uint8_t *x = (const uint8_t *)src1->data + i02 * src1->nb[2] + i03 * src1->nb[3];
+            uint8_t *d = (uint8_t *)dst->data + i02 * dst->nb[2] + i03 * dst->nb[3];
+            HIP_TRY(hipMemcpy2DAsync(g_src1.p, (size_t)ne10 * 4, x, src1->nb[1], (size_t)ne10 * 4, (size_t)ne11,
+                                     hipMemcpyHostToDevice, g_stream));
+            rc = ggml_hip_mul_mat_dev(w, (const float *)g_src1.p, ne11, ne10, (float *)g_dst.p, ne01, g_work.p, g_work.cap, g_stream);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy2DAsync(d, dst->nb[1], g_dst.p, (size_t)ne01 * 4, (size_t)ne01 * 4, (size_t)ne11,
+                                     hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipStreamSynchronize(g_stream));
+        }
+    return GGML_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// common.h -- shared declarations for the gfx950 kernels and the C-ABI layer (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/ggml_hip.h"
+
+#define QK 32
+
+// ---- reference block layouts (TypeDefinitions.cs:236-290); AoS, as they sit in a ggml_tensor ----
+#pragma pack(push, 1)
+struct block_q4_0 { float d; uint8_t qs[16]; };
+struct block_q4_1 { float d; float m; uint8_t qs[16]; };
+struct block_q5_0 { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; };
+struct block_q8_0 { float d; int8_t qs[32]; };
+struct block_q8_1 { float d; float s0; float s1; int8_t qs[32]; };
+#pragma pack(pop)
+static_assert(sizeof(block_q4_0) == 20, "Ggml.cs:76");
+static_assert(sizeof(block_q4_1) == 24, "Ggml.cs:77");
+static_assert(sizeof(block_q5_0) == 22, "Ggml.cs:80");
+static_assert(sizeof(block_q8_0) == 36, "Ggml.cs:82");
+static_assert(sizeof(block_q8_1) == 44, "Ggml.cs:83");
+static_assert(sizeof(ggml_tensor) == 176, "TypeDefinitions.cs:65-99");
+static_assert(offsetof(ggml_tensor, op) == 72 && offsetof(ggml_tensor, grad) == 80 &&
+              offsetof(ggml_tensor, n_tasks) == 136 && offsetof(ggml_tensor, data) == 160, "layout");
+
+// Rows of every device plane are padded to a multiple of this (the largest GEMM tile edge).
+#define ROW_PAD 128
+static inline int64_t pad_rows(int64_t n) { return (n + ROW_PAD - 1) / ROW_PAD * ROW_PAD; }
+
+// ---- resident weight: planar (block-major) layout, see DESIGN.md "Data layout in HBM" ----
+//   Q4_0/Q4_1/Q5_0: qs [nbk][Mpad][16] bytes of nibbles exactly as in the reference block
+//   Q8_0          : qs [nbk][2][Mpad][16] int8, plane 0 = even elements, plane 1 = odd elements of the block
+//   d   [nbk][Mpad] f32 (Q5_0: the half scale widened, exact)
+//   m   [nbk][Mpad] f32 (Q4_1 only);  qh [nbk][Mpad] u32 (Q5_0 only)
+//   F32/F16: dense [Mpad][K] row-major copy
+struct ggml_hip_weight {
+    int      type;
+    int64_t  M, K, Mpad, nbk;
+    uint8_t *qs;
+    uint32_t *qh;
+    float   *d;
+    float   *m;
+    void    *dense;
+    size_t   bytes;
+    int      device;
+};
+
+// ---- activation scratch ("wdata"), planar like the weights ----
+//   a8 [nbk][2][Npad][16] int8 (plane 0 even elements, plane 1 odd), ad [nbk][Npad] f32, as [nbk][Npad] i32 (block sums)
+struct act_planes {
+    int8_t  *a8;
+    float   *ad;
+    int32_t *as;
+    int64_t  Npad;
+};
+static inline size_t act_bytes(int64_t K, int64_t Npad) {
+    const int64_t nbk = K / QK;
+    return (size_t)nbk * 2 * Npad * 16 + (size_t)nbk * Npad * 4 * 2;
+}
+static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
+    const int64_t nbk = K / QK;
+    act_planes p;
+    p.a8 = (int8_t *)base;
+    p.ad = (float *)((uint8_t *)base + (size_t)nbk * 2 * Npad * 16);
+    p.as = (int32_t *)((uint8_t *)p.ad + (size_t)nbk * Npad * 4);
+    p.Npad = Npad;
+    return p;
+}
+
+// ---- kernel launchers (implemented in the .hip files) ----
+// layout.hip
+hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
+                                   ggml_hip_weight *w, hipStream_t st);
+hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
+hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
+                                    hipStream_t st);
+// quantize.hip
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, hipStream_t st);
+hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
+hipError_t launch_quantize_rows(int type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st);
+hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
+// gemv.hip / gemm_q.hip / dense.hip
+hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
+                        hipStream_t st);
+
+// N at or below this goes to the wave-reduction mat-vec kernel, above it to the MFMA kernel.
+#define GEMV_MAX_N 8

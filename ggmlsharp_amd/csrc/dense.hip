@@ -1,0 +1,89 @@
+// dense.hip -- K10: dense f32 x f32 and f16 x f32 mul_mat on the f32-input matrix cores.
+//
+// ggml_compute_forward_mul_mat_f32 (Ggml.cs:5969-6178) with ggml_vec_dot_f32 (Ggml.cs:2631-2640: f32 products,
+// f64 running sum) and ggml_compute_forward_mul_mat_f16_f32 (Ggml.cs:6180-6438: INIT rounds src1 to Half
+// :6362-6379, then ggml_vec_dot_f16 :2642-2651 multiplies (float)h * (float)h).
+// v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered f32 fmaf chain (no reduced-precision shortcut exists on
+// gfx950), i.e. the reference's sum with f32 instead of f64 accumulation: ~1e-6 relative at these K, inside the
+// 1e-3 budget.  Same orientation as the quantized kernel: MFMA rows = src1 rows n, MFMA cols = weight rows m.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+#define DT 64    // tile edge (n and m)
+#define DK 32    // k per stage
+#define DLD 33   // padded LDS row (floats): column reads hit 32 distinct banks
+
+template <bool W_F16>
+__global__ __launch_bounds__(256) void dense_kernel(const void *__restrict__ wv, const float *__restrict__ x,
+                                                   float *__restrict__ dst, int64_t M, int64_t N, int64_t K, int64_t ld1,
+                                                   int64_t ldd) {
+    __shared__ float sX[DT * DLD];
+    __shared__ float sW[DT * DLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wm_ = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * DT, n0 = (int64_t)blockIdx.y * DT;
+
+    const int srow = tid >> 2, sk = (tid & 3) * 8;
+    const int64_t xr = (n0 + srow) < N ? (n0 + srow) : (N - 1);
+    const float *xp = x + xr * ld1;
+    const int64_t wr = m0 + srow;  // < Mpad, padded rows are zero
+
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int64_t k0 = 0; k0 < K; k0 += DK) {
+        float xv[8], wv8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t k = k0 + sk + e;
+            float xe = k < K ? xp[k] : 0.0f;
+            float we;
+            if (W_F16) {
+                const __half *wp = (const __half *)wv + wr * K;
+                we = k < K ? __half2float(wp[k]) : 0.0f;
+                xe = __half2float(__float2half_rn(xe));  // (Half)src1, Ggml.cs:6369
+            } else {
+                const float *wp = (const float *)wv + wr * K;
+                we = k < K ? wp[k] : 0.0f;
+            }
+            xv[e] = xe;
+            wv8[e] = we;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sX[srow * DLD + sk + e] = xv[e];
+            sW[srow * DLD + sk + e] = wv8[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < DK / 2; ++s) {
+            const float a = sX[(wn * 32 + l31) * DLD + 2 * s + hh];
+            const float b = sW[(wm_ * 32 + l31) * DLD + 2 * s + hh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int64_t m = m0 + wm_ * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (n < N && m < M) dst[n * ldd + m] = acc[r];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
+                        hipStream_t st) {
+    if (N <= 0 || w->M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
+    if (w->type == GGML_TYPE_F16)
+        dense_kernel<true><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+    else
+        dense_kernel<false><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+    return hipGetLastError();
+}

@@ -1,0 +1,340 @@
+// gemm_q.hip -- K3: quantized mat-mat (N > GEMV_MAX_N) on the int8 matrix cores, block-scaled.
+//
+// COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698):
+//   dst[n*ldd + m] = sum_b (dw[m,b] * da[n,b]) * sumi_b(m,n),   sumi_b = exact int32 dot of one 32-element block
+// (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159; _q5_0_q8_0 1270-1298; _q8_0_q8_0 1362-1378; _q4_1_q8_1 1176-1198).
+// The reference's K-block of 32 is exactly one v_mfma_i32_32x32x32_i8 step, so each MFMA yields the 32x32 tile of
+// sumi_b for one k-block; the f32 scale-accumulate of Ggml.cs:1158 is then applied per tile on the VALU:
+//   acc[r] = fma((float)sumi[r], da[row(r)] * dw[col], acc[r]).
+// Arithmetic is the reference's (integer block dot, two f32 scales per block); only the order of the f32 adds over
+// blocks is the same here too (ascending b), with fma instead of mul+add.
+//
+// Orientation: MFMA rows = src1 rows n (A operand = Q8 activations), MFMA cols = weight rows m (B operand), so a
+// lane owns one m and the 16 accumulator registers walk n: the final stores are 128-byte segments of dst rows
+// (dst is [n][m] with m fastest, Ggml.cs:6692-6697).
+//
+// Operand images in LDS are [k-block][half h][row][16 B]: lane (row, h) reads its 16 int8 with one conflict-free
+// ds_read_b128.  Half h = 0 holds the even elements of the block, h = 1 the odd ones -- the order the nibble
+// unpack (q & 0x0F0F0F0F, (q >> 4) & 0x0F0F0F0F) produces for free; K1 writes the activations in the same order,
+// and the MFMA pairs element j of half h in A with element j of half h in B, so the block dot is unchanged.
+//
+// Workgroup = 256 threads = 2x2 waves, wave tile (32*IT) x (32*JT), 2 workgroups per CU (2 waves per SIMD so the
+// VALU epilogue issues at full rate).  K is streamed in stages of BKB k-blocks through a double-buffered LDS ring:
+// activations by global_load_lds (16 B/lane, image is lane-linear), weights through registers (nibble -> int8).
+#include "common.h"
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+#define BKB 4  // k-blocks per stage
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, 0);
+}
+
+// nibble word (elements interleaved) -> int8 words of (value - off), bytewise, no cross-byte borrow
+__device__ __forceinline__ uint32_t sub_bytes(uint32_t x, uint32_t off4) {
+    return ((x | 0x80808080u) - off4) ^ 0x80808080u;
+}
+
+__device__ __forceinline__ uint32_t q5_hi(uint32_t qh, int i, int sel) {
+    const uint32_t t = ((qh >> (8 * i + sel)) & 0x55u);
+    return (t * 0x00410410u) & 0x10101010u;
+}
+
+template <int TYPE, int IT, int JT>
+struct Tile {
+    static constexpr int TN = 64 * IT;  // src1 rows per workgroup
+    static constexpr int TM = 64 * JT;  // weight rows per workgroup
+    static constexpr int A_BYTES = BKB * 2 * TN * 16;
+    static constexpr int W_BYTES = BKB * 2 * TM * 16;
+    static constexpr int DA_BYTES = BKB * TN * 4;
+    static constexpr int DW_BYTES = BKB * TM * 4;
+    static constexpr int MW_BYTES = (TYPE == GGML_TYPE_Q4_1) ? BKB * TM * 4 : 0;
+    static constexpr int SA_BYTES = (TYPE == GGML_TYPE_Q4_1) ? BKB * TN * 4 : 0;
+    static constexpr int STAGE = A_BYTES + W_BYTES + DA_BYTES + DW_BYTES + MW_BYTES + SA_BYTES;
+    static constexpr int LDS = 2 * STAGE;
+};
+
+template <int TYPE, int IT, int JT>
+__global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict__ wqh,
+                                                       const float *__restrict__ wd, const float *__restrict__ wm,
+                                                       const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                                                       const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
+                                                       int64_t N, int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd) {
+    using T = Tile<TYPE, IT, JT>;
+    constexpr int TN = T::TN, TM = T::TM;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wm_ = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int64_t n0 = (int64_t)blockIdx.y * TN;
+
+    f32x4 acc[IT][JT][4];
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][j][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nstages = (int)((nbk + BKB - 1) / BKB);
+
+    // ---- staging helpers ----
+    constexpr int W_CHUNKS = BKB * TM;                               // 16-byte nibble chunks (Q4/Q5) per stage
+    constexpr int W_PER_THREAD = (W_CHUNKS + 255) / 256;
+    uint4 wreg[W_PER_THREAD];
+    uint32_t hreg[W_PER_THREAD];
+
+    auto stage_ptr = [&](int s) { return smem + (s & 1) * T::STAGE; };
+
+    auto issue_loads = [&](int s) {
+        uint8_t *sp = stage_ptr(s);
+        const int64_t kb0 = (int64_t)s * BKB;
+        // activations: [bb][h][TN rows][16 B], one 1-KiB wave instruction per 64 rows
+        {
+            uint8_t *sA = sp;
+            constexpr int A_CHUNKS = BKB * 2 * TN;
+#pragma unroll
+            for (int i = 0; i < A_CHUNKS / 256; ++i) {
+                const int c = tid + 256 * i;
+                const int bh = c / TN, row = c % TN;
+                int64_t b = kb0 + (bh >> 1);
+                if (b >= nbk) b = nbk - 1;  // tail stage: harmless re-read, its scales are zeroed below
+                const int8_t *g = a8 + (((b * 2 + (bh & 1)) * Npad) + n0 + row) * 16;
+                glds16(g, sA + (size_t)(c - lane) * 16);  // wave-uniform LDS base, hardware adds lane*16
+            }
+        }
+        // weights
+        if (TYPE == GGML_TYPE_Q8_0) {
+            uint8_t *sW = sp + T::A_BYTES;
+            constexpr int WC = BKB * 2 * TM;
+#pragma unroll
+            for (int i = 0; i < WC / 256; ++i) {
+                const int c = tid + 256 * i;
+                const int bh = c / TM, row = c % TM;
+                int64_t b = kb0 + (bh >> 1);
+                if (b >= nbk) b = nbk - 1;
+                const uint8_t *g = wqs + (((b * 2 + (bh & 1)) * Mpad) + m0 + row) * 16;
+                glds16(g, sW + (size_t)(c - lane) * 16);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < W_PER_THREAD; ++i) {
+                const int c = tid + 256 * i;
+                const int bb = c / TM, row = c % TM;
+                int64_t b = kb0 + bb;
+                if (b >= nbk) b = nbk - 1;
+                wreg[i] = *(const uint4 *)(wqs + ((b * Mpad) + m0 + row) * 16);
+                if (TYPE == GGML_TYPE_Q5_0) hreg[i] = wqh[b * Mpad + m0 + row];
+            }
+        }
+    };
+
+    // scales: loaded to registers with the stage's other loads, written to LDS after the compute phase
+    // (an LDS store right behind the load would stall on vmcnt(0) and drain the in-flight LDS-DMA).
+    // A block index past nbk gets scale 0, which turns the whole tail block into +0.
+    constexpr int SA_PER_THREAD = (BKB * TN + 255) / 256;
+    constexpr int SW_PER_THREAD = (BKB * TM + 255) / 256;
+    float dareg[SA_PER_THREAD], sareg[SA_PER_THREAD], dwreg[SW_PER_THREAD], mwreg[SW_PER_THREAD];
+    auto load_scales = [&](int s) {
+        const int64_t kb0 = (int64_t)s * BKB;
+#pragma unroll
+        for (int k = 0; k < SA_PER_THREAD; ++k) {
+            const int i = tid + 256 * k;
+            const int bb = i / TN, row = i % TN;
+            const int64_t b = kb0 + bb;
+            const bool ok = (i < BKB * TN) && (b < nbk);
+            dareg[k] = ok ? ad[b * Npad + n0 + row] : 0.0f;
+            if (TYPE == GGML_TYPE_Q4_1) sareg[k] = ok ? (float)as[b * Npad + n0 + row] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < SW_PER_THREAD; ++k) {
+            const int i = tid + 256 * k;
+            const int bb = i / TM, row = i % TM;
+            const int64_t b = kb0 + bb;
+            const bool ok = (i < BKB * TM) && (b < nbk);
+            dwreg[k] = ok ? wd[b * Mpad + m0 + row] : 0.0f;
+            if (TYPE == GGML_TYPE_Q4_1) mwreg[k] = ok ? wm[b * Mpad + m0 + row] : 0.0f;
+        }
+    };
+    auto store_scales = [&](int s) {
+        uint8_t *sp = stage_ptr(s);
+        float *sDa = (float *)(sp + T::A_BYTES + T::W_BYTES);
+        float *sDw = (float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES);
+        float *sMw = (float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES);
+        float *sSa = (float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES + T::MW_BYTES);
+#pragma unroll
+        for (int k = 0; k < SA_PER_THREAD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < BKB * TN) {
+                sDa[i] = dareg[k];
+                if (TYPE == GGML_TYPE_Q4_1) sSa[i] = sareg[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SW_PER_THREAD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < BKB * TM) {
+                sDw[i] = dwreg[k];
+                if (TYPE == GGML_TYPE_Q4_1) sMw[i] = mwreg[k];
+            }
+        }
+    };
+
+    auto store_weights = [&](int s) {
+        if (TYPE == GGML_TYPE_Q8_0) return;
+        uint8_t *sW = stage_ptr(s) + T::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < W_PER_THREAD; ++i) {
+            const int c = tid + 256 * i;
+            const int bb = c / TM, row = c % TM;
+            const uint32_t q[4] = {wreg[i].x, wreg[i].y, wreg[i].z, wreg[i].w};
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo[k] = q[k] & 0x0F0F0F0Fu;         // elements 8k+0,2,4,6
+                hi[k] = (q[k] >> 4) & 0x0F0F0F0Fu;  // elements 8k+1,3,5,7
+                if (TYPE == GGML_TYPE_Q4_0) {       // (nib - 8), Ggml.cs:1149-1150
+                    lo[k] = sub_bytes(lo[k], 0x08080808u);
+                    hi[k] = sub_bytes(hi[k], 0x08080808u);
+                } else if (TYPE == GGML_TYPE_Q5_0) {  // ((nib | bit << 4) - 16), Ggml.cs:1285-1289
+                    lo[k] = sub_bytes(lo[k] | q5_hi(hreg[i], k, 0), 0x10101010u);
+                    hi[k] = sub_bytes(hi[k] | q5_hi(hreg[i], k, 1), 0x10101010u);
+                }  // Q4_1: unsigned nibbles 0..15 as they are (Ggml.cs:1190-1191)
+            }
+            *(uint4 *)(sW + ((size_t)((bb * 2 + 0) * TM + row)) * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            *(uint4 *)(sW + ((size_t)((bb * 2 + 1) * TM + row)) * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        }
+    };
+
+    auto compute = [&](int s) {
+        const uint8_t *sp = stage_ptr(s);
+        const uint8_t *sA = sp;
+        const uint8_t *sW = sp + T::A_BYTES;
+        const float *sDa = (const float *)(sp + T::A_BYTES + T::W_BYTES);
+        const float *sDw = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES);
+#pragma unroll 1
+        for (int bb = 0; bb < BKB; ++bb) {
+            i32x4 af[IT], bf[JT];
+            float dw[JT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i)
+                af[i] = *(const i32x4 *)(sA + ((size_t)((bb * 2 + hh) * TN + wn * 32 * IT + 32 * i + l31)) * 16);
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int col = wm_ * 32 * JT + 32 * j;
+                bf[j] = *(const i32x4 *)(sW + ((size_t)((bb * 2 + hh) * TM + col + l31)) * 16);
+                dw[j] = sDw[bb * TM + col + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int row = wn * 32 * IT + 32 * i;
+                f32x4 da[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) da[k] = *(const f32x4 *)(sDa + bb * TN + row + 8 * k + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    const i32x16 t = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sc = da[r >> 2][r & 3] * dw[j];
+                        acc[i][j][r >> 2][r & 3] = fmaf((float)t[r], sc, acc[i][j][r >> 2][r & 3]);
+                    }
+                    if (TYPE == GGML_TYPE_Q4_1) {  // + m0 * d1 * sum(a)  (Ggml.cs:1190-1196 factorised)
+                        const float *sMw = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES);
+                        const float *sSa = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES + T::MW_BYTES);
+                        const float mw = sMw[bb * TM + wm_ * 32 * JT + 32 * j + l31];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 sa = *(const f32x4 *)(sSa + bb * TN + row + 8 * k + 4 * hh);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[i][j][k][e] = fmaf(mw, da[k][e] * sa[e], acc[i][j][k][e]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- main loop: double-buffered, one barrier per stage ----
+    issue_loads(0);
+    load_scales(0);
+    store_weights(0);
+    store_scales(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of stage 0 landed (this wave's part)
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const bool more = (s + 1) < nstages;
+        if (more) {
+            issue_loads(s + 1);
+            load_scales(s + 1);
+        }
+        compute(s);
+        if (more) {
+            store_weights(s + 1);
+            store_scales(s + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: dst[n][m], lanes along m ----
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int64_t m = m0 + wm_ * 32 * JT + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = n0 + wn * 32 * IT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (n < N && m < M) dst[n * ldd + m] = acc[i][j][r >> 2][r & 3];
+            }
+        }
+}
+
+template <int TYPE, int IT, int JT>
+hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    using T = Tile<TYPE, IT, JT>;
+    static bool attr_set = false;
+    auto kern = gemm_q_kernel<TYPE, IT, JT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((w->M + T::TM - 1) / T::TM), (unsigned)((N + T::TN - 1) / T::TN));
+    kern<<<grid, 256, T::LDS, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad, w->nbk, ldd);
+    return hipGetLastError();
+}
+
+template <int TYPE>
+hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    // 128x128 tiles when they already give >= 2 workgroups per CU, else 64x64 to fill the chip
+    const int64_t big = ((w->M + 127) / 128) * ((N + 127) / 128);
+    if (big >= 512) return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
+    return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
+}
+
+}  // namespace
+
+hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    if (N <= 0 || w->M <= 0) return hipSuccess;
+    switch (w->type) {
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
+    default: return hipErrorInvalidValue;
+    }
+}

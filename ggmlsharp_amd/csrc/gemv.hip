@@ -1,0 +1,162 @@
+// gemv.hip -- K2: quantized mat-vec / skinny mat-mat (N <= GEMV_MAX_N), HBM-bandwidth bound.
+//
+// Computes the COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698) for few src1 rows:
+//   dst[n*ldd + m] = sum_b dw[m,b] * da[n,b] * sum_{k in b} w[m,k] * a[n,k]
+// with the integer block sums exact (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159, _q5_0_q8_0 1270-1298,
+// _q8_0_q8_0 1362-1378, _q4_1_q8_1 1176-1198) and the f32 scale-accumulate per block as in :1158.
+// Only the order of the f32 additions over blocks differs from the scalar loop.
+//
+// Mapping, chosen for the planar weight layout ([k-block][row][16 B]):
+//   workgroup = 16 weight rows x all K; lane = (row r = lane & 15, k-lane kq = lane >> 4); the 4 waves x 4 k-lanes
+//   are 16 "k-workers", worker u takes blocks u, u+16, u+32, ...  A wave-wide 16-byte load therefore touches four
+//   256-byte contiguous segments, every lane keeps 4 independent loads in flight, and a row's dot product needs
+//   only two xor-shuffles plus one LDS pass to combine -- no atomics, fixed summation tree (deterministic).
+//   The Q8 activation vector (written by K1) is staged into LDS once per 128 k-blocks and read as broadcasts.
+#include "common.h"
+
+namespace {
+
+#define GV_ROWS 16
+#define GV_CHUNK 128  // k-blocks of activations staged in LDS at a time
+
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+}
+
+// bit e of qh for e = 8i + {0,2,4,6} (sel = 0) or 8i + {1,3,5,7} (sel = 1), moved to bit 4 of bytes 0..3
+__device__ __forceinline__ uint32_t q5_high_bits(uint32_t qh, int i, int sel) {
+    const uint32_t t = ((qh >> (8 * i + sel)) & 0x55u);
+    return (t * 0x00410410u) & 0x10101010u;
+}
+
+template <int TYPE, int NC>
+__global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
+                                                    const float *__restrict__ wd, const float *__restrict__ wm,
+                                                    const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                                                    const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
+                                                    int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd, int N) {
+    __shared__ uint4 sA[GV_CHUNK * 2 * NC];
+    __shared__ float sD[GV_CHUNK * NC];
+    __shared__ int sS[GV_CHUNK * NC];
+    __shared__ float sRed[4][NC][GV_ROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4, u = wave * 4 + kq;
+    const int64_t row = (int64_t)blockIdx.x * GV_ROWS + r;  // < Mpad by construction
+
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+
+    for (int64_t cb = 0; cb < nbk; cb += GV_CHUNK) {
+        const int nbc = (int)((nbk - cb) < GV_CHUNK ? (nbk - cb) : GV_CHUNK);
+        __syncthreads();  // previous chunk fully consumed
+        for (int i = tid; i < nbc * 2 * NC; i += 256) {
+            const int c = i % NC, bh = i / NC;  // bh = b_local*2 + h
+            const int cc = c < N ? c : N - 1;
+            sA[i] = *(const uint4 *)(a8 + (((cb * 2 + bh) * Npad) + cc) * 16);
+        }
+        for (int i = tid; i < nbc * NC; i += 256) {
+            const int c = i % NC, bl = i / NC;
+            const int cc = c < N ? c : N - 1;
+            sD[i] = ad[(cb + bl) * Npad + cc];
+            sS[i] = as[(cb + bl) * Npad + cc];
+        }
+        __syncthreads();
+
+        for (int bl0 = u; bl0 < nbc; bl0 += 64) {
+            uint4 q[4], q2[4];
+            float dw[4], mw[4];
+            uint32_t hb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bl = bl0 + 16 * j;
+                const bool ok = bl < nbc;
+                const int64_t b = cb + (ok ? bl : 0);
+                if (TYPE == GGML_TYPE_Q8_0) {
+                    q[j] = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + row) * 16);
+                    q2[j] = *(const uint4 *)(qs + ((b * 2 + 1) * Mpad + row) * 16);
+                } else {
+                    q[j] = *(const uint4 *)(qs + (b * Mpad + row) * 16);
+                }
+                dw[j] = ok ? wd[b * Mpad + row] : 0.0f;
+                if (TYPE == GGML_TYPE_Q4_1) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
+                if (TYPE == GGML_TYPE_Q5_0) hb[j] = qh[b * Mpad + row];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bl = (bl0 + 16 * j) < nbc ? (bl0 + 16 * j) : 0;  // dw = 0 kills the contribution
+                const uint32_t qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                uint32_t lo[4], hi[4];
+                if (TYPE == GGML_TYPE_Q8_0) {
+                    lo[0] = q[j].x; lo[1] = q[j].y; lo[2] = q[j].z; lo[3] = q[j].w;
+                    hi[0] = q2[j].x; hi[1] = q2[j].y; hi[2] = q2[j].z; hi[3] = q2[j].w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[i] = qq[i] & 0x0F0F0F0Fu;          // elements 8i+0,2,4,6  (Ggml.cs:1149)
+                        hi[i] = (qq[i] >> 4) & 0x0F0F0F0Fu;   // elements 8i+1,3,5,7  (Ggml.cs:1150)
+                        if (TYPE == GGML_TYPE_Q5_0) {         // Ggml.cs:1285-1289
+                            lo[i] |= q5_high_bits(hb[j], i, 0);
+                            hi[i] |= q5_high_bits(hb[j], i, 1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint4 a0 = sA[(bl * 2 + 0) * NC + c];
+                    const uint4 a1 = sA[(bl * 2 + 1) * NC + c];
+                    int s = 0;
+                    s = dot4(lo[0], a0.x, s); s = dot4(lo[1], a0.y, s); s = dot4(lo[2], a0.z, s); s = dot4(lo[3], a0.w, s);
+                    s = dot4(hi[0], a1.x, s); s = dot4(hi[1], a1.y, s); s = dot4(hi[2], a1.z, s); s = dot4(hi[3], a1.w, s);
+                    const float da = sD[bl * NC + c];
+                    const int sa = sS[bl * NC + c];
+                    if (TYPE == GGML_TYPE_Q4_0) s -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
+                    if (TYPE == GGML_TYPE_Q5_0) s -= 16 * sa;
+                    acc[c] = fmaf(dw[j] * da, (float)s, acc[c]);
+                    if (TYPE == GGML_TYPE_Q4_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float v = acc[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kq == 0) sRed[wave][c][r] = v;
+    }
+    __syncthreads();
+    if (tid < GV_ROWS * NC) {
+        const int c = tid / GV_ROWS, rr = tid % GV_ROWS;
+        const int64_t m = (int64_t)blockIdx.x * GV_ROWS + rr;
+        if (m < M && c < N) dst[(int64_t)c * ldd + m] = (sRed[0][c][rr] + sRed[1][c][rr]) + (sRed[2][c][rr] + sRed[3][c][rr]);
+    }
+}
+
+template <int TYPE>
+hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    dim3 grid((unsigned)((w->M + GV_ROWS - 1) / GV_ROWS));
+#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC><<<grid, 256, 0, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N)
+    if (N <= 1) GV_LAUNCH(1);
+    else if (N <= 2) GV_LAUNCH(2);
+    else if (N <= 4) GV_LAUNCH(4);
+    else GV_LAUNCH(8);
+#undef GV_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    if (N <= 0 || w->M <= 0) return hipSuccess;
+    if (N > GEMV_MAX_N) return hipErrorInvalidValue;
+    switch (w->type) {
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
+    default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,251 @@
+// ggml_host.cpp -- host mirror of the GGMLSharp public API for the mul_mat path (include/ggml.h).
+// Same pool arithmetic, struct layouts and graph walk as the reference; MUL_MAT nodes are dispatched to the
+// HIP path (Seam 1).  There is deliberately no CPU compute here.
+#include "common.h"
+#include "../../include/ggml.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+static_assert(sizeof(ggml_object) == 32, "TypeDefinitions.cs:48-56");
+static_assert(sizeof(ggml_context) == 88, "TypeDefinitions.cs:32-46");
+static_assert(sizeof(ggml_cgraph) == 98360, "TypeDefinitions.cs:102-121");
+
+namespace {
+
+constexpr int GGML_MAX_CONTEXTS = 64;  // TypeDefinitions.cs:224
+struct Container { bool used; ggml_context context; };
+Container g_contexts[GGML_MAX_CONTEXTS];
+std::mutex g_ctx_mu;  // ggml_critical_section_start/end (Ggml.cs:8451-8470)
+
+const int BLCK[GGML_TYPE_COUNT] = {1, 1, 32, 32, 16, 16, 32, 32, 32, 32, 1, 1, 1};
+const size_t TSIZE[GGML_TYPE_COUNT] = {4, 2, 20, 24, 10, 12, 22, 24, 36, 44, 1, 2, 4};
+
+bool type_ok(int t) { return t >= 0 && t < GGML_TYPE_COUNT; }
+
+// Ggml.cs:7722-7866
+ggml_tensor *new_tensor_impl(ggml_context *ctx, int type, int n_dims, const int64_t *ne, void *data) {
+    if (!ctx || !type_ok(type) || n_dims < 1 || n_dims > GGML_MAX_DIMS) return nullptr;
+    ggml_object *obj_cur = ctx->objects_end;
+    const uint64_t cur_offs = obj_cur == nullptr ? 0 : obj_cur->offs;
+    const uint64_t cur_size = obj_cur == nullptr ? 0 : obj_cur->size;
+    const uint64_t cur_end = cur_offs + cur_size;
+
+    uint64_t size_needed = 0;
+    if (data == nullptr && !ctx->no_alloc) {
+        size_needed += TSIZE[type] * (uint64_t)(ne[0] / BLCK[type]);
+        for (int i = 1; i < n_dims; i++) size_needed *= (uint64_t)ne[i];
+        size_needed = ((size_needed + GGML_MEM_ALIGN - 1) / GGML_MEM_ALIGN) * GGML_MEM_ALIGN;
+    }
+    uint8_t *mem_buffer = (uint8_t *)ctx->mem_buffer;
+    ggml_object *obj_new = (ggml_object *)(mem_buffer + cur_end);
+
+    if (ctx->scratch.data == nullptr || data != nullptr) {
+        size_needed += sizeof(ggml_tensor);
+        if (cur_end + size_needed + sizeof(ggml_object) > ctx->mem_size) {
+            fprintf(stderr, "ggml_new_tensor_impl: not enough space in the context's memory pool (needed %llu, available %llu)\n",
+                    (unsigned long long)(cur_end + size_needed + sizeof(ggml_object)), (unsigned long long)ctx->mem_size);
+            return nullptr;  // Ggml.cs:7757-7763
+        }
+        obj_new->offs = cur_end + sizeof(ggml_object);
+        obj_new->size = size_needed;
+        obj_new->next = nullptr;
+    } else {
+        if (ctx->scratch.offs + size_needed > ctx->scratch.size) {
+            fprintf(stderr, "ggml_new_tensor_impl: not enough space in the scratch memory\n");
+            return nullptr;
+        }
+        if (cur_end + sizeof(ggml_tensor) + sizeof(ggml_object) > ctx->mem_size) {
+            fprintf(stderr, "ggml_new_tensor_impl: not enough space in the context's memory pool\n");
+            return nullptr;
+        }
+        data = (uint8_t *)ctx->scratch.data + ctx->scratch.offs;
+        obj_new->offs = cur_end + sizeof(ggml_object);
+        obj_new->size = sizeof(ggml_tensor);
+        obj_new->next = nullptr;
+        ctx->scratch.offs += size_needed;
+    }
+    if (obj_cur != nullptr) obj_cur->next = obj_new; else ctx->objects_begin = obj_new;
+    ctx->objects_end = obj_new;
+
+    ggml_tensor *result = (ggml_tensor *)(mem_buffer + obj_new->offs);
+    memset(result, 0, sizeof *result);
+    result->type = type;
+    result->n_dims = n_dims;
+    result->op = GGML_OP_NONE;
+    result->data = (data == nullptr && !ctx->no_alloc) ? (void *)(result + 1) : data;  // Ggml.cs:7839
+    for (int i = 0; i < GGML_MAX_DIMS; i++) result->ne[i] = 1;
+    for (int i = 0; i < n_dims; i++) result->ne[i] = ne[i];
+    result->nb[0] = TSIZE[type];                                                   // Ggml.cs:7856-7861
+    result->nb[1] = result->nb[0] * (uint64_t)(result->ne[0] / BLCK[type]);
+    for (int i = 2; i < GGML_MAX_DIMS; i++) result->nb[i] = result->nb[i - 1] * (uint64_t)result->ne[i - 1];
+    ctx->n_objects++;
+    return result;
+}
+
+// Ggml.cs:7559-7619
+bool visit_parents(ggml_cgraph *g, ggml_tensor *node) {
+    for (int i = 0; i < g->n_nodes; i++) if (g->nodes[i] == node) return true;
+    for (int i = 0; i < g->n_leafs; i++) if (g->leafs[i] == node) return true;
+    if (node->src0 && !visit_parents(g, node->src0)) return false;
+    if (node->src1 && !visit_parents(g, node->src1)) return false;
+    for (int i = 0; i < GGML_MAX_OPT; ++i)
+        if (node->opt[i] != 0 && !visit_parents(g, (ggml_tensor *)(intptr_t)node->opt[i])) return false;
+    if (node->op == GGML_OP_NONE && node->grad == nullptr) {
+        if (g->n_leafs >= GGML_MAX_NODES) return false;
+        g->leafs[g->n_leafs++] = node;
+    } else {
+        if (g->n_nodes >= GGML_MAX_NODES) return false;
+        g->nodes[g->n_nodes] = node;
+        g->grads[g->n_nodes] = node->grad;
+        g->n_nodes++;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+ggml_context *ggml_init(const ggml_init_params *params) {
+    if (!params) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    ggml_context *ctx = nullptr;
+    for (int i = 0; i < GGML_MAX_CONTEXTS; i++)
+        if (!g_contexts[i].used) { g_contexts[i].used = true; ctx = &g_contexts[i].context; break; }
+    if (!ctx) return nullptr;  // Ggml.cs:1529-1536
+    const uint64_t mem_size = (params->mem_size + GGML_MEM_ALIGN - 1) & ~(uint64_t)(GGML_MEM_ALIGN - 1);
+    memset(ctx, 0, sizeof *ctx);
+    ctx->mem_size = mem_size;
+    ctx->mem_buffer_owned = params->mem_buffer ? 0 : 1;
+    ctx->mem_buffer = params->mem_buffer ? params->mem_buffer : aligned_alloc(GGML_MEM_ALIGN, mem_size ? mem_size : GGML_MEM_ALIGN);
+    ctx->no_alloc = params->no_alloc;
+    if (!ctx->mem_buffer) {
+        for (int i = 0; i < GGML_MAX_CONTEXTS; i++) if (&g_contexts[i].context == ctx) g_contexts[i].used = false;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void ggml_free(ggml_context *ctx) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (int i = 0; i < GGML_MAX_CONTEXTS; i++)
+        if (&g_contexts[i].context == ctx) {
+            g_contexts[i].used = false;
+            // the reference's ggml_free gives the device layer no callback; this mirror does, for every tensor in the pool
+            for (ggml_object *o = ctx->objects_begin; o != nullptr; o = o->next) {
+                const ggml_tensor *t = (const ggml_tensor *)((uint8_t *)ctx->mem_buffer + o->offs);
+                if (t->data) ggml_hip_invalidate(t->data);
+            }
+            if (ctx->mem_buffer_owned) free(ctx->mem_buffer);
+            break;
+        }
+}
+
+size_t ggml_used_mem(const ggml_context *ctx) {
+    return (!ctx || !ctx->objects_end) ? 0 : (size_t)(ctx->objects_end->offs + ctx->objects_end->size);
+}
+
+ggml_tensor *ggml_new_tensor(ggml_context *ctx, int type, int n_dims, const int64_t *ne) {
+    return new_tensor_impl(ctx, type, n_dims, ne, nullptr);
+}
+ggml_tensor *ggml_new_tensor_1d(ggml_context *ctx, int type, int64_t ne0) { return ggml_new_tensor(ctx, type, 1, &ne0); }
+ggml_tensor *ggml_new_tensor_2d(ggml_context *ctx, int type, int64_t ne0, int64_t ne1) {
+    const int64_t ne[2] = {ne0, ne1};
+    return ggml_new_tensor(ctx, type, 2, ne);
+}
+ggml_tensor *ggml_new_tensor_3d(ggml_context *ctx, int type, int64_t ne0, int64_t ne1, int64_t ne2) {
+    const int64_t ne[3] = {ne0, ne1, ne2};
+    return ggml_new_tensor(ctx, type, 3, ne);
+}
+ggml_tensor *ggml_new_tensor_4d(ggml_context *ctx, int type, int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3) {
+    const int64_t ne[4] = {ne0, ne1, ne2, ne3};
+    return ggml_new_tensor(ctx, type, 4, ne);
+}
+
+int64_t ggml_nelements(const ggml_tensor *t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+int64_t ggml_nrows(const ggml_tensor *t) { return t->ne[1] * t->ne[2] * t->ne[3]; }
+size_t ggml_nbytes(const ggml_tensor *t) { return ((size_t)ggml_nelements(t) * TSIZE[t->type]) / (size_t)BLCK[t->type]; }
+int ggml_blck_size(int type) { return type_ok(type) ? BLCK[type] : 0; }
+size_t ggml_type_size(int type) { return type_ok(type) ? TSIZE[type] : 0; }
+int ggml_is_quantized(int type) { return type >= GGML_TYPE_Q4_0 && type <= GGML_TYPE_Q8_1; }
+int ggml_is_contiguous(const ggml_tensor *t) {
+    return t->nb[0] == TSIZE[t->type] && t->nb[1] == (t->nb[0] * (uint64_t)t->ne[0]) / (uint64_t)BLCK[t->type] &&
+           t->nb[2] == t->nb[1] * (uint64_t)t->ne[1] && t->nb[3] == t->nb[2] * (uint64_t)t->ne[2];
+}
+int ggml_can_mul_mat(const ggml_tensor *t0, const ggml_tensor *t1) {
+    return t0->ne[0] == t1->ne[0] && t0->ne[2] == t1->ne[2] && t0->ne[3] == t1->ne[3];
+}
+
+ggml_tensor *ggml_set_f32(ggml_tensor *t, float value) {
+    if (!t || t->type != GGML_TYPE_F32) return t;  // the integer/f16 cases of Ggml.cs:2501-2565 are not on this path
+    const int64_t n = ggml_nrows(t), nc = t->ne[0];
+    for (int64_t i = 0; i < n; i++) {
+        float *row = (float *)((uint8_t *)t->data + i * t->nb[1]);
+        for (int64_t j = 0; j < nc; j++) row[j] = value;
+    }
+    return t;
+}
+float ggml_get_f32_1d(const ggml_tensor *t, int i) { return ((const float *)t->data)[i]; }
+void ggml_set_f32_1d(ggml_tensor *t, int i, float value) { ((float *)t->data)[i] = value; }
+
+ggml_tensor *ggml_mul_mat(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
+    if (!ctx || !a || !b) return nullptr;
+    if (!ggml_can_mul_mat(a, b)) return nullptr;   // Debug.Assert, Ggml.cs:8228
+    if (a->nb[0] > a->nb[1]) return nullptr;       // !ggml_is_transposed(a), Ggml.cs:8229
+    const bool is_node = a->grad != nullptr || b->grad != nullptr;
+    const int64_t ne[4] = {a->ne[1], b->ne[1], a->ne[2], b->ne[3]};
+    ggml_tensor *result = ggml_new_tensor(ctx, GGML_TYPE_F32, a->n_dims < b->n_dims ? a->n_dims : b->n_dims, ne);
+    if (!result) return nullptr;
+    result->op = GGML_OP_MUL_MAT;
+    result->grad = is_node ? ggml_new_tensor(ctx, GGML_TYPE_F32, result->n_dims, result->ne) : nullptr;  // ggml_dup_tensor
+    result->src0 = a;
+    result->src1 = b;
+    return result;
+}
+
+void ggml_build_forward_expand(ggml_cgraph *cgraph, ggml_tensor *tensor) { visit_parents(cgraph, tensor); }
+
+void ggml_build_forward(ggml_cgraph *out, ggml_tensor *tensor) {
+    out->n_nodes = 0; out->n_leafs = 0;
+    out->n_threads = GGML_DEFAULT_N_THREADS;
+    out->work_size = 0; out->work = nullptr;
+    out->perf_runs = 0; out->perf_cycles = 0; out->perf_time_us = 0;
+    visit_parents(out, tensor);
+}
+
+int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
+    (void)ctx;
+    if (!cgraph) return GGML_HIP_ERR_ARG;
+    // plan (Ggml.cs:3260-3519): offloaded MUL_MAT nodes take the reference's own "n_tasks = 1, no host work buffer"
+    // slot (:3368-3370); the Q8 scratch lives on the device (ggml_hip_mul_mat_work_size).
+    for (int i = 0; i < cgraph->n_nodes; i++) {
+        ggml_tensor *node = cgraph->nodes[i];
+        if (node->op == GGML_OP_NONE) continue;
+        if (node->op != GGML_OP_MUL_MAT) {
+            fprintf(stderr, "ggml_graph_compute: op %d is outside the MI355X mul_mat path (SURVEY.md 2.2)\n", node->op);
+            return GGML_HIP_ERR_TYPE;
+        }
+        node->n_tasks = 1;
+    }
+    cgraph->work_size = 0;
+    for (int i = 0; i < cgraph->n_nodes; i++) {
+        ggml_tensor *node = cgraph->nodes[i];
+        if (node->op == GGML_OP_NONE) continue;
+        ggml_compute_params params;
+        params.ith = 0; params.nth = node->n_tasks; params.wsize = 0; params.wdata = nullptr;
+        for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {  // Ggml.cs:3553-3670
+            params.type = phase;
+            const int rc = ggml_hip_compute_forward_mul_mat(&params, node->src0, node->src1, node);
+            if (rc != GGML_HIP_OK) return rc;
+        }
+        node->perf_runs++;
+    }
+    cgraph->perf_runs++;
+    return GGML_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// layout.hip -- re-layout kernels between the reference's AoS block rows and the resident planar layout.
+//
+// The reference stores a quantized row as consecutive AoS blocks (TypeDefinitions.cs:236-290; 20/24/22/36 bytes),
+// which is awkward for 16-byte coalesced loads.  Weights are therefore uploaded once and kept block-major
+// ("planar"): for k-block b, the 16 quant bytes of every row are contiguous, and the scales are a separate
+// f32 plane.  planar_to_aos is the exact inverse, so a download is byte-identical to the upload.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float half_bits_to_float(uint16_t h) {
+    // IEEE binary16 -> binary32, exact ((float)(Half) in Ggml.cs:1034, 1277)
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1Fu;
+    const uint32_t man = h & 0x3FFu;
+    uint32_t out;
+    if (exp == 0) {
+        if (man == 0) {
+            out = sign;
+        } else {
+            const float v = (float)man * 5.9604644775390625e-08f;  // man * 2^-24, exact
+            out = __float_as_uint(v) | sign;
+        }
+    } else if (exp == 31) {
+        out = sign | 0x7F800000u | (man << 13);
+    } else {
+        out = sign | ((exp + 112u) << 23) | (man << 13);
+    }
+    return __uint_as_float(out);
+}
+
+__device__ __forceinline__ uint16_t float_to_half_bits_exact(float f) {
+    // inverse of half_bits_to_float for values that came from a half (no rounding needed)
+    const uint32_t x = __float_as_uint(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t exp = (x >> 23) & 0xFFu;
+    const uint32_t man = x & 0x7FFFFFu;
+    if (exp == 0xFF) return (uint16_t)(sign | 0x7C00u | (man >> 13));
+    if (exp == 0 && man == 0) return (uint16_t)sign;
+    const int e = (int)exp - 127 + 15;
+    if (e <= 0) {  // was a half subnormal: value = hm * 2^-24
+        const uint32_t hm = (uint32_t)(fabsf(f) * 16777216.0f);
+        return (uint16_t)(sign | hm);
+    }
+    return (uint16_t)(sign | ((uint32_t)e << 10) | (man >> 13));
+}
+
+// one thread per (row, k-block); rows fastest so the planar stores coalesce
+template <int TYPE>
+__global__ void repack_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_t nb01, int64_t row_begin, int64_t rows,
+                                        int64_t Mpad, int64_t nbk, uint8_t *__restrict__ qs, uint32_t *__restrict__ qh,
+                                        float *__restrict__ d, float *__restrict__ mm) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (m >= rows) return;
+    const uint8_t *src = aos + (uint64_t)(row_begin + m) * nb01;
+    const int64_t pi = b * Mpad + m;
+    if (TYPE == GGML_TYPE_Q4_0) {
+        const uint32_t *s = (const uint32_t *)(src + b * 20);
+        d[pi] = __uint_as_float(s[0]);
+        *(uint4 *)(qs + pi * 16) = make_uint4(s[1], s[2], s[3], s[4]);
+    } else if (TYPE == GGML_TYPE_Q4_1) {
+        const uint32_t *s = (const uint32_t *)(src + b * 24);
+        d[pi] = __uint_as_float(s[0]);
+        mm[pi] = __uint_as_float(s[1]);
+        *(uint4 *)(qs + pi * 16) = make_uint4(s[2], s[3], s[4], s[5]);
+    } else if (TYPE == GGML_TYPE_Q5_0) {
+        const uint16_t *s = (const uint16_t *)(src + b * 22);
+        d[pi] = half_bits_to_float(s[0]);
+        qh[pi] = (uint32_t)s[1] | ((uint32_t)s[2] << 16);
+        uint32_t q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (uint32_t)s[3 + 2 * i] | ((uint32_t)s[4 + 2 * i] << 16);
+        *(uint4 *)(qs + pi * 16) = make_uint4(q[0], q[1], q[2], q[3]);
+    } else if (TYPE == GGML_TYPE_Q8_0) {
+        const uint32_t *s = (const uint32_t *)(src + b * 36);
+        d[pi] = __uint_as_float(s[0]);
+        // split the 32 quants into even / odd elements: plane h byte j = element 2j + h
+        uint32_t ev[4], od[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = s[1 + 2 * i], hi = s[2 + 2 * i];  // elements 8i..8i+3, 8i+4..8i+7
+            ev[i] = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi << 8) & 0xFF000000u);
+            od[i] = ((lo >> 8) & 0xFFu) | ((lo >> 16) & 0xFF00u) | ((hi << 8) & 0xFF0000u) | (hi & 0xFF000000u);
+        }
+        *(uint4 *)(qs + ((b * 2 + 0) * Mpad + m) * 16) = make_uint4(ev[0], ev[1], ev[2], ev[3]);
+        *(uint4 *)(qs + ((b * 2 + 1) * Mpad + m) * 16) = make_uint4(od[0], od[1], od[2], od[3]);
+    }
+}
+
+template <int TYPE>
+__global__ void planar_to_aos_kernel(uint8_t *__restrict__ aos, uint64_t nb01, int64_t rows, int64_t Mpad, int64_t nbk,
+                                     const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
+                                     const float *__restrict__ d, const float *__restrict__ mm) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (m >= rows) return;
+    uint8_t *dst = aos + (uint64_t)m * nb01;
+    const int64_t pi = b * Mpad + m;
+    if (TYPE == GGML_TYPE_Q4_0) {
+        uint32_t *s = (uint32_t *)(dst + b * 20);
+        const uint4 q = *(const uint4 *)(qs + pi * 16);
+        s[0] = __float_as_uint(d[pi]); s[1] = q.x; s[2] = q.y; s[3] = q.z; s[4] = q.w;
+    } else if (TYPE == GGML_TYPE_Q4_1) {
+        uint32_t *s = (uint32_t *)(dst + b * 24);
+        const uint4 q = *(const uint4 *)(qs + pi * 16);
+        s[0] = __float_as_uint(d[pi]); s[1] = __float_as_uint(mm[pi]);
+        s[2] = q.x; s[3] = q.y; s[4] = q.z; s[5] = q.w;
+    } else if (TYPE == GGML_TYPE_Q5_0) {
+        uint16_t *s = (uint16_t *)(dst + b * 22);
+        const uint4 q = *(const uint4 *)(qs + pi * 16);
+        const uint32_t h = qh[pi];
+        s[0] = float_to_half_bits_exact(d[pi]);
+        s[1] = (uint16_t)h; s[2] = (uint16_t)(h >> 16);
+        const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[3 + 2 * i] = (uint16_t)qq[i]; s[4 + 2 * i] = (uint16_t)(qq[i] >> 16); }
+    } else if (TYPE == GGML_TYPE_Q8_0) {
+        uint32_t *s = (uint32_t *)(dst + b * 36);
+        const uint4 e4 = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + m) * 16);
+        const uint4 o4 = *(const uint4 *)(qs + ((b * 2 + 1) * Mpad + m) * 16);
+        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w}, od[4] = {o4.x, o4.y, o4.z, o4.w};
+        s[0] = __float_as_uint(d[pi]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = ev[i], o = od[i];
+            s[1 + 2 * i] = (e & 0xFFu) | ((o & 0xFFu) << 8) | ((e & 0xFF00u) << 8) | ((o & 0xFF00u) << 16);
+            s[2 + 2 * i] = ((e >> 16) & 0xFFu) | ((o >> 8) & 0xFF00u) | ((e >> 8) & 0xFF0000u) | (o & 0xFF000000u);
+        }
+    }
+}
+
+// dense rows: plain strided copy (element size es bytes), rows fastest across blocks, 16 B per thread where possible
+__global__ void copy_rows_kernel(const uint8_t *__restrict__ src, uint64_t src_stride, uint8_t *__restrict__ dst,
+                                 uint64_t dst_stride, int64_t rows, int64_t row_bytes) {
+    const int64_t r = blockIdx.y;
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (r >= rows || c >= row_bytes) return;
+    *(uint32_t *)(dst + r * dst_stride + c) = *(const uint32_t *)(src + r * src_stride + c);
+}
+
+// [G][N][Ms] (rank-major all-gather result) -> [N][ldd] with column r*Ms + i
+__global__ void relayout_gathered_kernel(const float *__restrict__ g, int G, int64_t N, int64_t Ms, float *__restrict__ dst,
+                                         int64_t M, int64_t ldd) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // global column in [0, G*Ms)
+    const int64_t n = blockIdx.y;
+    if (col >= M || col >= (int64_t)G * Ms) return;
+    const int64_t r = col / Ms, i = col - r * Ms;
+    dst[n * ldd + col] = g[(r * N + n) * Ms + i];
+}
+
+}  // namespace
+
+hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
+                                   ggml_hip_weight *w, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
+        const int64_t row_bytes = w->K * (type == GGML_TYPE_F32 ? 4 : 2);
+        dim3 grid((unsigned)((row_bytes / 4 + 255) / 256), (unsigned)rows);
+        copy_rows_kernel<<<grid, 256, 0, st>>>(aos + (uint64_t)row_begin * nb01, nb01, (uint8_t *)w->dense,
+                                               (uint64_t)row_bytes, rows, row_bytes);
+        return hipGetLastError();
+    }
+    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)w->nbk);
+    switch (type) {
+    case GGML_TYPE_Q4_0: repack_to_planar_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q4_1: repack_to_planar_kernel<GGML_TYPE_Q4_1><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q5_0: repack_to_planar_kernel<GGML_TYPE_Q5_0><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q8_0: repack_to_planar_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st) {
+    if (w->M <= 0) return hipSuccess;
+    if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {
+        const int64_t row_bytes = w->K * (w->type == GGML_TYPE_F32 ? 4 : 2);
+        dim3 grid((unsigned)((row_bytes / 4 + 255) / 256), (unsigned)w->M);
+        copy_rows_kernel<<<grid, 256, 0, st>>>((const uint8_t *)w->dense, (uint64_t)row_bytes, aos, (uint64_t)row_bytes,
+                                               w->M, row_bytes);
+        return hipGetLastError();
+    }
+    const uint64_t nb01 = (uint64_t)ggml_hip_type_size(w->type) * (uint64_t)w->nbk;
+    dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)w->nbk);
+    switch (w->type) {
+    case GGML_TYPE_Q4_0: planar_to_aos_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q4_1: planar_to_aos_kernel<GGML_TYPE_Q4_1><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q5_0: planar_to_aos_kernel<GGML_TYPE_Q5_0><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q8_0: planar_to_aos_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
+                                    hipStream_t st) {
+    if (N <= 0 || M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)N);
+    relayout_gathered_kernel<<<grid, 256, 0, st>>>(g, G, N, Ms, dst, M, ldd);
+    return hipGetLastError();
+}

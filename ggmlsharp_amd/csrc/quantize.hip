@@ -1,0 +1,352 @@
+// quantize.hip -- block quantize / dequantize kernels (bandwidth-bound byte work, no MFMA).
+//
+// K1  quantize_act: the INIT phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6641-6654): every src1 row
+//     -> Q8_0 (quantize_row_q8_0_reference_impl, Ggml.cs:733-762, all 32 quants written = SURVEY D2 intent;
+//     Math.Round = round-half-even = v_rndne_f32), written straight into the planar scratch the
+//     dot kernels read (int8 even/odd planes + f32 scale plane + i32 block-sum plane).
+// K9  quantize_rows  : f32 rows -> reference AoS blocks, bit-exact (Q4_0 334-377, Q4_1 487-528, Q5_0 609-653,
+//                      Q8_0 733-762, Q8_1 781-823).
+// K8  dequantize_rows: reference AoS blocks -> f32 rows, bit-exact (Q4_0 886-910, Q4_1 962-987, Q5_0 1025-1061,
+//                      Q8_0 1104-1122 with signed quants).
+//
+// All float arithmetic here must round exactly like the C# scalar code: one IEEE operation per C# operator,
+// no fused multiply-add, correctly rounded division.  Built with -ffp-contract=off.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float half_bits_to_float_q(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1Fu;
+    const uint32_t man = h & 0x3FFu;
+    if (exp == 0) {
+        if (man == 0) return __uint_as_float(sign);
+        const float v = (float)man * 5.9604644775390625e-08f;
+        return __uint_as_float(__float_as_uint(v) | sign);
+    }
+    if (exp == 31) return __uint_as_float(sign | 0x7F800000u | (man << 13));
+    return __uint_as_float(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+// (Half)f: IEEE round-to-nearest-even, same bit algorithm as the oracle (checked against numpy there)
+__device__ __forceinline__ uint16_t float_to_half_bits_rne(float f) {
+    const uint32_t x = __float_as_uint(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t exp = (x >> 23) & 0xFFu;
+    uint32_t man = x & 0x7FFFFFu;
+    if (exp == 0xFF) return (uint16_t)(man == 0 ? (sign | 0x7C00u) : (sign | 0x7C00u | 0x0200u | (man >> 13)));
+    const int e = (int)exp - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t hm = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1u);
+        const uint32_t halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (hm & 1u))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t half = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;
+    return (uint16_t)(sign | half);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1.  Wave layout: lane = 8 * row_in_wave + t ; the 8 lanes of one row own one 32-element block, 4 floats each
+// (one coalesced 128-byte line per row per block).  A workgroup = 4 waves = 32 rows x BPB consecutive k-blocks.
+// ---------------------------------------------------------------------------------------------------------
+#define K1_BPB 8
+
+__global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restrict__ x, int64_t N, int64_t nbk, int64_t ld1,
+                                                          int8_t *__restrict__ a8, float *__restrict__ ad,
+                                                          int32_t *__restrict__ as, int64_t Npad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 7;
+    const int64_t n = (int64_t)blockIdx.y * 32 + wave * 8 + (lane >> 3);
+    const bool live = n < N;
+    const int64_t nr = live ? n : N - 1;  // clamp loads, skip stores
+    const int64_t b0 = (int64_t)blockIdx.x * K1_BPB;
+    const float *row = x + nr * ld1;
+
+    float4 v[K1_BPB];
+#pragma unroll
+    for (int j = 0; j < K1_BPB; ++j) {
+        const int64_t b = b0 + j;
+        v[j] = (b < nbk) ? *(const float4 *)(row + b * QK + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < K1_BPB; ++j) {
+        const int64_t b = b0 + j;
+        float amax = fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        const float d = amax / 127.0f;                      // Ggml.cs:751
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;       // Ggml.cs:752
+        const int q0 = (int)rintf(v[j].x * id);             // Ggml.cs:758-759 (all l, D2)
+        const int q1 = (int)rintf(v[j].y * id);
+        const int q2 = (int)rintf(v[j].z * id);
+        const int q3 = (int)rintf(v[j].w * id);
+        int s = q0 + q1 + q2 + q3;
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        // elements 4t, 4t+2 are even (plane 0 bytes 2t, 2t+1); 4t+1, 4t+3 odd (plane 1 bytes 2t, 2t+1)
+        const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2 & 0xFFu) << 8);
+        const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
+        const bool even_lane = (t & 1) == 0;
+        const uint32_t recv = (uint32_t)__shfl_xor((int)(even_lane ? o16 : e16), 1);
+        // even lane t: plane 0 bytes [2t, 2t+4) = own e16 | partner e16 << 16
+        // odd  lane t: plane 1 bytes [2t-2, 2t+2) = partner o16 | own o16 << 16
+        const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));
+        if (live && b < nbk) {
+            const int h = even_lane ? 0 : 1;
+            const int byte_off = even_lane ? 2 * t : 2 * t - 2;
+            *(uint32_t *)(a8 + ((b * 2 + h) * Npad + n) * 16 + byte_off) = word;
+            if (t == 0) {
+                ad[b * Npad + n] = d;
+                as[b * Npad + n] = s;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K9 / K8: one thread per block, rows contiguous.  These serve the Seam-2 row functions and ggml_cpy-style
+// callers; they are checked bit for bit against the oracle.
+// ---------------------------------------------------------------------------------------------------------
+template <int TYPE>
+__global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblocks, uint8_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    float v[QK];
+    const float4 *p = (const float4 *)(x + i * QK);
+#pragma unroll
+    for (int l = 0; l < QK / 4; ++l) {
+        const float4 f = p[l];
+        v[4 * l + 0] = f.x; v[4 * l + 1] = f.y; v[4 * l + 2] = f.z; v[4 * l + 3] = f.w;
+    }
+    if (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q5_0) {
+        float amax = 0.0f, mx = 0.0f;                       // Ggml.cs:343-354 / 616-627
+#pragma unroll
+        for (int l = 0; l < QK; ++l) {
+            const float a = fabsf(v[l]);
+            if (amax < a) { amax = a; mx = v[l]; }
+        }
+        if (TYPE == GGML_TYPE_Q4_0) {
+            const float d = mx / -8.0f;                     // Ggml.cs:356
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            uint8_t *o = out + i * 20;
+            *(uint32_t *)o = __float_as_uint(d);
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int l = 0; l < QK; l += 2) {
+                // (byte)Math.Min(15, Math.Round(v) + 8), Ggml.cs:366-367; rintf = half-to-even (D1)
+                const int q0 = (int)fminf(15.0f, rintf(v[l + 0] * id) + 8.0f);
+                const int q1 = (int)fminf(15.0f, rintf(v[l + 1] * id) + 8.0f);
+                w[l / 8] |= (uint32_t)((q0 & 0xFF) | ((q1 << 4) & 0xFF)) << (8 * ((l / 2) & 3));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(uint32_t *)(o + 4 + 4 * k) = w[k];
+        } else {
+            const float d = mx / -16.0f;                    // Ggml.cs:629
+            const float id = d != 0.0f ? 1.0f / d : 0.0f;
+            uint16_t *o = (uint16_t *)(out + i * 22);
+            o[0] = float_to_half_bits_rne(d);               // (Half)d, Ggml.cs:632
+            uint32_t qh = 0;
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int l = 0; l < QK; l += 2) {
+                int t0 = (int)(v[l + 0] * id + 16.5f); t0 = t0 > 31 ? 31 : t0;   // Ggml.cs:641-642
+                int t1 = (int)(v[l + 1] * id + 16.5f); t1 = t1 > 31 ? 31 : t1;
+                w[l / 8] |= (uint32_t)((t0 & 0x0F) | ((t1 & 0x0F) << 4)) << (8 * ((l / 2) & 3));
+                qh |= (uint32_t)((t0 & 0x10) >> 4) << (l + 0);
+                qh |= (uint32_t)((t1 & 0x10) >> 4) << (l + 1);
+            }
+            o[1] = (uint16_t)qh; o[2] = (uint16_t)(qh >> 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o[3 + 2 * k] = (uint16_t)w[k]; o[4 + 2 * k] = (uint16_t)(w[k] >> 16); }
+        }
+    } else if (TYPE == GGML_TYPE_Q4_1) {
+        float mn = 3.402823466e+38f, mx = -3.402823466e+38f;  // Ggml.cs:496-504
+#pragma unroll
+        for (int l = 0; l < QK; ++l) {
+            if (v[l] < mn) mn = v[l];
+            if (v[l] > mx) mx = v[l];
+        }
+        const float d = (mx - mn) / 15.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        uint8_t *o = out + i * 24;
+        *(uint32_t *)o = __float_as_uint(d);
+        *(uint32_t *)(o + 4) = __float_as_uint(mn);
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int l = 0; l < QK; l += 2) {
+            const int q0 = (int)rintf((v[l + 0] - mn) * id);  // Ggml.cs:514-518
+            const int q1 = (int)rintf((v[l + 1] - mn) * id);
+            w[l / 8] |= (uint32_t)((q0 & 0xFF) | ((q1 << 4) & 0xFF)) << (8 * ((l / 2) & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(uint32_t *)(o + 8 + 4 * k) = w[k];
+    } else {  // Q8_0 / Q8_1
+        float amax = 0.0f;
+#pragma unroll
+        for (int l = 0; l < QK; ++l) amax = fmaxf(amax, fabsf(v[l]));
+        const float d = amax / 127.0f;
+        const float id = d != 0.0f ? 1.0f / d : 0.0f;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int sum0 = 0, sum1 = 0;
+#pragma unroll
+        for (int l = 0; l < QK; ++l) {
+            const int q = (int)rintf(v[l] * id);
+            w[l / 4] |= ((uint32_t)q & 0xFFu) << (8 * (l & 3));
+            if (l < 16) sum0 += q; else sum1 += q;
+        }
+        if (TYPE == GGML_TYPE_Q8_0) {
+            uint32_t *o = (uint32_t *)(out + i * 36);
+            o[0] = __float_as_uint(d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[1 + k] = w[k];
+        } else {
+            uint32_t *o = (uint32_t *)(out + i * 44);
+            o[0] = __float_as_uint(d);
+            o[1] = __float_as_uint(d * (float)sum0);         // Ggml.cs:820-821 (D3 signed sums)
+            o[2] = __float_as_uint(d * (float)sum1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[3 + k] = w[k];
+        }
+    }
+}
+
+template <int TYPE>
+__global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t nblocks, float *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    float v[QK];
+    if (TYPE == GGML_TYPE_Q4_0) {
+        const uint32_t *s = (const uint32_t *)(in + i * 20);
+        const float d = __uint_as_float(s[0]);
+#pragma unroll
+        for (int l = 0; l < QK; l += 2) {
+            const uint32_t byte = (s[1 + l / 8] >> (8 * ((l / 2) & 3))) & 0xFFu;
+            v[l + 0] = (float)((int)(byte & 0x0F) - 8) * d;   // Ggml.cs:899-900
+            v[l + 1] = (float)((int)(byte >> 4) - 8) * d;
+        }
+    } else if (TYPE == GGML_TYPE_Q4_1) {
+        const uint32_t *s = (const uint32_t *)(in + i * 24);
+        const float d = __uint_as_float(s[0]), m = __uint_as_float(s[1]);
+#pragma unroll
+        for (int l = 0; l < QK; l += 2) {
+            const uint32_t byte = (s[2 + l / 8] >> (8 * ((l / 2) & 3))) & 0xFFu;
+            const float p0 = (float)(byte & 0x0F) * d, p1 = (float)(byte >> 4) * d;  // Ggml.cs:976-977, mul then add
+            v[l + 0] = p0 + m;
+            v[l + 1] = p1 + m;
+        }
+    } else if (TYPE == GGML_TYPE_Q5_0) {
+        const uint16_t *s = (const uint16_t *)(in + i * 22);
+        const float d = half_bits_to_float_q(s[0]);
+        const uint32_t qh = (uint32_t)s[1] | ((uint32_t)s[2] << 16);
+#pragma unroll
+        for (int l = 0; l < QK; l += 2) {
+            const uint32_t byte = (s[3 + l / 4] >> (8 * ((l / 2) & 1))) & 0xFFu;
+            const int vi0 = (int)((byte & 0x0F) | (((qh >> (l + 0)) & 1u) << 4));
+            const int vi1 = (int)((byte >> 4) | (((qh >> (l + 1)) & 1u) << 4));
+            v[l + 0] = (float)(vi0 - 16) * d;                  // Ggml.cs:1051-1052
+            v[l + 1] = (float)(vi1 - 16) * d;
+        }
+    } else {  // Q8_0
+        const uint32_t *s = (const uint32_t *)(in + i * 36);
+        const float d = __uint_as_float(s[0]);
+#pragma unroll
+        for (int l = 0; l < QK; ++l) {
+            const int q = (int)(int8_t)((s[1 + l / 4] >> (8 * (l & 3))) & 0xFFu);
+            v[l] = (float)q * d;                               // Ggml.cs:1119 (signed, D4)
+        }
+    }
+    float4 *o = (float4 *)(y + i * QK);
+#pragma unroll
+    for (int l = 0; l < QK / 4; ++l) o[l] = make_float4(v[4 * l + 0], v[4 * l + 1], v[4 * l + 2], v[4 * l + 3]);
+}
+
+// reference-format Q8_0 / Q8_1 rows (block_q8_0 36 B, block_q8_1 44 B) -> the planar scratch the dot kernels read.
+// Serves ggml_hip_vec_dot (Seam 2), whose vy argument is already-quantized blocks.
+template <int TYPE>
+__global__ void q8_aos_to_planes_kernel(const uint8_t *__restrict__ in, int64_t N, int64_t nbk, int8_t *__restrict__ a8,
+                                        float *__restrict__ ad, int32_t *__restrict__ as, int64_t Npad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * nbk) return;
+    const int64_t n = i / nbk, b = i % nbk;
+    constexpr int BS = TYPE == GGML_TYPE_Q8_0 ? 36 : 44;
+    constexpr int QOFF = TYPE == GGML_TYPE_Q8_0 ? 1 : 3;
+    const uint32_t *s = (const uint32_t *)(in + i * BS);
+    uint32_t ev[4], od[4];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = s[QOFF + 2 * k], hi = s[QOFF + 2 * k + 1];
+        ev[k] = (lo & 0xFFu) | ((lo >> 8) & 0xFF00u) | ((hi & 0xFFu) << 16) | ((hi << 8) & 0xFF000000u);
+        od[k] = ((lo >> 8) & 0xFFu) | ((lo >> 16) & 0xFF00u) | ((hi << 8) & 0xFF0000u) | (hi & 0xFF000000u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += (int)(int8_t)(lo >> (8 * e)) + (int)(int8_t)(hi >> (8 * e));
+    }
+    *(uint4 *)(a8 + ((b * 2 + 0) * Npad + n) * 16) = make_uint4(ev[0], ev[1], ev[2], ev[3]);
+    *(uint4 *)(a8 + ((b * 2 + 1) * Npad + n) * 16) = make_uint4(od[0], od[1], od[2], od[3]);
+    ad[b * Npad + n] = __uint_as_float(s[0]);
+    as[b * Npad + n] = sum;
+}
+
+}  // namespace
+
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    const int64_t nbk = K / QK;
+    dim3 grid((unsigned)((nbk + K1_BPB - 1) / K1_BPB), (unsigned)((N + 31) / 32));
+    quantize_act_kernel<<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_rows(int type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st) {
+    const int64_t nblocks = nrows * (k / QK);
+    if (nblocks <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nblocks + 127) / 128));
+    uint8_t *o = (uint8_t *)blocks;
+    switch (type) {
+    case GGML_TYPE_Q4_0: quantize_rows_kernel<GGML_TYPE_Q4_0><<<grid, 128, 0, st>>>(x, nblocks, o); break;
+    case GGML_TYPE_Q4_1: quantize_rows_kernel<GGML_TYPE_Q4_1><<<grid, 128, 0, st>>>(x, nblocks, o); break;
+    case GGML_TYPE_Q5_0: quantize_rows_kernel<GGML_TYPE_Q5_0><<<grid, 128, 0, st>>>(x, nblocks, o); break;
+    case GGML_TYPE_Q8_0: quantize_rows_kernel<GGML_TYPE_Q8_0><<<grid, 128, 0, st>>>(x, nblocks, o); break;
+    case GGML_TYPE_Q8_1: quantize_rows_kernel<GGML_TYPE_Q8_1><<<grid, 128, 0, st>>>(x, nblocks, o); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st) {
+    const int64_t nblocks = nrows * (k / QK);
+    if (nblocks <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nblocks + 127) / 128));
+    const uint8_t *in = (const uint8_t *)blocks;
+    switch (type) {
+    case GGML_TYPE_Q4_0: dequantize_rows_kernel<GGML_TYPE_Q4_0><<<grid, 128, 0, st>>>(in, nblocks, y); break;
+    case GGML_TYPE_Q4_1: dequantize_rows_kernel<GGML_TYPE_Q4_1><<<grid, 128, 0, st>>>(in, nblocks, y); break;
+    case GGML_TYPE_Q5_0: dequantize_rows_kernel<GGML_TYPE_Q5_0><<<grid, 128, 0, st>>>(in, nblocks, y); break;
+    case GGML_TYPE_Q8_0: dequantize_rows_kernel<GGML_TYPE_Q8_0><<<grid, 128, 0, st>>>(in, nblocks, y); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st) {
+    const int64_t nbk = K / QK, total = N * nbk;
+    if (total <= 0) return hipSuccess;
+    dim3 grid((unsigned)((total + 127) / 128));
+    if (q8type == GGML_TYPE_Q8_0)
+        q8_aos_to_planes_kernel<GGML_TYPE_Q8_0><<<grid, 128, 0, st>>>((const uint8_t *)blocks, N, nbk, p.a8, p.ad, p.as, p.Npad);
+    else if (q8type == GGML_TYPE_Q8_1)
+        q8_aos_to_planes_kernel<GGML_TYPE_Q8_1><<<grid, 128, 0, st>>>((const uint8_t *)blocks, N, nbk, p.a8, p.ad, p.as, p.Npad);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

@@ -1,0 +1,294 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs.  Bit-exact for quantize / dequantize / re-layout (byte and integer work); for mul_mat
+|gpu - ref| <= 1e-3 * |ref| + 1e-5 * rms(ref) per element and <= 1e-5 normwise (only the order of the f32
+block additions differs from the scalar reference, north_star tolerance is 1e-3 relative)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+QTYPES = [O.Q4_0, O.Q4_1, O.Q5_0, O.Q8_0]
+RNG = np.random.default_rng(20240613)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ggmlsharp_amd import device
+    device.init(0)
+    return device
+
+
+def _rand(shape, scale=1.0):
+    return (RNG.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _special_rows(k):
+    """rows that exercise the edge cases of the block quantizers."""
+    x = _rand((8, k))
+    x[0, :32] = 0.0                              # all-zero block: d = -0.0 / 0, id = 0
+    x[1, :32] = 2.5                              # constant block
+    x[2, :64] = np.round(x[2, :64] * 4) / 2      # many exact .5 ties after scaling
+    x[3, :32] = -np.abs(x[3, :32])               # all negative: max is negative, d positive
+    x[4, :32] *= 1e-30                           # tiny magnitudes
+    x[5, :32] *= 1e20                            # huge magnitudes
+    x[6, 0:32] = np.arange(32) - 16.0            # exact integers
+    x[7, 5] = -x[7, 5]
+    return x
+
+
+def assert_close(got, ref, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    rms = np.sqrt(np.mean(ref * ref)) if ref.size else 0.0
+    err = np.abs(got - ref)
+    bound = 1e-3 * np.abs(ref) + 1e-5 * rms
+    bad = err > bound
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} beyond 1e-3 rel; max err {err.max():.3e}, rms {rms:.3e}"
+    if ref.size and np.linalg.norm(ref) > 0:
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-5, what
+
+
+# ---------------------------------------------------------------- K9 / K8 bit-exact
+@pytest.mark.parametrize("t", QTYPES + [O.Q8_1])
+def test_quantize_rows_bit_exact(dev, t):
+    for k in (32, 64, 4096):
+        for x in (_special_rows(max(k, 64))[:, :k], _rand((37, k)), _rand((1, k), 1e-3), _rand((5, k), 300.0)):
+            x = np.ascontiguousarray(x)
+            want = O.quantize_row(t, x)
+            got = dev.quantize_rows(t, torch.from_numpy(x).cuda()).cpu().numpy()
+            assert np.array_equal(got, want), f"type {t} k {k}"
+
+
+@pytest.mark.parametrize("t", QTYPES)
+def test_dequantize_rows_bit_exact(dev, t):
+    for k in (32, 256, 4096):
+        x = np.ascontiguousarray(np.concatenate([_special_rows(max(k, 64))[:, :k], _rand((19, k), 3.0)]))
+        q = O.quantize_row(t, x)
+        want = O.dequantize_row(t, q, k)
+        got = dev.dequantize_rows(t, torch.from_numpy(q).cuda(), k).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # arbitrary block bytes (not produced by the quantizer): every nibble / high-bit / sign pattern
+    k = 1024
+    raw = RNG.integers(0, 256, size=(16, k // 32 * O.type_size(t)), dtype=np.uint8)
+    blocks = raw.reshape(-1, O.type_size(t))
+    if t in (O.Q4_0, O.Q4_1, O.Q8_0):
+        blocks[:, 0:4] = _rand(blocks.shape[0]).view(np.uint8).reshape(-1, 4)
+    if t == O.Q4_1:
+        blocks[:, 4:8] = _rand(blocks.shape[0]).view(np.uint8).reshape(-1, 4)
+    if t == O.Q5_0:
+        blocks[:, 0:2] = _rand(blocks.shape[0]).astype(np.float16).view(np.uint8).reshape(-1, 2)
+    want = O.dequantize_row(t, raw, k)
+    got = dev.dequantize_rows(t, torch.from_numpy(raw).cuda(), k).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_empty_inputs(dev):
+    x = torch.empty((0, 64), dtype=torch.float32, device="cuda")
+    assert dev.quantize_rows(O.Q4_0, x).shape == (0, 40)
+    w = dev.Weight.from_host(O.Q4_0, O.quantize_row(O.Q4_0, _rand((4, 64))), 64)
+    out = dev.mul_mat(w, torch.empty((0, 64), dtype=torch.float32, device="cuda"))
+    assert out.shape == (0, 4)
+
+
+# ---------------------------------------------------------------- re-layout round trip (byte-exact)
+@pytest.mark.parametrize("t", QTYPES + [O.F32, O.F16])
+def test_weight_roundtrip_bytes(dev, t):
+    for (M, K) in ((1, 32), (37, 256), (130, 4096)):
+        if t == O.F32:
+            rows = _rand((M, K)).view(np.uint8)
+        elif t == O.F16:
+            rows = _rand((M, K)).astype(np.float16).view(np.uint8)
+        else:
+            rows = RNG.integers(0, 256, size=(M, K // 32 * O.type_size(t)), dtype=np.uint8)
+        w = dev.Weight.from_host(t, rows, K)
+        assert np.array_equal(w.download(), rows.reshape(-1))
+        # a row shard, and the device-source path
+        if M > 4:
+            ws = dev.Weight.from_device(t, torch.from_numpy(rows).cuda(), K, row_begin=3, row_end=M - 1)
+            assert np.array_equal(ws.download(), rows[3:M - 1].reshape(-1))
+
+
+# ---------------------------------------------------------------- K1: activation planes == oracle Q8_0 blocks
+def test_quantize_act_planes_match_oracle(dev):
+    from ggmlsharp_amd._lib import lib
+    K = 256
+    for N in (1, 7, 33, 130):
+        x = np.ascontiguousarray(np.concatenate([_special_rows(K)[:min(N, 8)], _rand((max(N - 8, 0), K))])[:N])
+        w = dev.Weight.from_host(O.Q4_0, O.quantize_row(O.Q4_0, _rand((4, K))), K)
+        work = dev.alloc_work(O.Q4_0, K, N)
+        dev.mul_mat_init(w, torch.from_numpy(x).cuda(), work)
+        torch.cuda.synchronize()
+        raw = work.cpu().numpy()
+        nbk, Npad = K // 32, (N + 127) // 128 * 128
+        a8 = raw[: nbk * 2 * Npad * 16].view(np.int8).reshape(nbk, 2, Npad, 16)
+        ad = raw[nbk * 2 * Npad * 16: nbk * 2 * Npad * 16 + nbk * Npad * 4].view(np.float32).reshape(nbk, Npad)
+        asum = raw[nbk * 2 * Npad * 16 + nbk * Npad * 4: nbk * 2 * Npad * 16 + 2 * nbk * Npad * 4].view(np.int32).reshape(nbk, Npad)
+        ref = O.quantize_row(O.Q8_0, x).reshape(N, nbk, 36)
+        ref_d = ref[:, :, :4].copy().view(np.float32).reshape(N, nbk)
+        ref_q = ref[:, :, 4:].copy().view(np.int8)
+        assert np.array_equal(ad[:, :N].T.view(np.uint32), ref_d.view(np.uint32))
+        assert np.array_equal(a8[:, 0, :N, :].transpose(1, 0, 2), ref_q[:, :, 0::2])   # even elements
+        assert np.array_equal(a8[:, 1, :N, :].transpose(1, 0, 2), ref_q[:, :, 1::2])   # odd elements
+        assert np.array_equal(asum[:, :N].T, ref_q.astype(np.int32).sum(axis=2))
+        assert lib().ggml_hip_mul_mat_work_size(O.Q4_0, K, N) == raw.size
+
+
+# ---------------------------------------------------------------- mul_mat vs oracle
+SHAPES = [  # (M, K, N): ragged M / N, both kernels (N <= 8 mat-vec, N > 8 MFMA), tail stage (K/32 % 4 != 0)
+    (1, 32, 1), (16, 64, 1), (17, 96, 2), (200, 256, 3), (128, 4096, 1), (130, 352, 8),
+    (64, 128, 9), (33, 160, 17), (200, 256, 64), (128, 512, 128), (257, 1024, 130), (64, 11008, 40),
+]
+
+
+@pytest.mark.parametrize("t", QTYPES)
+def test_mul_mat_q_matches_oracle(dev, t):
+    for (M, K, N) in SHAPES:
+        w = _rand((M, K))
+        x = _rand((N, K), 2.0)
+        wq = O.quantize_row(t, w)
+        ref = O.mul_mat(t, wq, x, M, K, N, nth=4)[0, 0]
+        W = dev.Weight.from_host(t, wq, K)
+        got = dev.mul_mat(W, torch.from_numpy(x).cuda()).cpu().numpy()
+        assert_close(got, ref, f"type {t} M{M} K{K} N{N}")
+
+
+def test_mul_mat_q_strided_src1_and_dst(dev):
+    M, K, N = 96, 256, 20
+    wq = O.quantize_row(O.Q4_0, _rand((M, K)))
+    xbig = torch.from_numpy(_rand((N, K + 64))).cuda()
+    x = xbig[:, :K]
+    out_big = torch.full((N, M + 32), -7.0, dtype=torch.float32, device="cuda")
+    W = dev.Weight.from_host(O.Q4_0, wq, K)
+    dev.mul_mat(W, x, out=out_big[:, :M])
+    ref = O.mul_mat(O.Q4_0, wq, x.cpu().numpy(), M, K, N)[0, 0]
+    assert_close(out_big[:, :M].cpu().numpy(), ref)
+    assert torch.all(out_big[:, M:] == -7.0)
+
+
+def test_mul_mat_extreme_block_values(dev):
+    # every weight at the extreme quant and activations at +-amax: the largest possible integer block sums
+    M, K, N = 64, 128, 16
+    for t, lo in ((O.Q4_0, -8), (O.Q5_0, -16), (O.Q8_0, -127)):
+        w = np.full((M, K), float(lo), dtype=np.float32)
+        x = np.where(RNG.random((N, K)) < 0.5, -3.0, 3.0).astype(np.float32)
+        wq = O.quantize_row(t, w)
+        ref = O.mul_mat(t, wq, x, M, K, N)[0, 0]
+        got = dev.mul_mat(dev.Weight.from_host(t, wq, K), torch.from_numpy(x).cuda()).cpu().numpy()
+        assert_close(got, ref, f"extreme type {t}")
+    # raw Q8_0 weight bytes including -128
+    raw = RNG.integers(0, 256, size=(M, K // 32 * 36), dtype=np.uint8)
+    raw.reshape(-1, 36)[:, :4] = _rand(M * K // 32).view(np.uint8).reshape(-1, 4)
+    x = _rand((N, K))
+    ref = O.mul_mat(O.Q8_0, raw, x, M, K, N)[0, 0]
+    got = dev.mul_mat(dev.Weight.from_host(O.Q8_0, raw, K), torch.from_numpy(x).cuda()).cpu().numpy()
+    assert_close(got, ref, "raw q8_0")
+
+
+@pytest.mark.parametrize("t", [O.F32, O.F16])
+def test_mul_mat_dense_matches_oracle(dev, t):
+    for (M, K, N) in ((64, 128, 256), (1, 32, 1), (70, 100, 33), (256, 4096, 1)):  # first = BASELINE config 1
+        w = _rand((M, K))
+        x = _rand((N, K))
+        wraw = w if t == O.F32 else w.astype(np.float16).view(np.uint16)
+        ref = O.mul_mat(t, wraw, x, M, K, N, nth=4)[0, 0]
+        W = dev.Weight.from_host(t, wraw.view(np.uint8), K)
+        got = dev.mul_mat(W, torch.from_numpy(x).cuda()).cpu().numpy()
+        assert_close(got, ref, f"dense type {t} M{M} K{K} N{N}")
+
+
+# ---------------------------------------------------------------- Seam 2 host forms
+def test_row_functions_host_forms(dev):
+    from ggmlsharp_amd._lib import lib
+    L = lib()
+    k = 256
+    x = _rand(k)
+    for t in QTYPES:
+        want = O.quantize_row(t, x)
+        got = np.zeros_like(want)
+        assert L.ggml_hip_quantize_row(t, x.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), k) == 0
+        assert np.array_equal(got, want)
+        y = np.zeros(k, dtype=np.float32)
+        assert L.ggml_hip_dequantize_row(t, want.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), k) == 0
+        assert np.array_equal(y.view(np.uint32), O.dequantize_row(t, want, k).view(np.uint32))
+        vt = O.lib().oracle_vec_dot_type(t)
+        aq = O.quantize_row(vt, _rand(k))
+        s = np.zeros(1, dtype=np.float32)
+        assert L.ggml_hip_vec_dot(t, k, s.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p),
+                                  aq.ctypes.data_as(C.c_void_p)) == 0
+        ref = O.vec_dot(t, k, want, aq)
+        assert abs(s[0] - ref) <= 1e-3 * abs(ref) + 1e-5
+    # rejected types (null slots)
+    s = np.zeros(1, dtype=np.float32)
+    assert L.ggml_hip_vec_dot(O.Q8_1, 32, s.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                              x.ctypes.data_as(C.c_void_p)) == -2
+    assert L.ggml_hip_dequantize_row(O.Q8_1, x.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), 32) == -2
+
+
+# ---------------------------------------------------------------- Seam 1 through the ggml_* mirror (Test3-style program)
+def test_ggml_api_program_quantized_and_batched(dev):
+    from ggmlsharp_amd import ggml as G
+    K, M, N = 256, 48, 12
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    assert ctx
+    try:
+        for t in (G.Q4_0, G.Q8_0, G.F32):
+            Wt = G.ggml_new_tensor_3d(ctx, t, K, M, 2)
+            Xt = G.ggml_new_tensor_3d(ctx, G.F32, K, N, 2)
+            w = _rand((2, M, K))
+            x = _rand((2, N, K))
+            wraw = w.view(np.uint8).reshape(2, M, -1) if t == G.F32 else O.quantize_row(t, w)
+            G.tensor_bytes(Wt)[:] = wraw.reshape(-1)
+            G.tensor_f32(Xt)[:] = x.reshape(1, 2, N, K)
+            Y = G.ggml_mul_mat(ctx, Wt, Xt)
+            assert Y and Y.contents.ne[0] == M and Y.contents.ne[1] == N and Y.contents.ne[2] == 2
+            gf = G.ggml_build_forward(Y)
+            assert gf.n_nodes == 1 and gf.n_leafs == 2
+            G.ggml_graph_compute(ctx, gf)
+            got = G.tensor_f32(Y)[0]
+            ref = O.mul_mat(t, wraw, x, M, K, N, nth=2, ne2=2)[0]
+            assert_close(got, ref, f"ggml api type {t}")
+            # second compute hits the weight cache; after rewriting the weights the caller must invalidate
+            G.ggml_graph_compute(ctx, gf)
+            assert_close(G.tensor_f32(Y)[0], ref)
+        # shape errors surface as NULL / status instead of the reference's vanished Debug.Assert
+        bad = G.ggml_mul_mat(ctx, G.ggml_new_tensor_2d(ctx, G.F32, 64, 4), G.ggml_new_tensor_2d(ctx, G.F32, 32, 4))
+        assert not bad
+    finally:
+        G.ggml_free(ctx)
+
+
+def test_seam1_ignores_non_compute_phases_and_other_threads(dev):
+    from ggmlsharp_amd import ggml as G
+    from ggmlsharp_amd._lib import lib, ggml_compute_params
+    ctx = G.ggml_init(4 * 1024 * 1024)
+    try:
+        Wt = G.ggml_new_tensor_2d(ctx, G.F32, 32, 4)
+        Xt = G.ggml_new_tensor_2d(ctx, G.F32, 32, 2)
+        G.ggml_set_f32(Wt, 1.0)
+        G.ggml_set_f32(Xt, 2.0)
+        Y = G.ggml_mul_mat(ctx, Wt, Xt)
+        G.ggml_set_f32(Y, -1.0)
+        for (phase, ith) in ((0, 0), (2, 0), (1, 1)):
+            p = ggml_compute_params(phase, ith, 2, 0, None)
+            assert lib().ggml_hip_compute_forward_mul_mat(C.byref(p), Wt, Xt, Y) == 0
+            assert G.ggml_get_f32_1d(Y, 0) == -1.0
+        p = ggml_compute_params(1, 0, 2, 0, None)
+        assert lib().ggml_hip_compute_forward_mul_mat(C.byref(p), Wt, Xt, Y) == 0
+        assert G.ggml_get_f32_1d(Y, 0) == 64.0
+    finally:
+        G.ggml_free(ctx)
+
+
+# ---------------------------------------------------------------- multi-GPU re-layout helper
+def test_relayout_gathered(dev):
+    G_, N, Ms, M = 3, 5, 7, 19
+    g = _rand((G_, N, Ms))
+    out = dev.relayout_gathered(torch.from_numpy(g).cuda(), G_, N, Ms, M).cpu().numpy()
+    want = np.concatenate([g[r] for r in range(G_)], axis=1)[:, :M]
+    assert np.array_equal(out, want)
