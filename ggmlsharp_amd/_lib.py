@@ -147,6 +147,12 @@ def lib():
                 build()
             else:
                 raise RuntimeError(f"{LIB_PATH} is missing and hipcc is not available; there is no CPU fallback")
+        # torch ships its own libamdhip64 under the same SONAME as /opt/rocm's.  Whichever is loaded first serves
+        # the whole process, and torch cannot see the GPU if the system one got in first -- so let torch go first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

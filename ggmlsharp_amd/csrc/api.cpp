@@ -276,8 +276,9 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
 
 int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *d_dst,
                          int64_t ldd, void *d_work, size_t work_bytes, void *stream) {
-    if (!w || !d_src1 || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (!w) return fail(GGML_HIP_ERR_ARG, "null weight");
     if (N <= 0 || w->M <= 0) return GGML_HIP_OK;
+    if (!d_src1 || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
     if (!is_q(w->type)) {
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
@@ -289,6 +290,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
 }
 
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {
+    if (nrows <= 0) return GGML_HIP_OK;  // empty input: nothing to do (buffers may be null)
     if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q8_1))
         return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
@@ -298,6 +300,7 @@ int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_
 }
 
 int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, int64_t k, float *d_y, void *stream) {
+    if (nrows <= 0) return GGML_HIP_OK;
     if (!d_y || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0))
         return fail(GGML_HIP_ERR_TYPE, "dequantize: unsupported type %d (Q8_1 slot is null, Ggml.cs:278)", type);
