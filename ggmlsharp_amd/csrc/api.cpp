@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -49,6 +50,13 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
     case GGML_TYPE_Q4_1: return GGML_TYPE_Q8_1;
     default: return -1;
     }
+}
+
+// Which activation image K1 writes: the mat-vec kernel reads int8; the MFMA kernels read int8 (gemm_q.hip) or f16
+// (gemm_q16.hip).  GGML_HIP_GEMM=f16 selects the f16-MFMA kernel (developer A/B switch while it is being tuned).
+bool use_f16_image(int64_t N) {
+    static const bool want_f16 = [] { const char *e = getenv("GGML_HIP_GEMM"); return e && e[0] == 'f'; }();
+    return N > GEMV_MAX_N && want_f16;
 }
 
 int ensure_init() {
@@ -255,7 +263,7 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
         return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", ggml_hip_mul_mat_work_size(w->type, w->K, N));
     act_planes p = act_carve(d_work, w->K, pad_rows(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, (hipStream_t)stream));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, use_f16_image(N), (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
@@ -269,6 +277,8 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     act_planes p = act_carve((void *)d_work, w->K, pad_rows(N));
     if (N <= GEMV_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
+    else if (use_f16_image(N))
+        HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else
         HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     return GGML_HIP_OK;

@@ -47,8 +47,10 @@ struct ggml_hip_weight {
     int      device;
 };
 
-// ---- activation scratch ("wdata"), planar like the weights ----
-//   a8 [nbk][2][Npad][16] int8 (plane 0 even elements, plane 1 odd), ad [nbk][Npad] f32, as [nbk][Npad] i32 (block sums)
+// ---- activation scratch ("wdata"), planar like the weights; K1 writes one of two images into the `a8` region ----
+//   int8 image (mat-vec kernel):  [nbk][2][Npad][16] int8, plane 0 = even elements of the block, plane 1 = odd
+//   f16 image  (MFMA kernel)   :  [nbk][4][Npad][16 B] f16, panel p = elements e with e % 4 == p, in order
+//   ad [nbk][Npad] f32 block scales, as [nbk][Npad] i32 block sums of the quants
 struct act_planes {
     int8_t  *a8;
     float   *ad;
@@ -57,13 +59,13 @@ struct act_planes {
 };
 static inline size_t act_bytes(int64_t K, int64_t Npad) {
     const int64_t nbk = K / QK;
-    return (size_t)nbk * 2 * Npad * 16 + (size_t)nbk * Npad * 4 * 2;
+    return (size_t)nbk * 4 * Npad * 16 + (size_t)nbk * Npad * 4 * 2;
 }
 static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
     const int64_t nbk = K / QK;
     act_planes p;
     p.a8 = (int8_t *)base;
-    p.ad = (float *)((uint8_t *)base + (size_t)nbk * 2 * Npad * 16);
+    p.ad = (float *)((uint8_t *)base + (size_t)nbk * 4 * Npad * 16);
     p.as = (int32_t *)((uint8_t *)p.ad + (size_t)nbk * Npad * 4);
     p.Npad = Npad;
     return p;
@@ -77,13 +79,14 @@ hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStrea
 hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
                                     hipStream_t st);
 // quantize.hip
-hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, hipStream_t st);
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, bool f16_image, hipStream_t st);
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
 hipError_t launch_quantize_rows(int type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st);
 hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st);
 

@@ -22,6 +22,8 @@
 // VALU epilogue issues at full rate).  K is streamed in stages of BKB k-blocks through a double-buffered LDS ring:
 // activations by global_load_lds (16 B/lane, image is lane-linear), weights through registers (nibble -> int8).
 #include "common.h"
+#include <cstdlib>
+#include <utility>
 
 namespace {
 
@@ -30,6 +32,17 @@ using i32x16 = __attribute__((ext_vector_type(16))) int;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #define BKB 4  // k-blocks per stage
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), f(<1>), ... -- indices are constants inside f, so register
+// arrays indexed with them never become runtime-indexed (which would push them to scratch)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -216,55 +229,91 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
         }
     };
 
+    // One stage = BKB k-blocks x (IT x JT) MFMA tiles per wave, fully unrolled and software-pipelined by hand:
+    // while the VALU applies the block scales to tile t (cvt + mul + fma per element), the matrix core already
+    // runs tile t+1 into the other accumulator, and the LDS reads for the next k-block / next row group are in
+    // flight.  sched_barrier(0) between tiles keeps the compiler from hoisting all MFMAs (and their 16-register
+    // results) to the top, which is what it does otherwise and what makes the 2x2 wave tile spill.
     auto compute = [&](int s) {
         const uint8_t *sp = stage_ptr(s);
         const uint8_t *sA = sp;
         const uint8_t *sW = sp + T::A_BYTES;
         const float *sDa = (const float *)(sp + T::A_BYTES + T::W_BYTES);
         const float *sDw = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES);
-#pragma unroll 1
-        for (int bb = 0; bb < BKB; ++bb) {
-            i32x4 af[IT], bf[JT];
-            float dw[JT];
+        const float *sMw = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES);
+        const float *sSa = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES + T::MW_BYTES);
+        constexpr int NT = BKB * IT * JT;   // tiles per stage, order: bb slowest, then i, then j
+        constexpr int NG = BKB * IT;        // (bb, i) groups: one set of 16 row scales each
+
+        // fragment ring: a k-block's operands are fetched AHEAD tiles before its first MFMA issues
+        constexpr int TPB = IT * JT;                 // tiles per k-block
+        constexpr int AHEAD = TPB == 1 ? 2 : 1;      // k-blocks of look-ahead for the fragment loads
+        constexpr int RING = AHEAD + 1;
+        i32x4 af[RING][IT], bf[RING][JT];
+        float dw[RING][JT], mw[RING][JT];
+        f32x4 da[2][4], sa[2][4];
+        i32x16 tacc[2];
+        const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+        auto load_block = [&](auto bbc) {   // operand fragments + per-lane weight scales of k-block bb
+            constexpr int bb = decltype(bbc)::value, p = bb % RING;
 #pragma unroll
             for (int i = 0; i < IT; ++i)
-                af[i] = *(const i32x4 *)(sA + ((size_t)((bb * 2 + hh) * TN + wn * 32 * IT + 32 * i + l31)) * 16);
+                af[p][i] = *(const i32x4 *)(sA + ((size_t)((bb * 2 + hh) * TN + wn * 32 * IT + 32 * i + l31)) * 16);
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                const int col = wm_ * 32 * JT + 32 * j;
-                bf[j] = *(const i32x4 *)(sW + ((size_t)((bb * 2 + hh) * TM + col + l31)) * 16);
-                dw[j] = sDw[bb * TM + col + l31];
+                const int col = wm_ * 32 * JT + 32 * j + l31;
+                bf[p][j] = *(const i32x4 *)(sW + ((size_t)((bb * 2 + hh) * TM + col)) * 16);
+                dw[p][j] = sDw[bb * TM + col];
+                if (TYPE == GGML_TYPE_Q4_1) mw[p][j] = sMw[bb * TM + col];
             }
+        };
+        auto load_group = [&](auto gc) {    // the 16 per-register row scales of group g = bb * IT + i
+            constexpr int g = decltype(gc)::value, bb = g / IT, i = g % IT, p = g & 1;
+            const int row = wn * 32 * IT + 32 * i;
 #pragma unroll
-            for (int i = 0; i < IT; ++i) {
-                const int row = wn * 32 * IT + 32 * i;
-                f32x4 da[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) da[k] = *(const f32x4 *)(sDa + bb * TN + row + 8 * k + 4 * hh);
-#pragma unroll
-                for (int j = 0; j < JT; ++j) {
-                    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    const i32x16 t = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], zero, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sc = da[r >> 2][r & 3] * dw[j];
-                        acc[i][j][r >> 2][r & 3] = fmaf((float)t[r], sc, acc[i][j][r >> 2][r & 3]);
-                    }
-                    if (TYPE == GGML_TYPE_Q4_1) {  // + m0 * d1 * sum(a)  (Ggml.cs:1190-1196 factorised)
-                        const float *sMw = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES);
-                        const float *sSa = (const float *)(sp + T::A_BYTES + T::W_BYTES + T::DA_BYTES + T::DW_BYTES + T::MW_BYTES);
-                        const float mw = sMw[bb * TM + wm_ * 32 * JT + 32 * j + l31];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const f32x4 sa = *(const f32x4 *)(sSa + bb * TN + row + 8 * k + 4 * hh);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc[i][j][k][e] = fmaf(mw, da[k][e] * sa[e], acc[i][j][k][e]);
-                        }
-                    }
-                }
+            for (int k = 0; k < 4; ++k) {
+                da[p][k] = *(const f32x4 *)(sDa + bb * TN + row + 8 * k + 4 * hh);
+                if (TYPE == GGML_TYPE_Q4_1) sa[p][k] = *(const f32x4 *)(sSa + bb * TN + row + 8 * k + 4 * hh);
             }
-        }
+        };
+        auto mfma_tile = [&](auto tc) {
+            constexpr int t = decltype(tc)::value, bb = t / (IT * JT), i = (t / JT) % IT, j = t % JT;
+            tacc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[bb % RING][i], bf[bb % RING][j], zero, 0, 0, 0);
+        };
+
+        static_for<AHEAD>([&](auto bc) { load_block(bc); });
+        load_group(std::integral_constant<int, 0>{});
+        mfma_tile(std::integral_constant<int, 0>{});
+        static_for<NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int bb = t / (IT * JT), i = (t / JT) % IT, j = t % JT, g = t / JT;
+            if constexpr (t + 1 < NT) mfma_tile(std::integral_constant<int, t + 1>{});
+            // prefetch: a later k-block's fragments at the first tile of this block, next group's row scales at the
+            // first tile of this group (the ring slots they overwrite were last read by an earlier tile's MFMA)
+            if constexpr (i == 0 && j == 0 && bb + AHEAD < BKB) load_block(std::integral_constant<int, bb + AHEAD>{});
+            if constexpr (j == 0 && g + 1 < NG) load_group(std::integral_constant<int, g + 1>{});
+            const i32x16 tt = tacc[t & 1];
+            const float dwj = dw[bb % RING][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = da[g & 1][r >> 2][r & 3] * dwj;
+                acc[i][j][r >> 2][r & 3] = fmaf((float)tt[r], sc, acc[i][j][r >> 2][r & 3]);
+            }
+            if (TYPE == GGML_TYPE_Q4_1) {  // + m0 * d1 * sum(a)  (Ggml.cs:1190-1196 factorised)
+                const float mwj = mw[bb % RING][j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][k][e] = fmaf(mwj, da[g & 1][k][e] * sa[g & 1][k][e], acc[i][j][k][e]);
+            }
+            // pin: the optimiser otherwise sinks every tile's scale-accumulate below the last MFMA of the stage
+            // (the sums are only needed at the end), which serialises matrix core and VALU and blows the registers
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(acc[i][j][k]));
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     // ---- main loop: double-buffered, one barrier per stage ----
@@ -322,6 +371,9 @@ template <int TYPE>
 hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     // 128x128 tiles when they already give >= 2 workgroups per CU, else 64x64 to fill the chip
     const int64_t big = ((w->M + 127) / 128) * ((N + 127) / 128);
+    static const char *force = getenv("GGML_HIP_GEMM_TILE");  // developer override: "1" = 64x64, "2" = 128x128
+    if (force && force[0] == '1') return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
+    if (force && force[0] == '2') return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
     if (big >= 512) return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
     return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
 }

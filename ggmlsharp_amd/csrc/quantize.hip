@@ -59,6 +59,7 @@ __device__ __forceinline__ uint16_t float_to_half_bits_rne(float f) {
 // ---------------------------------------------------------------------------------------------------------
 #define K1_BPB 8
 
+template <bool F16>
 __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restrict__ x, int64_t N, int64_t nbk, int64_t ld1,
                                                           int8_t *__restrict__ a8, float *__restrict__ ad,
                                                           int32_t *__restrict__ as, int64_t Npad) {
@@ -93,7 +94,32 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        // elements 4t, 4t+2 are even (plane 0 bytes 2t, 2t+1); 4t+1, 4t+3 odd (plane 1 bytes 2t, 2t+1)
+        if (F16) {
+            // f16 image: element 4t+p goes to panel p, position t.  The 4 lanes of a group transpose their 4x4
+            // halves with two xor-shuffles so that lane t = 4u+v ends up with positions 4u..4u+3 of panel v (8 bytes).
+            const float r0 = rintf(v[j].x * id), r1 = rintf(v[j].y * id), r2 = rintf(v[j].z * id), r3 = rintf(v[j].w * id);
+            const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)r0), h1 = __builtin_bit_cast(uint16_t, (_Float16)r1);
+            const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)r2), h3 = __builtin_bit_cast(uint16_t, (_Float16)r3);
+            const uint32_t lo = h0 | (h1 << 16), hi = h2 | (h3 << 16);
+            const int vv = t & 3;
+            const uint32_t recv1 = (uint32_t)__shfl_xor((int)(vv < 2 ? hi : lo), 2);
+            const uint32_t X = vv < 2 ? lo : recv1;   // residues (2*(vv>>1), +1) of source lane vv & 1
+            const uint32_t Y = vv < 2 ? recv1 : hi;   // same residues of source lane (vv & 1) + 2
+            const bool odd = (vv & 1) != 0;
+            const uint32_t send2 = odd ? ((X & 0xFFFFu) | (Y << 16)) : ((X >> 16) | (Y & 0xFFFF0000u));
+            const uint32_t recv2 = (uint32_t)__shfl_xor((int)send2, 1);
+            const uint32_t o0 = odd ? ((recv2 & 0xFFFFu) | (X & 0xFFFF0000u)) : ((X & 0xFFFFu) | (recv2 << 16));
+            const uint32_t o1 = odd ? ((recv2 >> 16) | (Y & 0xFFFF0000u)) : ((Y & 0xFFFFu) | (recv2 & 0xFFFF0000u));
+            if (live && b < nbk) {
+                *(uint2 *)(a8 + ((b * 4 + vv) * Npad + n) * 16 + 8 * (t >> 2)) = make_uint2(o0, o1);
+                if (t == 0) {
+                    ad[b * Npad + n] = d;
+                    as[b * Npad + n] = s;
+                }
+            }
+            continue;
+        }
+        // int8 image: elements 4t, 4t+2 are even (plane 0 bytes 2t, 2t+1); 4t+1, 4t+3 odd (plane 1 bytes 2t, 2t+1)
         const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2 & 0xFFu) << 8);
         const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
         const bool even_lane = (t & 1) == 0;
@@ -299,11 +325,14 @@ __global__ void q8_aos_to_planes_kernel(const uint8_t *__restrict__ in, int64_t 
 
 }  // namespace
 
-hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, hipStream_t st) {
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, bool f16_image, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const int64_t nbk = K / QK;
     dim3 grid((unsigned)((nbk + K1_BPB - 1) / K1_BPB), (unsigned)((N + 31) / 32));
-    quantize_act_kernel<<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    if (f16_image)
+        quantize_act_kernel<true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    else
+        quantize_act_kernel<false><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     return hipGetLastError();
 }
 

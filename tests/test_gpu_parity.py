@@ -126,16 +126,22 @@ def test_quantize_act_planes_match_oracle(dev):
         torch.cuda.synchronize()
         raw = work.cpu().numpy()
         nbk, Npad = K // 32, (N + 127) // 128 * 128
-        a8 = raw[: nbk * 2 * Npad * 16].view(np.int8).reshape(nbk, 2, Npad, 16)
-        ad = raw[nbk * 2 * Npad * 16: nbk * 2 * Npad * 16 + nbk * Npad * 4].view(np.float32).reshape(nbk, Npad)
-        asum = raw[nbk * 2 * Npad * 16 + nbk * Npad * 4: nbk * 2 * Npad * 16 + 2 * nbk * Npad * 4].view(np.int32).reshape(nbk, Npad)
+        img = nbk * 4 * Npad * 16   # the image region is sized for the larger (f16) image
+        ad = raw[img: img + nbk * Npad * 4].view(np.float32).reshape(nbk, Npad)
+        asum = raw[img + nbk * Npad * 4: img + 2 * nbk * Npad * 4].view(np.int32).reshape(nbk, Npad)
         ref = O.quantize_row(O.Q8_0, x).reshape(N, nbk, 36)
         ref_d = ref[:, :, :4].copy().view(np.float32).reshape(N, nbk)
         ref_q = ref[:, :, 4:].copy().view(np.int8)
         assert np.array_equal(ad[:, :N].T.view(np.uint32), ref_d.view(np.uint32))
-        assert np.array_equal(a8[:, 0, :N, :].transpose(1, 0, 2), ref_q[:, :, 0::2])   # even elements
-        assert np.array_equal(a8[:, 1, :N, :].transpose(1, 0, 2), ref_q[:, :, 1::2])   # odd elements
         assert np.array_equal(asum[:, :N].T, ref_q.astype(np.int32).sum(axis=2))
+        if N <= 8:   # int8 image for the mat-vec kernel: plane 0 = even elements, plane 1 = odd elements
+            a8 = raw[: nbk * 2 * Npad * 16].view(np.int8).reshape(nbk, 2, Npad, 16)
+            assert np.array_equal(a8[:, 0, :N, :].transpose(1, 0, 2), ref_q[:, :, 0::2])
+            assert np.array_equal(a8[:, 1, :N, :].transpose(1, 0, 2), ref_q[:, :, 1::2])
+        else:        # f16 image for the MFMA kernel: panel p position t = element 4t + p, exact small integers
+            a16 = raw[:img].view(np.float16).reshape(nbk, 4, Npad, 8)
+            for p in range(4):
+                assert np.array_equal(a16[:, p, :N, :].transpose(1, 0, 2).astype(np.int32), ref_q[:, :, p::4].astype(np.int32))
         assert lib().ggml_hip_mul_mat_work_size(O.Q4_0, K, N) == raw.size
 
 

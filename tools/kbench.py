@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench + full-size parity check for the quantized mul_mat kernels (developer tool, GPU box).
+
+For each (type, M, K, N): checks the HIP result against an fp64 evaluation of the same integer/scale arithmetic
+(dequantised weights x dequantised Q8 activations, both produced by the bit-exact device kernels) and times the
+INIT (K1) and COMPUTE kernels separately with HIP events."""
+import argparse
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ggmlsharp_amd import device  # noqa: E402
+
+TYPES = {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q8_0": 8}
+
+
+def ev_ms(fn, iters):
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        fn()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def run(tname, M, K, N, iters, check=True, copies=1):
+    t = TYPES[tname]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    ws = []
+    for c in range(copies):
+        w = torch.randn((M, K), generator=g, device="cuda")
+        rows = device.quantize_rows(t, w)
+        ws.append(device.Weight.from_device(t, rows, K))
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    out = torch.empty((N, M), device="cuda")
+    work = device.alloc_work(t, K, N)
+    W = ws[0]
+    device.mul_mat(W, x, out=out, work=work)
+    msg = ""
+    if check:
+        wd = device.dequantize_rows(t, rows if copies == 1 else device.quantize_rows(t, w), K).double()
+        if copies > 1:
+            W = ws[-1]
+            device.mul_mat(W, x, out=out, work=work)
+        xq = device.dequantize_rows(8, device.quantize_rows(8, x.contiguous()), K).double()
+        ref = xq @ wd.T
+        err = (out.double() - ref).abs()
+        rms = ref.pow(2).mean().sqrt()
+        bad = (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item()
+        msg = f"max_err/rms {err.max().item() / rms.item():.2e} bad {bad}"
+    st = {"i": 0}
+
+    def init():
+        device.mul_mat_init(ws[st["i"] % copies], x, work)
+
+    def comp():
+        st["i"] += 1
+        device.mul_mat_compute(ws[st["i"] % copies], N, out, work)
+
+    t_init = ev_ms(init, iters)
+    t_comp = ev_ms(comp, iters)
+    flops = 2.0 * M * K * N
+    blk = {"q4_0": 20, "q4_1": 24, "q5_0": 22, "q8_0": 36}[tname]
+    ab = M * (K // 32) * blk + 4 * K * N + 4 * M * N
+    print(f"{tname} M{M} K{K} N{N}: init {t_init * 1e3:8.1f} us  compute {t_comp * 1e3:8.1f} us  "
+          f"{flops / t_comp / 1e9:9.1f} TOP/s  {ab / (t_init + t_comp) / 1e6:8.1f} GB/s  {msg}", flush=True)
+    for w_ in ws:
+        w_.free()
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", nargs="*", default=["q4_0:4096:4096:4096", "q4_0:4096:4096:512", "q4_0:4096:4096:1:32",
+                                                 "q8_0:4096:11008:512", "q5_0:4096:11008:512", "q4_0:32000:4096:512"])
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no-check", action="store_true")
+    a = ap.parse_args()
+    device.init(0)
+    for c in a.cfg:
+        p = c.split(":")
+        run(p[0], int(p[1]), int(p[2]), int(p[3]), a.iters, check=not a.no_check, copies=int(p[4]) if len(p) > 4 else 1)
