@@ -52,11 +52,15 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
     }
 }
 
-// Which activation image K1 writes: the mat-vec kernel reads int8; the MFMA kernels read int8 (gemm_q.hip) or f16
-// (gemm_q16.hip).  GGML_HIP_GEMM=f16 selects the f16-MFMA kernel (developer A/B switch while it is being tuned).
-bool use_f16_image(int64_t N) {
-    static const bool want_f16 = [] { const char *e = getenv("GGML_HIP_GEMM"); return e && e[0] == 'f'; }();
-    return N > GEMV_MAX_N && want_f16;
+// Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat:
+//   gemm_q16.hip (f16 matrix cores, 256 x 128 tiles, f16 image) when its grid fills the chip,
+//   gemm_q.hip   (int8 matrix cores, 128 x 128 or 64 x 64 tiles, int8 image) for smaller problems.
+// GGML_HIP_GEMM=i8 / f16 forces one of them (developer A/B switch).
+bool use_f16_image(int64_t M, int64_t N) {
+    static const int force = [] { const char *e = getenv("GGML_HIP_GEMM"); return !e ? 0 : (e[0] == 'f' ? 2 : 1); }();
+    if (N <= GEMV_MAX_N) return false;
+    if (force) return force == 2;
+    return ((M + 127) / 128) * ((N + 127) / 128) >= 384;
 }
 
 int ensure_init() {
@@ -251,7 +255,7 @@ int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? w->type : -1; }
 
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
     if (!is_q(type) || K <= 0 || N <= 0) return 0;
-    return act_bytes(K, pad_rows(N));
+    return act_bytes(K, pad_act(N));
 }
 
 int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, void *d_work,
@@ -262,8 +266,8 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     if (ld1 < w->K) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K");
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
         return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", ggml_hip_mul_mat_work_size(w->type, w->K, N));
-    act_planes p = act_carve(d_work, w->K, pad_rows(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, use_f16_image(N), (hipStream_t)stream));
+    act_planes p = act_carve(d_work, w->K, pad_act(N));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, use_f16_image(w->M, N), (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
@@ -274,10 +278,10 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     if (!is_q(w->type)) return fail(GGML_HIP_ERR_TYPE, "compute_dev is the quantized COMPUTE phase; use ggml_hip_mul_mat_dev for dense");
     if (ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ldd < M");
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N)) return fail(GGML_HIP_ERR_ARG, "work buffer too small");
-    act_planes p = act_carve((void *)d_work, w->K, pad_rows(N));
+    act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
     if (N <= GEMV_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (use_f16_image(N))
+    else if (use_f16_image(w->M, N))
         HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else
         HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
@@ -292,6 +296,10 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
     if (!is_q(w->type)) {
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
+        return GGML_HIP_OK;
+    }
+    if (N <= GEMV_MAX_N) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
+        HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
     int rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
@@ -370,7 +378,7 @@ int ggml_hip_vec_dot(int type, int n, float *s, const void *vx, const void *vy) 
     hipError_t e = hipSuccess;
     if (!rc) {
         e = hipMemcpyAsync(g_src1.p, vy, yb, hipMemcpyHostToDevice, g_stream);
-        if (e == hipSuccess) e = launch_q8_aos_to_planes(vt, g_src1.p, 1, n, act_carve(g_work.p, n, pad_rows(1)), g_stream);
+        if (e == hipSuccess) e = launch_q8_aos_to_planes(vt, g_src1.p, 1, n, act_carve(g_work.p, n, pad_act(1)), g_stream);
         if (e == hipSuccess) rc = ggml_hip_mul_mat_compute_dev(w, 1, (float *)g_dst.p, 1, g_work.p, wb, g_stream);
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(s, g_dst.p, 4, hipMemcpyDeviceToHost, g_stream);
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(g_stream);

@@ -25,9 +25,12 @@ static_assert(sizeof(ggml_tensor) == 176, "TypeDefinitions.cs:65-99");
 static_assert(offsetof(ggml_tensor, op) == 72 && offsetof(ggml_tensor, grad) == 80 &&
               offsetof(ggml_tensor, n_tasks) == 136 && offsetof(ggml_tensor, data) == 160, "layout");
 
-// Rows of every device plane are padded to a multiple of this (the largest GEMM tile edge).
+// Rows of the weight planes are padded to a multiple of ROW_PAD (the widest weight tile of any kernel), rows of the
+// activation planes to ACT_PAD (the widest activation tile).
 #define ROW_PAD 128
+#define ACT_PAD 256
 static inline int64_t pad_rows(int64_t n) { return (n + ROW_PAD - 1) / ROW_PAD * ROW_PAD; }
+static inline int64_t pad_act(int64_t n) { return (n + ACT_PAD - 1) / ACT_PAD * ACT_PAD; }
 
 // ---- resident weight: planar (block-major) layout, see DESIGN.md "Data layout in HBM" ----
 //   Q4_0/Q4_1/Q5_0: qs [nbk][Mpad][16] bytes of nibbles exactly as in the reference block
@@ -85,6 +88,8 @@ hipError_t launch_quantize_rows(int type, const float *x, int64_t nrows, int64_t
 hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,
+                               hipStream_t st);
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,

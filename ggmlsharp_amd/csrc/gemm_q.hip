@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
                                                        const float *__restrict__ wd, const float *__restrict__ wm,
                                                        const int8_t *__restrict__ a8, const float *__restrict__ ad,
                                                        const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
-                                                       int64_t N, int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd) {
+                                                       int64_t N, int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd,
+                                                       int tiles_m, int tiles_n) {
     using T = Tile<TYPE, IT, JT>;
     constexpr int TN = T::TN, TM = T::TM;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -88,8 +89,13 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wn = wave >> 1, wm_ = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.x * TM;
-    const int64_t n0 = (int64_t)blockIdx.y * TN;
+    // XCD-aware tile order (speed only): workgroups b, b+8, b+16, ... share an XCD and its L2; each XCD gets a
+    // contiguous run of the tile list ordered "m fastest", so its resident workgroups share activation panels.
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int64_t m0 = (int64_t)(t_lin % tiles_m) * TM;
+    const int64_t n0 = (int64_t)(t_lin / tiles_m) * TN;
 
     f32x4 acc[IT][JT][4];
 #pragma unroll
@@ -109,45 +115,76 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
 
     auto stage_ptr = [&](int s) { return smem + (s & 1) * T::STAGE; };
 
+    // Every global address = uniform 64-bit base advancing by a constant per stage + per-thread 32-bit offset fixed
+    // for the whole kernel: no 64-bit or integer-multiply VALU work (both quarter-rate) inside the loop.
+    constexpr int A_PER_THREAD = BKB * 2 * TN / 256;
+    constexpr int W8_PER_THREAD = BKB * 2 * TM / 256;                   // Q8_0: int8 planes go straight to LDS
+    constexpr int SA_PER_THREAD = (BKB * TN + 255) / 256;
+    constexpr int SW_PER_THREAD = (BKB * TM + 255) / 256;
+    const uint32_t a_blk = (uint32_t)(2 * Npad * 16);
+    const uint32_t w_blk = (uint32_t)(Mpad * (TYPE == GGML_TYPE_Q8_0 ? 32 : 16));
+    uint32_t offA[A_PER_THREAD], offW[TYPE == GGML_TYPE_Q8_0 ? W8_PER_THREAD : W_PER_THREAD], offH[W_PER_THREAD];
+    uint32_t offDa[SA_PER_THREAD], offDw[SW_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+        const int c = tid + 256 * i, bh = c / TN, row = c % TN;          // bh = bb * 2 + half
+        offA[i] = (uint32_t)(bh >> 1) * a_blk + (uint32_t)(((bh & 1) * Npad + n0 + row) * 16);
+    }
+    if (TYPE == GGML_TYPE_Q8_0) {
+#pragma unroll
+        for (int i = 0; i < W8_PER_THREAD; ++i) {
+            const int c = tid + 256 * i, bh = c / TM, row = c % TM;
+            offW[i] = (uint32_t)(bh >> 1) * w_blk + (uint32_t)(((bh & 1) * Mpad + m0 + row) * 16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < W_PER_THREAD; ++i) {
+            const int c = tid + 256 * i, bb = c / TM, row = c % TM;
+            offW[i] = (uint32_t)bb * w_blk + (uint32_t)((m0 + row) * 16);
+            offH[i] = (uint32_t)((bb * Mpad + m0 + row) * 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SA_PER_THREAD; ++k) {
+        const int i = tid + 256 * k, bb = i / TN, row = i % TN;
+        offDa[k] = (uint32_t)((bb * Npad + n0 + row) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < SW_PER_THREAD; ++k) {
+        const int i = tid + 256 * k, bb = i / TM, row = i % TM;
+        offDw[k] = (uint32_t)((bb * Mpad + m0 + row) * 4);
+    }
+
     auto issue_loads = [&](int s) {
         uint8_t *sp = stage_ptr(s);
         const int64_t kb0 = (int64_t)s * BKB;
+        const int64_t left = nbk - kb0;                                  // k-blocks this stage really has (uniform)
+        const uint8_t *gA = (const uint8_t *)a8 + kb0 * a_blk;
+        const uint8_t *gW = wqs + kb0 * w_blk;
         // activations: [bb][h][TN rows][16 B], one 1-KiB wave instruction per 64 rows
-        {
-            uint8_t *sA = sp;
-            constexpr int A_CHUNKS = BKB * 2 * TN;
 #pragma unroll
-            for (int i = 0; i < A_CHUNKS / 256; ++i) {
-                const int c = tid + 256 * i;
-                const int bh = c / TN, row = c % TN;
-                int64_t b = kb0 + (bh >> 1);
-                if (b >= nbk) b = nbk - 1;  // tail stage: harmless re-read, its scales are zeroed below
-                const int8_t *g = a8 + (((b * 2 + (bh & 1)) * Npad) + n0 + row) * 16;
-                glds16(g, sA + (size_t)(c - lane) * 16);  // wave-uniform LDS base, hardware adds lane*16
-            }
+        for (int i = 0; i < A_PER_THREAD; ++i) {
+            const int c = tid + 256 * i, bb = (c / TN) >> 1;
+            // a k-block past the end re-reads block 0 of the stage (harmless: its scales are zeroed below)
+            const uint32_t off = offA[i] - (bb >= left ? (uint32_t)bb * a_blk : 0u);
+            glds16(gA + off, sp + (size_t)(c - lane) * 16);              // wave-uniform LDS base, hardware adds lane*16
         }
-        // weights
         if (TYPE == GGML_TYPE_Q8_0) {
             uint8_t *sW = sp + T::A_BYTES;
-            constexpr int WC = BKB * 2 * TM;
 #pragma unroll
-            for (int i = 0; i < WC / 256; ++i) {
-                const int c = tid + 256 * i;
-                const int bh = c / TM, row = c % TM;
-                int64_t b = kb0 + (bh >> 1);
-                if (b >= nbk) b = nbk - 1;
-                const uint8_t *g = wqs + (((b * 2 + (bh & 1)) * Mpad) + m0 + row) * 16;
-                glds16(g, sW + (size_t)(c - lane) * 16);
+            for (int i = 0; i < W8_PER_THREAD; ++i) {
+                const int c = tid + 256 * i, bb = (c / TM) >> 1;
+                const uint32_t off = offW[i] - (bb >= left ? (uint32_t)bb * w_blk : 0u);
+                glds16(gW + off, sW + (size_t)(c - lane) * 16);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < W_PER_THREAD; ++i) {
-                const int c = tid + 256 * i;
-                const int bb = c / TM, row = c % TM;
-                int64_t b = kb0 + bb;
-                if (b >= nbk) b = nbk - 1;
-                wreg[i] = *(const uint4 *)(wqs + ((b * Mpad) + m0 + row) * 16);
-                if (TYPE == GGML_TYPE_Q5_0) hreg[i] = wqh[b * Mpad + m0 + row];
+                const int c = tid + 256 * i, bb = c / TM;
+                const bool dead = bb >= left;
+                wreg[i] = *(const uint4 *)(gW + (offW[i] - (dead ? (uint32_t)bb * w_blk : 0u)));
+                if (TYPE == GGML_TYPE_Q5_0)
+                    hreg[i] = *(const uint32_t *)((const uint8_t *)(wqh + kb0 * Mpad) + (offH[i] - (dead ? (uint32_t)(bb * Mpad * 4) : 0u)));
             }
         }
     };
@@ -155,28 +192,29 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
     // scales: loaded to registers with the stage's other loads, written to LDS after the compute phase
     // (an LDS store right behind the load would stall on vmcnt(0) and drain the in-flight LDS-DMA).
     // A block index past nbk gets scale 0, which turns the whole tail block into +0.
-    constexpr int SA_PER_THREAD = (BKB * TN + 255) / 256;
-    constexpr int SW_PER_THREAD = (BKB * TM + 255) / 256;
     float dareg[SA_PER_THREAD], sareg[SA_PER_THREAD], dwreg[SW_PER_THREAD], mwreg[SW_PER_THREAD];
     auto load_scales = [&](int s) {
         const int64_t kb0 = (int64_t)s * BKB;
+        const int64_t left = nbk - kb0;
+        const uint8_t *gDa = (const uint8_t *)(ad + kb0 * Npad), *gSa = (const uint8_t *)(as + kb0 * Npad);
+        const uint8_t *gDw = (const uint8_t *)(wd + kb0 * Mpad), *gMw = (const uint8_t *)(wm + kb0 * Mpad);
 #pragma unroll
         for (int k = 0; k < SA_PER_THREAD; ++k) {
-            const int i = tid + 256 * k;
-            const int bb = i / TN, row = i % TN;
-            const int64_t b = kb0 + bb;
-            const bool ok = (i < BKB * TN) && (b < nbk);
-            dareg[k] = ok ? ad[b * Npad + n0 + row] : 0.0f;
-            if (TYPE == GGML_TYPE_Q4_1) sareg[k] = ok ? (float)as[b * Npad + n0 + row] : 0.0f;
+            const int i = tid + 256 * k, bb = i / TN;
+            const bool ok = (i < BKB * TN) && (bb < left);
+            const uint32_t off = offDa[k] - (ok ? 0u : (uint32_t)(bb * Npad * 4));   // dead block: re-read block 0 of the stage
+            const float v = *(const float *)(gDa + off);
+            dareg[k] = ok ? v : 0.0f;
+            if (TYPE == GGML_TYPE_Q4_1) { const int sv = *(const int32_t *)(gSa + off); sareg[k] = ok ? (float)sv : 0.0f; }
         }
 #pragma unroll
         for (int k = 0; k < SW_PER_THREAD; ++k) {
-            const int i = tid + 256 * k;
-            const int bb = i / TM, row = i % TM;
-            const int64_t b = kb0 + bb;
-            const bool ok = (i < BKB * TM) && (b < nbk);
-            dwreg[k] = ok ? wd[b * Mpad + m0 + row] : 0.0f;
-            if (TYPE == GGML_TYPE_Q4_1) mwreg[k] = ok ? wm[b * Mpad + m0 + row] : 0.0f;
+            const int i = tid + 256 * k, bb = i / TM;
+            const bool ok = (i < BKB * TM) && (bb < left);
+            const uint32_t off = offDw[k] - (ok ? 0u : (uint32_t)(bb * Mpad * 4));
+            const float v = *(const float *)(gDw + off);
+            dwreg[k] = ok ? v : 0.0f;
+            if (TYPE == GGML_TYPE_Q4_1) { const float v2 = *(const float *)(gMw + off); mwreg[k] = ok ? v2 : 0.0f; }
         }
     };
     auto store_scales = [&](int s) {
@@ -362,8 +400,10 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((unsigned)((w->M + T::TM - 1) / T::TM), (unsigned)((N + T::TN - 1) / T::TN));
-    kern<<<grid, 256, T::LDS, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad, w->nbk, ldd);
+    const int tiles_m = (int)((w->M + T::TM - 1) / T::TM), tiles_n = (int)((N + T::TN - 1) / T::TN);
+    dim3 grid((unsigned)(tiles_m * tiles_n));
+    kern<<<grid, 256, T::LDS, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad, w->nbk, ldd,
+                                    tiles_m, tiles_n);
     return hipGetLastError();
 }
 

@@ -29,9 +29,15 @@ __device__ __forceinline__ uint32_t q5_high_bits(uint32_t qh, int i, int sel) {
     return (t * 0x00410410u) & 0x10101010u;
 }
 
-template <int TYPE, int NC>
+// FUSED = true : src1 is f32; every workgroup quantizes the activation chunk itself (the INIT phase of
+//                 Ggml.cs:6641-6654 / quantize_row_q8_0 733-762, same arithmetic as K1, bit-exact) straight into LDS,
+//                 so the whole mul_mat at small N is ONE launch and one dependent memory round trip.
+// FUSED = false: src1 was quantized earlier (K1 planes, or reference Q8 blocks through ggml_hip_vec_dot).
+// The weight loads of a chunk are issued before the activations are staged, so both latencies overlap.
+template <int TYPE, int NC, bool FUSED>
 __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
                                                     const float *__restrict__ wd, const float *__restrict__ wm,
+                                                    const float *__restrict__ x, int64_t ld1,
                                                     const int8_t *__restrict__ a8, const float *__restrict__ ad,
                                                     const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
                                                     int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd, int N) {
@@ -42,7 +48,12 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4, u = wave * 4 + kq;
-    const int64_t row = (int64_t)blockIdx.x * GV_ROWS + r;  // < Mpad by construction
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a contiguous range of
+    // row tiles -- neighbouring tiles share the 128-byte lines of the scale plane.  Bijective for any grid size.
+    const int nt = gridDim.x, xcd = blockIdx.x & 7, q8 = nt >> 3, r8 = nt & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int64_t row = (int64_t)tile * GV_ROWS + r;  // < Mpad by construction
+    constexpr int BPL = GV_CHUNK / 16;                       // k-blocks per lane per chunk (8)
 
     float acc[NC];
 #pragma unroll
@@ -50,72 +61,122 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
 
     for (int64_t cb = 0; cb < nbk; cb += GV_CHUNK) {
         const int nbc = (int)((nbk - cb) < GV_CHUNK ? (nbk - cb) : GV_CHUNK);
-        __syncthreads();  // previous chunk fully consumed
-        for (int i = tid; i < nbc * 2 * NC; i += 256) {
-            const int c = i % NC, bh = i / NC;  // bh = b_local*2 + h
-            const int cc = c < N ? c : N - 1;
-            sA[i] = *(const uint4 *)(a8 + (((cb * 2 + bh) * Npad) + cc) * 16);
+
+        // 1. all of this lane's weight loads for the chunk go out first (8 x 16 B + scales in flight per lane)
+        uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
+        float dw[BPL], mw[TYPE == GGML_TYPE_Q4_1 ? BPL : 1];
+        uint32_t hb[TYPE == GGML_TYPE_Q5_0 ? BPL : 1];
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            const int bl = u + 16 * j;
+            const bool ok = bl < nbc;
+            const int64_t b = cb + (ok ? bl : 0);
+            if (TYPE == GGML_TYPE_Q8_0) {
+                q[j] = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + row) * 16);
+                q2[j] = *(const uint4 *)(qs + ((b * 2 + 1) * Mpad + row) * 16);
+            } else {
+                q[j] = *(const uint4 *)(qs + (b * Mpad + row) * 16);
+            }
+            dw[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
+            if (TYPE == GGML_TYPE_Q4_1) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
+            if (TYPE == GGML_TYPE_Q5_0) hb[j] = qh[b * Mpad + row];
         }
-        for (int i = tid; i < nbc * NC; i += 256) {
-            const int c = i % NC, bl = i / NC;
-            const int cc = c < N ? c : N - 1;
-            sD[i] = ad[(cb + bl) * Npad + cc];
-            sS[i] = as[(cb + bl) * Npad + cc];
+
+        // 2. activations of the chunk -> LDS (int8 even/odd planes + scale + block sum)
+        __syncthreads();  // previous chunk fully consumed
+        if (FUSED) {
+            const int t = tid & 7, grp = tid >> 3;             // 8 lanes per 32-element block, 32 groups
+            constexpr int ITEMS = GV_CHUNK * NC / 32;         // (column, k-block) items per group: 4 * NC
+            constexpr int UNR = 4;                              // loads in flight per lane
+#pragma unroll 1
+            for (int it0 = 0; it0 < ITEMS; it0 += UNR) {
+                float4 v[UNR];
+#pragma unroll
+                for (int k = 0; k < UNR; ++k) {
+                    const int w0 = grp + 32 * (it0 + k);
+                    const int c = w0 / GV_CHUNK, bl = w0 % GV_CHUNK;
+                    const int cc = c < N ? c : N - 1;
+                    const int blc = bl < nbc ? bl : nbc - 1;
+                    v[k] = *(const float4 *)(x + (int64_t)cc * ld1 + (cb + blc) * QK + 4 * t);
+                }
+#pragma unroll
+                for (int k = 0; k < UNR; ++k) {
+                    const int w0 = grp + 32 * (it0 + k);
+                    const int c = w0 / GV_CHUNK, bl = w0 % GV_CHUNK;
+                    const bool live = c < N && bl < nbc;       // uniform over the 8 lanes of the group
+                    float amax = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+                    amax = fmaxf(amax, __shfl_xor(amax, 1));
+                    amax = fmaxf(amax, __shfl_xor(amax, 2));
+                    amax = fmaxf(amax, __shfl_xor(amax, 4));
+                    const float d = amax / 127.0f;                  // Ggml.cs:751
+                    const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
+                    const int q0 = (int)rintf(v[k].x * id), q1 = (int)rintf(v[k].y * id);   // Ggml.cs:758-759 (D1, D2)
+                    const int q2_ = (int)rintf(v[k].z * id), q3 = (int)rintf(v[k].w * id);
+                    int sum = q0 + q1 + q2_ + q3;
+                    sum += __shfl_xor(sum, 1);
+                    sum += __shfl_xor(sum, 2);
+                    sum += __shfl_xor(sum, 4);
+                    const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2_ & 0xFFu) << 8);
+                    const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
+                    const bool even_lane = (t & 1) == 0;
+                    const uint32_t recv = (uint32_t)__shfl_xor((int)(even_lane ? o16 : e16), 1);
+                    const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));
+                    if (live) {
+                        uint8_t *base = (uint8_t *)sA;
+                        const int h = even_lane ? 0 : 1, off = even_lane ? 2 * t : 2 * t - 2;
+                        *(uint32_t *)(base + ((bl * 2 + h) * NC + c) * 16 + off) = word;
+                        if (t == 0) { sD[bl * NC + c] = d; sS[bl * NC + c] = sum; }
+                    }
+                }
+            }
+        } else {
+            for (int i = tid; i < nbc * 2 * NC; i += 256) {
+                const int c = i % NC, bh = i / NC;  // bh = b_local*2 + h
+                const int cc = c < N ? c : N - 1;
+                sA[i] = *(const uint4 *)(a8 + (((cb * 2 + bh) * Npad) + cc) * 16);
+            }
+            for (int i = tid; i < nbc * NC; i += 256) {
+                const int c = i % NC, bl = i / NC;
+                const int cc = c < N ? c : N - 1;
+                sD[i] = ad[(cb + bl) * Npad + cc];
+                sS[i] = as[(cb + bl) * Npad + cc];
+            }
         }
         __syncthreads();
 
-        for (int bl0 = u; bl0 < nbc; bl0 += 64) {
-            uint4 q[4], q2[4];
-            float dw[4], mw[4];
-            uint32_t hb[4];
+        // 3. integer block dots + f32 scale-accumulate (Ggml.cs:1136-1159)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int bl = bl0 + 16 * j;
-                const bool ok = bl < nbc;
-                const int64_t b = cb + (ok ? bl : 0);
-                if (TYPE == GGML_TYPE_Q8_0) {
-                    q[j] = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + row) * 16);
-                    q2[j] = *(const uint4 *)(qs + ((b * 2 + 1) * Mpad + row) * 16);
-                } else {
-                    q[j] = *(const uint4 *)(qs + (b * Mpad + row) * 16);
-                }
-                dw[j] = ok ? wd[b * Mpad + row] : 0.0f;
-                if (TYPE == GGML_TYPE_Q4_1) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
-                if (TYPE == GGML_TYPE_Q5_0) hb[j] = qh[b * Mpad + row];
-            }
+        for (int j = 0; j < BPL; ++j) {
+            const int bl = (u + 16 * j) < nbc ? (u + 16 * j) : 0;
+            const uint32_t qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            uint32_t lo[4], hi[4];
+            if (TYPE == GGML_TYPE_Q8_0) {
+                lo[0] = q[j].x; lo[1] = q[j].y; lo[2] = q[j].z; lo[3] = q[j].w;
+                hi[0] = q2[j].x; hi[1] = q2[j].y; hi[2] = q2[j].z; hi[3] = q2[j].w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int bl = (bl0 + 16 * j) < nbc ? (bl0 + 16 * j) : 0;  // dw = 0 kills the contribution
-                const uint32_t qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-                uint32_t lo[4], hi[4];
-                if (TYPE == GGML_TYPE_Q8_0) {
-                    lo[0] = q[j].x; lo[1] = q[j].y; lo[2] = q[j].z; lo[3] = q[j].w;
-                    hi[0] = q2[j].x; hi[1] = q2[j].y; hi[2] = q2[j].z; hi[3] = q2[j].w;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        lo[i] = qq[i] & 0x0F0F0F0Fu;          // elements 8i+0,2,4,6  (Ggml.cs:1149)
-                        hi[i] = (qq[i] >> 4) & 0x0F0F0F0Fu;   // elements 8i+1,3,5,7  (Ggml.cs:1150)
-                        if (TYPE == GGML_TYPE_Q5_0) {         // Ggml.cs:1285-1289
-                            lo[i] |= q5_high_bits(hb[j], i, 0);
-                            hi[i] |= q5_high_bits(hb[j], i, 1);
-                        }
+                for (int i = 0; i < 4; ++i) {
+                    lo[i] = qq[i] & 0x0F0F0F0Fu;          // elements 8i+0,2,4,6  (Ggml.cs:1149)
+                    hi[i] = (qq[i] >> 4) & 0x0F0F0F0Fu;   // elements 8i+1,3,5,7  (Ggml.cs:1150)
+                    if (TYPE == GGML_TYPE_Q5_0) {         // Ggml.cs:1285-1289
+                        lo[i] |= q5_high_bits(hb[j], i, 0);
+                        hi[i] |= q5_high_bits(hb[j], i, 1);
                     }
                 }
+            }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const uint4 a0 = sA[(bl * 2 + 0) * NC + c];
-                    const uint4 a1 = sA[(bl * 2 + 1) * NC + c];
-                    int s = 0;
-                    s = dot4(lo[0], a0.x, s); s = dot4(lo[1], a0.y, s); s = dot4(lo[2], a0.z, s); s = dot4(lo[3], a0.w, s);
-                    s = dot4(hi[0], a1.x, s); s = dot4(hi[1], a1.y, s); s = dot4(hi[2], a1.z, s); s = dot4(hi[3], a1.w, s);
-                    const float da = sD[bl * NC + c];
-                    const int sa = sS[bl * NC + c];
-                    if (TYPE == GGML_TYPE_Q4_0) s -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
-                    if (TYPE == GGML_TYPE_Q5_0) s -= 16 * sa;
-                    acc[c] = fmaf(dw[j] * da, (float)s, acc[c]);
-                    if (TYPE == GGML_TYPE_Q4_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);
-                }
+            for (int c = 0; c < NC; ++c) {
+                const uint4 a0 = sA[(bl * 2 + 0) * NC + c];
+                const uint4 a1 = sA[(bl * 2 + 1) * NC + c];
+                int s = 0;
+                s = dot4(lo[0], a0.x, s); s = dot4(lo[1], a0.y, s); s = dot4(lo[2], a0.z, s); s = dot4(lo[3], a0.w, s);
+                s = dot4(hi[0], a1.x, s); s = dot4(hi[1], a1.y, s); s = dot4(hi[2], a1.z, s); s = dot4(hi[3], a1.w, s);
+                const float da = sD[bl * NC + c];
+                const int sa = sS[bl * NC + c];
+                if (TYPE == GGML_TYPE_Q4_0) s -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
+                if (TYPE == GGML_TYPE_Q5_0) s -= 16 * sa;
+                acc[c] = fmaf(dw[j] * da, (float)s, acc[c]);
+                if (TYPE == GGML_TYPE_Q4_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);
             }
         }
     }
@@ -130,15 +191,16 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
     __syncthreads();
     if (tid < GV_ROWS * NC) {
         const int c = tid / GV_ROWS, rr = tid % GV_ROWS;
-        const int64_t m = (int64_t)blockIdx.x * GV_ROWS + rr;
+        const int64_t m = (int64_t)tile * GV_ROWS + rr;
         if (m < M && c < N) dst[(int64_t)c * ldd + m] = (sRed[0][c][rr] + sRed[1][c][rr]) + (sRed[2][c][rr] + sRed[3][c][rr]);
     }
 }
 
-template <int TYPE>
-hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+template <int TYPE, bool FUSED>
+hipError_t launch_typed(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
+                        int64_t ldd, hipStream_t st) {
     dim3 grid((unsigned)((w->M + GV_ROWS - 1) / GV_ROWS));
-#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC><<<grid, 256, 0, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N)
+#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED><<<grid, 256, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
     else if (N <= 4) GV_LAUNCH(4);
@@ -147,16 +209,28 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     return hipGetLastError();
 }
 
-}  // namespace
-
-hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+template <bool FUSED>
+hipError_t launch_any(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
+                      int64_t ldd, hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
     if (N > GEMV_MAX_N) return hipErrorInvalidValue;
     switch (w->type) {
-    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1, FUSED>(w, x, ld1, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }
+}
+
+}  // namespace
+
+hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    return launch_any<false>(w, nullptr, 0, p, N, dst, ldd, st);
+}
+
+hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,
+                               hipStream_t st) {
+    act_planes none = {nullptr, nullptr, nullptr, 0};
+    return launch_any<true>(w, x, ld1, none, N, dst, ldd, st);
 }

@@ -179,5 +179,5 @@ def test_argument_validation_without_touching_a_device():
     assert L.ggml_hip_weight_upload(G.Q4_0, p, 48, 1, 30, 0, 1, None, C.byref(h)) == _lib.ERR_SHAPE     # K % 32
     assert L.ggml_hip_weight_upload(G.Q4_0, p, 64, 1, 20, 0, 1, None, C.byref(h)) == _lib.ERR_SHAPE     # nb01 < row
     assert L.ggml_hip_weight_upload(G.Q4_0, None, 64, 1, 40, 0, 1, None, C.byref(h)) == _lib.ERR_ARG
-    assert L.ggml_hip_mul_mat_work_size(G.Q4_0, 4096, 512) == 128 * 4 * 512 * 16 + 2 * 128 * 512 * 4
+    assert L.ggml_hip_mul_mat_work_size(G.Q4_0, 4096, 500) == 128 * 4 * 512 * 16 + 2 * 128 * 512 * 4   # rows padded to 256
     assert L.ggml_hip_mul_mat_work_size(G.F32, 4096, 512) == 0                                          # Ggml.cs:3360-3364

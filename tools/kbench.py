@@ -66,6 +66,22 @@ def run(tname, M, K, N, iters, check=True, copies=1):
 
     t_init = ev_ms(init, iters)
     t_comp = ev_ms(comp, iters)
+    if N <= 8:   # launch-bound from Python: replay a captured graph of `reps` whole mul_mat calls instead
+        reps = max(copies, 32)
+
+        def full():
+            st["i"] += 1
+            device.mul_mat(ws[st["i"] % copies], x, out=out, work=work)
+        full()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(reps):
+                full()
+        t_graph = ev_ms(gr.replay, 20) / reps
+        ab1 = M * (K // 32) * {"q4_0": 20, "q4_1": 24, "q5_0": 22, "q8_0": 36}[tname] + 4 * K * N + 4 * M * N
+        print(f"   graph-replayed whole mul_mat (fused, {copies} rotating weight copies): {t_graph * 1e3:7.2f} us/call  "
+              f"{ab1 / t_graph / 1e6:8.1f} GB/s algorithmic", flush=True)
     flops = 2.0 * M * K * N
     blk = {"q4_0": 20, "q4_1": 24, "q5_0": 22, "q8_0": 36}[tname]
     ab = M * (K // 32) * blk + 4 * K * N + 4 * M * N

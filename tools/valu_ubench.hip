@@ -54,6 +54,28 @@ __global__ void k(float *out, long long *cyc, int n) {
             t[it & 15] += it;
         } else if (MODE == 6) {
             T = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, T, 0, 0, 0);
+        } else if (MODE == 7) {   // 32 v_mul_f32_dpp row_newbcast
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(a[r]) : "v"(s[r]), "v"(dw));
+                asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "=v"(s[r]) : "v"(a[r]), "v"(da));
+            }
+        } else if (MODE == 8) {   // f16 epilogue: 16 dpp mul + 16 fma + 2 f16 MFMAs
+            using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+            using f32x16 = __attribute__((ext_vector_type(16))) float;
+            f16x8 ha = __builtin_bit_cast(f16x8, fa), hb = __builtin_bit_cast(f16x8, fb);
+            f32x16 X = {0};
+            X = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, X, 0, 0, 0);
+            X = __builtin_amdgcn_mfma_f32_32x32x16_f16(hb, ha, X, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sc;
+                asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(sc) : "v"(s[r]), "v"(dw));
+                a[r] = fmaf(X[r], sc, a[r]);
+            }
+        } else if (MODE == 9) {   // 32 v_mul_lo_u32
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { t[r] = t[r] * (it + 3); t[r] = t[r] * (t[(r + 1) & 15] | 1); }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(a[r]), "+v"(s[r]), "+v"(t[r]));
@@ -94,6 +116,9 @@ int main() {
         run<4>("mix 16cvt+16mul+16fma", w, d_out, d_cyc);
         run<5>("mix(pk) + 1 mfma_i8", w, d_out, d_cyc);
         run<6>("1 mfma_i32_32x32x32_i8", w, d_out, d_cyc);
+        run<7>("32 v_mul_f32_dpp", w, d_out, d_cyc);
+        run<8>("f16 tile: 2 mfma + 16 dpp + 16 fma", w, d_out, d_cyc);
+        run<9>("32 v_mul_lo_u32", w, d_out, d_cyc);
     }
     return 0;
 }
