@@ -53,14 +53,13 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
 }
 
 // Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat:
-//   gemm_q16.hip (f16 matrix cores, 256 x 128 tiles, f16 image) when its grid fills the chip,
-//   gemm_q.hip   (int8 matrix cores, 128 x 128 or 64 x 64 tiles, int8 image) for smaller problems.
-// GGML_HIP_GEMM=i8 / f16 forces one of them (developer A/B switch).
+//   gemm_q.hip   (int8 matrix cores, 128 x 128 or 64 x 64 tiles, int8 image) -- the default,
+//   gemm_q16.hip (f16 matrix cores, 128 x 128 tiles, f16 image) with GGML_HIP_GEMM=f16 (developer A/B switch).
 bool use_f16_image(int64_t M, int64_t N) {
     static const int force = [] { const char *e = getenv("GGML_HIP_GEMM"); return !e ? 0 : (e[0] == 'f' ? 2 : 1); }();
     if (N <= GEMV_MAX_N) return false;
-    if (force) return force == 2;
-    return ((M + 127) / 128) * ((N + 127) / 128) >= 384;
+    (void)M;
+    return force == 2;   // default: the int8-MFMA kernel (A/B on one device: 255 us vs 277 us on 4096^3)
 }
 
 int ensure_init() {
