@@ -24,7 +24,7 @@ BLCK_SIZE = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q4_2: 16, Q4_3: 16, Q5_0: 32, Q
 TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 20, Q4_1: 24, Q4_2: 10, Q4_3: 12, Q5_0: 22, Q5_1: 24, Q8_0: 36, Q8_1: 44,
              I8: 1, I16: 2, I32: 4}
 
-GGML_OP_NONE, GGML_OP_MUL_MAT = 0, 20
+GGML_OP_NONE, GGML_OP_ADD, GGML_OP_MUL_MAT, GGML_OP_CPY = 0, 2, 20, 22
 GGML_TASK_INIT, GGML_TASK_COMPUTE, GGML_TASK_FINALIZE = 0, 1, 2
 
 OK, ERR_NO_DEVICE, ERR_TYPE, ERR_SHAPE, ERR_ARG, ERR_RUNTIME = 0, -1, -2, -3, -4, -5
@@ -100,6 +100,10 @@ SYMBOLS = {
     "ggml_hip_quantize_row": (C.c_int, [C.c_int, _P, _P, C.c_int]),
     "ggml_hip_dequantize_row": (C.c_int, [C.c_int, _P, _P, C.c_int]),
     "ggml_hip_vec_dot": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "ggml_hip_compute_forward_cpy": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
+    "ggml_hip_compute_forward_add": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
+    "ggml_hip_quantize_rows_src_dev": (C.c_int, [C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "ggml_hip_add_q_f32_rows_dev": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
     # ggml.h (host mirror)
     "ggml_init": (_P, [C.POINTER(ggml_init_params)]),
@@ -122,6 +126,10 @@ SYMBOLS = {
     "ggml_get_f32_1d": (C.c_float, [_T, C.c_int]),
     "ggml_set_f32_1d": (None, [_T, C.c_int, C.c_float]),
     "ggml_mul_mat": (_T, [_P, _T, _T]),
+    "ggml_view_tensor": (_T, [_P, _T]),
+    "ggml_dup_tensor": (_T, [_P, _T]),
+    "ggml_cpy": (_T, [_P, _T, _T]),
+    "ggml_add": (_T, [_P, _T, _T]),
     "ggml_build_forward": (None, [C.POINTER(ggml_cgraph), _T]),
     "ggml_build_forward_expand": (None, [C.POINTER(ggml_cgraph), _T]),
     "ggml_graph_compute": (C.c_int, [_P, C.POINTER(ggml_cgraph)]),

@@ -166,6 +166,17 @@ int make_weight(int type, const void *rows, bool rows_on_host, int64_t ne00, int
     return GGML_HIP_OK;
 }
 
+void invalidate_locked(const void *host_ptr) {
+    for (auto it = g_cache.begin(); it != g_cache.end();) {
+        if (std::get<0>(it->first) == host_ptr) {
+            for (ggml_hip_weight *w : it->second) ggml_hip_weight_free(w);
+            it = g_cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 void free_cache_locked() {
     for (auto &kv : g_cache)
         for (ggml_hip_weight *w : kv.second) ggml_hip_weight_free(w);
@@ -312,7 +323,7 @@ int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_
     if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q8_1))
         return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
     if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:336)");
-    HIP_TRY(launch_quantize_rows(type, d_x, nrows, k, d_blocks, (hipStream_t)stream));
+    HIP_TRY(launch_quantize_rows(type, GGML_TYPE_F32, d_x, k, nrows, k, d_blocks, (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
@@ -395,16 +406,114 @@ int ggml_hip_relayout_gathered_dev(const float *d_gathered, int G, int64_t N, in
     return GGML_HIP_OK;
 }
 
+int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int64_t ld, int64_t nrows, int64_t k,
+                                   void *d_blocks, void *stream) {
+    if (nrows <= 0) return GGML_HIP_OK;
+    if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q8_1))
+        return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
+    if (src_type != GGML_TYPE_F32 && src_type != GGML_TYPE_F16) return fail(GGML_HIP_ERR_TYPE, "quantize: source must be F32 or F16");
+    if (k % QK != 0 || ld < k) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 or ld < k");
+    if (src_type == GGML_TYPE_F16 && ld % 8 != 0) return fail(GGML_HIP_ERR_SHAPE, "f16 rows must be 16-byte aligned (ld %% 8)");
+    if (src_type == GGML_TYPE_F32 && ld % 4 != 0) return fail(GGML_HIP_ERR_SHAPE, "f32 rows must be 16-byte aligned (ld %% 4)");
+    HIP_TRY(launch_quantize_rows(type, src_type, d_x, ld, nrows, k, d_blocks, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_add_q_f32_rows_dev(int type, const void *d_blocks_in, const float *d_x, int64_t nrows, int64_t k,
+                                void *d_blocks_out, void *stream) {
+    if (nrows <= 0) return GGML_HIP_OK;
+    if (!d_blocks_in || !d_x || !d_blocks_out) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0))
+        return fail(GGML_HIP_ERR_TYPE, "add_q_f32: unsupported type %d", type);
+    if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:4893)");
+    HIP_TRY(launch_add_q_f32(type, d_blocks_in, d_x, nrows, k, d_blocks_out, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_cpy, quantizing branch of dup_f32 / dup_f16 (Ggml.cs:4339-4363, 3935-3966) */
+int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 struct ggml_tensor *dst) {
+    if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const int st = src0->type, dt = dst->type;
+    if (st != GGML_TYPE_F32 && st != GGML_TYPE_F16) return fail(GGML_HIP_ERR_TYPE, "cpy: src0 must be F32 or F16 (Ggml.cs:4602-4619)");
+    if (!(dt == GGML_TYPE_Q4_0 || dt == GGML_TYPE_Q4_1 || dt == GGML_TYPE_Q5_0 || dt == GGML_TYPE_Q8_0))
+        return fail(GGML_HIP_ERR_TYPE, "cpy: only the quantizing branch is on this path (dst type %d)", dt);
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t n_src = ne00 * ne01 * ne02 * ne03, n_dst = dst->ne[0] * dst->ne[1] * dst->ne[2] * dst->ne[3];
+    if (n_src != n_dst) return fail(GGML_HIP_ERR_SHAPE, "cpy: element counts differ (Ggml.cs:8281)");
+    const size_t es = st == GGML_TYPE_F32 ? 4 : 2;
+    if (src0->nb[0] != es) return fail(GGML_HIP_ERR_SHAPE, "cpy: src0 rows must be contiguous");
+    if (dst->nb[0] != TSIZE[dt] || dst->nb[1] != dst->nb[0] * (uint64_t)(dst->ne[0] / QK) || dst->nb[2] != dst->nb[1] * (uint64_t)dst->ne[1] ||
+        dst->nb[3] != dst->nb[2] * (uint64_t)dst->ne[2])
+        return fail(GGML_HIP_ERR_SHAPE, "cpy: dst must be contiguous (Ggml.cs:4290)");
+    if (ne00 % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "cpy: ne00 %% 32 != 0");
+    if (src0->nb[1] % 16 != 0 && ne01 * ne02 * ne03 > 1) return fail(GGML_HIP_ERR_SHAPE, "cpy: src0 row stride must be a multiple of 16 bytes");
+    if (!src0->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (n_src == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t row_in = (size_t)ne00 * es, rs = TSIZE[dt] * (size_t)(ne00 / QK);   // rs as in Ggml.cs:4345
+    if (g_src1.ensure(row_in * ne01) || g_dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+    size_t id = 0;
+    for (int64_t i03 = 0; i03 < ne03; ++i03)
+        for (int64_t i02 = 0; i02 < ne02; ++i02) {
+            const uint8_t *src = (const uint8_t *)src0->data + i02 * src0->nb[2] + i03 * src0->nb[3];
+            HIP_TRY(hipMemcpy2DAsync(g_src1.p, row_in, src, src0->nb[1], row_in, (size_t)ne01, hipMemcpyHostToDevice, g_stream));
+            rc = ggml_hip_quantize_rows_src_dev(dt, st, g_src1.p, ne00, ne01, ne00, g_dst.p, g_stream);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync((uint8_t *)dst->data + id, g_dst.p, rs * ne01, hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipStreamSynchronize(g_stream));
+            id += rs * ne01;
+        }
+    invalidate_locked(dst->data);   // dst is usually a future src0: its cached device copy (if any) is now stale
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906) */
+int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const int t = src0->type;
+    if (!(t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q8_0))
+        return fail(GGML_HIP_ERR_TYPE, "add: only a quantized src0 (add_q_f32) is on this path, got type %d", t);
+    if (dst->type != t || src1->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "add_q_f32: dst must have src0's type, src1 F32 (Ggml.cs:4863-4865)");
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != src1->ne[i] || src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: shapes differ (Ggml.cs:4803)");
+    if (src0->nb[0] != TSIZE[t] || dst->nb[0] != TSIZE[t] || src1->nb[0] != 4) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: permuted operand (Ggml.cs:4853-4854)");
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    if (ne00 % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "ne00 %% 32 != 0 (Ggml.cs:4893)");
+    if (src1->nb[1] % 16 != 0 && ne01 > 1) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: src1 row stride must be a multiple of 16 bytes");
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (ne00 * ne01 * ne02 * ne03 == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t rs = TSIZE[t] * (size_t)(ne00 / QK), rx = (size_t)ne00 * 4;
+    if (g_stage.ensure(rs * ne01) || g_src1.ensure(rx * ne01) || g_dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+    for (int64_t i03 = 0; i03 < ne03; ++i03)
+        for (int64_t i02 = 0; i02 < ne02; ++i02) {
+            const uint8_t *a = (const uint8_t *)src0->data + i02 * src0->nb[2] + i03 * src0->nb[3];
+            const uint8_t *b = (const uint8_t *)src1->data + i02 * src1->nb[2] + i03 * src1->nb[3];
+            // the reference offsets dst rows by i3*nb0 (Ggml.cs:4891), an upstream typo for nb3; intent is followed
+            uint8_t *d = (uint8_t *)dst->data + i02 * dst->nb[2] + i03 * dst->nb[3];
+            HIP_TRY(hipMemcpy2DAsync(g_stage.p, rs, a, src0->nb[1], rs, (size_t)ne01, hipMemcpyHostToDevice, g_stream));
+            HIP_TRY(hipMemcpy2DAsync(g_src1.p, rx, b, src1->nb[1], rx, (size_t)ne01, hipMemcpyHostToDevice, g_stream));
+            rc = ggml_hip_add_q_f32_rows_dev(t, g_stage.p, (const float *)g_src1.p, ne01, ne00, g_dst.p, g_stream);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy2DAsync(d, dst->nb[1], g_dst.p, rs, rs, (size_t)ne01, hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipStreamSynchronize(g_stream));
+        }
+    invalidate_locked(dst->data);
+    return GGML_HIP_OK;
+}
+
 void ggml_hip_invalidate(const void *host_ptr) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto it = g_cache.begin(); it != g_cache.end();) {
-        if (std::get<0>(it->first) == host_ptr) {
-            for (ggml_hip_weight *w : it->second) ggml_hip_weight_free(w);
-            it = g_cache.erase(it);
-        } else {
-            ++it;
-        }
-    }
+    invalidate_locked(host_ptr);
 }
 
 void ggml_hip_invalidate_all(void) {

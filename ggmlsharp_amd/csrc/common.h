@@ -84,7 +84,10 @@ hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms
 // quantize.hip
 hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, bool f16_image, hipStream_t st);
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
-hipError_t launch_quantize_rows(int type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st);
+hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,
+                                hipStream_t st);
+hipError_t launch_add_q_f32(int type, const void *blocks_in, const float *x, int64_t nrows, int64_t k, void *blocks_out,
+                            hipStream_t st);
 hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);

@@ -207,6 +207,45 @@ ggml_tensor *ggml_mul_mat(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
     return result;
 }
 
+ggml_tensor *ggml_view_tensor(ggml_context *ctx, ggml_tensor *src) {
+    if (!ctx || !src) return nullptr;
+    ggml_tensor *result = new_tensor_impl(ctx, src->type, src->n_dims, src->ne, src->data);
+    if (!result) return nullptr;
+    for (int i = 0; i < GGML_MAX_DIMS; ++i) result->nb[i] = src->nb[i];
+    return result;
+}
+
+ggml_tensor *ggml_dup_tensor(ggml_context *ctx, const ggml_tensor *src) {
+    if (!ctx || !src) return nullptr;
+    return new_tensor_impl(ctx, src->type, src->n_dims, src->ne, nullptr);
+}
+
+ggml_tensor *ggml_cpy(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
+    if (!ctx || !a || !b) return nullptr;
+    if (ggml_nelements(a) != ggml_nelements(b)) return nullptr;   // Debug.Assert, Ggml.cs:8281
+    if (a->grad != nullptr || b->grad != nullptr) return nullptr;  // "TODO: implement backward", Ggml.cs:8284-8288
+    ggml_tensor *result = ggml_view_tensor(ctx, b);
+    if (!result) return nullptr;
+    result->op = GGML_OP_CPY;
+    result->src0 = a;
+    result->src1 = b;
+    return result;
+}
+
+ggml_tensor *ggml_add(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
+    if (!ctx || !a || !b) return nullptr;
+    for (int i = 0; i < GGML_MAX_DIMS; ++i)
+        if (a->ne[i] != b->ne[i]) return nullptr;                   // ggml_are_same_shape, Ggml.cs:7874
+    const bool is_node = a->grad != nullptr || b->grad != nullptr;
+    ggml_tensor *result = ggml_dup_tensor(ctx, a);
+    if (!result) return nullptr;
+    result->op = GGML_OP_ADD;
+    result->grad = is_node ? ggml_dup_tensor(ctx, result) : nullptr;
+    result->src0 = a;
+    result->src1 = b;
+    return result;
+}
+
 void ggml_build_forward_expand(ggml_cgraph *cgraph, ggml_tensor *tensor) { visit_parents(cgraph, tensor); }
 
 void ggml_build_forward(ggml_cgraph *out, ggml_tensor *tensor) {
@@ -225,7 +264,7 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
     for (int i = 0; i < cgraph->n_nodes; i++) {
         ggml_tensor *node = cgraph->nodes[i];
         if (node->op == GGML_OP_NONE) continue;
-        if (node->op != GGML_OP_MUL_MAT) {
+        if (node->op != GGML_OP_MUL_MAT && node->op != GGML_OP_CPY && node->op != GGML_OP_ADD) {
             fprintf(stderr, "ggml_graph_compute: op %d is outside the MI355X mul_mat path (SURVEY.md 2.2)\n", node->op);
             return GGML_HIP_ERR_TYPE;
         }
@@ -239,7 +278,10 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         params.ith = 0; params.nth = node->n_tasks; params.wsize = 0; params.wdata = nullptr;
         for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {  // Ggml.cs:3553-3670
             params.type = phase;
-            const int rc = ggml_hip_compute_forward_mul_mat(&params, node->src0, node->src1, node);
+            int rc;
+            if (node->op == GGML_OP_MUL_MAT) rc = ggml_hip_compute_forward_mul_mat(&params, node->src0, node->src1, node);
+            else if (node->op == GGML_OP_CPY) rc = ggml_hip_compute_forward_cpy(&params, node->src0, node);   // Ggml.cs:8659-8663
+            else rc = ggml_hip_compute_forward_add(&params, node->src0, node->src1, node);                    // Ggml.cs:8566-8570
             if (rc != GGML_HIP_OK) return rc;
         }
         node->perf_runs++;

@@ -143,17 +143,9 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
 // K9 / K8: one thread per block, rows contiguous.  These serve the Seam-2 row functions and ggml_cpy-style
 // callers; they are checked bit for bit against the oracle.
 // ---------------------------------------------------------------------------------------------------------
+// ---- one block: 32 floats <-> one reference-format block (bit-exact statements of the reference's row functions) ----
 template <int TYPE>
-__global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblocks, uint8_t *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblocks) return;
-    float v[QK];
-    const float4 *p = (const float4 *)(x + i * QK);
-#pragma unroll
-    for (int l = 0; l < QK / 4; ++l) {
-        const float4 f = p[l];
-        v[4 * l + 0] = f.x; v[4 * l + 1] = f.y; v[4 * l + 2] = f.z; v[4 * l + 3] = f.w;
-    }
+__device__ __forceinline__ void quant_block(const float (&v)[QK], uint8_t *__restrict__ out) {
     if (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q5_0) {
         float amax = 0.0f, mx = 0.0f;                       // Ggml.cs:343-354 / 616-627
 #pragma unroll
@@ -164,7 +156,7 @@ __global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblock
         if (TYPE == GGML_TYPE_Q4_0) {
             const float d = mx / -8.0f;                     // Ggml.cs:356
             const float id = d != 0.0f ? 1.0f / d : 0.0f;
-            uint8_t *o = out + i * 20;
+            uint8_t *o = out;
             *(uint32_t *)o = __float_as_uint(d);
             uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -179,7 +171,7 @@ __global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblock
         } else {
             const float d = mx / -16.0f;                    // Ggml.cs:629
             const float id = d != 0.0f ? 1.0f / d : 0.0f;
-            uint16_t *o = (uint16_t *)(out + i * 22);
+            uint16_t *o = (uint16_t *)(out);
             o[0] = float_to_half_bits_rne(d);               // (Half)d, Ggml.cs:632
             uint32_t qh = 0;
             uint32_t w[4] = {0, 0, 0, 0};
@@ -204,7 +196,7 @@ __global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblock
         }
         const float d = (mx - mn) / 15.0f;
         const float id = d != 0.0f ? 1.0f / d : 0.0f;
-        uint8_t *o = out + i * 24;
+        uint8_t *o = out;
         *(uint32_t *)o = __float_as_uint(d);
         *(uint32_t *)(o + 4) = __float_as_uint(mn);
         uint32_t w[4] = {0, 0, 0, 0};
@@ -231,12 +223,12 @@ __global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblock
             if (l < 16) sum0 += q; else sum1 += q;
         }
         if (TYPE == GGML_TYPE_Q8_0) {
-            uint32_t *o = (uint32_t *)(out + i * 36);
+            uint32_t *o = (uint32_t *)(out);
             o[0] = __float_as_uint(d);
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[1 + k] = w[k];
         } else {
-            uint32_t *o = (uint32_t *)(out + i * 44);
+            uint32_t *o = (uint32_t *)(out);
             o[0] = __float_as_uint(d);
             o[1] = __float_as_uint(d * (float)sum0);         // Ggml.cs:820-821 (D3 signed sums)
             o[2] = __float_as_uint(d * (float)sum1);
@@ -247,12 +239,9 @@ __global__ void quantize_rows_kernel(const float *__restrict__ x, int64_t nblock
 }
 
 template <int TYPE>
-__global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t nblocks, float *__restrict__ y) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nblocks) return;
-    float v[QK];
+__device__ __forceinline__ void dequant_block(const uint8_t *__restrict__ in, float (&v)[QK]) {
     if (TYPE == GGML_TYPE_Q4_0) {
-        const uint32_t *s = (const uint32_t *)(in + i * 20);
+        const uint32_t *s = (const uint32_t *)(in);
         const float d = __uint_as_float(s[0]);
 #pragma unroll
         for (int l = 0; l < QK; l += 2) {
@@ -261,7 +250,7 @@ __global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t n
             v[l + 1] = (float)((int)(byte >> 4) - 8) * d;
         }
     } else if (TYPE == GGML_TYPE_Q4_1) {
-        const uint32_t *s = (const uint32_t *)(in + i * 24);
+        const uint32_t *s = (const uint32_t *)(in);
         const float d = __uint_as_float(s[0]), m = __uint_as_float(s[1]);
 #pragma unroll
         for (int l = 0; l < QK; l += 2) {
@@ -271,7 +260,7 @@ __global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t n
             v[l + 1] = p1 + m;
         }
     } else if (TYPE == GGML_TYPE_Q5_0) {
-        const uint16_t *s = (const uint16_t *)(in + i * 22);
+        const uint16_t *s = (const uint16_t *)(in);
         const float d = half_bits_to_float_q(s[0]);
         const uint32_t qh = (uint32_t)s[1] | ((uint32_t)s[2] << 16);
 #pragma unroll
@@ -283,7 +272,7 @@ __global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t n
             v[l + 1] = (float)(vi1 - 16) * d;
         }
     } else {  // Q8_0
-        const uint32_t *s = (const uint32_t *)(in + i * 36);
+        const uint32_t *s = (const uint32_t *)(in);
         const float d = __uint_as_float(s[0]);
 #pragma unroll
         for (int l = 0; l < QK; ++l) {
@@ -291,9 +280,68 @@ __global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t n
             v[l] = (float)q * d;                               // Ggml.cs:1119 (signed, D4)
         }
     }
+}
+
+template <int TYPE> struct BlockBytes { static constexpr int value = TYPE == GGML_TYPE_Q4_0 ? 20 : TYPE == GGML_TYPE_Q4_1 ? 24 : TYPE == GGML_TYPE_Q5_0 ? 22 : TYPE == GGML_TYPE_Q8_0 ? 36 : 44; };
+
+// K9: rows of f32 (SRC_F16 = false) or f16 (true; widened exactly first, Ggml.cs:3951-3956) -> blocks.
+// Row r of the source starts at x + r * ld elements; blocks of a row are contiguous, rows of blocks are contiguous.
+template <int TYPE, bool SRC_F16>
+__global__ void quantize_rows_kernel(const void *__restrict__ x, int64_t ld, int64_t nbr, int64_t nblocks, uint8_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    const int64_t r = i / nbr, bi = i - r * nbr;
+    float v[QK];
+    if (SRC_F16) {
+        const uint4 *p = (const uint4 *)((const uint16_t *)x + r * ld + bi * QK);
+#pragma unroll
+        for (int l = 0; l < QK / 8; ++l) {
+            const uint4 h = p[l];
+            const uint32_t w[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[8 * l + 2 * k + 0] = half_bits_to_float_q((uint16_t)(w[k] & 0xFFFFu));
+                v[8 * l + 2 * k + 1] = half_bits_to_float_q((uint16_t)(w[k] >> 16));
+            }
+        }
+    } else {
+        const float4 *p = (const float4 *)((const float *)x + r * ld + bi * QK);
+#pragma unroll
+        for (int l = 0; l < QK / 4; ++l) {
+            const float4 f = p[l];
+            v[4 * l + 0] = f.x; v[4 * l + 1] = f.y; v[4 * l + 2] = f.z; v[4 * l + 3] = f.w;
+        }
+    }
+    quant_block<TYPE>(v, out + i * BlockBytes<TYPE>::value);
+}
+
+template <int TYPE>
+__global__ void dequantize_rows_kernel(const uint8_t *__restrict__ in, int64_t nblocks, float *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    float v[QK];
+    dequant_block<TYPE>(in + i * BlockBytes<TYPE>::value, v);
     float4 *o = (float4 *)(y + i * QK);
 #pragma unroll
     for (int l = 0; l < QK / 4; ++l) o[l] = make_float4(v[4 * l + 0], v[4 * l + 1], v[4 * l + 2], v[4 * l + 3]);
+}
+
+// ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906) per block: dequantize_row_q -> ggml_vec_acc_f32 (y += x) ->
+// quantize_row_q, all in registers: 0.625 + 4 B read, 0.625 B written per element (Q4_0).  Bit-exact composition.
+template <int TYPE>
+__global__ void add_q_f32_kernel(const uint8_t *__restrict__ in, const float *__restrict__ x, int64_t nblocks,
+                                 uint8_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nblocks) return;
+    float v[QK];
+    dequant_block<TYPE>(in + i * BlockBytes<TYPE>::value, v);
+    const float4 *p = (const float4 *)(x + i * QK);
+#pragma unroll
+    for (int l = 0; l < QK / 4; ++l) {
+        const float4 f = p[l];
+        v[4 * l + 0] += f.x; v[4 * l + 1] += f.y; v[4 * l + 2] += f.z; v[4 * l + 3] += f.w;
+    }
+    quant_block<TYPE>(v, out + i * BlockBytes<TYPE>::value);
 }
 
 // reference-format Q8_0 / Q8_1 rows (block_q8_0 36 B, block_q8_1 44 B) -> the planar scratch the dot kernels read.
@@ -336,17 +384,38 @@ hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1
     return hipGetLastError();
 }
 
-hipError_t launch_quantize_rows(int type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st) {
-    const int64_t nblocks = nrows * (k / QK);
+hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,
+                                hipStream_t st) {
+    const int64_t nbr = k / QK, nblocks = nrows * nbr;
     if (nblocks <= 0) return hipSuccess;
     dim3 grid((unsigned)((nblocks + 127) / 128));
     uint8_t *o = (uint8_t *)blocks;
+#define QR(T) do { if (src_type == GGML_TYPE_F16) quantize_rows_kernel<T, true><<<grid, 128, 0, st>>>(x, ld, nbr, nblocks, o); \
+                   else quantize_rows_kernel<T, false><<<grid, 128, 0, st>>>(x, ld, nbr, nblocks, o); } while (0)
     switch (type) {
-    case GGML_TYPE_Q4_0: quantize_rows_kernel<GGML_TYPE_Q4_0><<<grid, 128, 0, st>>>(x, nblocks, o); break;
-    case GGML_TYPE_Q4_1: quantize_rows_kernel<GGML_TYPE_Q4_1><<<grid, 128, 0, st>>>(x, nblocks, o); break;
-    case GGML_TYPE_Q5_0: quantize_rows_kernel<GGML_TYPE_Q5_0><<<grid, 128, 0, st>>>(x, nblocks, o); break;
-    case GGML_TYPE_Q8_0: quantize_rows_kernel<GGML_TYPE_Q8_0><<<grid, 128, 0, st>>>(x, nblocks, o); break;
-    case GGML_TYPE_Q8_1: quantize_rows_kernel<GGML_TYPE_Q8_1><<<grid, 128, 0, st>>>(x, nblocks, o); break;
+    case GGML_TYPE_Q4_0: QR(GGML_TYPE_Q4_0); break;
+    case GGML_TYPE_Q4_1: QR(GGML_TYPE_Q4_1); break;
+    case GGML_TYPE_Q5_0: QR(GGML_TYPE_Q5_0); break;
+    case GGML_TYPE_Q8_0: QR(GGML_TYPE_Q8_0); break;
+    case GGML_TYPE_Q8_1: QR(GGML_TYPE_Q8_1); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef QR
+    return hipGetLastError();
+}
+
+hipError_t launch_add_q_f32(int type, const void *blocks_in, const float *x, int64_t nrows, int64_t k, void *blocks_out,
+                            hipStream_t st) {
+    const int64_t nblocks = nrows * (k / QK);
+    if (nblocks <= 0) return hipSuccess;
+    dim3 grid((unsigned)((nblocks + 127) / 128));
+    const uint8_t *in = (const uint8_t *)blocks_in;
+    uint8_t *o = (uint8_t *)blocks_out;
+    switch (type) {
+    case GGML_TYPE_Q4_0: add_q_f32_kernel<GGML_TYPE_Q4_0><<<grid, 128, 0, st>>>(in, x, nblocks, o); break;
+    case GGML_TYPE_Q4_1: add_q_f32_kernel<GGML_TYPE_Q4_1><<<grid, 128, 0, st>>>(in, x, nblocks, o); break;
+    case GGML_TYPE_Q5_0: add_q_f32_kernel<GGML_TYPE_Q5_0><<<grid, 128, 0, st>>>(in, x, nblocks, o); break;
+    case GGML_TYPE_Q8_0: add_q_f32_kernel<GGML_TYPE_Q8_0><<<grid, 128, 0, st>>>(in, x, nblocks, o); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

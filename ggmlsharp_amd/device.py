@@ -119,6 +119,27 @@ def quantize_rows(type, x):
     return out
 
 
+def quantize_rows_from(type, x):
+    """x f32 or f16 [nrows, k] on the device (row stride may exceed k) -> reference-format blocks."""
+    assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, torch.float16)
+    nrows, k = x.shape
+    out = torch.empty((nrows, k // 32 * TYPE_SIZE[type]), dtype=torch.uint8, device=x.device)
+    check(lib().ggml_hip_quantize_rows_src_dev(type, 0 if x.dtype == torch.float32 else 1, C.c_void_p(x.data_ptr()),
+                                               x.stride(0), nrows, k, C.c_void_p(out.data_ptr()), _stream()),
+          "ggml_hip_quantize_rows_src_dev")
+    return out
+
+
+def add_q_f32_rows(type, blocks, x):
+    """blocks uint8 [nrows, k/32*type_size], x f32 [nrows, k] -> quantize(dequantize(blocks) + x)."""
+    assert blocks.is_cuda and x.is_cuda and blocks.is_contiguous() and x.is_contiguous() and x.dtype == torch.float32
+    nrows, k = x.shape
+    out = torch.empty_like(blocks)
+    check(lib().ggml_hip_add_q_f32_rows_dev(type, C.c_void_p(blocks.data_ptr()), C.c_void_p(x.data_ptr()), nrows, k,
+                                            C.c_void_p(out.data_ptr()), _stream()), "ggml_hip_add_q_f32_rows_dev")
+    return out
+
+
 def dequantize_rows(type, blocks, k):
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
     nrows = blocks.numel() // (k // 32 * TYPE_SIZE[type])

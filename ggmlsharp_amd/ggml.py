@@ -57,6 +57,14 @@ def ggml_mul_mat(ctx, a, b):
     return _lib.lib().ggml_mul_mat(ctx, a, b)
 
 
+def ggml_cpy(ctx, a, b):
+    return _lib.lib().ggml_cpy(ctx, a, b)
+
+
+def ggml_add(ctx, a, b):
+    return _lib.lib().ggml_add(ctx, a, b)
+
+
 def ggml_build_forward(tensor):
     g = ggml_cgraph()
     _lib.lib().ggml_build_forward(C.byref(g), tensor)

@@ -5,8 +5,9 @@
  * In the reference this surface is C# (`public static` members of GGMLSharp.Ggml).  No .NET toolchain exists in the
  * build image, so the host side above the C-ABI (ggml_hip.h) is written in C++ with the same names, argument
  * meaning, struct layouts and pool arithmetic, exported with C linkage so the parity tests read like the
- * reference's own Test0/Test3 programs.  A GGML_OP_MUL_MAT node is computed by the HIP path through
- * ggml_hip_compute_forward_mul_mat -- the product has no CPU compute path; any other op in a graph is reported
+ * reference's own Test0/Test3 programs.  GGML_OP_MUL_MAT nodes are computed by the HIP path through
+ * ggml_hip_compute_forward_mul_mat, GGML_OP_CPY (f32/f16 -> quantized) and GGML_OP_ADD (quantized + f32) through
+ * ggml_hip_compute_forward_cpy / _add -- the product has no CPU compute path; any other op in a graph is reported
  * as unsupported (out of scope).
  *
  * Deviations from the reference signatures, all forced by C linkage or by the missing error channel:
@@ -108,6 +109,15 @@ void  ggml_set_f32_1d(struct ggml_tensor *t, int i, float value);
 /* Ggml.cs:7137-7151 -> ggml_mul_mat_impl 8222-8246: result F32 {a.ne1, b.ne1, a.ne2, b.ne3}; NULL if !ggml_can_mul_mat
  * or a is transposed (the reference Debug.Asserts, :8228-8229) */
 struct ggml_tensor *ggml_mul_mat(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
+
+/* Ggml.cs:3751-3763, 2425-2428 */
+struct ggml_tensor *ggml_view_tensor(struct ggml_context *ctx, struct ggml_tensor *src);
+struct ggml_tensor *ggml_dup_tensor(struct ggml_context *ctx, const struct ggml_tensor *src);
+/* Ggml.cs:7169-7175 -> ggml_cpy_impl 8275-8299: a view of b with op = CPY, src0 = a, src1 = b.
+ * The only public way to make a quantized tensor; NULL if element counts differ (:8281). */
+struct ggml_tensor *ggml_cpy(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
+/* Ggml.cs:6846-6852 -> ggml_add_impl 7868-7891: result has a's type and shape; NULL unless same shape (:7874). */
+struct ggml_tensor *ggml_add(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
 
 /* Ggml.cs:7648-7673 */
 void ggml_build_forward(struct ggml_cgraph *out, struct ggml_tensor *tensor);

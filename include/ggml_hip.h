@@ -181,6 +181,24 @@ int ggml_hip_quantize_row(int type, const float *x, void *y, int k);
 int ggml_hip_dequantize_row(int type, const void *x, float *y, int k);
 int ggml_hip_vec_dot(int type, int n, float *s, const void *vx, const void *vy);  /* vy in vec_dot_type blocks */
 
+/* ---------------- neighbours of the path (SURVEY.md 8(f) "next") ----------------
+ * ggml_compute_forward_cpy -> ggml_compute_forward_dup_f32 / _dup_f16, quantizing branch (Ggml.cs:8659-8663,
+ * 4339-4363, 3935-3966): src0 F32 or F16 with contiguous rows, dst a contiguous Q4_0 / Q4_1 / Q5_0 / Q8_0 tensor with
+ * the same element count.  This is the only public way to produce a quantized tensor in the reference; on the device
+ * it uses the intended quantize_row_q4_0 (== _reference), not the broken AVX packNibbles path.
+ * Same offload convention as Seam 1 (acts for ith == 0, COMPUTE phase). */
+int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 struct ggml_tensor *dst);
+/* ggml_compute_forward_add for a quantized src0 = ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906):
+ * dst row = quantize_row_q(dequantize_row_q(src0 row) + src1 row); src1 F32, dst the type and shape of src0. */
+int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 const struct ggml_tensor *src1, struct ggml_tensor *dst);
+/* Device forms.  src_type F32 or F16; source rows ld elements apart; blocks of all rows contiguous. */
+int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int64_t ld, int64_t nrows, int64_t k,
+                                   void *d_blocks, void *stream);
+int ggml_hip_add_q_f32_rows_dev(int type, const void *d_blocks_in, const float *d_x, int64_t nrows, int64_t k,
+                                void *d_blocks_out, void *stream);
+
 /* ---------------- multi-GPU helper ----------------
  * After an all-gather of per-rank dst shards ([G][N][Ms], rank-major) produce the reference layout
  * [N][G*Ms -> M] (SURVEY.md 8(e) "layout catch").  rows of the last rank beyond M are dropped. */

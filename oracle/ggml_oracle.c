@@ -728,6 +728,58 @@ int oracle_mul_mat(const oracle_tensor *src0, const oracle_tensor *src1, const o
     return 0;
 }
 
+/* ================= neighbours of the path: cpy (f32/f16 -> Q) and add_q_f32 ================= */
+
+static int q_rw_ok(int t) { return t == ORACLE_TYPE_Q4_0 || t == ORACLE_TYPE_Q4_1 || t == ORACLE_TYPE_Q5_0 || t == ORACLE_TYPE_Q8_0; }
+
+/* Ggml.cs:4339-4363 (dup_f32) and 3935-3966 (dup_f16): rows of src0 in (i03, i02, i01) order, dst written densely */
+int oracle_cpy_to_q(const oracle_tensor *src0, const oracle_tensor *dst) {
+    if ((src0->type != ORACLE_TYPE_F32 && src0->type != ORACLE_TYPE_F16) || !q_rw_ok(dst->type)) return -1;
+    if (nelements(src0) != nelements(dst)) return -2;                       /* Ggml.cs:8281 */
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    if (ne00 % 32 != 0 || src0->nb[0] != TYPE_SIZE[src0->type]) return -2;
+    const size_t rs = TYPE_SIZE[dst->type] * (size_t)(ne00 / BLCK_SIZE[dst->type]);   /* :4345 */
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)ne00);
+    if (!tmp) return -2;
+    size_t id = 0;
+    for (int64_t i03 = 0; i03 < ne03; i03++)
+        for (int64_t i02 = 0; i02 < ne02; i02++)
+            for (int64_t i01 = 0; i01 < ne01; i01++) {
+                const uint8_t *row = (const uint8_t *)src0->data + i01 * src0->nb[1] + i02 * src0->nb[2] + i03 * src0->nb[3];
+                const float *xf = (const float *)row;
+                if (src0->type == ORACLE_TYPE_F16) {                        /* :3951-3956 */
+                    for (int64_t i = 0; i < ne00; i++) tmp[i] = oracle_f16_to_f32(((const uint16_t *)row)[i]);
+                    xf = tmp;
+                }
+                oracle_quantize_row(dst->type, xf, (uint8_t *)dst->data + id, (int)ne00);
+                id += rs;
+            }
+    free(tmp);
+    return 0;
+}
+
+int oracle_add_q_f32(const oracle_tensor *src0, const oracle_tensor *src1, const oracle_tensor *dst) {
+    const int t = src0->type;
+    if (!q_rw_ok(t) || dst->type != t || src1->type != ORACLE_TYPE_F32) return -1;
+    for (int i = 0; i < 4; i++) if (src0->ne[i] != src1->ne[i] || src0->ne[i] != dst->ne[i]) return -2;
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    if (ne00 % 32 != 0 || src0->nb[0] != TYPE_SIZE[t] || src1->nb[0] != 4 || dst->nb[0] != TYPE_SIZE[t]) return -2;
+    float *w = (float *)malloc(sizeof(float) * (size_t)ne00);
+    if (!w) return -2;
+    for (int64_t i03 = 0; i03 < ne03; i03++)
+        for (int64_t i02 = 0; i02 < ne02; i02++)
+            for (int64_t i01 = 0; i01 < ne01; i01++) {
+                const uint8_t *a = (const uint8_t *)src0->data + i01 * src0->nb[1] + i02 * src0->nb[2] + i03 * src0->nb[3];
+                const float *b = (const float *)((const uint8_t *)src1->data + i01 * src1->nb[1] + i02 * src1->nb[2] + i03 * src1->nb[3]);
+                uint8_t *d = (uint8_t *)dst->data + i01 * dst->nb[1] + i02 * dst->nb[2] + i03 * dst->nb[3];
+                oracle_dequantize_row(t, a, w, (int)ne00);                  /* :4896 */
+                for (int64_t i = 0; i < ne00; i++) w[i] += b[i];           /* :4898, ggml_vec_acc_f32 */
+                oracle_quantize_row(t, w, d, (int)ne00);                    /* :4900 */
+            }
+    free(w);
+    return 0;
+}
+
 /* ================= Test3 LCG (Test3/Program.cs:98-107) ================= */
 static uint64_t lcg_next = 1;
 void oracle_xsrand(uint64_t seed) { lcg_next = seed; }

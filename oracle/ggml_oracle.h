@@ -120,6 +120,16 @@ size_t oracle_mul_mat_work_size(const oracle_tensor *src0, const oracle_tensor *
 int oracle_mul_mat(const oracle_tensor *src0, const oracle_tensor *src1, const oracle_tensor *dst,
                    void *wdata, size_t wsize, int nth);
 
+/* ggml_compute_forward_cpy -> dup_f32 / dup_f16, quantizing branch (Ggml.cs:4339-4363, 3935-3966): every src0 row
+ * (F32, or F16 widened to f32 first) -> quantize_row_q into a contiguous dst.  quantize_row_q4_0 == _reference (D5).
+ * Returns 0, -1 unsupported types, -2 shape / stride precondition. */
+int oracle_cpy_to_q(const oracle_tensor *src0, const oracle_tensor *dst);
+
+/* ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906): per row dequantize_row_q -> y += x (ggml_vec_acc_f32) ->
+ * quantize_row_q.  The dst row offset uses nb3 for i3 (the reference has `i3*nb0`, Ggml.cs:4891, an upstream typo
+ * that only matters for ne03 > 1; intent followed, "I" policy). */
+int oracle_add_q_f32(const oracle_tensor *src0, const oracle_tensor *src1, const oracle_tensor *dst);
+
 /* Test3's LCG (Test3/Program.cs:98-107): xsrand(seed); xrand() -> (next >> 16) & 0x7FFF. */
 void     oracle_xsrand(uint64_t seed);
 uint32_t oracle_xrand(void);

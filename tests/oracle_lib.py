@@ -44,6 +44,8 @@ def lib():
         L.oracle_mul_mat.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor), C.POINTER(OTensor),
                                      C.c_void_p, C.c_size_t, C.c_int]
         L.oracle_mul_mat_work_size.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor)]
+        L.oracle_cpy_to_q.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor)]
+        L.oracle_add_q_f32.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor), C.POINTER(OTensor)]
         _lib = L
     return _lib
 
@@ -123,3 +125,34 @@ def mul_mat(t, w_raw, x, M, K, N, nth=1, ne2=1, ne3=1):
     rc = lib().oracle_mul_mat(C.byref(s0), C.byref(s1), C.byref(d), _p(work), ws, nth)
     assert rc == 0, rc
     return dst
+
+
+def cpy_to_q(t_dst, src):
+    """src: f32 or f16 numpy [..., ne0] (contiguous) -> raw blocks of type t_dst, same leading shape."""
+    src = np.ascontiguousarray(src)
+    st = F32 if src.dtype == np.float32 else F16
+    shape = list(src.shape)
+    ne = list(reversed(shape)) + [1] * (4 - len(shape))
+    k = shape[-1]
+    rb = k // blck_size(t_dst) * type_size(t_dst)
+    out = np.zeros(shape[:-1] + [rb], dtype=np.uint8)
+    s0 = make_tensor(st, src.view(np.uint16) if st == F16 else src, ne)
+    d = make_tensor(t_dst, out, ne)
+    rc = lib().oracle_cpy_to_q(C.byref(s0), C.byref(d))
+    assert rc == 0, rc
+    return out
+
+
+def add_q_f32(t, blocks, x):
+    """blocks: uint8 [..., k/32*type_size] of type t; x: f32 [..., k] -> quantize(dequantize(blocks) + x)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    shape = list(x.shape)
+    ne = list(reversed(shape)) + [1] * (4 - len(shape))
+    out = np.zeros_like(blocks)
+    s0 = make_tensor(t, blocks, ne)
+    s1 = make_tensor(F32, x, ne)
+    d = make_tensor(t, out, ne)
+    rc = lib().oracle_add_q_f32(C.byref(s0), C.byref(s1), C.byref(d))
+    assert rc == 0, rc
+    return out

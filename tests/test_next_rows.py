@@ -1,0 +1,143 @@
+"""SURVEY.md 8(f) "next" rows: ggml_cpy f32/f16 -> quantized (the only public way to make a Q tensor in the reference)
+and ggml_add with a quantized src0 (add_q_f32).  CPU: the oracle composes its own row functions; host-mirror node
+construction.  GPU: the HIP path through the C-ABI, bit-exact against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ggmlsharp_amd import _lib
+from ggmlsharp_amd import ggml as G
+
+RNG = np.random.default_rng(77)
+QT = [O.Q4_0, O.Q4_1, O.Q5_0, O.Q8_0]
+
+
+def _rand(shape, scale=1.0):
+    return (RNG.standard_normal(shape) * scale).astype(np.float32)
+
+
+# ------------------------------------------------------------------ CPU: oracle
+@pytest.mark.parametrize("t", QT)
+def test_oracle_cpy_is_rowwise_quantize(t):
+    x = _rand((2, 3, 5, 64))
+    got = O.cpy_to_q(t, x)
+    assert np.array_equal(got, O.quantize_row(t, x))
+    xh = x.astype(np.float16)
+    got_h = O.cpy_to_q(t, xh)
+    assert np.array_equal(got_h, O.quantize_row(t, xh.astype(np.float32)))   # f16 widened exactly, then quantized
+
+
+@pytest.mark.parametrize("t", QT)
+def test_oracle_add_q_f32_is_dequant_add_requant(t):
+    w = _rand((4, 96), 2.0)
+    b = O.quantize_row(t, w)
+    x = _rand((4, 96), 0.5)
+    got = O.add_q_f32(t, b, x)
+    want = O.quantize_row(t, (O.dequantize_row(t, b, 96) + x).astype(np.float32))
+    assert np.array_equal(got, want)
+    # adding zero to a Q8_0 row is the identity on its values (quantize . dequantize fixed point)
+    if t == O.Q8_0:
+        same = O.add_q_f32(t, b, np.zeros_like(x))
+        assert np.array_equal(O.dequantize_row(t, same, 96), O.dequantize_row(t, b, 96))
+
+
+def test_host_mirror_cpy_and_add_nodes():
+    ctx = G.ggml_init(4 * 1024 * 1024)
+    try:
+        a = G.ggml_new_tensor_2d(ctx, G.F32, 64, 6)
+        b = G.ggml_new_tensor_2d(ctx, G.Q4_0, 64, 6)
+        c = G.ggml_cpy(ctx, a, b)
+        cc = c.contents
+        assert cc.op == _lib.GGML_OP_CPY and cc.type == G.Q4_0 and cc.data == b.contents.data      # a view of b (Ggml.cs:8292)
+        assert (cc.nb[0], cc.nb[1]) == (20, 40)
+        assert C.addressof(cc.src0.contents) == C.addressof(a.contents) and C.addressof(cc.src1.contents) == C.addressof(b.contents)
+        assert not G.ggml_cpy(ctx, a, G.ggml_new_tensor_2d(ctx, G.Q4_0, 64, 5))                       # element counts differ
+        x = G.ggml_new_tensor_2d(ctx, G.F32, 64, 6)
+        s = G.ggml_add(ctx, b, x)
+        sc = s.contents
+        assert sc.op == _lib.GGML_OP_ADD and sc.type == G.Q4_0 and sc.data != b.contents.data        # a dup of a (Ggml.cs:7883)
+        assert not G.ggml_add(ctx, b, G.ggml_new_tensor_2d(ctx, G.F32, 64, 5))
+        gf = G.ggml_build_forward(G.ggml_mul_mat(ctx, s, x))
+        assert (gf.n_nodes, gf.n_leafs) == (2, 2)                                                     # add, mul_mat ; b, x
+    finally:
+        G.ggml_free(ctx)
+
+
+# ------------------------------------------------------------------ GPU: HIP path
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", QT)
+def test_device_quantize_from_f16_and_strided_rows(t):
+    torch = pytest.importorskip("torch")
+    from ggmlsharp_amd import device
+    device.init(0)
+    x = _rand((9, 256))
+    big = torch.zeros((9, 320), dtype=torch.float32, device="cuda")
+    big[:, :256] = torch.from_numpy(x).cuda()
+    got = device.quantize_rows_from(t, big[:, :256]).cpu().numpy()            # row stride 320 elements
+    assert np.array_equal(got, O.quantize_row(t, x))
+    xh = x.astype(np.float16)
+    got_h = device.quantize_rows_from(t, torch.from_numpy(xh).cuda()).cpu().numpy()
+    assert np.array_equal(got_h, O.cpy_to_q(t, xh))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", QT)
+def test_device_add_q_f32_bit_exact(t):
+    torch = pytest.importorskip("torch")
+    from ggmlsharp_amd import device
+    device.init(0)
+    w = _rand((33, 512), 3.0)
+    x = _rand((33, 512))
+    x[0, :32] = 0.0
+    b = O.quantize_row(t, w)
+    got = device.add_q_f32_rows(t, torch.from_numpy(b).cuda(), torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(got, O.add_q_f32(t, b, x))
+
+
+@pytest.mark.gpu
+def test_ggml_program_cpy_then_mul_mat_then_add():
+    """Reference-style program: make Q weights with ggml_cpy (f32 -> Q4_0 and f16 -> Q8_0), multiply, then add_q_f32."""
+    pytest.importorskip("torch")
+    from ggmlsharp_amd import device
+    device.init(0)
+    K, M, N = 128, 40, 6
+    ctx = G.ggml_init(32 * 1024 * 1024)
+    try:
+        for src_t, dst_t, npdt in ((G.F32, G.Q4_0, np.float32), (G.F16, G.Q8_0, np.float16)):
+            w = _rand((M, K)).astype(npdt)
+            Wf = G.ggml_new_tensor_2d(ctx, src_t, K, M)
+            G.tensor_bytes(Wf)[:] = w.view(np.uint8).reshape(-1)
+            Wq = G.ggml_new_tensor_2d(ctx, dst_t, K, M)
+            X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+            x = _rand((N, K))
+            G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
+            cp = G.ggml_cpy(ctx, Wf, Wq)
+            gf = G.ggml_build_forward(cp)
+            G.ggml_graph_compute(ctx, gf)
+            want_q = O.cpy_to_q(dst_t, w)
+            assert np.array_equal(G.tensor_bytes(Wq), want_q.reshape(-1))            # bit-exact quantized weights
+            Y = G.ggml_mul_mat(ctx, Wq, X)
+            G.ggml_graph_compute(ctx, G.ggml_build_forward(Y))
+            ref = O.mul_mat(dst_t, want_q, x, M, K, N)[0, 0]
+            got = G.tensor_f32(Y)[0, 0]
+            rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+            assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms)
+            # add_q_f32: Wq + delta -> new quantized tensor
+            D = G.ggml_new_tensor_2d(ctx, G.F32, K, M)
+            delta = _rand((M, K), 0.3)
+            G.tensor_f32(D)[:] = delta.reshape(1, 1, M, K)
+            S = G.ggml_add(ctx, Wq, D)
+            G.ggml_graph_compute(ctx, G.ggml_build_forward(S))
+            assert np.array_equal(G.tensor_bytes(S), O.add_q_f32(dst_t, want_q, delta).reshape(-1))
+            # rewriting the weights through cpy invalidates the cached device copy: the next mul_mat sees new data
+            w2 = _rand((M, K)).astype(npdt)
+            G.tensor_bytes(Wf)[:] = w2.view(np.uint8).reshape(-1)
+            G.ggml_graph_compute(ctx, gf)
+            G.ggml_graph_compute(ctx, G.ggml_build_forward(Y))
+            ref2 = O.mul_mat(dst_t, O.cpy_to_q(dst_t, w2), x, M, K, N)[0, 0]
+            got2 = G.tensor_f32(Y)[0, 0]
+            assert np.all(np.abs(got2 - ref2) <= 1e-3 * np.abs(ref2) + 1e-5 * rms)
+    finally:
+        G.ggml_free(ctx)
