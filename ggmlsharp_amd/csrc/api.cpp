@@ -53,13 +53,13 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
 }
 
 // Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat:
-//   gemm_q.hip   (int8 matrix cores, 128 x 128 or 64 x 64 tiles, int8 image) -- the default,
-//   gemm_q16.hip (f16 matrix cores, 128 x 128 tiles, f16 image) with GGML_HIP_GEMM=f16 (developer A/B switch).
-bool use_f16_image(int64_t M, int64_t N) {
-    static const int force = [] { const char *e = getenv("GGML_HIP_GEMM"); return !e ? 0 : (e[0] == 'f' ? 2 : 1); }();
-    if (N <= GEMV_MAX_N) return false;
-    (void)M;
-    return force == 2;   // default: the int8-MFMA kernel (A/B on one device: 255 us vs 277 us on 4096^3)
+//   gemm_q16.hip (f16 matrix cores, register-tile design, f16 image) -- the default,
+//   gemm_q.hip   (int8 matrix cores, int8 image) with GGML_HIP_GEMM=i8 (developer A/B switch).
+// Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip.
+int act_image_kind(int type, int64_t N) {
+    static const bool force_i8 = [] { const char *e = getenv("GGML_HIP_GEMM"); return e && e[0] == 'i'; }();
+    if (N <= GEMV_MAX_N || force_i8) return 0;
+    return gemm_q16_image_kind(type);
 }
 
 int ensure_init() {
@@ -100,8 +100,9 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
         total = (size_t)w->Mpad * K * (type == GGML_TYPE_F32 ? 4 : 2);
     } else {
         w->nbk = K / QK;
-        const size_t qs_bytes = (size_t)w->nbk * w->Mpad * (type == GGML_TYPE_Q8_0 ? 32 : 16);
-        const size_t plane = (size_t)w->nbk * w->Mpad * 4;
+        const int64_t nba = pad_kblocks(w->nbk) + K_LOOKAHEAD;   // allocated k-blocks (zero past the real end)
+        const size_t qs_bytes = (size_t)nba * w->Mpad * (type == GGML_TYPE_Q8_0 ? 32 : 16);
+        const size_t plane = (size_t)nba * w->Mpad * 4;
         off_qs = 0; total = qs_bytes;
         off_d = total; total += plane;
         if (type == GGML_TYPE_Q4_1) { off_m = total; total += plane; }
@@ -277,7 +278,7 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
         return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", ggml_hip_mul_mat_work_size(w->type, w->K, N));
     act_planes p = act_carve(d_work, w->K, pad_act(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, use_f16_image(w->M, N), (hipStream_t)stream));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, N), (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
@@ -291,7 +292,7 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
     if (N <= GEMV_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (use_f16_image(w->M, N))
+    else if (act_image_kind(w->type, N) != 0)
         HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else
         HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));

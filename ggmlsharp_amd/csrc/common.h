@@ -27,8 +27,14 @@ static_assert(offsetof(ggml_tensor, op) == 72 && offsetof(ggml_tensor, grad) == 
 
 // Rows of the weight planes are padded to a multiple of ROW_PAD (the widest weight tile of any kernel), rows of the
 // activation planes to ACT_PAD (the widest activation tile).
-#define ROW_PAD 128
+#define ROW_PAD 256
 #define ACT_PAD 256
+// k-blocks: every plane (weights and activation scratch) is allocated for K_STAGE_PAD-aligned k-blocks, zero-filled
+// past the real end (zero scale => the pad blocks add +0), plus K_LOOKAHEAD spare blocks on the weight side for the
+// register prefetch of gemm_q16.hip.  Kernels that loop over the real nbk are unaffected.
+#define K_STAGE_PAD 4
+#define K_LOOKAHEAD 2
+__host__ __device__ static inline int64_t pad_kblocks(int64_t nbk) { return (nbk + K_STAGE_PAD - 1) / K_STAGE_PAD * K_STAGE_PAD; }
 static inline int64_t pad_rows(int64_t n) { return (n + ROW_PAD - 1) / ROW_PAD * ROW_PAD; }
 static inline int64_t pad_act(int64_t n) { return (n + ACT_PAD - 1) / ACT_PAD * ACT_PAD; }
 
@@ -61,11 +67,11 @@ struct act_planes {
     int64_t  Npad;
 };
 static inline size_t act_bytes(int64_t K, int64_t Npad) {
-    const int64_t nbk = K / QK;
+    const int64_t nbk = pad_kblocks(K / QK);
     return (size_t)nbk * 4 * Npad * 16 + (size_t)nbk * Npad * 4 * 2;
 }
 static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
-    const int64_t nbk = K / QK;
+    const int64_t nbk = pad_kblocks(K / QK);
     act_planes p;
     p.a8 = (int8_t *)base;
     p.ad = (float *)((uint8_t *)base + (size_t)nbk * 4 * Npad * 16);
@@ -82,7 +88,8 @@ hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStrea
 hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
                                     hipStream_t st);
 // quantize.hip
-hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, bool f16_image, hipStream_t st);
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st);
+int gemm_q16_image_kind(int type);   // which f16 image (1 nibble order, 2 byte-plane order) gemm_q16.hip wants for a weight type
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
 hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,
                                 hipStream_t st);

@@ -1,33 +1,33 @@
-// gemm_q16.hip -- K3: quantized mat-mat for large N, block-scaled, on the f16 matrix cores.
+// gemm_q16.hip -- K3: quantized mat-mat for large N, block-scaled, on the f16 matrix cores (v5, register-tile design).
 //
 // COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698):
 //   dst[n*ldd + m] = sum_b (dw[m,b] * da[n,b]) * sumi_b(m,n),   sumi_b = the integer dot of one 32-element block
 // (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159; _q5_0_q8_0 1270-1298; _q8_0_q8_0 1362-1378; _q4_1_q8_1 1176-1198).
 //
 // Why f16 operands for an integer dot: every operand is a small integer (weights in [-128,127], Q8 activations in
-// [-127,127]) and is exact in f16; every product (< 2^14) and every 32-term block sum (< 2^19) is exact in the f32
+// [-127,127]) and is exact in f16; every product and every 32-term block sum (< 2^19) is exact in the f32
 // accumulator of v_mfma_f32_32x32x16_f16.  Two MFMAs (K = 2 x 16 = one quant block) return sumi_b for a 32x32 tile
-// bit-exactly and ALREADY IN F32.  The int8 MFMA (gemm_q.hip) returns int32, and its 16 v_cvt_f32_i32 per tile are
-// half-rate VALU ops: measured (tools/valu_ubench.hip) they are ~45 % of that kernel's VALU time, and
-// the VALU scale-accumulate -- the reference's own f32 work per block, Ggml.cs:1158 -- is what bounds this path.
+// bit-exactly and ALREADY IN F32: no v_cvt_f32_i32 (half rate on gfx950).  What bounds this path is the reference's
+// own per-block f32 work (Ggml.cs:1158): one multiply and one fma per output per block, i.e. 32 VALU instructions
+// next to 2 MFMAs (64 matrix-pipe cycles) per 32x32 tile and k-block.  Everything else is designed to stay off the
+// VALU:
+//   * activations: K1 writes them as f16, already in MFMA fragment order; they reach LDS by global_load_lds (DMA, no
+//     VALU) and a fragment is one conflict-free ds_read_b128;
+//   * activation scales da: a broadcast ds_read_b128 hands every lane the 4 row scales of 4 accumulator registers;
+//   * weights: each lane loads ITS OWN 8 bytes (16 nibbles) of the resident 4-bit planes straight from L2 into
+//     registers and expands them there, once per k-block for a 64 x 128 (m x n) wave tile: 9 VALU per 8 nibbles
+//     (see unpack), amortised over 4 n-tiles;
+//   * no weight staging through LDS, no 64-bit or integer-multiply address arithmetic in the loop.
 //
 // Orientation: MFMA rows = src1 rows n (A = activations), MFMA cols = weight rows m (B = weights): a lane owns one
 // m, so dst stores are 128-byte segments along m (dst is [n][m], m fastest, Ggml.cs:6692-6697).
 //
-// Element order inside a block: MFMA kk (0/1) lane half h supplies k-slots 8h..8h+7, and the MFMA pairs slot with
-// slot, so any fixed permutation of the 32 elements is fine as long as A and B use the same one.  "Panel"
-// p = 2*kk + h holds the 8 elements e = p, p+4, ..., p+28 -- what the nibble unpack ((q >> 4p) & 0x000F000F)
-// yields for free; K1 writes the activations in the same order.  LDS images are [k-block][panel][row][16 B]; a
-// fragment is one conflict-free ds_read_b128.
-//
-// Structure: workgroup = 512 threads = 8 waves as 4(n) x 2(m), wave tile 32(n) x 64(m), workgroup tile 128 x 128,
-// two workgroups per CU = 4 waves per SIMD (<= 128 VGPRs): the VALU scale-accumulate, which bounds this kernel,
-// always has several waves to issue from, and one workgroup's barrier / staging bubbles are filled by the other.
-// K streams in stages of 2 k-blocks through a double-buffered LDS ring: activations by global_load_lds (f16
-// planes from K1), weights through registers (nibble/byte -> f16: as_f16(0x6400 | q) = 1024 + q).
-// Row scales: lane 16q+k keeps da of MFMA row R(k, q>>1) in ONE register and every product da*dw is a
-// v_mul_f32_dpp row_share:k, instead of 16 broadcast ds_read_b128 per tile row -- LDS traffic is the second
-// resource this kernel is short of.
+// Element order inside a block (the MFMA pairs k-slot with k-slot, so any permutation is fine as long as A and B use
+// the same one): lane half h and MFMA kk cover the 8 elements e_i = 16h + 8kk + i, i.e. dword kk of the lane's 8
+// bytes; k-slots hold [e0, e4, e1, e5, e2, e6, e3, e7] -- what (x & 0x000F000F), (x & 0x00F000F0) yield without a
+// shift.  The second mask leaves the nibble 4 bits up, i.e. the weight times 16; K1 stores the matching activations
+// divided by 16 (exact in f16), so the products are unchanged.  "Panel" p = 2*kk + h of the activation image holds
+// those 8 f16 for every row: image [k-block][panel][row][16 B].
 #include "common.h"
 #include <cstdlib>
 #include <utility>
@@ -38,14 +38,20 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr int TN = 128, TM = 128, BKB = 2;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-__device__ __forceinline__ void glds16(const void *g, void *l) {
-    __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)l, 16, 0, 0);
+// Raw buffer addressing everywhere: a 128-bit descriptor in SGPRs + a per-thread 32-bit offset fixed for the whole kernel
+// + a uniform 32-bit offset that advances per k-block / stage.  No 64-bit VGPR addresses, no address VALU in the loop.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void blds16(rsrc_t r, void *l, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)l, 16, (int)voff, (int)soff, 0, 0);
 }
 
 template <typename F, int... Is>
@@ -57,310 +63,386 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// two small unsigned integers in the low bits of each 16-bit half -> two f16 of (value - off)
-__device__ __forceinline__ uint32_t u16pair_to_f16(uint32_t pair, float off_plus_1024) {
-    const uint32_t bits = pair | 0x64006400u;          // as f16: 1024 + value (ulp is 1 in [1024, 2048))
+// (bits & mask) | 0x6400 in each half is the f16 1024 + v (ulp 1 in [1024, 2048)); subtracting 1024 + off is exact.
+__device__ __forceinline__ uint32_t magic_sub(uint32_t bits, float off_plus_1024) {
     const f16x2 v = __builtin_bit_cast(f16x2, bits);
     const _Float16 o = (_Float16)off_plus_1024;
-    const f16x2 r = v - (f16x2){o, o};                 // exact
+    const f16x2 r = v - (f16x2){o, o};
     return __builtin_bit_cast(uint32_t, r);
 }
 
-__device__ __forceinline__ uint32_t q5_hi16(uint32_t qh, int i, int p) {
-    const uint32_t t = qh >> (8 * i + p);              // bits of elements 8i+p (-> bit 4) and 8i+4+p (-> bit 20)
-    return ((t & 1u) << 4) | ((t & 0x10u) << 16);
+// 8 nibbles (one dword of the reference's qs bytes, Ggml.cs:1149-1150) -> 8 f16 in k-slot order
+// [e0, e4, 16*e1, 16*e5, e2, e6, 16*e3, 16*e7], each minus OFF (Q4_0: 8, Q4_1: 0).  9 VALU.
+template <int OFF>
+__device__ __forceinline__ f16x8 unpack_nib8(uint32_t x) {
+    const uint32_t y = x >> 8;
+    u32x4 o;
+    o[0] = magic_sub((x & 0x000F000Fu) | 0x64006400u, 1024.0f + OFF);
+    o[1] = magic_sub((x & 0x00F000F0u) | 0x64006400u, 1024.0f + 16.0f * OFF);
+    o[2] = magic_sub((y & 0x000F000Fu) | 0x64006400u, 1024.0f + OFF);
+    o[3] = magic_sub((y & 0x00F000F0u) | 0x64006400u, 1024.0f + 16.0f * OFF);
+    return __builtin_bit_cast(f16x8, o);
 }
 
-// sc[r] = da_row[r] * dw for the 16 accumulator registers of a 32x32 tile: lane 16q+k of `vda` holds the scale of
-// MFMA row R(k, q>>1), and row_share:r hands every lane the value of lane r of its own 16-lane row.
-__device__ __forceinline__ void scale16(float (&sc)[16], float vda, float dw) {
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %12, %16, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %13, %16, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %14, %16, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %15, %16, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
-        : "=&v"(sc[0]), "=&v"(sc[1]), "=&v"(sc[2]), "=&v"(sc[3]), "=&v"(sc[4]), "=&v"(sc[5]), "=&v"(sc[6]), "=&v"(sc[7]),
-          "=&v"(sc[8]), "=&v"(sc[9]), "=&v"(sc[10]), "=&v"(sc[11]), "=&v"(sc[12]), "=&v"(sc[13]), "=&v"(sc[14]), "=&v"(sc[15])
-        : "v"(vda), "v"(dw));
+// Q5_0 (Ggml.cs:1285-1289): t8 = the 8 high bits of elements e0..e7 (bit i of t8 = element e_i); value = (nib | hb << 4) - 16
+__device__ __forceinline__ f16x8 unpack_q5(uint32_t x, uint32_t t8) {
+    const uint32_t y = x >> 8;
+    // spread: bit i of t8 -> bit 4 (+16 for i >= 4) in the plain slots, bit 8 (+16) in the x16 slots
+    const uint32_t h0 = ((t8 & 0x01u) << 4) | ((t8 & 0x10u) << 16);
+    const uint32_t h1 = ((t8 & 0x02u) << 7) | ((t8 & 0x20u) << 19);
+    const uint32_t h2 = ((t8 & 0x04u) << 2) | ((t8 & 0x40u) << 14);
+    const uint32_t h3 = ((t8 & 0x08u) << 5) | ((t8 & 0x80u) << 17);
+    u32x4 o;
+    o[0] = magic_sub((x & 0x000F000Fu) | h0 | 0x64006400u, 1024.0f + 16.0f);
+    o[1] = magic_sub((x & 0x00F000F0u) | h1 | 0x64006400u, 1024.0f + 256.0f);
+    o[2] = magic_sub((y & 0x000F000Fu) | h2 | 0x64006400u, 1024.0f + 16.0f);
+    o[3] = magic_sub((y & 0x00F000F0u) | h3 | 0x64006400u, 1024.0f + 256.0f);
+    return __builtin_bit_cast(f16x8, o);
 }
 
-template <int TYPE>
-struct Lds {
-    static constexpr int A_BYTES = BKB * 4 * TN * 16;      // 16 KB f16 activation image
-    static constexpr int W_BYTES = BKB * 4 * TM * 16;      // 16 KB f16 weight image
-    static constexpr int SC_BYTES = BKB * TN * 4;          // one f32 plane (TN == TM)
-    static constexpr int NSC = (TYPE == GGML_TYPE_Q4_1) ? 4 : 2;  // da, dw (+ mw, sa)
-    static constexpr int STAGE = A_BYTES + W_BYTES + NSC * SC_BYTES;
-    static constexpr int TOTAL = 2 * STAGE;
+// Q8_0: 8 signed bytes (two dwords of one plane) -> 8 f16 in k-slot order [b0, b2, b1, b3, b4, b6, b5, b7]
+__device__ __forceinline__ f16x8 unpack_i8x8(uint32_t x0, uint32_t x1) {
+    const uint32_t u0 = x0 ^ 0x80808080u, u1 = x1 ^ 0x80808080u;   // signed byte -> biased unsigned
+    u32x4 o;
+    o[0] = magic_sub((u0 & 0x00FF00FFu) | 0x64006400u, 1024.0f + 128.0f);
+    o[1] = magic_sub(((u0 >> 8) & 0x00FF00FFu) | 0x64006400u, 1024.0f + 128.0f);
+    o[2] = magic_sub((u1 & 0x00FF00FFu) | 0x64006400u, 1024.0f + 128.0f);
+    o[3] = magic_sub(((u1 >> 8) & 0x00FF00FFu) | 0x64006400u, 1024.0f + 128.0f);
+    return __builtin_bit_cast(f16x8, o);
+}
+
+template <int TYPE> struct WT {
+    static constexpr int QW = (TYPE == GGML_TYPE_Q8_0) ? 4 : 2;     // raw dwords per lane, m-tile and k-block
 };
 
-template <int TYPE>
-__global__ __launch_bounds__(512, 4) void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict__ wqh,
-                                                         const float *__restrict__ wd, const float *__restrict__ wm,
-                                                         const uint8_t *__restrict__ a16, const float *__restrict__ ad,
-                                                         const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
-                                                         int64_t N, int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd,
-                                                         int tiles_m, int tiles_n, int dbg) {
-    using L = Lds<TYPE>;
+// WMT x WNT 32x32 tiles per wave, WGM x WGN waves per workgroup, KB k-blocks per LDS stage
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
+struct Cfg {
+    static constexpr int TM = WGM * WMT * 32, TN = WGN * WNT * 32, NT = WGM * WGN * 64;
+    static constexpr int A_BYTES = KB * 4 * TN * 16;       // f16 activation image of one stage
+    static constexpr int NSC = (TYPE == GGML_TYPE_Q4_1) ? 2 : 1;
+    static constexpr int SC_BYTES = KB * TN * 4;           // one f32 plane of row scales
+    static constexpr int STAGE = A_BYTES + NSC * SC_BYTES;
+    static constexpr int TOTAL = 2 * STAGE;
+    static constexpr int A_CHUNKS = KB * 4 * TN;           // 16-byte pieces
+    static_assert(A_CHUNKS % NT == 0, "DMA rounds");
+    static constexpr int A_ROUNDS = A_CHUNKS / NT;
+    static constexpr int SC_CHUNKS = KB * TN / 4;          // 16-byte pieces per plane
+    static_assert(SC_CHUNKS % 64 == 0 && SC_CHUNKS <= NT, "scale DMA is whole waves");
+    static constexpr int WPS = 2;                          // waves per SIMD aimed at (256 registers each)
+};
+
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
+__global__ __launch_bounds__(WGM * WGN * 64, (Cfg<TYPE, WMT, WNT, WGM, WGN, KB>::WPS))
+void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict__ wqh, const float *__restrict__ wd,
+                     const float *__restrict__ wm, const uint8_t *__restrict__ a16, const float *__restrict__ ad,
+                     const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nstages,
+                     int ldd, int tiles_m, int tiles_n, uint32_t wq_bytes, uint32_t wd_bytes, uint32_t a_bytes,
+                     uint32_t ad_bytes, uint32_t dst_bytes) {
+    using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
+    constexpr int QW = WT<TYPE>::QW;
+    constexpr int NTILE = WMT * WNT;
+    static_assert(KB % 2 == 0, "fragment buffers alternate by k-block parity");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wn = wave >> 1, wm_ = wave & 1;
+    const int wn = wave / WGM, wm_ = wave % WGM;           // waves of one workgroup: m fastest
 
-    // XCD-aware tile order (speed only): workgroups b, b+8, b+16, ... share an XCD and its L2.  Give each XCD a
-    // contiguous run of the tile list ordered "m fastest", so concurrently resident workgroups of one XCD share their
-    // activation panel (same n tile) and walk neighbouring weight panels.
+    // XCD-aware tile order (speed only): workgroups b, b+8, b+16, ... share an XCD and its L2.  Each XCD gets a
+    // contiguous run of the tile list ordered "m fastest": its resident workgroups share few activation panels and
+    // walk all weight panels together.
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int64_t m0 = (int64_t)(t_lin % tiles_m) * TM;
-    const int64_t n0 = (int64_t)(t_lin / tiles_m) * TN;
-    const int nstages = (int)((nbk + BKB - 1) / BKB);
+    const int m0 = (t_lin % tiles_m) * C::TM;
+    const int n0 = (t_lin / tiles_m) * C::TN;
 
-    f32x16 acc[2];
+    float acc[WMT][WNT][16];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    auto stage_ptr = [&](int s) { return smem + (s & 1) * L::STAGE; };
+    // ---- activation image + row scales: global -> LDS by DMA, one stage (KB k-blocks) at a time ----
+    // Chunk c = tid + NT*i of a stage is [bb][panel][TN rows] x 16 B.  NT is a multiple of TN and NT/TN divides 4, so
+    // the row and the low bits of the panel are per-thread constants and everything that depends on i is uniform:
+    // ONE per-thread 32-bit offset serves every DMA of the kernel.  K (weights and image) is zero-padded to whole
+    // stages by the host side, so there is no tail logic anywhere in the loop.
+    constexpr int P = C::NT / C::TN;
+    static_assert(C::NT % C::TN == 0 && (P == 1 || P == 2 || P == 4), "chunk decomposition");
+    const uint32_t a_pan = (uint32_t)(Npad * 16);                       // bytes of one panel of the f16 image
+    const uint32_t a_blk = 4 * a_pan;                                   // bytes of one k-block
+    const uint32_t voffA = (uint32_t)(((tid / C::TN) * Npad + n0 + (tid % C::TN)) * 16);
+    const uint32_t voffS = (uint32_t)(((tid / (C::TN / 4)) * Npad + n0 + 4 * (tid % (C::TN / 4))) * 4);
+    const rsrc_t rA = make_rsrc(a16, a_bytes), rAd = make_rsrc(ad, ad_bytes), rAs = make_rsrc(asd, ad_bytes);
 
-    // ---- global -> LDS-DMA (activations) / registers (weights, scales) for one stage ----
-    // Every address is "uniform 64-bit base that advances by a constant per stage" + "per-thread 32-bit offset fixed
-    // for the whole kernel", so the loop has no 64-bit or integer-multiply VALU work (both are quarter-rate).
-    // thread t expands half of weight chunk t>>1: panels 2*(t&1), 2*(t&1)+1 (Q8_0: chunk = (k-block, plane, row))
-    uint4 wreg;
-    uint32_t hreg = 0;
-    float screg, sc2reg = 0.0f;
+    // One DMA piece = one wave-instruction = 1 KiB.  A piece costs its wave ~100 issue cycles, so the pieces of stage
+    // s+1 are spread over the first tiles of stage s (one per tile) instead of being issued as a burst.  Pieces past
+    // the end of K are dropped by the descriptor's range check (they would only fill a buffer nobody reads).
+    constexpr int NPIECE = C::A_ROUNDS + 1;
+    auto dma_piece = [&](int s, auto pc) {
+        constexpr int i = decltype(pc)::value;
+        uint8_t *sp = smem + (s & 1) * C::STAGE;
+        if constexpr (i < C::A_ROUNDS) {
+            constexpr int bb = (P * i) >> 2, pan = (P * i) & 3;
+            blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voffA, (uint32_t)s * KB * a_blk + bb * a_blk + pan * a_pan);
+        } else if (wave < C::SC_CHUNKS / 64) {                           // uniform per wave
+            const uint32_t sS0 = (uint32_t)s * KB * (uint32_t)(Npad * 4);
+            blds16(rAd, sp + C::A_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            if (TYPE == GGML_TYPE_Q4_1) blds16(rAs, sp + C::A_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+        }
+    };
 
-    const uint32_t a_blk = (uint32_t)(4 * Npad * 16);                 // bytes of one k-block of the f16 image
+    // ---- weights: registers only.  Lane (l31, hh) of m-tile i owns row m0 + (wm_*WMT + i)*32 + l31, byte half hh ----
+    struct Raw { uint32_t q[WMT][QW]; uint32_t qh[WMT]; float d[WMT]; float mn[WMT]; };
+    struct Frag { f16x8 b[WMT][2]; float d[WMT]; float mn[WMT]; };
+    uint32_t offW[WMT], offD[WMT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+        const int m = m0 + (wm_ * WMT + i) * 32 + l31;
+        offW[i] = (TYPE == GGML_TYPE_Q8_0) ? (uint32_t)((hh * Mpad + m) * 16) : (uint32_t)(m * 16 + 8 * hh);
+        offD[i] = (uint32_t)(m * 4);
+    }
     const uint32_t w_blk = (uint32_t)(Mpad * (TYPE == GGML_TYPE_Q8_0 ? 32 : 16));
-    uint32_t offA[2], offW, offS, offH;
-    int bbA[2], bbW, bbS;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {                                     // 1024 16-byte chunks: [bb][p][128 rows]
-        const int c = tid + 512 * i, bp = c >> 7, row = c & 127;      // bp = bb * 4 + panel
-        bbA[i] = bp >> 2;
-        offA[i] = (uint32_t)bbA[i] * a_blk + (uint32_t)(((bp & 3) * Npad + n0 + row) * 16);
-    }
-    if (TYPE == GGML_TYPE_Q8_0) {
-        const int bh = tid >> 7, row = tid & 127;                     // bh = bb * 2 + plane: 512 chunks, one per thread
-        bbW = bh >> 1;
-        offW = (uint32_t)bbW * w_blk + (uint32_t)(((bh & 1) * Mpad + m0 + row) * 16);
-        offH = 0;
-    } else {
-        const int c = tid >> 1, row = c & 127;
-        bbW = c >> 7;
-        offW = (uint32_t)bbW * w_blk + (uint32_t)((m0 + row) * 16);
-        offH = (uint32_t)((bbW * Mpad + m0 + row) * 4);
-    }
-    {
-        const int i = tid & 255, row = i & 127;
-        bbS = i >> 7;
-        offS = (uint32_t)((bbS * (tid < 256 ? Npad : Mpad) + (tid < 256 ? n0 : m0) + row) * 4);
-    }
-    const bool odd_tail = (nbk & 1) != 0;                             // last stage holds one real k-block
+    const uint32_t d_blk = (uint32_t)(Mpad * 4);
 
-    auto issue_loads = [&](int s) {
-        uint8_t *sA = stage_ptr(s);
-        const int64_t kb0 = (int64_t)s * BKB;
-        const bool tail = odd_tail && s == nstages - 1;               // uniform
-        const uint8_t *gA = a16 + kb0 * a_blk;
-        const uint8_t *gW = wqs + kb0 * w_blk;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // tail stage: the missing k-block re-reads the previous one (harmless, its weight scales are zero)
-            const uint32_t off = offA[i] - ((tail && bbA[i]) ? a_blk : 0u);
-            glds16(gA + off, sA + (size_t)(tid + 512 * i - lane) * 16);
-        }
-        wreg = *(const uint4 *)(gW + (offW - ((tail && bbW) ? w_blk : 0u)));
-        if (TYPE == GGML_TYPE_Q5_0) hreg = *(const uint32_t *)((const uint8_t *)(wqh + kb0 * Mpad) + (offH - ((tail && bbW) ? (uint32_t)(Mpad * 4) : 0u)));
-        {   // scales: threads 0..255 -> da[bb][row], 256..511 -> dw[bb][row]
-            const bool dead = tail && bbS;                            // this thread's k-block is past the end
-            if (tid < 256) {
-                const uint32_t off = offS - (dead ? (uint32_t)(Npad * 4) : 0u);
-                screg = *(const float *)((const uint8_t *)(ad + kb0 * Npad) + off);
-                if (TYPE == GGML_TYPE_Q4_1) sc2reg = (float)*(const int32_t *)((const uint8_t *)(as + kb0 * Npad) + off);
-            } else {
-                const uint32_t off = offS - (dead ? (uint32_t)(Mpad * 4) : 0u);
-                const float v = *(const float *)((const uint8_t *)(wd + kb0 * Mpad) + off);
-                screg = dead ? 0.0f : v;                              // scale 0 turns a k-block past the end into +0
-                if (TYPE == GGML_TYPE_Q4_1) {
-                    const float v2 = *(const float *)((const uint8_t *)(wm + kb0 * Mpad) + off);
-                    sc2reg = dead ? 0.0f : v2;
-                }
-            }
-        }
-    };
-
-    auto store_stage = [&](int s) {
-        uint8_t *sp = stage_ptr(s);
-        uint8_t *sW = sp + L::A_BYTES;
-        float *sSc = (float *)(sp + L::A_BYTES + L::W_BYTES);   // [da | dw | sa | mw], BKB*128 floats each
-        const uint32_t q[4] = {wreg.x, wreg.y, wreg.z, wreg.w};
-        if (TYPE == GGML_TYPE_Q8_0) {
-            // plane h byte j = element 2j + h (signed): bytes (0,2) of every word -> panel h, bytes (1,3) -> panel h + 2
-            const int bh = tid >> 7, row = tid & 127, bb = bh >> 1, h = bh & 1;
-            uint32_t pa[4], pb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t x = q[k] ^ 0x80808080u;   // signed byte -> biased unsigned
-                pa[k] = u16pair_to_f16(x & 0x00FF00FFu, 1024.0f + 128.0f);
-                pb[k] = u16pair_to_f16((x >> 8) & 0x00FF00FFu, 1024.0f + 128.0f);
-            }
-            *(uint4 *)(sW + ((size_t)((bb * 4 + h) * TM + row)) * 16) = make_uint4(pa[0], pa[1], pa[2], pa[3]);
-            *(uint4 *)(sW + ((size_t)((bb * 4 + h + 2) * TM + row)) * 16) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+    // the planes carry two spare (zero) k-blocks past the padded end, so the look-ahead never needs a bounds check
+    const rsrc_t rWq = make_rsrc(wqs, wq_bytes), rWd = make_rsrc(wd, wd_bytes);
+    const rsrc_t rWh = make_rsrc(TYPE == GGML_TYPE_Q5_0 ? (const void *)wqh : (const void *)wd, wd_bytes);
+    const rsrc_t rWm = make_rsrc(TYPE == GGML_TYPE_Q4_1 ? (const void *)wm : (const void *)wd, wd_bytes);
+    auto load_raw_one = [&](int kb, Raw &r, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t sq = (uint32_t)kb * w_blk, sd = (uint32_t)kb * d_blk;
+        if constexpr (QW == 4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rWq, (int)offW[i], (int)sq, 0);
+            r.q[i][0] = v[0]; r.q[i][1] = v[1]; r.q[i][2] = v[2]; r.q[i][3] = v[3];
         } else {
-            const int c = tid >> 1, bb = c >> 7, row = c & 127;
-            constexpr float OFF = TYPE == GGML_TYPE_Q4_0 ? 8.0f : (TYPE == GGML_TYPE_Q5_0 ? 16.0f : 0.0f);
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int p = 2 * (tid & 1) + pp;
-                uint32_t w[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t pair = (q[k] >> (4 * p)) & 0x000F000Fu;           // elements 8k+p, 8k+4+p (Ggml.cs:1149-1150)
-                    if (TYPE == GGML_TYPE_Q5_0) pair |= q5_hi16(hreg, k, p);   // Ggml.cs:1285-1289
-                    w[k] = u16pair_to_f16(pair, 1024.0f + OFF);
-                }
-                *(uint4 *)(sW + ((size_t)((bb * 4 + p) * TM + row)) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-            }
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rWq, (int)offW[i], (int)sq, 0);
+            r.q[i][0] = v[0]; r.q[i][1] = v[1];
         }
-        sSc[tid] = screg;                                  // tid < 256: da, else dw (contiguous planes)
-        if (TYPE == GGML_TYPE_Q4_1) sSc[512 + tid] = sc2reg;
+        r.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)offD[i], (int)sd, 0));
+        if constexpr (TYPE == GGML_TYPE_Q5_0) r.qh[i] = __builtin_amdgcn_raw_buffer_load_b32(rWh, (int)offD[i], (int)sd, 0);
+        if constexpr (TYPE == GGML_TYPE_Q4_1) r.mn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)offD[i], (int)sd, 0));
+    };
+    auto unpack_one = [&](const Raw &r, Frag &f, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (TYPE == GGML_TYPE_Q4_0) {
+            f.b[i][0] = unpack_nib8<8>(r.q[i][0]);
+            f.b[i][1] = unpack_nib8<8>(r.q[i][1]);
+        } else if constexpr (TYPE == GGML_TYPE_Q4_1) {
+            f.b[i][0] = unpack_nib8<0>(r.q[i][0]);
+            f.b[i][1] = unpack_nib8<0>(r.q[i][1]);
+        } else if constexpr (TYPE == GGML_TYPE_Q5_0) {
+            const uint32_t t16 = r.qh[i] >> (16 * hh);
+            f.b[i][0] = unpack_q5(r.q[i][0], t16 & 0xFFu);
+            f.b[i][1] = unpack_q5(r.q[i][1], (t16 >> 8) & 0xFFu);
+        } else {
+            f.b[i][0] = unpack_i8x8(r.q[i][0], r.q[i][1]);
+            f.b[i][1] = unpack_i8x8(r.q[i][QW - 2], r.q[i][QW - 1]);
+        }
+        f.d[i] = r.d[i];
+        if constexpr (TYPE == GGML_TYPE_Q4_1) f.mn[i] = r.mn[i];
     };
 
-    // ---- one stage: BKB k-blocks x 2 tiles (32 x 32) x 2 MFMAs per wave ----
-    auto compute = [&](int s) {
-        const uint8_t *sp = stage_ptr(s);
-        const uint8_t *sA = sp;
-        const uint8_t *sW = sp + L::A_BYTES;
-        const float *sDa = (const float *)(sp + L::A_BYTES + L::W_BYTES);
-        const float *sDw = sDa + BKB * TN;
-        const float *sSa = sDw + BKB * TM;                 // Q4_1 only
-        const float *sMw = sSa + BKB * TN;                 // Q4_1 only
-        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const int row0 = wn * 32;
-        // lane 16q + k owns the scale of MFMA row R(k, q>>1) = (k&3) + 8*(k>>2) + 4*(q>>1)
-        const int myrow = row0 + (lane & 3) + 8 * ((lane >> 2) & 3) + 4 * hh;
-        constexpr int NT = BKB * 2;
+    Raw raw;
+    Frag frag[2];                                           // k-block kb uses frag[kb & 1]
 
-        f16x8 af[2], bf[2][2];
-        float vda, vsa = 0.0f, dw[2], mw[2];
+    // ---- one stage: KB k-blocks x NTILE tiles, software-pipelined: MFMAs of tile t+1 are issued before the
+    //      scale-accumulate of tile t.  Register budget (256 at two waves per SIMD) is what shapes the order:
+    //      * activation fragments of the next n-tile are fetched right after the last MFMA that reads the current ones,
+    //      * the row scales of the next n-tile replace the current ones group by group as the last scale-accumulate
+    //        of the current n-tile retires them,
+    //      * the weights of k-block kb+1 are expanded, m-tile by m-tile, right after the last MFMA that reads the
+    //        current fragments of that m-tile, and the raw loads of kb+2 start right after.
+    //      The scale-accumulate itself is inline asm, 4 accumulator registers at a time (mul into a temp, fmac): left
+    //      to the scheduler, the 16 products of a tile are hoisted far above their fmacs and the kernel spills. ----
+    auto compute = [&](int s) {
+        const uint8_t *sp = smem + (s & 1) * C::STAGE;
+        const uint8_t *sA = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
+        const float *sDa = (const float *)(sp + C::A_BYTES) + wn * WNT * 32 + 4 * hh;
+        const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
+        const int kb0 = s * KB;
+        constexpr int LAST = KB * NTILE - 1;
+
+        f16x8 af[2];
+        f32x4 da[4], sa[4];
         f32x16 tacc[2];
 
-        auto load_block = [&](auto bc) {
-            constexpr int bb = decltype(bc)::value;
+        auto fetch_af = [&](auto nc) {                                   // nc = n-tile index within the stage
+            constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                af[kk] = *(const f16x8 *)(sA + ((size_t)((bb * 4 + 2 * kk + hh) * TN + row0 + l31)) * 16);
-            vda = sDa[bb * TN + myrow];
-            if (TYPE == GGML_TYPE_Q4_1) vsa = sSa[bb * TN + myrow];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wm_ * 64 + 32 * j + l31;
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    bf[j][kk] = *(const f16x8 *)(sW + ((size_t)((bb * 4 + 2 * kk + hh) * TM + col)) * 16);
-                dw[j] = sDw[bb * TM + col];
-                if (TYPE == GGML_TYPE_Q4_1) mw[j] = sMw[bb * TM + col];
-            }
+            for (int kk = 0; kk < 2; ++kk) af[kk] = *(const f16x8 *)(sA + ((bb * 4 + 2 * kk) * C::TN + 32 * j) * 16);
         };
-        auto mfma_tile = [&](auto tc) {
-            constexpr int t = decltype(tc)::value, j = t & 1;
-            f32x16 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[j][0], zero, 0, 0, 0);
-            tacc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[j][1], x, 0, 0, 0);
+        auto fetch_da = [&](auto nc, auto gc) {
+            constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT, q = decltype(gc)::value;
+            da[q] = *(const f32x4 *)(sDa + bb * C::TN + 32 * j + 8 * q);
+            if constexpr (TYPE == GGML_TYPE_Q4_1) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
+        };
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // MFMAs of tile t in two halves (one wave cannot issue the second before the first has left the matrix pipe, so
+        // VALU work goes between them), then everything that becomes possible once both are issued
+        f32x16 thalf;
+        auto issue_a = [&](auto tc) {
+            constexpr int t = decltype(tc)::value, bb = t / NTILE, i = t % WMT;
+            thalf = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], frag[bb & 1].b[i][0], zero, 0, 0, 0);
+        };
+        auto issue_b = [&](auto tc) {
+            constexpr int t = decltype(tc)::value, bb = t / NTILE, j = (t % NTILE) / WMT, i = t % WMT;
+            tacc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], frag[bb & 1].b[i][1], thalf, 0, 0, 0);
+            if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
+            if constexpr (j == WNT - 1) {
+                unpack_one(raw, frag[(bb + 1) & 1], std::integral_constant<int, i>{});
+                load_raw_one(kb0 + bb + 2, raw, std::integral_constant<int, i>{});
+            }
         };
 
-        load_block(std::integral_constant<int, 0>{});
-        mfma_tile(std::integral_constant<int, 0>{});
-        static_for<NT>([&](auto tc) {
-            constexpr int t = decltype(tc)::value, bb = t >> 1, j = t & 1;
-            // tile t+1's MFMAs go out before tile t's scale-accumulate (matrix-core latency hidden behind the VALU)
-            if constexpr (j == 0) mfma_tile(std::integral_constant<int, t + 1>{});
-            float sc[16];
-            scale16(sc, vda, dw[j]);                                   // d1 * d0, Ggml.cs:1158
-            const f32x16 tt = tacc[t & 1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = fmaf(tt[r], sc[r], acc[j][r]);
-            if (TYPE == GGML_TYPE_Q4_1) {                              // + m0 * d1 * sum(a) (Ggml.cs:1190-1196 factorised)
-                float ds[16];
-                scale16(ds, vda * vsa, mw[j]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] += ds[r];
-            }
-            // pin: keeps the optimiser from sinking the scale-accumulates below the stage's last MFMA
-            asm volatile("" : "+v"(acc[j]));
-            if constexpr (j == 1 && bb + 1 < BKB) {
-                load_block(std::integral_constant<int, bb + 1>{});
-                mfma_tile(std::integral_constant<int, t + 1>{});
-            }
+        fetch_af(std::integral_constant<int, 0>{});
+        static_for<4>([&](auto gc) { fetch_da(std::integral_constant<int, 0>{}, gc); });
+        issue_a(std::integral_constant<int, 0>{});
+        issue_b(std::integral_constant<int, 0>{});
+
+        static_for<KB * NTILE>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, bb = t / NTILE, tl = t % NTILE, j = tl / WMT, i = tl % WMT;
+            if constexpr (t < NPIECE) dma_piece(s + 1, tc);
+            if constexpr (t < LAST) issue_a(std::integral_constant<int, t + 1>{});
+            const float dw = frag[bb & 1].d[i];
+            float *ac = acc[i][j];
+            static_for<4>([&](auto gc) {
+                constexpr int q = decltype(gc)::value;
+                float t0, t1, t2, t3;
+                // acc += (sumi * d1) * d0, Ggml.cs:1158.  The other MFMA result rides along as a dummy operand of
+                // group 0 so that its MFMAs stay above this tile's VALU work (they are what it overlaps with).
+                // Hazard note (inline asm is not padded by hipcc): an MFMA result needs 12 wait states before a VALU
+                // reads it.  Tile t's MFMAs are pinned above tile t-1's 32 VALU instructions, so only the first tile of
+                // a stage can be short of them: it carries its own s_nop.
+                if constexpr (t == 0 && q == 0) asm volatile("s_nop 11" : "+v"(tacc[0]));
+                if constexpr (q == 0 && t < LAST) {
+                    asm volatile("v_mul_f32 %4, %8, %12\n\tv_mul_f32 %5, %9, %13\n\tv_mul_f32 %6, %10, %14\n\tv_mul_f32 %7, %11, %15\n\t"
+                                 "v_fmac_f32 %0, %4, %16\n\tv_fmac_f32 %1, %5, %16\n\tv_fmac_f32 %2, %6, %16\n\tv_fmac_f32 %3, %7, %16"
+                                 : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                                 : "v"(tacc[t & 1][0]), "v"(tacc[t & 1][1]), "v"(tacc[t & 1][2]), "v"(tacc[t & 1][3]), "v"(da[0][0]),
+                                   "v"(da[0][1]), "v"(da[0][2]), "v"(da[0][3]), "v"(dw), "v"(thalf));
+                } else {
+                    asm volatile("v_mul_f32 %4, %8, %12\n\tv_mul_f32 %5, %9, %13\n\tv_mul_f32 %6, %10, %14\n\tv_mul_f32 %7, %11, %15\n\t"
+                                 "v_fmac_f32 %0, %4, %16\n\tv_fmac_f32 %1, %5, %16\n\tv_fmac_f32 %2, %6, %16\n\tv_fmac_f32 %3, %7, %16"
+                                 : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3]), "=&v"(t0), "=&v"(t1),
+                                   "=&v"(t2), "=&v"(t3)
+                                 : "v"(tacc[t & 1][4 * q + 0]), "v"(tacc[t & 1][4 * q + 1]), "v"(tacc[t & 1][4 * q + 2]),
+                                   "v"(tacc[t & 1][4 * q + 3]), "v"(da[q][0]), "v"(da[q][1]), "v"(da[q][2]), "v"(da[q][3]), "v"(dw));
+                }
+                if constexpr (TYPE == GGML_TYPE_Q4_1) {                       // + m0 * (d1 * sum(a)) (Ggml.cs:1190-1196 factorised)
+                    const float mw = frag[bb & 1].mn[i];
+                    asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
+                                 : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3])
+                                 : "v"(sa[q][0]), "v"(sa[q][1]), "v"(sa[q][2]), "v"(sa[q][3]), "v"(mw));
+                }
+                if constexpr (q == 1 && t < LAST) {
+                    issue_b(std::integral_constant<int, t + 1>{});
+                    asm volatile("" : "+v"(tacc[(t + 1) & 1]));              // the second MFMA stays above groups 2, 3
+                }
+                // this group's row scales are dead after the n-tile's last m-tile: fetch the next n-tile's into their place
+                if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT)
+                    fetch_da(std::integral_constant<int, bb * WNT + j + 1>{}, gc);
+            });
         });
     };
 
-    // ---- main loop: double-buffered, one barrier per stage ----
-    issue_loads(0);
-    store_stage(0);
+    // ---- main loop: double-buffered LDS, one barrier per stage.  vmcnt(0), not a counted wait: hipcc is free to sink
+    //      the weight loads (read-only buffer loads) below an asm wait, so "all but the youngest N" is not a statement
+    //      about the DMA pieces.  The youngest loads at a stage end were issued two tiles earlier and have mostly
+    //      landed. ----
+    static_for<NPIECE>([&](auto pc) { dma_piece(0, pc); });
+    static_for<WMT>([&](auto ic) { load_raw_one(0, raw, ic); });
+    static_for<WMT>([&](auto ic) { unpack_one(raw, frag[0], ic); load_raw_one(1, raw, ic); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
     for (int s = 0; s < nstages; ++s) {
-        const bool more = (s + 1) < nstages && !(dbg & 1);   // dbg bit 0: timing ablation, no staging after stage 0
-        if (more) issue_loads(s + 1);
-        if (!(dbg & 2)) compute(s);                          // dbg bit 1: timing ablation, staging only
-        if (more) store_stage(s + 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        compute(s);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 
-    // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31] ----
+    // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
+    const rsrc_t rD = make_rsrc(dst, dst_bytes);
+    const bool full = n0 + C::TN <= N && m0 + C::TM <= M;                    // uniform
+    const uint32_t lane_off = (uint32_t)((4 * hh * ldd + l31) * 4);
+    if (full) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t m = m0 + wm_ * 64 + 32 * j + l31;
+        for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (n < N && m < M) dst[n * ldd + m] = acc[j][r];
-        }
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nr = n0 + (wn * WNT + j) * 32 + (r & 3) + 8 * (r >> 2), mb = m0 + (wm_ * WMT + i) * 32;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                                                          (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                const int mb = m0 + (wm_ * WMT + i) * 32, nb = n0 + (wn * WNT + j) * 32;
+                if (mb >= M || nb >= N) continue;                              // uniform
+                const bool mok = mb + l31 < M;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nr = nb + (r & 3) + 8 * (r >> 2);
+                    if (mok && nr + 4 * hh < N)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                                                              (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+                }
+            }
     }
+}
+
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
+hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
+    static bool attr_set = false;
+    auto kern = gemm_q16_kernel<TYPE, WMT, WNT, WGM, WGN, KB>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (w->Mpad % C::TM != 0 || p.Npad % C::TN != 0) return hipErrorInvalidValue;
+    const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
+    dim3 grid((unsigned)(tiles_m * tiles_n));
+    const int nstages = (int)((w->nbk + KB - 1) / KB);      // planes and image are zero-padded to whole stages (KB | K_STAGE_PAD)
+    static_assert(K_STAGE_PAD % KB == 0, "stage padding");
+    const uint64_t nba = (uint64_t)pad_kblocks(w->nbk);
+    const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * (TYPE == GGML_TYPE_Q8_0 ? 32 : 16);
+    const uint64_t wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4, a_bytes = nba * 4 * (uint64_t)p.Npad * 16;
+    const uint64_t ad_bytes = nba * (uint64_t)p.Npad * 4, dst_bytes = ((uint64_t)(N - 1) * (uint64_t)ldd + (uint64_t)w->M) * 4;
+    constexpr uint64_t LIM = 0xFFFFFFFFull;                  // 32-bit buffer offsets
+    if (wq_bytes > LIM || a_bytes > LIM || dst_bytes > LIM) return hipErrorNotSupported;
+    kern<<<grid, C::NT, C::TOTAL, st>>>(w->qs, w->qh, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
+                                        (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
+                                        (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes);
+    return hipGetLastError();
 }
 
 template <int TYPE>
 hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
-    using L = Lds<TYPE>;
-    static bool attr_set = false;
-    auto kern = gemm_q16_kernel<TYPE>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static const int dbg = [] { const char *e = getenv("GGML_HIP_GEMM_DBG"); return e ? atoi(e) : 0; }();  // developer ablations
-    const int tiles_m = (int)((w->M + TM - 1) / TM), tiles_n = (int)((N + TN - 1) / TN);
-    dim3 grid((unsigned)(tiles_m * tiles_n));
-    kern<<<grid, 512, L::TOTAL, st>>>(w->qs, w->qh, w->d, w->m, (const uint8_t *)p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad,
-                                      w->nbk, ldd, tiles_m, tiles_n, dbg);
-    return hipGetLastError();
+    // big tile (256 x 128, 8 tiles per wave) when it still fills the chip with >= 2 workgroups per CU; else 128 x 64
+    const int64_t big = ((w->M + 255) / 256) * ((N + 127) / 128);
+    if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
+    return launch_cfg<TYPE, 2, 2, 2, 1, 4>(w, p, N, dst, ldd, st);
 }
 
 }  // namespace
 
+int gemm_q16_image_kind(int type) { return type == GGML_TYPE_Q8_0 ? 2 : 1; }
+
 hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
-    if (p.Npad % TN != 0) return hipErrorInvalidValue;
     switch (w->type) {
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);

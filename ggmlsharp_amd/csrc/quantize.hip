@@ -59,7 +59,10 @@ __device__ __forceinline__ uint16_t float_to_half_bits_rne(float f) {
 // ---------------------------------------------------------------------------------------------------------
 #define K1_BPB 8
 
-template <bool F16>
+// IMG: 0 = int8 even/odd planes; 1 = f16 image in nibble order (Q4_0/Q4_1/Q5_0 weights); 2 = f16 image in byte-plane
+// order (Q8_0 weights) -- the k-slot orders of gemm_q16.hip.  The f16 images carry `as` as the float d * sum(q)
+// (the Q8_1 s0 + s1 of Ggml.cs:820-821, intent D3) instead of the integer sum.
+template <int IMG>
 __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restrict__ x, int64_t N, int64_t nbk, int64_t ld1,
                                                           int8_t *__restrict__ a8, float *__restrict__ ad,
                                                           int32_t *__restrict__ as, int64_t Npad) {
@@ -94,27 +97,48 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        if (F16) {
-            // f16 image: element 4t+p goes to panel p, position t.  The 4 lanes of a group transpose their 4x4
-            // halves with two xor-shuffles so that lane t = 4u+v ends up with positions 4u..4u+3 of panel v (8 bytes).
+        if (IMG != 0) {
             const float r0 = rintf(v[j].x * id), r1 = rintf(v[j].y * id), r2 = rintf(v[j].z * id), r3 = rintf(v[j].w * id);
-            const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)r0), h1 = __builtin_bit_cast(uint16_t, (_Float16)r1);
-            const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)r2), h3 = __builtin_bit_cast(uint16_t, (_Float16)r3);
-            const uint32_t lo = h0 | (h1 << 16), hi = h2 | (h3 << 16);
-            const int vv = t & 3;
-            const uint32_t recv1 = (uint32_t)__shfl_xor((int)(vv < 2 ? hi : lo), 2);
-            const uint32_t X = vv < 2 ? lo : recv1;   // residues (2*(vv>>1), +1) of source lane vv & 1
-            const uint32_t Y = vv < 2 ? recv1 : hi;   // same residues of source lane (vv & 1) + 2
-            const bool odd = (vv & 1) != 0;
-            const uint32_t send2 = odd ? ((X & 0xFFFFu) | (Y << 16)) : ((X >> 16) | (Y & 0xFFFF0000u));
-            const uint32_t recv2 = (uint32_t)__shfl_xor((int)send2, 1);
-            const uint32_t o0 = odd ? ((recv2 & 0xFFFFu) | (X & 0xFFFF0000u)) : ((X & 0xFFFFu) | (recv2 << 16));
-            const uint32_t o1 = odd ? ((recv2 >> 16) | (Y & 0xFFFF0000u)) : ((Y & 0xFFFFu) | (recv2 & 0xFFFF0000u));
+            const bool odd = (t & 1) != 0;
+            uint32_t o0, o1;
+            int panel, half8;
+            if (IMG == 1) {
+                // lane t owns elements 4t..4t+3 = e_i, i = 4(t&1) + c, of (h = t>>2, kk = (t>>1)&1); k-slots are
+                // [e0, e4, e1/16, e5/16, e2, e6, e3/16, e7/16]: dword c = [even lane's c-th value, odd lane's c-th value]
+                const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)r0), h1 = __builtin_bit_cast(uint16_t, (_Float16)(r1 * 0.0625f));
+                const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)r2), h3 = __builtin_bit_cast(uint16_t, (_Float16)(r3 * 0.0625f));
+                const uint32_t send = odd ? (h0 | (h1 << 16)) : (h2 | (h3 << 16));
+                const uint32_t recv = (uint32_t)__shfl_xor((int)send, 1);
+                // even lane writes dwords 0, 1; odd lane dwords 2, 3
+                o0 = odd ? ((recv & 0xFFFFu) | (h2 << 16)) : (h0 | (recv << 16));
+                o1 = odd ? ((recv >> 16) | (h3 << 16)) : (h1 | (recv & 0xFFFF0000u));
+                panel = 2 * ((t >> 1) & 1) + (t >> 2);
+                half8 = t & 1;
+            } else {
+                // plane h holds elements 2jj + h; lane t owns jj = 2(t&3), 2(t&3)+1 of kk = t>>2: x, z -> plane 0, y, w ->
+                // plane 1; k-slots [jj0, jj2, jj1, jj3, jj4, jj6, jj5, jj7]: dword pair u = (t&3)>>1 of the panel row is
+                // [even.x, odd.x], [even.z, odd.z] (plane 0) or the same with y, w (plane 1)
+                const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)r0), h1 = __builtin_bit_cast(uint16_t, (_Float16)r1);
+                const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)r2), h3 = __builtin_bit_cast(uint16_t, (_Float16)r3);
+                const uint32_t send = odd ? (h0 | (h2 << 16)) : (h1 | (h3 << 16));
+                const uint32_t recv = (uint32_t)__shfl_xor((int)send, 1);
+                // even lane writes plane 0 (x, z of both lanes), odd lane plane 1 (y, w of both lanes)
+                o0 = odd ? ((recv & 0xFFFFu) | (h1 << 16)) : (h0 | (recv << 16));
+                o1 = odd ? ((recv >> 16) | (h3 << 16)) : (h2 | (recv & 0xFFFF0000u));
+                panel = 2 * (t >> 2) + (t & 1);
+                half8 = (t & 3) >> 1;
+            }
             if (live && b < nbk) {
-                *(uint2 *)(a8 + ((b * 4 + vv) * Npad + n) * 16 + 8 * (t >> 2)) = make_uint2(o0, o1);
+                *(uint2 *)(a8 + ((b * 4 + panel) * Npad + n) * 16 + 8 * half8) = make_uint2(o0, o1);
                 if (t == 0) {
                     ad[b * Npad + n] = d;
-                    as[b * Npad + n] = s;
+                    as[b * Npad + n] = (int32_t)__float_as_uint(d * (float)s);
+                }
+            } else if (live && b < pad_kblocks(nbk)) {     // zero pad blocks up to a whole stage (finite * 0 = 0)
+                *(uint2 *)(a8 + ((b * 4 + panel) * Npad + n) * 16 + 8 * half8) = make_uint2(0u, 0u);
+                if (t == 0) {
+                    ad[b * Npad + n] = 0.0f;
+                    as[b * Npad + n] = 0;
                 }
             }
             continue;
@@ -373,14 +397,16 @@ __global__ void q8_aos_to_planes_kernel(const uint8_t *__restrict__ in, int64_t 
 
 }  // namespace
 
-hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, bool f16_image, hipStream_t st) {
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const int64_t nbk = K / QK;
     dim3 grid((unsigned)((nbk + K1_BPB - 1) / K1_BPB), (unsigned)((N + 31) / 32));
-    if (f16_image)
-        quantize_act_kernel<true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    if (image == 1)
+        quantize_act_kernel<1><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    else if (image == 2)
+        quantize_act_kernel<2><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     else
-        quantize_act_kernel<false><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        quantize_act_kernel<0><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     return hipGetLastError();
 }
 
