@@ -9,7 +9,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libggml_hip.so")
+LIB_PATH = os.environ.get("GGML_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libggml_hip.so")   # env: developer ablation builds
 
 GGML_MAX_DIMS = 4
 GGML_MAX_OPT = 4
@@ -92,6 +92,7 @@ SYMBOLS = {
     "ggml_hip_weight_cols": (C.c_int64, [_P]),
     "ggml_hip_weight_type": (C.c_int, [_P]),
     "ggml_hip_mul_mat_work_size": (C.c_size_t, [C.c_int, C.c_int64, C.c_int64]),
+    "ggml_hip_act_image_kind": (C.c_int, [C.c_int, C.c_int64]),
     "ggml_hip_mul_mat_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),
     "ggml_hip_mul_mat_init_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_size_t, _P]),
     "ggml_hip_mul_mat_compute_dev": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),

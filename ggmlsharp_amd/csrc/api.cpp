@@ -53,12 +53,14 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
 }
 
 // Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat:
-//   gemm_q16.hip (f16 matrix cores, register-tile design, f16 image) -- the default,
-//   gemm_q.hip   (int8 matrix cores, int8 image) with GGML_HIP_GEMM=i8 (developer A/B switch).
-// Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip.
+//   gemm_qmx.hip (MX matrix path, bf6 operands, one MFMA per tile and block) -- the default for Q4_0 / Q4_1,
+//   gemm_q16.hip (f16 matrix cores, register-tile design) -- the default for Q5_0 / Q8_0; GGML_HIP_GEMM=f16 forces it,
+//   gemm_q.hip   (int8 matrix cores, int8 image) with GGML_HIP_GEMM=i8 (developer A/B switches).
+// Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip, 3 = the bf6 image of gemm_qmx.hip.
 int act_image_kind(int type, int64_t N) {
-    static const bool force_i8 = [] { const char *e = getenv("GGML_HIP_GEMM"); return e && e[0] == 'i'; }();
-    if (N <= GEMV_MAX_N || force_i8) return 0;
+    static const int force = [] { const char *e = getenv("GGML_HIP_GEMM"); return !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : 0)); }();
+    if (N <= GEMV_MAX_N || force == 1) return 0;
+    if (force != 2 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1)) return 3;
     return gemm_q16_image_kind(type);
 }
 
@@ -95,7 +97,7 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
     ggml_hip_weight *w = new ggml_hip_weight();
     memset(w, 0, sizeof *w);
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = g_device;
-    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, total = 0;
+    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, total = 0;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
         total = (size_t)w->Mpad * K * (type == GGML_TYPE_F32 ? 4 : 2);
     } else {
@@ -107,6 +109,10 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
         off_d = total; total += plane;
         if (type == GGML_TYPE_Q4_1) { off_m = total; total += plane; }
         if (type == GGML_TYPE_Q5_0) { off_qh = total; total += plane; }
+        if (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) {   // bf6 operand planes of the MX mat-mat kernel (0.75 B / weight)
+            off_6a = total; total += (size_t)nba * w->Mpad * 16;
+            off_6b = total; total += (size_t)nba * w->Mpad * 8;
+        }
     }
     if (total == 0) total = 16;
     void *base = nullptr;
@@ -120,6 +126,7 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
         w->d = (float *)((uint8_t *)base + off_d);
         if (type == GGML_TYPE_Q4_1) w->m = (float *)((uint8_t *)base + off_m);
         if (type == GGML_TYPE_Q5_0) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
+        if (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
     }
     *out = w;
     return GGML_HIP_OK;
@@ -156,6 +163,7 @@ int make_weight(int type, const void *rows, bool rows_on_host, int64_t ne00, int
     } else if (e == hipSuccess) {
         e = launch_repack_to_planar(type, dev_rows, nb01, row_begin, rows_n, w, st);
     }
+    if (e == hipSuccess) e = launch_nibbles_to_bf6(w, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (staging) (void)hipFree(staging);
     if (e != hipSuccess) {
@@ -282,6 +290,8 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     return GGML_HIP_OK;
 }
 
+int ggml_hip_act_image_kind(int type, int64_t N) { return act_image_kind(type, N); }
+
 int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_dst, int64_t ldd, const void *d_work,
                                  size_t work_bytes, void *stream) {
     if (!w || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
@@ -292,6 +302,8 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
     if (N <= GEMV_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
+    else if (act_image_kind(w->type, N) == 3)
+        HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else if (act_image_kind(w->type, N) != 0)
         HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else

@@ -51,6 +51,8 @@ struct ggml_hip_weight {
     uint32_t *qh;
     float   *d;
     float   *m;
+    uint8_t *q6a;     // Q4_0 / Q4_1: bf6 (e3m2) codes of nib - 8, [nbk][Mpad][16 B] = the first 16 bytes of each 24-byte
+    uint8_t *q6b;     //   MFMA fragment (element e at bits [6e, 6e+5]), and [nbk][Mpad][8 B] = the last 8 (gemm_qmx.hip)
     void    *dense;
     size_t   bytes;
     int      device;
@@ -58,8 +60,10 @@ struct ggml_hip_weight {
 
 // ---- activation scratch ("wdata"), planar like the weights; K1 writes one of two images into the `a8` region ----
 //   int8 image (mat-vec kernel):  [nbk][2][Npad][16] int8, plane 0 = even elements of the block, plane 1 = odd
-//   f16 image  (MFMA kernel)   :  [nbk][4][Npad][16 B] f16, panel p = elements e with e % 4 == p, in order
-//   ad [nbk][Npad] f32 block scales, as [nbk][Npad] i32 block sums of the quants
+//   f16 images (gemm_q16.hip)  :  [nbk][4][Npad][16 B] f16, panel p = 2*kk + h, k-slot orders in gemm_q16.hip
+//   bf6 image  (gemm_qmx.hip)  :  per k-block [2][Npad][16 B] then [2][Npad][8 B]: half 0 = digits ah, half 1 = digits al
+//                                 of a = 16*ah + al, 32 bf6 codes per 24-byte fragment
+//   ad [nbk][Npad] f32 block scales, as [nbk][Npad] i32 block sums of the quants (MFMA images: the float d * sum)
 struct act_planes {
     int8_t  *a8;
     float   *ad;
@@ -85,6 +89,7 @@ static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
                                    ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
+hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
                                     hipStream_t st);
 // quantize.hip
@@ -102,6 +107,7 @@ hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t
                                hipStream_t st);
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st);
 

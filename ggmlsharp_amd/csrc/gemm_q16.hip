@@ -266,7 +266,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         const float *sDa = (const float *)(sp + C::A_BYTES) + wn * WNT * 32 + 4 * hh;
         const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
         const int kb0 = s * KB;
-        constexpr int LAST = KB * NTILE - 1;
+        constexpr int LAST = KB * NTILE - 1, DRAIN = (KB - 1) * NTILE + NTILE / 2;
+        static_assert(NPIECE <= DRAIN, "all DMA pieces are issued before the drain point");
 
         f16x8 af[2];
         f32x4 da[4], sa[4];
@@ -308,6 +309,11 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         static_for<KB * NTILE>([&](auto tc) {
             constexpr int t = decltype(tc)::value, bb = t / NTILE, tl = t % NTILE, j = tl / WMT, i = tl % WMT;
             if constexpr (t < NPIECE) dma_piece(s + 1, tc);
+            // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
+            // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
+            // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
+            // flight across the barrier.
+            if constexpr (t == DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (t < LAST) issue_a(std::integral_constant<int, t + 1>{});
             const float dw = frag[bb & 1].d[i];
             float *ac = acc[i][j];
@@ -351,10 +357,9 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         });
     };
 
-    // ---- main loop: double-buffered LDS, one barrier per stage.  vmcnt(0), not a counted wait: hipcc is free to sink
-    //      the weight loads (read-only buffer loads) below an asm wait, so "all but the youngest N" is not a statement
-    //      about the DMA pieces.  The youngest loads at a stage end were issued two tiles earlier and have mostly
-    //      landed. ----
+    // ---- main loop: double-buffered LDS, one barrier per stage.  The DMA drain is a vmcnt(0) placed where it is free
+    //      (see DRAIN in compute), not a counted wait at the barrier: hipcc may sink the weight loads (read-only buffer
+    //      loads) below an asm wait, so "all but the youngest N" would not be a statement about the DMA pieces. ----
     static_for<NPIECE>([&](auto pc) { dma_piece(0, pc); });
     static_for<WMT>([&](auto ic) { load_raw_one(0, raw, ic); });
     static_for<WMT>([&](auto ic) { unpack_one(raw, frag[0], ic); load_raw_one(1, raw, ic); });
@@ -363,7 +368,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
     for (int s = 0; s < nstages; ++s) {
         compute(s);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }

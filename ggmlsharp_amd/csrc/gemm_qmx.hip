@@ -1,0 +1,370 @@
+// gemm_qmx.hip -- K3m: quantized mat-mat for large N with 4-bit weights (Q4_0, Q4_1), block-scaled, on the MX matrix
+// path of gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4 with bf6 = e3m2 operands).
+//
+// COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698):
+//   dst[n*ldd + m] = sum_b (dw[m,b] * da[n,b]) * sumi_b(m,n),   sumi_b = the integer dot of one 32-element block
+// (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159; _q4_1_q8_1 1176-1198).
+//
+// One MFMA per 32x32 tile and quant block, exact:  the instruction multiplies 32x64 by 64x32 with one power-of-two
+// (E8M0) scale per operand row and 32-element K group.  Every 4-bit weight (nib - 8, in [-8, 7]) is exact in bf6
+// (e3m2 holds every integer up to 8).  A Q8 activation a in [-127, 127] is split as a = 16*ah + al with ah in [-8, 8],
+// al in [-8, 7], both exact in bf6: K group 0 carries ah with block scale 2^4, K group 1 carries al with scale 2^0,
+// and the weights of the block sit in both groups.  So D = 16*sum(w*ah) + sum(w*al) = sumi_b, every partial sum an
+// integer below 2^24, i.e. bit-exact in the f32 accumulator -- in 32 matrix-pipe cycles instead of the 64 of two
+// f16 MFMAs (gemm_q16.hip), with NO weight expansion on the VALU: the resident bf6 planes (layout.hip, built once at
+// upload) are loaded straight into the B operand registers.  Measured (tools/tile_ubench.hip): 54 ns per tile and
+// k-block per SIMD against 78 ns for the f16 form, next to a floor of 36 ns for the 32 scale-accumulate VALU
+// instructions alone -- the reference's own per-block f32 work (Ggml.cs:1158), which is what bounds this path.
+// Operand layout (probed with exact integer data, tools/mx_probe.hip): lane l holds row/col l & 31, K elements
+// 32*(l >> 5) .. +31, element e at bits [6e, 6e+5] of a 192-bit fragment (6 VGPRs); the scale byte of a lane applies
+// to that lane's row and K group.
+//
+// Everything else follows gemm_q16.hip: MFMA rows = src1 rows n, cols = weight rows m (dst stores are 128-byte
+// segments along m); activations reach LDS by DMA (K1 writes the bf6 image), row scales by broadcast ds_read_b128;
+// raw buffer addressing; inline-asm scale-accumulate; K zero-padded to whole stages by the host side.
+#include "common.h"
+#include <cstdlib>
+#include <utility>
+
+// Developer timing ablations (never in the product build): -DGGML_MX_DBG=<bits>  1 no barrier / DMA, 2 no LDS fragment
+// or scale reads after the first, 4 no weight reloads, 8 no MFMA after the first, 16 no scale-accumulate.
+#ifndef GGML_MX_DBG
+#define GGML_MX_DBG 0
+#endif
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void blds16(rsrc_t r, void *l, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)l, 16, (int)voff, (int)soff, 0, 0);
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// WMT x WNT 32x32 tiles per wave, WGM x WGN waves per workgroup, KB k-blocks per LDS stage
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
+struct Cfg {
+    static constexpr int TM = WGM * WMT * 32, TN = WGN * WNT * 32, NT = WGM * WGN * 64;
+    static constexpr int A16_BYTES = KB * 2 * TN * 16;     // first 16 bytes of every 24-byte activation fragment
+    static constexpr int A8_BYTES = KB * 2 * TN * 8;       // last 8 bytes
+    static constexpr int NSC = (TYPE == GGML_TYPE_Q4_1) ? 2 : 1;
+    static constexpr int SC_BYTES = KB * TN * 4;           // one f32 plane of row scales
+    static constexpr int STAGE = A16_BYTES + A8_BYTES + NSC * SC_BYTES;
+    static constexpr int TOTAL = 2 * STAGE;
+    static constexpr int P = NT / TN;
+    static_assert(NT % TN == 0 && (P == 1 || P == 2 || P == 4), "chunk decomposition");
+    static_assert((KB * 2 * TN) % NT == 0 && (KB * TN) % NT == 0, "DMA rounds");
+    static constexpr int A16_ROUNDS = KB * 2 * TN / NT, A8_ROUNDS = KB * TN / NT;
+    static constexpr int SC_CHUNKS = KB * TN / 4;          // 16-byte pieces per plane
+    static_assert(SC_CHUNKS % 64 == 0 && SC_CHUNKS <= NT, "scale DMA is whole waves");
+    static constexpr int NPIECE = A16_ROUNDS + A8_ROUNDS + 1;
+    static_assert(NPIECE <= KB * WMT * WNT, "one DMA piece per tile");
+};
+
+// FB = weight fragment buffers: 2 = fragments of k-block kb+2 are loaded into the buffer k-block kb has just released;
+// 1 = in place, for kb+1 (enough look-ahead when a wave has >= 4 m-tiles between two uses of a fragment)
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB>
+__global__ __launch_bounds__(WGM * WGN * 64, 2)
+void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                     const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
+                     const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nstages,
+                     int ldd, int tiles_m, int tiles_n, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes,
+                     uint32_t ad_bytes, uint32_t dst_bytes) {
+    using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
+    constexpr int NTILE = WMT * WNT, P = C::P;
+    static_assert(KB % 2 == 0, "fragment buffers alternate by k-block parity");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave / WGM, wm_ = wave % WGM;           // waves of one workgroup: m fastest
+
+    // XCD-aware tile order (speed only): workgroups b, b+8, b+16, ... share an XCD and its L2.  Each XCD gets a
+    // contiguous run of the tile list ordered "m fastest".
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (t_lin % tiles_m) * C::TM;
+    const int n0 = (t_lin / tiles_m) * C::TN;
+
+    float acc[WMT][WNT][16];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- activation image (K1, kind 3) + row scales: global -> LDS by DMA, one piece (1 KiB per wave) per tile ----
+    // image per k-block: [half][Npad][16 B] then [half][Npad][8 B]  (half 0 = the 16*ah group, half 1 = the al group);
+    // LDS stage: [bb][half][TN][16 B] then [bb][half][TN][8 B] then the scale planes.  Chunk c = tid + NT*i splits into a
+    // per-thread part (one 32-bit offset per region for the whole kernel) and a part that is uniform in i.
+    const uint32_t a_blk = (uint32_t)Npad * 48u;
+    const int t16 = tid / C::TN, t8 = tid / (C::TN / 2);
+    const uint32_t voff16 = (uint32_t)(t16 >> 1) * a_blk + (uint32_t)(((t16 & 1) * Npad + n0 + tid % C::TN) * 16);
+    const uint32_t voff8 = (uint32_t)(t8 >> 1) * a_blk + (uint32_t)(32 * Npad + (t8 & 1) * Npad * 8 + n0 * 8 + (tid % (C::TN / 2)) * 16);
+    const uint32_t voffS = (uint32_t)(((tid / (C::TN / 4)) * Npad + n0 + 4 * (tid % (C::TN / 4))) * 4);
+    const rsrc_t rA = make_rsrc(a6, a_bytes), rAd = make_rsrc(ad, ad_bytes), rAs = make_rsrc(asd, ad_bytes);
+    // Pieces past the end of K are dropped by the descriptor's range check (they would fill a buffer nobody reads).
+    auto dma_piece = [&](int s, auto pc) {
+        constexpr int i = decltype(pc)::value;
+        uint8_t *sp = smem + (s & 1) * C::STAGE;
+        const uint32_t s0 = (uint32_t)s * KB * a_blk;
+        if constexpr (i < C::A16_ROUNDS) {
+            constexpr int u = P * i;
+            blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voff16, s0 + (u >> 1) * a_blk + (u & 1) * (uint32_t)(Npad * 16));
+        } else if constexpr (i < C::A16_ROUNDS + C::A8_ROUNDS) {
+            constexpr int i8 = i - C::A16_ROUNDS, u = 2 * P * i8;
+            blds16(rA, sp + C::A16_BYTES + (size_t)(wave * 64 + C::NT * i8) * 16, voff8, s0 + (u >> 1) * a_blk);
+        } else if (wave < C::SC_CHUNKS / 64) {                           // uniform per wave
+            const uint32_t sS0 = (uint32_t)s * KB * (uint32_t)(Npad * 4);
+            blds16(rAd, sp + C::A16_BYTES + C::A8_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            if (TYPE == GGML_TYPE_Q4_1)
+                blds16(rAs, sp + C::A16_BYTES + C::A8_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+        }
+    };
+
+    // ---- weights: the bf6 planes go straight into the B operand registers (both lane halves hold the same block) ----
+    struct Frag { u32x4 lo[WMT]; u32x2 hi[WMT]; float d[WMT]; float mn[WMT]; };
+    // one per-thread offset per plane; the m-tiles of a wave are 32 rows apart = a constant the instruction's immediate
+    // offset field takes
+    const int mrow = m0 + wm_ * WMT * 32 + l31;
+    const uint32_t offA = (uint32_t)(mrow * 16), offB = (uint32_t)(mrow * 8), offD = (uint32_t)(mrow * 4);
+    const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4);
+    const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
+    const rsrc_t rWm = make_rsrc(TYPE == GGML_TYPE_Q4_1 ? (const void *)wm : (const void *)wd, wd_bytes);
+    // the planes carry spare (zero) k-blocks past the padded end, so the look-ahead never needs a bounds check
+    auto load_frag_one = [&](int kb, Frag &f, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        f.lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)(offA + 512u * i), (int)((uint32_t)kb * wa_blk), 0);
+        f.hi[i] = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)(offB + 256u * i), (int)((uint32_t)kb * wb_blk), 0);
+        f.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
+        if constexpr (TYPE == GGML_TYPE_Q4_1)
+            f.mn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
+    };
+
+    Frag frag[FB];                                          // k-block kb uses frag[kb % FB]
+    const int scale_a = hh ? 127 : 131;                     // E8M0: K group 0 (the ah digits) carries 2^4
+
+    auto compute = [&](int s) {
+        const uint8_t *sp = smem + (s & 1) * C::STAGE;
+        const uint8_t *sA16 = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
+        const uint8_t *sA8 = sp + C::A16_BYTES + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 8;
+        const float *sDa = (const float *)(sp + C::A16_BYTES + C::A8_BYTES) + wn * WNT * 32 + 4 * hh;
+        const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
+        const int kb0 = s * KB;
+        constexpr int LAST = KB * NTILE - 1, DRAIN = (KB - 1) * NTILE + NTILE / 2;
+        static_assert(C::NPIECE <= DRAIN, "all DMA pieces are issued before the drain point");
+
+        u32x4 af_lo;
+        u32x2 af_hi;
+        f32x4 da[4], sa[4];
+        f32x16 tacc[2];
+        float dcur[WMT], mcur[WMT];
+
+        auto fetch_af = [&](auto nc) {                                   // nc = n-tile index within the stage
+            constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT;
+            af_lo = *(const u32x4 *)(sA16 + (bb * 2 * C::TN + 32 * j) * 16);
+            af_hi = *(const u32x2 *)(sA8 + (bb * 2 * C::TN + 32 * j) * 8);
+        };
+        auto fetch_da = [&](auto nc, auto gc) {
+            constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT, q = decltype(gc)::value;
+            da[q] = *(const f32x4 *)(sDa + bb * C::TN + 32 * j + 8 * q);
+            if constexpr (TYPE == GGML_TYPE_Q4_1) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
+        };
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // the MFMA of tile t, then everything that becomes possible once it is issued
+        auto issue = [&](auto tc) {
+            constexpr int t = decltype(tc)::value, bb = t / NTILE, j = (t % NTILE) / WMT, i = t % WMT;
+            Frag &f = frag[bb % FB];
+            const i32x8 a = {(int)af_lo[0], (int)af_lo[1], (int)af_lo[2], (int)af_lo[3], (int)af_hi[0], (int)af_hi[1], 0, 0};
+            const i32x8 b = {(int)f.lo[i][0], (int)f.lo[i][1], (int)f.lo[i][2], (int)f.lo[i][3], (int)f.hi[i][0], (int)f.hi[i][1], 0, 0};
+            if constexpr (!(GGML_MX_DBG & 8) || t == 0)
+                tacc[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, zero, 3, 3, 0, scale_a, 0, 127);
+            else
+                asm volatile("" : "+v"(tacc[t & 1]));
+            if constexpr (j == 0) {                                       // first use of this block's scales: keep them
+                dcur[i] = f.d[i];                                         // (the buffer is reloaded before the last use)
+                if constexpr (TYPE == GGML_TYPE_Q4_1) mcur[i] = fmaf(8.0f, f.d[i], f.mn[i]);   // nib = (nib - 8) + 8
+            }
+            if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & 2)) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
+            // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
+            if constexpr (j == WNT - 1 && !(GGML_MX_DBG & 4)) load_frag_one(kb0 + bb + FB, f, std::integral_constant<int, i>{});
+        };
+
+        fetch_af(std::integral_constant<int, 0>{});
+        static_for<4>([&](auto gc) { fetch_da(std::integral_constant<int, 0>{}, gc); });
+        issue(std::integral_constant<int, 0>{});
+
+        static_for<KB * NTILE>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, bb = t / NTILE, tl = t % NTILE, j = tl / WMT, i = tl % WMT;
+            // this tile's weight scales, read before issue(t + 1) may replace them with the next block's (WMT == 1)
+            const float dw = dcur[i];
+            const float mw = TYPE == GGML_TYPE_Q4_1 ? mcur[i] : 0.0f;
+            if constexpr (t < C::NPIECE && !(GGML_MX_DBG & 1)) dma_piece(s + 1, tc);
+            // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
+            // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
+            // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
+            // flight across the barrier.
+            if constexpr (t == DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (t < LAST) issue(std::integral_constant<int, t + 1>{});
+            float *ac = acc[i][j];
+            static_for<4>([&](auto gc) {
+                constexpr int q = decltype(gc)::value;
+                float t0, t1, t2, t3;
+                // Hazard note (inline asm is not padded by hipcc): an MFMA result needs 12 wait states before a VALU
+                // reads it.  Tile t's MFMA is pinned above tile t-1's 32 VALU instructions, so only the first tile of
+                // a stage can be short of them: it carries its own s_nop.
+                if constexpr (t == 0 && q == 0) asm volatile("s_nop 11" : "+v"(tacc[0]));
+                // acc += (sumi * d1) * d0, Ggml.cs:1158.  The other MFMA result rides along as a dummy operand of
+                // group 0 so that its MFMA stays above this tile's VALU work (which is what it overlaps with).
+                if constexpr ((GGML_MX_DBG & 16) != 0) {
+                    asm volatile("" : "+v"(ac[4 * q]) : "v"(tacc[t & 1]), "v"(da[q]), "v"(dw), "v"(tacc[(t + 1) & 1]));
+                } else if constexpr (q == 0 && t < LAST) {
+                    asm volatile("v_mul_f32 %4, %8, %12\n\tv_mul_f32 %5, %9, %13\n\tv_mul_f32 %6, %10, %14\n\tv_mul_f32 %7, %11, %15\n\t"
+                                 "v_fmac_f32 %0, %4, %16\n\tv_fmac_f32 %1, %5, %16\n\tv_fmac_f32 %2, %6, %16\n\tv_fmac_f32 %3, %7, %16"
+                                 : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                                 : "v"(tacc[t & 1][0]), "v"(tacc[t & 1][1]), "v"(tacc[t & 1][2]), "v"(tacc[t & 1][3]), "v"(da[0][0]),
+                                   "v"(da[0][1]), "v"(da[0][2]), "v"(da[0][3]), "v"(dw), "v"(tacc[(t + 1) & 1]));
+                } else {
+                    asm volatile("v_mul_f32 %4, %8, %12\n\tv_mul_f32 %5, %9, %13\n\tv_mul_f32 %6, %10, %14\n\tv_mul_f32 %7, %11, %15\n\t"
+                                 "v_fmac_f32 %0, %4, %16\n\tv_fmac_f32 %1, %5, %16\n\tv_fmac_f32 %2, %6, %16\n\tv_fmac_f32 %3, %7, %16"
+                                 : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3]), "=&v"(t0), "=&v"(t1),
+                                   "=&v"(t2), "=&v"(t3)
+                                 : "v"(tacc[t & 1][4 * q + 0]), "v"(tacc[t & 1][4 * q + 1]), "v"(tacc[t & 1][4 * q + 2]),
+                                   "v"(tacc[t & 1][4 * q + 3]), "v"(da[q][0]), "v"(da[q][1]), "v"(da[q][2]), "v"(da[q][3]), "v"(dw));
+                }
+                if constexpr (TYPE == GGML_TYPE_Q4_1) {                       // + (m0 + 8 d0) * (d1 * sum(a)) (Ggml.cs:1190-1196 factorised)
+                    asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
+                                 : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3])
+                                 : "v"(sa[q][0]), "v"(sa[q][1]), "v"(sa[q][2]), "v"(sa[q][3]), "v"(mw));
+                }
+                // this group's row scales are dead after the n-tile's last m-tile: fetch the next n-tile's into their place
+                if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & 2))
+                    fetch_da(std::integral_constant<int, bb * WNT + j + 1>{}, gc);
+            });
+        });
+    };
+
+    // ---- main loop: double-buffered LDS, one barrier per stage (vmcnt(0): see gemm_q16.hip) ----
+    static_for<C::NPIECE>([&](auto pc) { dma_piece(0, pc); });
+    static_for<WMT>([&](auto ic) {
+        load_frag_one(0, frag[0], ic);
+        if constexpr (FB == 2) load_frag_one(1, frag[FB - 1], ic);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
+    for (int s = 0; s < nstages; ++s) {
+        compute(s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(GGML_MX_DBG & 1)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
+    const rsrc_t rD = make_rsrc(dst, dst_bytes);
+    const bool full = n0 + C::TN <= N && m0 + C::TM <= M;                    // uniform
+    const uint32_t lane_off = (uint32_t)((4 * hh * ldd + l31) * 4);
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nr = n0 + (wn * WNT + j) * 32 + (r & 3) + 8 * (r >> 2), mb = m0 + (wm_ * WMT + i) * 32;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                                                          (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                const int mb = m0 + (wm_ * WMT + i) * 32, nb = n0 + (wn * WNT + j) * 32;
+                if (mb >= M || nb >= N) continue;                              // uniform
+                const bool mok = mb + l31 < M;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nr = nb + (r & 3) + 8 * (r >> 2);
+                    if (mok && nr + 4 * hh < N)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                                                              (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+                }
+            }
+    }
+}
+
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB>
+hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
+    static bool attr_set = false;
+    auto kern = gemm_qmx_kernel<TYPE, WMT, WNT, WGM, WGN, KB, FB>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (w->Mpad % C::TM != 0 || p.Npad % C::TN != 0 || !w->q6a || !w->q6b) return hipErrorInvalidValue;
+    const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
+    dim3 grid((unsigned)(tiles_m * tiles_n));
+    const int nstages = (int)((w->nbk + KB - 1) / KB);      // planes and image are zero-padded to whole stages (KB | K_STAGE_PAD)
+    static_assert(K_STAGE_PAD % KB == 0, "stage padding");
+    const uint64_t nba = (uint64_t)pad_kblocks(w->nbk);
+    const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16;
+    const uint64_t wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4, a_bytes = nba * 48 * (uint64_t)p.Npad;
+    const uint64_t ad_bytes = nba * (uint64_t)p.Npad * 4, dst_bytes = ((uint64_t)(N - 1) * (uint64_t)ldd + (uint64_t)w->M) * 4;
+    constexpr uint64_t LIM = 0xFFFFFFFFull;                  // 32-bit buffer offsets
+    if (wq_bytes > LIM || a_bytes > LIM || dst_bytes > LIM) return hipErrorNotSupported;
+    kern<<<grid, C::NT, C::TOTAL, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
+                                        (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
+                                        (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes);
+    return hipGetLastError();
+}
+
+template <int TYPE>
+hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    // the largest tile that still gives the chip ~2 workgroups per CU; small problems get more, smaller workgroups
+    static const int var = [] { const char *e = getenv("GGML_HIP_MX_TILE"); return e ? atoi(e) : 0; }();   // developer A/B switch
+    const int64_t tm256 = (w->M + 255) / 256, tm128 = (w->M + 127) / 128, tn128 = (N + 127) / 128;
+    // (Q4_1 carries a second scale plane and would spill at 8 tiles per wave)
+    if (TYPE != GGML_TYPE_Q4_1 && tm256 * tn128 >= 384) {
+        constexpr int T0 = TYPE == GGML_TYPE_Q4_1 ? GGML_TYPE_Q4_0 : TYPE;
+        // 256 x 128 with waves of 128 x 64 (half the LDS reads, weights single-buffered) measured 10 % slower: A/B only
+        if (var == 2) return launch_cfg<T0, 4, 2, 2, 2, 4, 1>(w, p, N, dst, ldd, st);
+        return launch_cfg<T0, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                 // 256 x 128, waves 64 x 128
+    }
+    if (tm128 * tn128 >= 384) return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);   // 128 x 128, 4 tiles per wave
+    return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
+}
+
+}  // namespace
+
+hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    if (N <= 0 || w->M <= 0) return hipSuccess;
+    switch (w->type) {
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
+    default: return hipErrorInvalidValue;
+    }
+}

@@ -149,7 +149,45 @@ __global__ void relayout_gathered_kernel(const float *__restrict__ g, int G, int
     dst[n * ldd + col] = g[(r * N + n) * Ms + i];
 }
 
+// bf6 (e3m2) code of an integer |v| <= 8: 1 = 2^0, 2, 3 = 1.5 * 2, 4, 5 = 1.25 * 4, 6, 7, 8 (all exact)
+__device__ __forceinline__ uint32_t bf6_code(int v) {
+    const uint64_t tab = 0ull | (12ull << 5) | (16ull << 10) | (18ull << 15) | (20ull << 20) | (21ull << 25) | (22ull << 30) |
+                         (23ull << 35) | (24ull << 40);
+    const int a = v < 0 ? -v : v;
+    return (uint32_t)((tab >> (5 * a)) & 31u) | (v < 0 ? 32u : 0u);
+}
+
+// nibble plane -> bf6 planes for gemm_qmx.hip: element e of the block (byte e/2, low nibble first, Ggml.cs:1149-1150)
+// at bits [6e, 6e+5] of a 192-bit fragment; value nib - 8 for Q4_0 and for Q4_1 (whose + 8 moves into the min term).
+__global__ void nibbles_to_bf6_kernel(const uint8_t *__restrict__ qs, int64_t rows, int64_t Mpad, uint8_t *__restrict__ q6a,
+                                      uint8_t *__restrict__ q6b) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (m >= rows) return;
+    const int64_t pi = b * Mpad + m;
+    const uint4 q = *(const uint4 *)(qs + pi * 16);
+    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+    uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int nib = (int)((qq[e >> 3] >> (4 * (e & 7))) & 0xFu);
+        const uint32_t c = bf6_code(nib - 8);
+        const int bit = 6 * e, wdx = bit >> 5, sh = bit & 31;
+        out[wdx] |= c << sh;
+        if (sh > 26) out[wdx + 1] |= c >> (32 - sh);
+    }
+    *(uint4 *)(q6a + pi * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+    *(uint2 *)(q6b + pi * 8) = make_uint2(out[4], out[5]);
+}
+
 }  // namespace
+
+hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st) {
+    if (!w->q6a || w->M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)w->nbk);
+    nibbles_to_bf6_kernel<<<grid, 256, 0, st>>>(w->qs, w->M, w->Mpad, w->q6a, w->q6b);
+    return hipGetLastError();
+}
 
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
                                    ggml_hip_weight *w, hipStream_t st) {

@@ -53,6 +53,14 @@ __device__ __forceinline__ uint16_t float_to_half_bits_rne(float f) {
     return (uint16_t)(sign | half);
 }
 
+// bf6 (e3m2) code of an integer |v| <= 8 (see layout.hip)
+__device__ __forceinline__ uint32_t bf6_code_q(int v) {
+    const uint64_t tab = 0ull | (12ull << 5) | (16ull << 10) | (18ull << 15) | (20ull << 20) | (21ull << 25) | (22ull << 30) |
+                         (23ull << 35) | (24ull << 40);
+    const int a = v < 0 ? -v : v;
+    return (uint32_t)((tab >> (5 * a)) & 31u) | (v < 0 ? 32u : 0u);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K1.  Wave layout: lane = 8 * row_in_wave + t ; the 8 lanes of one row own one 32-element block, 4 floats each
 // (one coalesced 128-byte line per row per block).  A workgroup = 4 waves = 32 rows x BPB consecutive k-blocks.
@@ -60,7 +68,7 @@ __device__ __forceinline__ uint16_t float_to_half_bits_rne(float f) {
 #define K1_BPB 8
 
 // IMG: 0 = int8 even/odd planes; 1 = f16 image in nibble order (Q4_0/Q4_1/Q5_0 weights); 2 = f16 image in byte-plane
-// order (Q8_0 weights) -- the k-slot orders of gemm_q16.hip.  The f16 images carry `as` as the float d * sum(q)
+// order (Q8_0 weights) -- the k-slot orders of gemm_q16.hip; 3 = bf6 digit image of gemm_qmx.hip.  The f16 images carry `as` as the float d * sum(q)
 // (the Q8_1 s0 + s1 of Ggml.cs:820-821, intent D3) instead of the integer sum.
 template <int IMG>
 __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restrict__ x, int64_t N, int64_t nbk, int64_t ld1,
@@ -97,6 +105,38 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
+        if (IMG == 3) {
+            // bf6 image of gemm_qmx.hip: a = 16*ah + al, ah = floor((a + 8) / 16) in [-8, 8], al in [-8, 7]; lane t owns
+            // elements 4t..4t+3 = bits [24t, 24t+24) of both 192-bit fragments; the 4 lanes of a group (u = t & 3) hold
+            // 96 bits = dwords 3g..3g+2 (g = t >> 2), and lane u < 3 assembles dword 3g + u from its own value and
+            // its right neighbour's.
+            const int qv[4] = {q0, q1, q2, q3};
+            uint32_t vh = 0, vl = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ah = (qv[c] + 8) >> 4, al = qv[c] - 16 * ah;
+                vh |= bf6_code_q(ah) << (6 * c);
+                vl |= bf6_code_q(al) << (6 * c);
+            }
+            const uint32_t nh = (uint32_t)__shfl_down((int)vh, 1), nl = (uint32_t)__shfl_down((int)vl, 1);
+            const int u = t & 3, g = t >> 2, idx = 3 * g + u;
+            const uint32_t dh = (vh >> (8 * u)) | (u < 3 ? nh << (24 - 8 * u) : 0u);
+            const uint32_t dl = (vl >> (8 * u)) | (u < 3 ? nl << (24 - 8 * u) : 0u);
+            const bool pad = !(b < nbk);
+            if (live && u < 3 && b < pad_kblocks(nbk)) {
+                uint8_t *blk = (uint8_t *)a8 + b * Npad * 48;
+                uint8_t *p0, *p1;                              // half 0 (ah), half 1 (al)
+                if (idx < 4) { p0 = blk + n * 16 + 4 * idx; p1 = p0 + Npad * 16; }
+                else { p0 = blk + Npad * 32 + n * 8 + 4 * (idx - 4); p1 = p0 + Npad * 8; }
+                *(uint32_t *)p0 = pad ? 0u : dh;
+                *(uint32_t *)p1 = pad ? 0u : dl;
+            }
+            if (live && t == 0 && b < pad_kblocks(nbk)) {
+                ad[b * Npad + n] = pad ? 0.0f : d;
+                as[b * Npad + n] = pad ? 0 : (int32_t)__float_as_uint(d * (float)s);
+            }
+            continue;
+        }
         if (IMG != 0) {
             const float r0 = rintf(v[j].x * id), r1 = rintf(v[j].y * id), r2 = rintf(v[j].z * id), r3 = rintf(v[j].w * id);
             const bool odd = (t & 1) != 0;
@@ -405,6 +445,8 @@ hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1
         quantize_act_kernel<1><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     else if (image == 2)
         quantize_act_kernel<2><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    else if (image == 3)
+        quantize_act_kernel<3><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     else
         quantize_act_kernel<0><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     return hipGetLastError();

@@ -161,6 +161,9 @@ int     ggml_hip_weight_type(const ggml_hip_weight *w);
  * (the reference's dst layout: element (i01, ic) at ic*ne0 + i01, Ggml.cs:6692-6697).
  * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378). */
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);
+/* Which layout step 1 writes into d_work for this weight type and N (introspection for tests and profiling tools):
+ * 0 = int8 planes (mat-vec and int8-MFMA kernels), 1 / 2 = f16 images (gemm_q16.hip), 3 = bf6 digit image (gemm_qmx.hip). */
+int    ggml_hip_act_image_kind(int type, int64_t N);
 int    ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1,
                             float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, void *stream);
 /* The two steps separately (same arguments), so a harness can time the dominant kernel alone. */

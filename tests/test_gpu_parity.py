@@ -116,35 +116,86 @@ def test_weight_roundtrip_bytes(dev, t):
 
 
 # ---------------------------------------------------------------- K1: activation planes == oracle Q8_0 blocks
-def test_quantize_act_planes_match_oracle(dev):
+_BF6 = {0: 0, 12: 1, 16: 2, 18: 3, 20: 4, 21: 5, 22: 6, 23: 7, 24: 8}   # e3m2 code -> integer (the only codes K1 may emit)
+
+
+def _decode_bf6_fragments(frag):
+    """frag: uint8 [..., 24] = 32 bf6 codes, element e at bits [6e, 6e+5] -> int32 [..., 32]"""
+    bits = np.unpackbits(frag, axis=-1, bitorder="little").reshape(frag.shape[:-1] + (32, 6))
+    code = (bits * (1 << np.arange(6))).sum(axis=-1)
+    mag = np.vectorize(lambda c: _BF6.get(int(c) & 31, 99))(code)
+    assert (mag != 99).all(), "K1 emitted a bf6 code that is not a small integer"
+    return np.where(code & 32, -mag, mag).astype(np.int32)
+
+
+def _decode_act_image(kind, raw, nbk, Npad, N):
+    """the device image K1 wrote (layouts: csrc/common.h, gemm_q16.hip, gemm_qmx.hip) -> Q8_0 quants int32 [N][nbk][32]"""
+    q = np.zeros((N, nbk, 32), np.int32)
+    if kind == 0:      # int8 planes: plane 0 = even elements, plane 1 = odd elements
+        a8 = raw[: nbk * 2 * Npad * 16].view(np.int8).reshape(nbk, 2, Npad, 16)
+        q[:, :, 0::2] = a8[:, 0, :N, :].transpose(1, 0, 2)
+        q[:, :, 1::2] = a8[:, 1, :N, :].transpose(1, 0, 2)
+    elif kind == 1:    # f16, panel 2kk+h, k-slots [e0, e4, e1/16, e5/16, e2, e6, e3/16, e7/16], e_i = 16h + 8kk + i
+        a16 = raw[: nbk * 4 * Npad * 16].view(np.float16).reshape(nbk, 4, Npad, 8).astype(np.float64)
+        for kk in range(2):
+            for h in range(2):
+                pan = a16[:, 2 * kk + h, :N, :].transpose(1, 0, 2)
+                for slot, (i, sc) in enumerate([(0, 1), (4, 1), (1, 16), (5, 16), (2, 1), (6, 1), (3, 16), (7, 16)]):
+                    v = pan[:, :, slot] * sc
+                    assert (v == np.round(v)).all()
+                    q[:, :, 16 * h + 8 * kk + i] = v
+    elif kind == 2:    # f16, panel 2kk+h, plane h byte jj = element 2jj + h, k-slots jj = 8kk + [0, 2, 1, 3, 4, 6, 5, 7]
+        a16 = raw[: nbk * 4 * Npad * 16].view(np.float16).reshape(nbk, 4, Npad, 8).astype(np.float64)
+        for kk in range(2):
+            for h in range(2):
+                pan = a16[:, 2 * kk + h, :N, :].transpose(1, 0, 2)
+                for slot, jj in enumerate([0, 2, 1, 3, 4, 6, 5, 7]):
+                    q[:, :, 2 * (8 * kk + jj) + h] = pan[:, :, slot]
+    else:              # bf6 digits: per k-block [2][Npad][16 B] then [2][Npad][8 B]; a = 16 * ah + al
+        img = raw[: nbk * 48 * Npad].reshape(nbk, 48 * Npad)
+        p16 = img[:, : 32 * Npad].reshape(nbk, 2, Npad, 16)
+        p8 = img[:, 32 * Npad:].reshape(nbk, 2, Npad, 8)
+        frag = np.concatenate([p16, p8], axis=-1)[:, :, :N, :]            # [nbk][2][N][24]
+        dig = _decode_bf6_fragments(np.ascontiguousarray(frag))          # [nbk][2][N][32]
+        assert np.abs(dig[:, 0]).max() <= 8 and dig[:, 1].min() >= -8 and dig[:, 1].max() <= 7
+        q[:] = (16 * dig[:, 0] + dig[:, 1]).transpose(1, 0, 2)
+    return q
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0])
+def test_quantize_act_planes_match_oracle(dev, t):
+    """INIT phase (Ggml.cs:6641-6654): whatever image the selected kernel wants, it must hold exactly the oracle's Q8_0 row."""
     from ggmlsharp_amd._lib import lib
-    K = 256
+    K = 256 + 32    # 9 k-blocks: the pad blocks up to a whole stage (12) must be written as zeros
     for N in (1, 7, 33, 130):
         x = np.ascontiguousarray(np.concatenate([_special_rows(K)[:min(N, 8)], _rand((max(N - 8, 0), K))])[:N])
-        w = dev.Weight.from_host(O.Q4_0, O.quantize_row(O.Q4_0, _rand((4, K))), K)
-        work = dev.alloc_work(O.Q4_0, K, N)
+        w = dev.Weight.from_host(t, O.quantize_row(t, _rand((4, K))), K)
+        work = dev.alloc_work(t, K, N)
+        work.fill_(0x7F)     # poison: NaN patterns in every float view
         dev.mul_mat_init(w, torch.from_numpy(x).cuda(), work)
         torch.cuda.synchronize()
         raw = work.cpu().numpy()
         nbk, Npad = K // 32, (N + 255) // 256 * 256
-        img = nbk * 4 * Npad * 16   # the image region is sized for the larger (f16) image
-        ad = raw[img: img + nbk * Npad * 4].view(np.float32).reshape(nbk, Npad)
-        asum = raw[img + nbk * Npad * 4: img + 2 * nbk * Npad * 4].view(np.int32).reshape(nbk, Npad)
+        nba = (nbk + 3) // 4 * 4
+        img = nba * 4 * Npad * 16   # the image region is sized for the largest (f16) image
+        ad = raw[img: img + nba * Npad * 4].view(np.float32).reshape(nba, Npad)
+        asum = raw[img + nba * Npad * 4: img + 2 * nba * Npad * 4].reshape(nba, Npad, 4)
         ref = O.quantize_row(O.Q8_0, x).reshape(N, nbk, 36)
         ref_d = ref[:, :, :4].copy().view(np.float32).reshape(N, nbk)
-        ref_q = ref[:, :, 4:].copy().view(np.int8)
-        assert np.array_equal(ad[:, :N].T.view(np.uint32), ref_d.view(np.uint32))
-        assert np.array_equal(asum[:, :N].T, ref_q.astype(np.int32).sum(axis=2))
-        f16_image = N > 8 and os.environ.get("GGML_HIP_GEMM", "").startswith("f")   # which MFMA kernel is selected
-        if not f16_image:   # int8 image: plane 0 = even elements, plane 1 = odd elements
-            a8 = raw[: nbk * 2 * Npad * 16].view(np.int8).reshape(nbk, 2, Npad, 16)
-            assert np.array_equal(a8[:, 0, :N, :].transpose(1, 0, 2), ref_q[:, :, 0::2])
-            assert np.array_equal(a8[:, 1, :N, :].transpose(1, 0, 2), ref_q[:, :, 1::2])
-        else:        # f16 image for the MFMA kernel: panel p position t = element 4t + p, exact small integers
-            a16 = raw[:img].view(np.float16).reshape(nbk, 4, Npad, 8)
-            for p in range(4):
-                assert np.array_equal(a16[:, p, :N, :].transpose(1, 0, 2).astype(np.int32), ref_q[:, :, p::4].astype(np.int32))
-        assert lib().ggml_hip_mul_mat_work_size(O.Q4_0, K, N) == raw.size
+        ref_q = ref[:, :, 4:].copy().view(np.int8).astype(np.int32)
+        kind = lib().ggml_hip_act_image_kind(t, N)
+        assert kind == (0 if N <= 8 else (3 if t == O.Q4_0 else 2)) or os.environ.get("GGML_HIP_GEMM")
+        assert np.array_equal(ad[:nbk, :N].T.view(np.uint32), ref_d.view(np.uint32))
+        sums = ref_q.sum(axis=2)
+        if kind == 0:
+            assert np.array_equal(asum[:nbk, :N].copy().view(np.int32)[..., 0].T, sums)
+        else:   # the MFMA images carry the float d * sum(q) (the Q8_1 s0 + s1 of Ggml.cs:820-821)
+            assert np.array_equal(asum[:nbk, :N].copy().view(np.float32)[..., 0].T.view(np.uint32), (ref_d * sums.astype(np.float32)).view(np.uint32))
+        q = _decode_act_image(kind, raw, nba, Npad, N)
+        assert np.array_equal(q[:, :nbk], ref_q)
+        if kind != 0:    # pad k-blocks: zero quants, zero scales (finite * 0 = 0 in the kernels)
+            assert not q[:, nbk:].any() and not ad[nbk:, :N].any()
+        assert lib().ggml_hip_mul_mat_work_size(t, K, N) == raw.size
 
 
 # ---------------------------------------------------------------- mul_mat vs oracle
