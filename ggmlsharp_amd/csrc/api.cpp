@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -52,16 +53,28 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
     }
 }
 
-// Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat:
-//   gemm_qmx.hip (MX matrix path, bf6 operands, one MFMA per tile and block) -- the default for Q4_0 / Q4_1,
-//   gemm_q16.hip (f16 matrix cores, register-tile design) -- the default for Q5_0 / Q8_0; GGML_HIP_GEMM=f16 forces it,
-//   gemm_q.hip   (int8 matrix cores, int8 image) with GGML_HIP_GEMM=i8 (developer A/B switches).
+// Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat (measured on MI355X):
+//   gemm_qmx.hip (MX matrix path, bf6 operands, one MFMA per tile and block) -- Q4_0 / Q4_1,
+//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 when its 256 x 128 tile fills the chip,
+//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q8_0, and Q5_0 on small grids.
+// GGML_HIP_GEMM=mx|f16|i8 forces one where the type allows it (developer A/B switch).
 // Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip, 3 = the bf6 image of gemm_qmx.hip.
-int act_image_kind(int type, int64_t N) {
-    static const int force = [] { const char *e = getenv("GGML_HIP_GEMM"); return !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : 0)); }();
+std::atomic<int> g_force_gemm{-1};   // -1: read GGML_HIP_GEMM once; 0 auto, 1 int8, 2 f16, 3 MX (ggml_hip_debug_force_gemm)
+
+int act_image_kind(int type, int64_t M, int64_t N) {
+    int force = g_force_gemm.load();
+    if (force < 0) {
+        const char *e = getenv("GGML_HIP_GEMM");
+        force = !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'm' ? 3 : 0)));
+        g_force_gemm.store(force);
+    }
     if (N <= GEMV_MAX_N || force == 1) return 0;
-    if (force != 2 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1)) return 3;
-    return gemm_q16_image_kind(type);
+    const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
+    if (force == 2) return gemm_q16_image_kind(type);
+    if (q4) return 3;
+    if (force == 3) return gemm_q16_image_kind(type);   // no MX form for this type: the next matrix-core kernel
+    const bool fills = ((M + 255) / 256) * ((N + 127) / 128) >= 384;
+    return (type == GGML_TYPE_Q5_0 && fills) ? gemm_q16_image_kind(type) : 0;
 }
 
 int ensure_init() {
@@ -286,11 +299,23 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
         return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", ggml_hip_mul_mat_work_size(w->type, w->K, N));
     act_planes p = act_carve(d_work, w->K, pad_act(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, N), (hipStream_t)stream));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, w->M, N), (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
-int ggml_hip_act_image_kind(int type, int64_t N) { return act_image_kind(type, N); }
+int ggml_hip_act_image_kind(int type, int64_t M, int64_t N) { return act_image_kind(type, M, N); }
+void ggml_hip_debug_force_gemm(int which) { g_force_gemm.store(which < 0 || which > 3 ? 0 : which); }
+
+int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
+                              int image_kind, void *stream) {
+    if (N <= 0) return GGML_HIP_OK;
+    if (!d_src1 || !d_work) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (K <= 0 || K % QK != 0 || ld1 < K) return fail(GGML_HIP_ERR_SHAPE, "K %% 32 != 0 or ld1 < K");
+    if (image_kind < 0 || image_kind > 3) return fail(GGML_HIP_ERR_ARG, "image kind %d", image_kind);
+    if (work_bytes < act_bytes(K, pad_act(N))) return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", act_bytes(K, pad_act(N)));
+    HIP_TRY(launch_quantize_act(d_src1, N, K, ld1, act_carve(d_work, K, pad_act(N)), image_kind, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
 
 int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_dst, int64_t ldd, const void *d_work,
                                  size_t work_bytes, void *stream) {
@@ -302,9 +327,9 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
     if (N <= GEMV_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (act_image_kind(w->type, N) == 3)
+    else if (act_image_kind(w->type, w->M, N) == 3)
         HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (act_image_kind(w->type, N) != 0)
+    else if (act_image_kind(w->type, w->M, N) != 0)
         HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else
         HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));

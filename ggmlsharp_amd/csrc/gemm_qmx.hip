@@ -27,7 +27,7 @@
 #include <utility>
 
 // Developer timing ablations (never in the product build): -DGGML_MX_DBG=<bits>  1 no barrier / DMA, 2 no LDS fragment
-// or scale reads after the first, 4 no weight reloads, 8 no MFMA after the first, 16 no scale-accumulate.
+// or scale reads after the first, 4 no weight reloads, 8 no MFMA after the first, 16 no scale-accumulate, 32 no row-scale reads, 64 no fragment reads.
 #ifndef GGML_MX_DBG
 #define GGML_MX_DBG 0
 #endif
@@ -206,7 +206,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                 dcur[i] = f.d[i];                                         // (the buffer is reloaded before the last use)
                 if constexpr (TYPE == GGML_TYPE_Q4_1) mcur[i] = fmaf(8.0f, f.d[i], f.mn[i]);   // nib = (nib - 8) + 8
             }
-            if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & 2)) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
+            if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 64))) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
             if constexpr (j == WNT - 1 && !(GGML_MX_DBG & 4)) load_frag_one(kb0 + bb + FB, f, std::integral_constant<int, i>{});
         };
@@ -259,7 +259,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                                  : "v"(sa[q][0]), "v"(sa[q][1]), "v"(sa[q][2]), "v"(sa[q][3]), "v"(mw));
                 }
                 // this group's row scales are dead after the n-tile's last m-tile: fetch the next n-tile's into their place
-                if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & 2))
+                if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 32)))
                     fetch_da(std::integral_constant<int, bb * WNT + j + 1>{}, gc);
             });
         });

@@ -110,13 +110,18 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
             // elements 4t..4t+3 = bits [24t, 24t+24) of both 192-bit fragments; the 4 lanes of a group (u = t & 3) hold
             // 96 bits = dwords 3g..3g+2 (g = t >> 2), and lane u < 3 assembles dword 3g + u from its own value and
             // its right neighbour's.
-            const int qv[4] = {q0, q1, q2, q3};
+            // digits in float arithmetic (exact: |q| <= 127), codes from the f32 bit pattern: for an integer 1 <= |v| <= 8
+            // the bf6 code (exponent bias 3, 2 mantissa bits) is (f32 bits >> 21) - ((127 - 3) << 2); 0 clamps to code 0
+            const float rv[4] = {rintf(v[j].x * id), rintf(v[j].y * id), rintf(v[j].z * id), rintf(v[j].w * id)};
             uint32_t vh = 0, vl = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int ah = (qv[c] + 8) >> 4, al = qv[c] - 16 * ah;
-                vh |= bf6_code_q(ah) << (6 * c);
-                vl |= bf6_code_q(al) << (6 * c);
+                const float ah = floorf(fmaf(rv[c], 0.0625f, 0.5f));       // floor((q + 8) / 16)
+                const float al = fmaf(ah, -16.0f, rv[c]);                    // q - 16 ah, in [-8, 7]
+                const uint32_t bh = __float_as_uint(ah), bl = __float_as_uint(al);
+                const int ch = max((int)((bh & 0x7FFFFFFFu) >> 21) - 496, 0), cl = max((int)((bl & 0x7FFFFFFFu) >> 21) - 496, 0);
+                vh |= ((uint32_t)ch | ((bh >> 26) & 32u)) << (6 * c);
+                vl |= ((uint32_t)cl | ((bl >> 26) & 32u)) << (6 * c);
             }
             const uint32_t nh = (uint32_t)__shfl_down((int)vh, 1), nl = (uint32_t)__shfl_down((int)vl, 1);
             const int u = t & 3, g = t >> 2, idx = 3 * g + u;

@@ -161,9 +161,17 @@ int     ggml_hip_weight_type(const ggml_hip_weight *w);
  * (the reference's dst layout: element (i01, ic) at ic*ne0 + i01, Ggml.cs:6692-6697).
  * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378). */
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);
-/* Which layout step 1 writes into d_work for this weight type and N (introspection for tests and profiling tools):
+/* Which layout step 1 writes into d_work for this weight type, M rows and N (introspection for tests and profiling tools):
  * 0 = int8 planes (mat-vec and int8-MFMA kernels), 1 / 2 = f16 images (gemm_q16.hip), 3 = bf6 digit image (gemm_qmx.hip). */
-int    ggml_hip_act_image_kind(int type, int64_t N);
+int    ggml_hip_act_image_kind(int type, int64_t M, int64_t N);
+/* Developer / test switch: which matrix-core kernel serves N > 8 -- 0 automatic (by type and grid size), 1 int8 MFMA
+ * (gemm_q.hip), 2 f16 MFMA (gemm_q16.hip), 3 MX (gemm_qmx.hip, Q4_0 / Q4_1 only; other types fall to 2).  Same results
+ * within the documented tolerance whichever runs; the environment variable GGML_HIP_GEMM=i8|f16|mx sets the initial value. */
+void   ggml_hip_debug_force_gemm(int which);
+/* Step 1 alone with an explicit layout: every src1 row -> Q8_0 (quantize_row_q8_0, Ggml.cs:733-762, the loop of
+ * Ggml.cs:6641-6654) written as image `image_kind` (see above) into d_work. */
+int    ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
+                                 int image_kind, void *stream);
 int    ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1,
                             float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, void *stream);
 /* The two steps separately (same arguments), so a harness can time the dominant kernel alone. */

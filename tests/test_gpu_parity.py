@@ -162,10 +162,10 @@ def _decode_act_image(kind, raw, nbk, Npad, N):
     return q
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0])
-def test_quantize_act_planes_match_oracle(dev, t):
+@pytest.mark.parametrize("t,force", [(O.Q4_0, ""), (O.Q8_0, ""), (O.Q5_0, "f16"), (O.Q8_0, "f16")])
+def test_quantize_act_planes_match_oracle(dev, t, force):
     """INIT phase (Ggml.cs:6641-6654): whatever image the selected kernel wants, it must hold exactly the oracle's Q8_0 row."""
-    from ggmlsharp_amd._lib import lib
+    from ggmlsharp_amd._lib import lib, check
     K = 256 + 32    # 9 k-blocks: the pad blocks up to a whole stage (12) must be written as zeros
     for N in (1, 7, 33, 130):
         x = np.ascontiguousarray(np.concatenate([_special_rows(K)[:min(N, 8)], _rand((max(N - 8, 0), K))])[:N])
@@ -178,13 +178,19 @@ def test_quantize_act_planes_match_oracle(dev, t):
         nbk, Npad = K // 32, (N + 255) // 256 * 256
         nba = (nbk + 3) // 4 * 4
         img = nba * 4 * Npad * 16   # the image region is sized for the largest (f16) image
-        ad = raw[img: img + nba * Npad * 4].view(np.float32).reshape(nba, Npad)
-        asum = raw[img + nba * Npad * 4: img + 2 * nba * Npad * 4].reshape(nba, Npad, 4)
         ref = O.quantize_row(O.Q8_0, x).reshape(N, nbk, 36)
         ref_d = ref[:, :, :4].copy().view(np.float32).reshape(N, nbk)
         ref_q = ref[:, :, 4:].copy().view(np.int8).astype(np.int32)
-        kind = lib().ggml_hip_act_image_kind(t, N)
-        assert kind == (0 if N <= 8 else (3 if t == O.Q4_0 else 2)) or os.environ.get("GGML_HIP_GEMM")
+        kind = lib().ggml_hip_act_image_kind(t, 4, N)
+        if force == "f16":     # the f16 images serve big grids only: write them through the explicit-layout entry
+            kind = 0 if N <= 8 else (2 if t == O.Q8_0 else 1)
+            if kind:
+                work.fill_(0x7F)
+                check(lib().ggml_hip_quantize_act_dev(C.c_void_p(torch.from_numpy(x).cuda().data_ptr()), N, K, K, C.c_void_p(work.data_ptr()), work.numel(), kind, None), "quantize_act")
+                torch.cuda.synchronize()
+                raw = work.cpu().numpy()
+        ad = raw[img: img + nba * Npad * 4].view(np.float32).reshape(nba, Npad)
+        asum = raw[img + nba * Npad * 4: img + 2 * nba * Npad * 4].reshape(nba, Npad, 4)
         assert np.array_equal(ad[:nbk, :N].T.view(np.uint32), ref_d.view(np.uint32))
         sums = ref_q.sum(axis=2)
         if kind == 0:
@@ -202,19 +208,28 @@ def test_quantize_act_planes_match_oracle(dev, t):
 SHAPES = [  # (M, K, N): ragged M / N, both kernels (N <= 8 mat-vec, N > 8 MFMA), tail stage (K/32 % 4 != 0)
     (1, 32, 1), (16, 64, 1), (17, 96, 2), (200, 256, 3), (128, 4096, 1), (130, 352, 8),
     (64, 128, 9), (33, 160, 17), (200, 256, 64), (128, 512, 128), (257, 1024, 130), (64, 11008, 40),
+    (600, 288, 300),    # several workgroup tiles in both directions, ragged edges, K/32 = 9 (pad k-blocks)
 ]
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])   # 0 = automatic choice, 1 int8 MFMA, 2 f16 MFMA, 3 MX (Q4_0 / Q4_1)
 @pytest.mark.parametrize("t", QTYPES)
-def test_mul_mat_q_matches_oracle(dev, t):
-    for (M, K, N) in SHAPES:
-        w = _rand((M, K))
-        x = _rand((N, K), 2.0)
-        wq = O.quantize_row(t, w)
-        ref = O.mul_mat(t, wq, x, M, K, N, nth=4)[0, 0]
-        W = dev.Weight.from_host(t, wq, K)
-        got = dev.mul_mat(W, torch.from_numpy(x).cuda()).cpu().numpy()
-        assert_close(got, ref, f"type {t} M{M} K{K} N{N}")
+def test_mul_mat_q_matches_oracle(dev, t, kernel):
+    from ggmlsharp_amd._lib import lib
+    lib().ggml_hip_debug_force_gemm(kernel)
+    try:
+        for (M, K, N) in SHAPES:
+            if kernel and N <= 8:
+                continue          # the mat-vec kernel serves N <= 8 whatever is forced
+            w = _rand((M, K))
+            x = _rand((N, K), 2.0)
+            wq = O.quantize_row(t, w)
+            ref = O.mul_mat(t, wq, x, M, K, N, nth=4)[0, 0]
+            W = dev.Weight.from_host(t, wq, K)
+            got = dev.mul_mat(W, torch.from_numpy(x).cuda()).cpu().numpy()
+            assert_close(got, ref, f"type {t} M{M} K{K} N{N} kernel {kernel}")
+    finally:
+        lib().ggml_hip_debug_force_gemm(0)
 
 
 def test_small_n_fused_path_equals_two_step_path(dev):
