@@ -3,8 +3,8 @@
 
 Workload (BASELINE.json `metric`): Q4_0 mul_mat M=4096, K=4096, N=4096, f32 activations and weights already
 resident in HBM.  One step = one pass of ggml_compute_forward_mul_mat_q_f32 over that input:
-INIT phase (quantize the 4096 src1 rows to Q8_0) + COMPUTE phase (block-scaled int8 MFMA mat-mat) [+ the
-all-gather of dst shards and the re-layout when --gpus > 1].
+INIT phase (quantize the 4096 src1 rows to Q8_0) + COMPUTE phase (block-scaled exact-integer MFMA mat-mat on the MX
+matrix path, gemm_qmx.hip) [+ the all-gather of dst shards and the re-layout when --gpus > 1].
   value  = effective GFLOP/s = 2*M*K*N*(ranks) / step time  (whole job)
   roofline = the dominant kernel (COMPUTE phase) alone, timed with HIP events on its stream
   cpu_baseline = the oracle's scalar CPU path (reference algorithm) on the host cores, bounded sample
@@ -27,7 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 Q4_0 = 2
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x BF16 per clock, ~5 PF dense
+I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x BF16 per clock, ~5 PF dense.  The MX kernel issues bf6 MFMAs
+                            # (4x BF16 per clock, ~10 PF) over twice the algorithmic K (two digits per Q8 activation): the same
+                            # 5 PF ceiling in algorithmic FLOPs.
 
 
 def algorithmic_bytes(M, K, N, blk=20):
@@ -195,16 +197,23 @@ def main():
         achieved = 2.0 * M * K * N / (t_comp * 1e-3) / 1e12
         ab = algorithmic_bytes(M, K, N)
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json)
+        kernels = {0: ("gemm_q_kernel<Q4_0,2,2>", "v_mfma_i32_32x32x32_i8 + f32 block-scale epilogue on the VALU"),
+                   1: ("gemm_q16_kernel<Q4_0,2,4,4,1>", "2 x v_mfma_f32_32x32x16_f16 per tile and block + f32 block-scale epilogue on the VALU"),
+                   3: ("gemm_qmx_kernel<Q4_0,2,4,4,1>", "1 x v_mfma_scale_f32_32x32x64_f8f6f4 (bf6 digits, exact) per tile and block + f32 block-scale epilogue on the VALU")}
+        from ggmlsharp_amd._lib import lib
+        kname, kdesc = kernels.get(lib().ggml_hip_act_image_kind(Q4_0, M, N), kernels[0])
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f)["gemm_q_kernel<Q4_0,2,2> M=4096 K=4096 N=4096"]["traffic_bytes"]
+                traffic = json.load(f)[f"{kname} M=4096 K=4096 N=4096"]["traffic_bytes"]
         except Exception:
             pass
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
-                           "kernel": "gemm_q_kernel<Q4_0,2,2> (v_mfma_i32_32x32x32_i8 + f32 block-scale epilogue on the VALU)",
+                           "kernel": f"{kname} ({kdesc})",
                            "kernel_ms": round(t_comp, 5), "init_kernel_ms": round(t_init, 5),
                            "algorithmic_bytes": ab,
+                           "note": "the binding unit is the VALU, not the matrix pipe: the reference applies two f32 scales per 32-element "
+                                   "block (Ggml.cs:1158) = 32 VALU instructions per 32x32 tile and block, floor ~55 us for this shape",
                            "hbm_view": {"achieved_GBs": round(ab / ((t_init + t_comp) * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                                         "frac": round(ab / ((t_init + t_comp) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                         "note": "algorithmic bytes / (INIT + COMPUTE kernel time); this shape is MFMA/VALU-bound, not HBM-bound"}}

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_r01 + gpurun_out/pmc_r01_* (tools/profile_r01.sh) into the committed profiles/ files."""
+import collections
+import csv
+import glob
+import json
+import re
+import shutil
+
+PAT = re.compile("gemm_q|gemv_q|quantize_act")
+
+
+def short(n):
+    m = re.search(r"(\w+_kernel<[^>]*>|\w+_kernel)", n)
+    return m.group(1) if m else n[:40]
+
+
+shutil.copy(glob.glob("gpurun_out/prof_r01/*/*_kernel_stats.csv")[0], "profiles/r01_bench_kernel_stats.csv")
+lines = ["# rocprofv3 --pmc summaries, round 1, MI355X (gfx950), ROCm 7.2.  Averages per dispatch, in millions.",
+         "# Collected by tools/profile_r01.sh around tools/kbench.py --cfg q4_0:4096:4096:4096 q4_0:4096:4096:1:32 (separate passes",
+         "# per counter set, --kernel-trace only).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles.",
+         "# FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads half the bytes of a 16-B/lane stream",
+         "# (MI355X_MICROARCH.md, HBM) -- the batch-1 mat-vec confirms it against its 10.5 MB of algorithmic bytes.", ""]
+traffic = {}
+for d in sorted(glob.glob("gpurun_out/pmc_r01_*/")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in glob.glob(d + "*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if PAT.search(r["Kernel_Name"]):
+                k = short(r["Kernel_Name"])
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta[k] = (r["VGPR_Count"], r.get("Accum_VGPR_Count", "?"), r["LDS_Block_Size"], r["Grid_Size"], r["Workgroup_Size"])
+    dur = collections.defaultdict(list)
+    for f in glob.glob(d + "*/*_kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            if PAT.search(r["Kernel_Name"]):
+                dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    lines.append(f"## pass {d.split('pmc_r01_')[1].strip('/')}")
+    for k, c in sorted(agg.items()):
+        lines.append(f"{k}  vgpr/agpr/lds/grid/wg {meta[k]}  dur_us {sum(dur[k]) / len(dur[k]) / 1e3:.1f} (n={len(dur[k])})")
+        for name, v in sorted(c.items()):
+            lines.append(f"    {name:28s} {sum(v) / len(v) / 1e6:12.4f} M")
+            if name in ("FETCH_SIZE", "WRITE_SIZE"):
+                traffic.setdefault(k, {})[name + "_KB"] = round(sum(v) / len(v), 1)
+    lines.append("")
+open("profiles/r01_pmc_summary.txt", "w").write("\n".join(lines))
+out = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC (separate --pmc passes), round 1. bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: "
+                   "FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream; the batch-1 kernel confirms it)."}
+names = {"gemm_qmx_kernel<2, 2, 4, 4, 1, 4, 2>": "gemm_qmx_kernel<Q4_0,2,4,4,1> M=4096 K=4096 N=4096",
+         "gemv_q_kernel<2, 1, true>": "gemv_q_kernel<Q4_0,1,fused> M=4096 K=4096 N=1",
+         "quantize_act_kernel<3>": "quantize_act_kernel<bf6 image> N=4096 K=4096"}
+for k, t in traffic.items():
+    if k in names and "FETCH_SIZE_KB" in t and "WRITE_SIZE_KB" in t:
+        out[names[k]] = dict(t, traffic_bytes=int((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024))
+json.dump(out, open("profiles/r01_traffic.json", "w"), indent=1)
+print(open("profiles/r01_pmc_summary.txt").read())
+print(json.dumps(out, indent=1))
