@@ -18,6 +18,19 @@ namespace {
 
 #define GV_ROWS 16
 #define GV_CHUNK 128  // k-blocks of activations staged in LDS at a time
+#ifndef GV_NT
+#define GV_NT 1       // non-temporal weight loads (A/B: -DGV_NT=0)
+#endif
+
+using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
+__device__ __forceinline__ uint4 ld_w(const uint8_t *p) {
+#if GV_NT
+    const u32x4v v = __builtin_nontemporal_load((const u32x4v *)p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return *(const uint4 *)p;
+#endif
+}
 
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
@@ -71,11 +84,12 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
             const int bl = u + 16 * j;
             const bool ok = bl < nbc;
             const int64_t b = cb + (ok ? bl : 0);
+            // once-read weight stream: non-temporal loads (MI355X_MICROARCH.md nt-weights: issued -> landed -18 %)
             if (TYPE == GGML_TYPE_Q8_0) {
-                q[j] = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + row) * 16);
-                q2[j] = *(const uint4 *)(qs + ((b * 2 + 1) * Mpad + row) * 16);
+                q[j] = ld_w(qs + ((b * 2 + 0) * Mpad + row) * 16);
+                q2[j] = ld_w(qs + ((b * 2 + 1) * Mpad + row) * 16);
             } else {
-                q[j] = *(const uint4 *)(qs + (b * Mpad + row) * 16);
+                q[j] = ld_w(qs + (b * Mpad + row) * 16);
             }
             dw[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
             if (TYPE == GGML_TYPE_Q4_1) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
