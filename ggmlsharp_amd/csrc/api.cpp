@@ -54,25 +54,30 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
 }
 
 // Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat (measured on MI355X):
-//   gemm_qmx.hip (MX matrix path, bf6 operands, one MFMA per tile and block) -- Q4_0 / Q4_1,
+//   gemm_qmx.hip (MX matrix path, bf6 digits, one exact MFMA per tile and block) -- Q4_0 / Q4_1,
 //   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 when its 256 x 128 tile fills the chip,
 //   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q8_0, and Q5_0 on small grids.
-// GGML_HIP_GEMM=mx|f16|i8 forces one where the type allows it (developer A/B switch).
+// GGML_HIP_GEMM=mx|f16|i8 forces one (developer A/B switch).  The MX kernel also has a two-digit form for Q5_0 / Q8_0
+// (two MFMAs per tile and block); it measured no faster than the kernels above, so its digit planes
+// (1.5 B / weight) are only built for weights uploaded while "mx" is forced.
 // Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip, 3 = the bf6 image of gemm_qmx.hip.
 std::atomic<int> g_force_gemm{-1};   // -1: read GGML_HIP_GEMM once; 0 auto, 1 int8, 2 f16, 3 MX (ggml_hip_debug_force_gemm)
 
-int act_image_kind(int type, int64_t M, int64_t N) {
+int gemm_force() {
     int force = g_force_gemm.load();
     if (force < 0) {
         const char *e = getenv("GGML_HIP_GEMM");
         force = !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'm' ? 3 : 0)));
         g_force_gemm.store(force);
     }
+    return force;
+}
+
+int act_image_kind(int type, int64_t M, int64_t N) {
+    const int force = gemm_force();
     if (N <= GEMV_MAX_N || force == 1) return 0;
-    const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
     if (force == 2) return gemm_q16_image_kind(type);
-    if (q4) return 3;
-    if (force == 3) return gemm_q16_image_kind(type);   // no MX form for this type: the next matrix-core kernel
+    if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
     const bool fills = ((M + 255) / 256) * ((N + 127) / 128) >= 384;
     return (type == GGML_TYPE_Q5_0 && fills) ? gemm_q16_image_kind(type) : 0;
 }
@@ -111,6 +116,7 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
     memset(w, 0, sizeof *w);
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = g_device;
     size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, total = 0;
+    bool with6 = false;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
         total = (size_t)w->Mpad * K * (type == GGML_TYPE_F32 ? 4 : 2);
     } else {
@@ -122,9 +128,12 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
         off_d = total; total += plane;
         if (type == GGML_TYPE_Q4_1) { off_m = total; total += plane; }
         if (type == GGML_TYPE_Q5_0) { off_qh = total; total += plane; }
-        if (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) {   // bf6 operand planes of the MX mat-mat kernel (0.75 B / weight)
-            off_6a = total; total += (size_t)nba * w->Mpad * 16;
-            off_6b = total; total += (size_t)nba * w->Mpad * 8;
+        const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
+        with6 = q4 || gemm_force() == 3;
+        if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
+            const size_t nf = q4 ? 1 : 2;
+            off_6a = total; total += (size_t)nba * nf * w->Mpad * 16;
+            off_6b = total; total += (size_t)nba * nf * w->Mpad * 8;
         }
     }
     if (total == 0) total = 16;
@@ -139,7 +148,7 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
         w->d = (float *)((uint8_t *)base + off_d);
         if (type == GGML_TYPE_Q4_1) w->m = (float *)((uint8_t *)base + off_m);
         if (type == GGML_TYPE_Q5_0) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
-        if (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
+        if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
     }
     *out = w;
     return GGML_HIP_OK;

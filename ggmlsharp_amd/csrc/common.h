@@ -51,8 +51,9 @@ struct ggml_hip_weight {
     uint32_t *qh;
     float   *d;
     float   *m;
-    uint8_t *q6a;     // Q4_0 / Q4_1: bf6 (e3m2) codes of nib - 8, [nbk][Mpad][16 B] = the first 16 bytes of each 24-byte
-    uint8_t *q6b;     //   MFMA fragment (element e at bits [6e, 6e+5]), and [nbk][Mpad][8 B] = the last 8 (gemm_qmx.hip)
+    uint8_t *q6a;     // bf6 (e3m2) digit codes, [nbk][NF][Mpad][16 B] = the first 16 bytes of each 24-byte MFMA fragment
+    uint8_t *q6b;     //   (element e at bits [6e, 6e+5]) and [nbk][NF][Mpad][8 B] = the last 8; NF = 1 (Q4_0, Q4_1: nib - 8)
+                      //   or 2 (Q5_0, Q8_0: w = 16 * wh + wl, fragment 0 = wl, fragment 1 = wh) -- gemm_qmx.hip
     void    *dense;
     size_t   bytes;
     int      device;

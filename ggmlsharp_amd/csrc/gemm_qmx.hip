@@ -1,4 +1,4 @@
-// gemm_qmx.hip -- K3m: quantized mat-mat for large N with 4-bit weights (Q4_0, Q4_1), block-scaled, on the MX matrix
+// gemm_qmx.hip -- K3m: quantized mat-mat for large N (Q4_0, Q4_1; Q5_0, Q8_0 with two weight digits), block-scaled, on the MX matrix
 // path of gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4 with bf6 = e3m2 operands).
 //
 // COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698):
@@ -18,6 +18,10 @@
 // Operand layout (probed with exact integer data, tools/mx_probe.hip): lane l holds row/col l & 31, K elements
 // 32*(l >> 5) .. +31, element e at bits [6e, 6e+5] of a 192-bit fragment (6 VGPRs); the scale byte of a lane applies
 // to that lane's row and K group.
+//
+// Wider weights (Q5_0 in [-16, 15], Q8_0 in [-128, 127]) get the same two-digit split as the activations, w = 16*wh + wl:
+// two fragments per block and two chained MFMAs, B = wh with block scale 2^4 and B = wl with 2^0, against the SAME A
+// operand: 256*sum(wh*ah) + 16*(sum(wh*al) + sum(wl*ah)) + sum(wl*al) = sumi_b, |sumi_b| < 2^19, still bit-exact.
 //
 // Everything else follows gemm_q16.hip: MFMA rows = src1 rows n, cols = weight rows m (dst stores are 128-byte
 // segments along m); activations reach LDS by DMA (K1 writes the bf6 image), row scales by broadcast ds_read_b128;
@@ -90,6 +94,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                      uint32_t ad_bytes, uint32_t dst_bytes) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
     constexpr int NTILE = WMT * WNT, P = C::P;
+    constexpr int NF = (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) ? 1 : 2;   // weight digits (fragments) per block
     static_assert(KB % 2 == 0, "fragment buffers alternate by k-block parity");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -144,19 +149,23 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     };
 
     // ---- weights: the bf6 planes go straight into the B operand registers (both lane halves hold the same block) ----
-    struct Frag { u32x4 lo[WMT]; u32x2 hi[WMT]; float d[WMT]; float mn[WMT]; };
+    struct Frag { u32x4 lo[WMT][NF]; u32x2 hi[WMT][NF]; float d[WMT]; float mn[WMT]; };   // [.][0] = low digit, [.][1] = high digit
     // one per-thread offset per plane; the m-tiles of a wave are 32 rows apart = a constant the instruction's immediate
     // offset field takes
     const int mrow = m0 + wm_ * WMT * 32 + l31;
     const uint32_t offA = (uint32_t)(mrow * 16), offB = (uint32_t)(mrow * 8), offD = (uint32_t)(mrow * 4);
-    const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4);
+    const uint32_t wa_frag = (uint32_t)(Mpad * 16), wb_frag = (uint32_t)(Mpad * 8);                 // planes are [nbk][NF][Mpad][16 | 8]
+    const uint32_t wa_blk = NF * wa_frag, wb_blk = NF * wb_frag, d_blk = (uint32_t)(Mpad * 4);
     const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
     const rsrc_t rWm = make_rsrc(TYPE == GGML_TYPE_Q4_1 ? (const void *)wm : (const void *)wd, wd_bytes);
     // the planes carry spare (zero) k-blocks past the padded end, so the look-ahead never needs a bounds check
     auto load_frag_one = [&](int kb, Frag &f, auto ic) {
         constexpr int i = decltype(ic)::value;
-        f.lo[i] = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)(offA + 512u * i), (int)((uint32_t)kb * wa_blk), 0);
-        f.hi[i] = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)(offB + 256u * i), (int)((uint32_t)kb * wb_blk), 0);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            f.lo[i][g] = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)(offA + 512u * i), (int)((uint32_t)kb * wa_blk + g * wa_frag), 0);
+            f.hi[i][g] = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)(offB + 256u * i), (int)((uint32_t)kb * wb_blk + g * wb_frag), 0);
+        }
         f.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
         if constexpr (TYPE == GGML_TYPE_Q4_1)
             f.mn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
@@ -197,11 +206,16 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             constexpr int t = decltype(tc)::value, bb = t / NTILE, j = (t % NTILE) / WMT, i = t % WMT;
             Frag &f = frag[bb % FB];
             const i32x8 a = {(int)af_lo[0], (int)af_lo[1], (int)af_lo[2], (int)af_lo[3], (int)af_hi[0], (int)af_hi[1], 0, 0};
-            const i32x8 b = {(int)f.lo[i][0], (int)f.lo[i][1], (int)f.lo[i][2], (int)f.lo[i][3], (int)f.hi[i][0], (int)f.hi[i][1], 0, 0};
-            if constexpr (!(GGML_MX_DBG & 8) || t == 0)
-                tacc[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, zero, 3, 3, 0, scale_a, 0, 127);
-            else
+            const i32x8 b = {(int)f.lo[i][0][0], (int)f.lo[i][0][1], (int)f.lo[i][0][2], (int)f.lo[i][0][3], (int)f.hi[i][0][0], (int)f.hi[i][0][1], 0, 0};
+            if constexpr (GGML_MX_DBG & 8 && t != 0) {
                 asm volatile("" : "+v"(tacc[t & 1]));
+            } else if constexpr (NF == 1) {
+                tacc[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, zero, 3, 3, 0, scale_a, 0, 127);
+            } else {      // high weight digit (x 2^4) first, then the low digit on top
+                const i32x8 bh = {(int)f.lo[i][1][0], (int)f.lo[i][1][1], (int)f.lo[i][1][2], (int)f.lo[i][1][3], (int)f.hi[i][1][0], (int)f.hi[i][1][1], 0, 0};
+                const f32x16 x = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bh, zero, 3, 3, 0, scale_a, 0, 131);
+                tacc[t & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, x, 3, 3, 0, scale_a, 0, 127);
+            }
             if constexpr (j == 0) {                                       // first use of this block's scales: keep them
                 dcur[i] = f.d[i];                                         // (the buffer is reloaded before the last use)
                 if constexpr (TYPE == GGML_TYPE_Q4_1) mcur[i] = fmaf(8.0f, f.d[i], f.mn[i]);   // nib = (nib - 8) + 8
@@ -331,7 +345,8 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     const int nstages = (int)((w->nbk + KB - 1) / KB);      // planes and image are zero-padded to whole stages (KB | K_STAGE_PAD)
     static_assert(K_STAGE_PAD % KB == 0, "stage padding");
     const uint64_t nba = (uint64_t)pad_kblocks(w->nbk);
-    const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16;
+    constexpr int NF = (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) ? 1 : 2;
+    const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16 * NF;
     const uint64_t wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4, a_bytes = nba * 48 * (uint64_t)p.Npad;
     const uint64_t ad_bytes = nba * (uint64_t)p.Npad * 4, dst_bytes = ((uint64_t)(N - 1) * (uint64_t)ldd + (uint64_t)w->M) * 4;
     constexpr uint64_t LIM = 0xFFFFFFFFull;                  // 32-bit buffer offsets
@@ -347,12 +362,13 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // the largest tile that still gives the chip ~2 workgroups per CU; small problems get more, smaller workgroups
     static const int var = [] { const char *e = getenv("GGML_HIP_MX_TILE"); return e ? atoi(e) : 0; }();   // developer A/B switch
     const int64_t tm256 = (w->M + 255) / 256, tm128 = (w->M + 127) / 128, tn128 = (N + 127) / 128;
-    // (Q4_1 carries a second scale plane and would spill at 8 tiles per wave)
-    if (TYPE != GGML_TYPE_Q4_1 && tm256 * tn128 >= 384) {
-        constexpr int T0 = TYPE == GGML_TYPE_Q4_1 ? GGML_TYPE_Q4_0 : TYPE;
-        // 256 x 128 with waves of 128 x 64 (half the LDS reads, weights single-buffered) measured 10 % slower: A/B only
-        if (var == 2) return launch_cfg<T0, 4, 2, 2, 2, 4, 1>(w, p, N, dst, ldd, st);
-        return launch_cfg<T0, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                 // 256 x 128, waves 64 x 128
+    // 8 tiles per wave only where the registers allow it: one weight digit and one scale plane (Q4_0)
+    if constexpr (TYPE == GGML_TYPE_Q4_0) {
+        if (tm256 * tn128 >= 384) {
+            // 256 x 128 with waves of 128 x 64 (half the LDS reads, weights single-buffered) measured 10 % slower: A/B only
+            if (var == 2) return launch_cfg<TYPE, 4, 2, 2, 2, 4, 1>(w, p, N, dst, ldd, st);
+            return launch_cfg<TYPE, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                 // 256 x 128, waves 64 x 128
+        }
     }
     if (tm128 * tn128 >= 384) return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);   // 128 x 128, 4 tiles per wave
     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
@@ -365,6 +381,8 @@ hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, fl
     switch (w->type) {
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }
 }

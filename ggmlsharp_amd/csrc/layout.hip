@@ -157,27 +157,52 @@ __device__ __forceinline__ uint32_t bf6_code(int v) {
     return (uint32_t)((tab >> (5 * a)) & 31u) | (v < 0 ? 32u : 0u);
 }
 
-// nibble plane -> bf6 planes for gemm_qmx.hip: element e of the block (byte e/2, low nibble first, Ggml.cs:1149-1150)
-// at bits [6e, 6e+5] of a 192-bit fragment; value nib - 8 for Q4_0 and for Q4_1 (whose + 8 moves into the min term).
-__global__ void nibbles_to_bf6_kernel(const uint8_t *__restrict__ qs, int64_t rows, int64_t Mpad, uint8_t *__restrict__ q6a,
-                                      uint8_t *__restrict__ q6b) {
+// resident quant planes -> bf6 operand planes of gemm_qmx.hip, [nbk][NF][Mpad][16 B] and [nbk][NF][Mpad][8 B]: element e of
+// the block at bits [6e, 6e+5] of a 192-bit fragment.  Q4_0 / Q4_1 (NF = 1): the value nib - 8 (Q4_1's + 8 moves into
+// its min term).  Q5_0 / Q8_0 (NF = 2): w = 16 * wh + wl, fragment 0 = the low digits wl in [-8, 7], fragment 1 = the
+// high digits wh = floor((w + 8) / 16).
+template <int TYPE>
+__global__ void quants_to_bf6_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh, int64_t rows, int64_t Mpad,
+                                     uint8_t *__restrict__ q6a, uint8_t *__restrict__ q6b) {
+    constexpr int NF = (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) ? 1 : 2;
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t b = blockIdx.y;
     if (m >= rows) return;
     const int64_t pi = b * Mpad + m;
-    const uint4 q = *(const uint4 *)(qs + pi * 16);
-    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
-    uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+    int v[32];
+    if (TYPE == GGML_TYPE_Q8_0) {      // plane h byte j = element 2j + h (signed)
+        const uint4 e4 = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + m) * 16), o4 = *(const uint4 *)(qs + ((b * 2 + 1) * Mpad + m) * 16);
+        const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w}, od[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        const int nib = (int)((qq[e >> 3] >> (4 * (e & 7))) & 0xFu);
-        const uint32_t c = bf6_code(nib - 8);
-        const int bit = 6 * e, wdx = bit >> 5, sh = bit & 31;
-        out[wdx] |= c << sh;
-        if (sh > 26) out[wdx + 1] |= c >> (32 - sh);
+        for (int j = 0; j < 16; ++j) {
+            v[2 * j + 0] = (int)(int8_t)(ev[j >> 2] >> (8 * (j & 3)));
+            v[2 * j + 1] = (int)(int8_t)(od[j >> 2] >> (8 * (j & 3)));
+        }
+    } else {
+        const uint4 q = *(const uint4 *)(qs + pi * 16);
+        const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t hb = TYPE == GGML_TYPE_Q5_0 ? qh[pi] : 0u;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int nib = (int)((qq[e >> 3] >> (4 * (e & 7))) & 0xFu);       // byte e/2, low nibble first (Ggml.cs:1149-1150)
+            v[e] = TYPE == GGML_TYPE_Q5_0 ? (nib | (int)(((hb >> e) & 1u) << 4)) - 16 : nib - 8;   // Ggml.cs:1285-1289
+        }
     }
-    *(uint4 *)(q6a + pi * 16) = make_uint4(out[0], out[1], out[2], out[3]);
-    *(uint2 *)(q6b + pi * 8) = make_uint2(out[4], out[5]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        uint32_t out[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int hi = (v[e] + 8) >> 4, lo = v[e] - 16 * hi;
+            const uint32_t c = bf6_code(NF == 1 ? v[e] : (f == 0 ? lo : hi));
+            const int bit = 6 * e, wdx = bit >> 5, sh = bit & 31;
+            out[wdx] |= c << sh;
+            if (sh > 26) out[wdx + 1] |= c >> (32 - sh);
+        }
+        const int64_t po = (b * NF + f) * Mpad + m;
+        *(uint4 *)(q6a + po * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+        *(uint2 *)(q6b + po * 8) = make_uint2(out[4], out[5]);
+    }
 }
 
 }  // namespace
@@ -185,7 +210,13 @@ __global__ void nibbles_to_bf6_kernel(const uint8_t *__restrict__ qs, int64_t ro
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st) {
     if (!w->q6a || w->M <= 0) return hipSuccess;
     dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)w->nbk);
-    nibbles_to_bf6_kernel<<<grid, 256, 0, st>>>(w->qs, w->M, w->Mpad, w->q6a, w->q6b);
+    switch (w->type) {
+    case GGML_TYPE_Q4_0: quants_to_bf6_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->q6a, w->q6b); break;
+    case GGML_TYPE_Q4_1: quants_to_bf6_kernel<GGML_TYPE_Q4_1><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->q6a, w->q6b); break;
+    case GGML_TYPE_Q5_0: quants_to_bf6_kernel<GGML_TYPE_Q5_0><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->q6a, w->q6b); break;
+    case GGML_TYPE_Q8_0: quants_to_bf6_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->q6a, w->q6b); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

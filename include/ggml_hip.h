@@ -165,8 +165,9 @@ size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);
  * 0 = int8 planes (mat-vec and int8-MFMA kernels), 1 / 2 = f16 images (gemm_q16.hip), 3 = bf6 digit image (gemm_qmx.hip). */
 int    ggml_hip_act_image_kind(int type, int64_t M, int64_t N);
 /* Developer / test switch: which matrix-core kernel serves N > 8 -- 0 automatic (by type and grid size), 1 int8 MFMA
- * (gemm_q.hip), 2 f16 MFMA (gemm_q16.hip), 3 MX (gemm_qmx.hip, Q4_0 / Q4_1 only; other types fall to 2).  Same results
- * within the documented tolerance whichever runs; the environment variable GGML_HIP_GEMM=i8|f16|mx sets the initial value. */
+ * (gemm_q.hip), 2 f16 MFMA (gemm_q16.hip), 3 MX (gemm_qmx.hip; for Q5_0 / Q8_0 its two-digit form, which needs the
+ * weight to have been uploaded while 3 was in force -- the digit planes are not built otherwise).  Same results within
+ * the documented tolerance whichever runs; the environment variable GGML_HIP_GEMM=i8|f16|mx sets the initial value. */
 void   ggml_hip_debug_force_gemm(int which);
 /* Step 1 alone with an explicit layout: every src1 row -> Q8_0 (quantize_row_q8_0, Ggml.cs:733-762, the loop of
  * Ggml.cs:6641-6654) written as image `image_kind` (see above) into d_work. */
