@@ -201,7 +201,7 @@ def main():
                    1: ("gemm_q16_kernel<Q4_0,2,4,4,1>", "2 x v_mfma_f32_32x32x16_f16 per tile and block + f32 block-scale epilogue on the VALU"),
                    3: ("gemm_qmx_kernel<Q4_0,2,4,4,1>", "1 x v_mfma_scale_f32_32x32x64_f8f6f4 (bf6 digits, exact) per tile and block + f32 block-scale epilogue on the VALU")}
         from ggmlsharp_amd._lib import lib
-        kname, kdesc = kernels.get(lib().ggml_hip_act_image_kind(Q4_0, M, N), kernels[0])
+        kname, kdesc = kernels.get(lib().ggml_hip_act_image_kind(Q4_0, M, K, N), kernels[0])
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
                 traffic = json.load(f)[f"{kname} M=4096 K=4096 N=4096"]["traffic_bytes"]

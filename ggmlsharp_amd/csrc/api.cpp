@@ -73,9 +73,12 @@ int gemm_force() {
     return force;
 }
 
-int act_image_kind(int type, int64_t M, int64_t N) {
+int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
     if (N <= GEMV_MAX_N || force == 1) return 0;
+    // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
+    const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
+    if ((nba + K_LOOKAHEAD) * (uint64_t)pad_rows(M) * 32 > 0xFFFFFFFFull || nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
     if (force == 2) return gemm_q16_image_kind(type);
     if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
     const bool fills = ((M + 255) / 256) * ((N + 127) / 128) >= 384;
@@ -308,11 +311,11 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
         return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", ggml_hip_mul_mat_work_size(w->type, w->K, N));
     act_planes p = act_carve(d_work, w->K, pad_act(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, w->M, N), (hipStream_t)stream));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, w->M, w->K, N), (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
-int ggml_hip_act_image_kind(int type, int64_t M, int64_t N) { return act_image_kind(type, M, N); }
+int ggml_hip_act_image_kind(int type, int64_t M, int64_t K, int64_t N) { return act_image_kind(type, M, K, N); }
 void ggml_hip_debug_force_gemm(int which) { g_force_gemm.store(which < 0 || which > 3 ? 0 : which); }
 
 int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
@@ -336,9 +339,9 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
     if (N <= GEMV_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (act_image_kind(w->type, w->M, N) == 3)
+    else if (act_image_kind(w->type, w->M, w->K, N) == 3)
         HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (act_image_kind(w->type, w->M, N) != 0)
+    else if (act_image_kind(w->type, w->M, w->K, N) != 0)
         HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else
         HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));

@@ -85,6 +85,29 @@ static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
     return p;
 }
 
+// ---- cross-lane moves inside a group of 8 lanes as DPP modifiers (no LDS round trip, unlike __shfl_xor = ds_bpermute) ----
+#ifdef __HIPCC__
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+#define DPP_XOR1 0xB1        /* quad_perm:[1,0,3,2] */
+#define DPP_XOR2 0x4E        /* quad_perm:[2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141 /* lane i <-> 7 - i inside each group of 8: joins the two quads once they are uniform */
+#define DPP_NEXT 0x101       /* row_shl:1: lane i reads lane i + 1 (inside a row of 16) */
+// max / sum over the 8 lanes t = lane & 7 of a group, result in every lane
+__device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    return fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+}
+__device__ __forceinline__ int group8_sum(int v) {
+    v += dpp_i<DPP_XOR1>(v);
+    v += dpp_i<DPP_XOR2>(v);
+    return v + dpp_i<DPP_HALF_MIRROR>(v);
+}
+#endif
+
 // ---- kernel launchers (implemented in the .hip files) ----
 // layout.hip
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,

@@ -296,7 +296,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     }
 
     // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
-    const rsrc_t rD = make_rsrc(dst, dst_bytes);
+    // descriptor based at the workgroup's tile origin: offsets below stay inside 32 bits for any dst size
+    (void)dst_bytes;
+    const rsrc_t rD = make_rsrc(dst + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
     const bool full = n0 + C::TN <= N && m0 + C::TM <= M;                    // uniform
     const uint32_t lane_off = (uint32_t)((4 * hh * ldd + l31) * 4);
     if (full) {
@@ -306,7 +308,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             for (int j = 0; j < WNT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int nr = n0 + (wn * WNT + j) * 32 + (r & 3) + 8 * (r >> 2), mb = m0 + (wm_ * WMT + i) * 32;
+                    const int nr = (wn * WNT + j) * 32 + (r & 3) + 8 * (r >> 2), mb = (wm_ * WMT + i) * 32;   // relative to (n0, m0)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
                                                           (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
                 }
@@ -315,13 +317,13 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         for (int i = 0; i < WMT; ++i)
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
-                const int mb = m0 + (wm_ * WMT + i) * 32, nb = n0 + (wn * WNT + j) * 32;
-                if (mb >= M || nb >= N) continue;                              // uniform
-                const bool mok = mb + l31 < M;
+                const int mb = (wm_ * WMT + i) * 32, nb = (wn * WNT + j) * 32;        // relative to (n0, m0)
+                if (m0 + mb >= M || n0 + nb >= N) continue;                    // uniform
+                const bool mok = m0 + mb + l31 < M;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nr = nb + (r & 3) + 8 * (r >> 2);
-                    if (mok && nr + 4 * hh < N)
+                    if (mok && n0 + nr + 4 * hh < N)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
                                                               (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
                 }
@@ -350,7 +352,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     const uint64_t wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4, a_bytes = nba * 48 * (uint64_t)p.Npad;
     const uint64_t ad_bytes = nba * (uint64_t)p.Npad * 4, dst_bytes = ((uint64_t)(N - 1) * (uint64_t)ldd + (uint64_t)w->M) * 4;
     constexpr uint64_t LIM = 0xFFFFFFFFull;                  // 32-bit buffer offsets
-    if (wq_bytes > LIM || a_bytes > LIM || dst_bytes > LIM) return hipErrorNotSupported;
+    if (wq_bytes > LIM || a_bytes > LIM || (uint64_t)C::TN * (uint64_t)ldd * 4 > LIM) return hipErrorNotSupported;   // api.cpp routes such shapes to gemm_q.hip
     kern<<<grid, C::NT, C::TOTAL, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
                                         (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
                                         (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes);

@@ -119,21 +119,16 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
                     const int c = w0 / GV_CHUNK, bl = w0 % GV_CHUNK;
                     const bool live = c < N && bl < nbc;       // uniform over the 8 lanes of the group
                     float amax = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
-                    amax = fmaxf(amax, __shfl_xor(amax, 1));
-                    amax = fmaxf(amax, __shfl_xor(amax, 2));
-                    amax = fmaxf(amax, __shfl_xor(amax, 4));
+                    amax = group8_max(amax);
                     const float d = amax / 127.0f;                  // Ggml.cs:751
                     const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
                     const int q0 = (int)rintf(v[k].x * id), q1 = (int)rintf(v[k].y * id);   // Ggml.cs:758-759 (D1, D2)
                     const int q2_ = (int)rintf(v[k].z * id), q3 = (int)rintf(v[k].w * id);
-                    int sum = q0 + q1 + q2_ + q3;
-                    sum += __shfl_xor(sum, 1);
-                    sum += __shfl_xor(sum, 2);
-                    sum += __shfl_xor(sum, 4);
+                    const int sum = group8_sum(q0 + q1 + q2_ + q3);
                     const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2_ & 0xFFu) << 8);
                     const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
                     const bool even_lane = (t & 1) == 0;
-                    const uint32_t recv = (uint32_t)__shfl_xor((int)(even_lane ? o16 : e16), 1);
+                    const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)(even_lane ? o16 : e16));
                     const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));
                     if (live) {
                         uint8_t *base = (uint8_t *)sA;

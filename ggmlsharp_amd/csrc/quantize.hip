@@ -82,6 +82,16 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
     const int64_t b0 = (int64_t)blockIdx.x * K1_BPB;
     const float *row = x + nr * ld1;
 
+    // (IMG 3) per-thread store offsets inside a k-block of the bf6 image: dword idx = 3 (t >> 2) + (t & 3) of the fragment
+    const int idx6 = 3 * (t >> 2) + (t & 3);
+    const uint32_t off6 = idx6 < 4 ? (uint32_t)(n * 16 + 4 * idx6) : (uint32_t)(Npad * 32 + n * 8 + 4 * (idx6 - 4));
+    const uint32_t half6 = idx6 < 4 ? (uint32_t)(Npad * 16) : (uint32_t)(Npad * 8);   // half 0 (ah) -> half 1 (al)
+    const uint32_t offS = (uint32_t)(n * 4);
+    const uint32_t img_bytes = (uint32_t)(pad_kblocks(nbk) * Npad * 48), sc_bytes = (uint32_t)(pad_kblocks(nbk) * Npad * 4);
+    const __amdgpu_buffer_rsrc_t rImg = __builtin_amdgcn_make_buffer_rsrc((void *)a8, 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rAd = __builtin_amdgcn_make_buffer_rsrc((void *)ad, 0, (int)sc_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rAs = __builtin_amdgcn_make_buffer_rsrc((void *)as, 0, (int)sc_bytes, 0x00020000);
+
     float4 v[K1_BPB];
 #pragma unroll
     for (int j = 0; j < K1_BPB; ++j) {
@@ -92,19 +102,14 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
     for (int j = 0; j < K1_BPB; ++j) {
         const int64_t b = b0 + j;
         float amax = fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
-        amax = fmaxf(amax, __shfl_xor(amax, 2));
-        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        amax = group8_max(amax);
         const float d = amax / 127.0f;                      // Ggml.cs:751
         const float id = d != 0.0f ? 1.0f / d : 0.0f;       // Ggml.cs:752
         const int q0 = (int)rintf(v[j].x * id);             // Ggml.cs:758-759 (all l, D2)
         const int q1 = (int)rintf(v[j].y * id);
         const int q2 = (int)rintf(v[j].z * id);
         const int q3 = (int)rintf(v[j].w * id);
-        int s = q0 + q1 + q2 + q3;
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
+        const int s = group8_sum(q0 + q1 + q2 + q3);
         if (IMG == 3) {
             // bf6 image of gemm_qmx.hip: a = 16*ah + al, ah = floor((a + 8) / 16) in [-8, 8], al in [-8, 7]; lane t owns
             // elements 4t..4t+3 = bits [24t, 24t+24) of both 192-bit fragments; the 4 lanes of a group (u = t & 3) hold
@@ -123,22 +128,23 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
                 vh |= ((uint32_t)ch | ((bh >> 26) & 32u)) << (6 * c);
                 vl |= ((uint32_t)cl | ((bl >> 26) & 32u)) << (6 * c);
             }
-            const uint32_t nh = (uint32_t)__shfl_down((int)vh, 1), nl = (uint32_t)__shfl_down((int)vl, 1);
+            const uint32_t nh = (uint32_t)dpp_i<DPP_NEXT>((int)vh), nl = (uint32_t)dpp_i<DPP_NEXT>((int)vl);
             const int u = t & 3, g = t >> 2, idx = 3 * g + u;
             const uint32_t dh = (vh >> (8 * u)) | (u < 3 ? nh << (24 - 8 * u) : 0u);
             const uint32_t dl = (vl >> (8 * u)) | (u < 3 ? nl << (24 - 8 * u) : 0u);
+            // stores: one buffer descriptor per plane, the k-block in the uniform offset, the row / dword in a per-thread
+            // offset that is the same for every k-block (no 64-bit address arithmetic per store)
             const bool pad = !(b < nbk);
-            if (live && u < 3 && b < pad_kblocks(nbk)) {
-                uint8_t *blk = (uint8_t *)a8 + b * Npad * 48;
-                uint8_t *p0, *p1;                              // half 0 (ah), half 1 (al)
-                if (idx < 4) { p0 = blk + n * 16 + 4 * idx; p1 = p0 + Npad * 16; }
-                else { p0 = blk + Npad * 32 + n * 8 + 4 * (idx - 4); p1 = p0 + Npad * 8; }
-                *(uint32_t *)p0 = pad ? 0u : dh;
-                *(uint32_t *)p1 = pad ? 0u : dl;
-            }
-            if (live && t == 0 && b < pad_kblocks(nbk)) {
-                ad[b * Npad + n] = pad ? 0.0f : d;
-                as[b * Npad + n] = pad ? 0 : (int32_t)__float_as_uint(d * (float)s);
+            if (b < pad_kblocks(nbk)) {
+                const uint32_t soff = (uint32_t)b * (uint32_t)(Npad * 48);
+                if (live && u < 3) {
+                    __builtin_amdgcn_raw_buffer_store_b32(pad ? 0u : dh, rImg, (int)off6, (int)soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pad ? 0u : dl, rImg, (int)(off6 + half6), (int)soff, 0);
+                }
+                if (live && t == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(pad ? 0u : __float_as_uint(d), rAd, (int)offS, (int)((uint32_t)b * (uint32_t)(Npad * 4)), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pad ? 0u : __float_as_uint(d * (float)s), rAs, (int)offS, (int)((uint32_t)b * (uint32_t)(Npad * 4)), 0);
+                }
             }
             continue;
         }
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
                 const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)r0), h1 = __builtin_bit_cast(uint16_t, (_Float16)(r1 * 0.0625f));
                 const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)r2), h3 = __builtin_bit_cast(uint16_t, (_Float16)(r3 * 0.0625f));
                 const uint32_t send = odd ? (h0 | (h1 << 16)) : (h2 | (h3 << 16));
-                const uint32_t recv = (uint32_t)__shfl_xor((int)send, 1);
+                const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)send);
                 // even lane writes dwords 0, 1; odd lane dwords 2, 3
                 o0 = odd ? ((recv & 0xFFFFu) | (h2 << 16)) : (h0 | (recv << 16));
                 o1 = odd ? ((recv >> 16) | (h3 << 16)) : (h1 | (recv & 0xFFFF0000u));
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
                 const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)r0), h1 = __builtin_bit_cast(uint16_t, (_Float16)r1);
                 const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)r2), h3 = __builtin_bit_cast(uint16_t, (_Float16)r3);
                 const uint32_t send = odd ? (h0 | (h2 << 16)) : (h1 | (h3 << 16));
-                const uint32_t recv = (uint32_t)__shfl_xor((int)send, 1);
+                const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)send);
                 // even lane writes plane 0 (x, z of both lanes), odd lane plane 1 (y, w of both lanes)
                 o0 = odd ? ((recv & 0xFFFFu) | (h1 << 16)) : (h0 | (recv << 16));
                 o1 = odd ? ((recv >> 16) | (h3 << 16)) : (h2 | (recv & 0xFFFF0000u));
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
         const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2 & 0xFFu) << 8);
         const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
         const bool even_lane = (t & 1) == 0;
-        const uint32_t recv = (uint32_t)__shfl_xor((int)(even_lane ? o16 : e16), 1);
+        const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)(even_lane ? o16 : e16));
         // even lane t: plane 0 bytes [2t, 2t+4) = own e16 | partner e16 << 16
         // odd  lane t: plane 1 bytes [2t-2, 2t+2) = partner o16 | own o16 << 16
         const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));

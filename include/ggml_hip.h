@@ -161,9 +161,9 @@ int     ggml_hip_weight_type(const ggml_hip_weight *w);
  * (the reference's dst layout: element (i01, ic) at ic*ne0 + i01, Ggml.cs:6692-6697).
  * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378). */
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);
-/* Which layout step 1 writes into d_work for this weight type, M rows and N (introspection for tests and profiling tools):
+/* Which layout step 1 writes into d_work for this weight type, M rows, K and N (introspection for tests and profiling tools):
  * 0 = int8 planes (mat-vec and int8-MFMA kernels), 1 / 2 = f16 images (gemm_q16.hip), 3 = bf6 digit image (gemm_qmx.hip). */
-int    ggml_hip_act_image_kind(int type, int64_t M, int64_t N);
+int    ggml_hip_act_image_kind(int type, int64_t M, int64_t K, int64_t N);
 /* Developer / test switch: which matrix-core kernel serves N > 8 -- 0 automatic (by type and grid size), 1 int8 MFMA
  * (gemm_q.hip), 2 f16 MFMA (gemm_q16.hip), 3 MX (gemm_qmx.hip; for Q5_0 / Q8_0 its two-digit form, which needs the
  * weight to have been uploaded while 3 was in force -- the digit planes are not built otherwise).  Same results within
