@@ -110,6 +110,38 @@ struct Scratch {
 };
 Scratch g_src1, g_dst, g_work, g_stage;
 
+// ---- graph-level residency: between ggml_hip_graph_begin / _end the device copy of every offloaded
+// node's dst stays alive, keyed by the host pointer of the tensor data.  A later node whose src1 IS that tensor reads it
+// from HBM instead of taking it back over PCIe, and the device -> host copies (the reference's contract: every node's
+// data is in host memory when ggml_graph_compute returns) are synchronised once, at graph end, behind the compute. ----
+struct Resident { void *p; size_t bytes; };
+int g_graph_depth = 0;
+std::map<const void *, Resident> g_resident;          // host data pointer -> device copy (graph scope)
+std::vector<Resident> g_pool;                          // device buffers free for reuse
+uint64_t g_h2d_bytes = 0, g_d2h_bytes = 0, g_resident_hits = 0;
+
+void *pool_take(size_t n) {
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (g_pool[i].bytes >= n && g_pool[i].bytes <= 2 * n + 4096) {
+            void *p = g_pool[i].p;
+            g_resident[nullptr] = g_pool[i];   // placeholder slot, replaced by the caller's key
+            g_pool.erase(g_pool.begin() + (long)i);
+            return p;
+        }
+    void *p = nullptr;
+    if (hipMalloc(&p, n) != hipSuccess) return nullptr;
+    g_resident[nullptr] = Resident{p, n};
+    return p;
+}
+void pool_drain_locked(bool free_all) {
+    for (auto &kv : g_resident) g_pool.push_back(kv.second);
+    g_resident.clear();
+    if (free_all) {
+        for (Resident &r : g_pool) (void)hipFree(r.p);
+        g_pool.clear();
+    }
+}
+
 // ---- weight cache for Seam 1, keyed by the host pointer + shape ----
 using CacheKey = std::tuple<const void *, int, int64_t, int64_t, int64_t, int64_t, uint64_t, uint64_t, uint64_t>;
 std::map<CacheKey, std::vector<ggml_hip_weight *>> g_cache;
@@ -252,6 +284,7 @@ void ggml_hip_shutdown(void) {
     (void)hipSetDevice(g_device);
     free_cache_locked();
     g_src1.release(); g_dst.release(); g_work.release(); g_stage.release();
+    pool_drain_locked(true); g_graph_depth = 0;
     if (g_stream) (void)hipStreamDestroy(g_stream);
     g_stream = nullptr;
     g_inited = false;
@@ -505,6 +538,7 @@ int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const
     int rc = ensure_init();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_graph_depth > 0) HIP_TRY(hipStreamSynchronize(g_stream));   // operands may be dst of an earlier node still on its way to the host
     const size_t row_in = (size_t)ne00 * es, rs = TSIZE[dt] * (size_t)(ne00 / QK);   // rs as in Ggml.cs:4345
     if (g_src1.ensure(row_in * ne01) || g_dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
     size_t id = 0;
@@ -542,6 +576,7 @@ int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const
     int rc = ensure_init();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_graph_depth > 0) HIP_TRY(hipStreamSynchronize(g_stream));   // operands may be dst of an earlier node still on its way to the host
     const size_t rs = TSIZE[t] * (size_t)(ne00 / QK), rx = (size_t)ne00 * 4;
     if (g_stage.ensure(rs * ne01) || g_src1.ensure(rx * ne01) || g_dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
     for (int64_t i03 = 0; i03 < ne03; ++i03)
@@ -619,22 +654,81 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
     }
     const size_t x_bytes = (size_t)ne11 * ne10 * 4, d_bytes = (size_t)ne11 * ne01 * 4;
     const size_t w_bytes = ggml_hip_mul_mat_work_size(type, ne00, ne11);
-    if (g_src1.ensure(x_bytes) || g_dst.ensure(d_bytes) || g_work.ensure(w_bytes ? w_bytes : 16))
+    const int64_t nslice = ne02 * ne03;
+    // graph scope: is src1 the (contiguous) dst of an earlier offloaded node?  will dst be kept?
+    const bool src1_contig = src1->nb[1] == (uint64_t)ne10 * 4 && src1->nb[2] == src1->nb[1] * (uint64_t)ne11 &&
+                             src1->nb[3] == src1->nb[2] * (uint64_t)ne12;
+    const bool dst_contig = dst->nb[1] == (uint64_t)ne01 * 4 && dst->nb[2] == dst->nb[1] * (uint64_t)ne11 &&
+                            dst->nb[3] == dst->nb[2] * (uint64_t)ne02;
+    const uint8_t *x_res = nullptr;
+    if (g_graph_depth > 0 && src1_contig) {
+        auto r = g_resident.find(src1->data);
+        if (r != g_resident.end() && r->second.bytes >= x_bytes * (size_t)nslice) { x_res = (const uint8_t *)r->second.p; ++g_resident_hits; }
+    }
+    uint8_t *d_res = nullptr;
+    if (g_graph_depth > 0 && dst_contig) {
+        auto old = g_resident.find(dst->data);           // the same tensor computed again: reuse its buffer
+        if (old != g_resident.end() && old->second.bytes >= d_bytes * (size_t)nslice) {
+            d_res = (uint8_t *)old->second.p;
+        } else {
+            if (old != g_resident.end()) { g_pool.push_back(old->second); g_resident.erase(old); }
+            d_res = (uint8_t *)pool_take(d_bytes * (size_t)nslice);
+            if (!d_res) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for a resident dst");
+            g_resident[dst->data] = g_resident[nullptr];
+            g_resident.erase(nullptr);
+        }
+    }
+    if ((!x_res && g_src1.ensure(x_bytes)) || (!d_res && g_dst.ensure(d_bytes)) || g_work.ensure(w_bytes ? w_bytes : 16))
         return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
     for (int64_t i03 = 0; i03 < ne03; ++i03)
         for (int64_t i02 = 0; i02 < ne02; ++i02) {  // slice offsets as in Ggml.cs:6566-6570
-            const ggml_hip_weight *w = it->second[(size_t)(i03 * ne02 + i02)];
+            const int64_t sl = i03 * ne02 + i02;
+            const ggml_hip_weight *w = it->second[(size_t)sl];
             const uint8_t *x = (const uint8_t *)src1->data + i02 * src1->nb[2] + i03 * src1->nb[3];
             uint8_t *d = (uint8_t *)dst->data + i02 * dst->nb[2] + i03 * dst->nb[3];
-            HIP_TRY(hipMemcpy2DAsync(g_src1.p, (size_t)ne10 * 4, x, src1->nb[1], (size_t)ne10 * 4, (size_t)ne11,
-                                     hipMemcpyHostToDevice, g_stream));
-            rc = ggml_hip_mul_mat_dev(w, (const float *)g_src1.p, ne11, ne10, (float *)g_dst.p, ne01, g_work.p, g_work.cap, g_stream);
+            const float *xd = x_res ? (const float *)(x_res + (size_t)sl * x_bytes) : (const float *)g_src1.p;
+            float *dd = d_res ? (float *)(d_res + (size_t)sl * d_bytes) : (float *)g_dst.p;
+            if (!x_res) {
+                // src1 comes from host memory: inside a graph scope an earlier node's device -> host copy into that
+                // very memory may still be in flight, and a pageable source is read when the copy is enqueued
+                if (g_graph_depth > 0) HIP_TRY(hipStreamSynchronize(g_stream));
+                HIP_TRY(hipMemcpy2DAsync(g_src1.p, (size_t)ne10 * 4, x, src1->nb[1], (size_t)ne10 * 4, (size_t)ne11,
+                                         hipMemcpyHostToDevice, g_stream));
+                g_h2d_bytes += x_bytes;
+            }
+            rc = ggml_hip_mul_mat_dev(w, xd, ne11, ne10, dd, ne01, g_work.p, g_work.cap, g_stream);
             if (rc) return rc;
-            HIP_TRY(hipMemcpy2DAsync(d, dst->nb[1], g_dst.p, (size_t)ne01 * 4, (size_t)ne01 * 4, (size_t)ne11,
+            HIP_TRY(hipMemcpy2DAsync(d, dst->nb[1], dd, (size_t)ne01 * 4, (size_t)ne01 * 4, (size_t)ne11,
                                      hipMemcpyDeviceToHost, g_stream));
-            HIP_TRY(hipStreamSynchronize(g_stream));
+            g_d2h_bytes += d_bytes;
+            // outside a graph scope the call returns with dst on the host; inside, ggml_hip_graph_end waits once
+            // (the scratch buffers are reused in stream order)
+            if (g_graph_depth == 0) HIP_TRY(hipStreamSynchronize(g_stream));
         }
     return GGML_HIP_OK;
+}
+
+/* Graph scope for ggml_graph_compute's node loop (Ggml.cs:3539-3704): see "graph-level residency" above. */
+int ggml_hip_graph_begin(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ++g_graph_depth;
+    return GGML_HIP_OK;
+}
+int ggml_hip_graph_end(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_graph_depth <= 0) return fail(GGML_HIP_ERR_ARG, "ggml_hip_graph_end without ggml_hip_graph_begin");
+    hipError_t e = g_stream ? hipStreamSynchronize(g_stream) : hipSuccess;   // every node's dst is on the host from here on
+    if (--g_graph_depth == 0) pool_drain_locked(false);
+    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "graph_end: %s", hipGetErrorString(e));
+    return GGML_HIP_OK;
+}
+void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (h2d_bytes) *h2d_bytes = g_h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = g_d2h_bytes;
+    if (resident_hits) *resident_hits = g_resident_hits;
 }
 
 }  // extern "C"

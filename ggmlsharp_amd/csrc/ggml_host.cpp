@@ -271,6 +271,9 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         node->n_tasks = 1;
     }
     cgraph->work_size = 0;
+    // graph scope: results of offloaded nodes stay in HBM for the nodes that consume them
+    int grc = ggml_hip_graph_begin();
+    if (grc != GGML_HIP_OK) return grc;
     for (int i = 0; i < cgraph->n_nodes; i++) {
         ggml_tensor *node = cgraph->nodes[i];
         if (node->op == GGML_OP_NONE) continue;
@@ -282,12 +285,12 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
             if (node->op == GGML_OP_MUL_MAT) rc = ggml_hip_compute_forward_mul_mat(&params, node->src0, node->src1, node);
             else if (node->op == GGML_OP_CPY) rc = ggml_hip_compute_forward_cpy(&params, node->src0, node);   // Ggml.cs:8659-8663
             else rc = ggml_hip_compute_forward_add(&params, node->src0, node->src1, node);                    // Ggml.cs:8566-8570
-            if (rc != GGML_HIP_OK) return rc;
+            if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }
         }
         node->perf_runs++;
     }
     cgraph->perf_runs++;
-    return GGML_HIP_OK;
+    return ggml_hip_graph_end();
 }
 
 }  // extern "C"

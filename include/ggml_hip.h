@@ -129,6 +129,15 @@ int  ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params,
                                       struct ggml_tensor *dst);
 void ggml_hip_invalidate(const void *host_ptr);      /* drop the cached device copy keyed by this src0->data */
 void ggml_hip_invalidate_all(void);
+/* Graph scope around the node loop of ggml_graph_compute (Ggml.cs:3539-3704), SURVEY 8(f) row 3.  Between begin and end
+ * the device copy of every offloaded node's dst is kept (keyed by tensor->data): a later MUL_MAT whose src1 is that
+ * tensor reads it from HBM instead of copying it host -> device again, and the device -> host copies of the node
+ * results are synchronised once, in ggml_hip_graph_end -- after which every node's data is in host memory, as the
+ * reference guarantees on return from ggml_graph_compute.  Calls nest; buffers are recycled across graphs. */
+int  ggml_hip_graph_begin(void);
+int  ggml_hip_graph_end(void);
+/* Bytes moved over PCIe by seam 1 so far and the number of src1 operands served from a resident dst (tests, tuning). */
+void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits);
 
 /* ---------------- resident weights (device level) ---------------- */
 typedef struct ggml_hip_weight ggml_hip_weight;      /* opaque: one 2-D weight matrix, re-laid-out on the device */

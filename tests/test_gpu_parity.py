@@ -353,6 +353,47 @@ def test_ggml_api_program_quantized_and_batched(dev):
         G.ggml_free(ctx)
 
 
+def test_graph_residency_chained_mul_mats(dev):
+    """Y2 = W2 * (W1 * X) in one graph.  The intermediate is consumed from HBM (no second host ->
+    device copy), both node results are in host memory when ggml_graph_compute returns, values match the oracle chain."""
+    from ggmlsharp_amd import ggml as G
+    from ggmlsharp_amd._lib import lib
+    K, M1, M2, N = 256, 96, 40, 24
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    try:
+        for t in (G.Q4_0, G.Q8_0):
+            for batch in (1, 2):
+                W1 = G.ggml_new_tensor_3d(ctx, t, K, M1, batch)
+                W2 = G.ggml_new_tensor_3d(ctx, t, M1, M2, batch)
+                X = G.ggml_new_tensor_3d(ctx, G.F32, K, N, batch)
+                w1, w2, x = _rand((batch, M1, K)), _rand((batch, M2, M1)), _rand((batch, N, K))
+                w1q, w2q = O.quantize_row(t, w1), O.quantize_row(t, w2)
+                G.tensor_bytes(W1)[:] = w1q.reshape(-1)
+                G.tensor_bytes(W2)[:] = w2q.reshape(-1)
+                G.tensor_f32(X)[:] = x.reshape(1, batch, N, K)
+                Y1 = G.ggml_mul_mat(ctx, W1, X)
+                Y2 = G.ggml_mul_mat(ctx, W2, Y1)
+                gf = G.ggml_build_forward(Y2)
+                assert gf.n_nodes == 2
+                c0 = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+                c1 = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+                lib().ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c0])
+                G.ggml_graph_compute(ctx, gf)
+                lib().ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c1])
+                ref1 = O.mul_mat(t, w1q, x, M1, K, N, nth=2, ne2=batch)[0]
+                ref2 = O.mul_mat(t, w2q, np.ascontiguousarray(ref1), M2, M1, N, nth=2, ne2=batch)[0]
+                assert_close(G.tensor_f32(Y1)[0], ref1, f"graph node 1 type {t} batch {batch}")
+                assert_close(G.tensor_f32(Y2)[0], ref2, f"graph node 2 type {t} batch {batch}")
+                assert c1[2].value - c0[2].value == 1                                  # Y1 was read from HBM
+                assert c1[0].value - c0[0].value == batch * N * K * 4                  # only X went host -> device
+                assert c1[1].value - c0[1].value == batch * N * (M1 + M2) * 4          # both results came back
+                # again: the buffers are recycled, the results are the same
+                G.ggml_graph_compute(ctx, gf)
+                assert_close(G.tensor_f32(Y2)[0], ref2)
+    finally:
+        G.ggml_free(ctx)
+
+
 def test_seam1_ignores_non_compute_phases_and_other_threads(dev):
     from ggmlsharp_amd import ggml as G
     from ggmlsharp_amd._lib import lib, ggml_compute_params
