@@ -209,6 +209,7 @@ SHAPES = [  # (M, K, N): ragged M / N, both kernels (N <= 8 mat-vec, N > 8 MFMA)
     (1, 32, 1), (16, 64, 1), (17, 96, 2), (200, 256, 3), (128, 4096, 1), (130, 352, 8),
     (64, 128, 9), (33, 160, 17), (200, 256, 64), (128, 512, 128), (257, 1024, 130), (64, 11008, 40),
     (600, 288, 300),    # several workgroup tiles in both directions, ragged edges, K/32 = 9 (pad k-blocks)
+    (1, 32, 9), (31, 64, 33), (257, 96, 257), (129, 32, 65),   # one k-block (three pad blocks per stage), one-row weights
 ]
 
 
