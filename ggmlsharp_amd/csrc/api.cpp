@@ -152,8 +152,13 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = g_device;
     size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, total = 0;
     bool with6 = false;
+    size_t off_p16 = 0;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
-        total = (size_t)w->Mpad * K * (type == GGML_TYPE_F32 ? 4 : 2);
+        total = ((size_t)w->Mpad * K * (type == GGML_TYPE_F32 ? 4 : 2) + 255) / 256 * 256;
+        if (type == GGML_TYPE_F16) {   // k-panel copy for the f16 MFMA kernel (dense16.hip)
+            off_p16 = total;
+            total += (size_t)(dense16_kpad(K) / 8 + DENSE16_SPARE_PANELS) * w->Mpad * 16;
+        }
     } else {
         w->nbk = K / QK;
         const int64_t nba = pad_kblocks(w->nbk) + K_LOOKAHEAD;   // allocated k-blocks (zero past the real end)
@@ -178,6 +183,7 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
     w->bytes = total;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
         w->dense = base;
+        if (type == GGML_TYPE_F16) w->p16 = (uint8_t *)base + off_p16;
     } else {
         w->qs = (uint8_t *)base + off_qs;
         w->d = (float *)((uint8_t *)base + off_d);
@@ -221,6 +227,7 @@ int make_weight(int type, const void *rows, bool rows_on_host, int64_t ne00, int
         e = launch_repack_to_planar(type, dev_rows, nb01, row_begin, rows_n, w, st);
     }
     if (e == hipSuccess) e = launch_nibbles_to_bf6(w, st);
+    if (e == hipSuccess) e = launch_f16_rows_to_panels(w, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (staging) (void)hipFree(staging);
     if (e != hipSuccess) {
@@ -331,7 +338,9 @@ int64_t ggml_hip_weight_cols(const ggml_hip_weight *w) { return w ? w->K : 0; }
 int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? w->type : -1; }
 
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
-    if (!is_q(type) || K <= 0 || N <= 0) return 0;
+    if (K <= 0 || N <= 0) return 0;
+    if (type == GGML_TYPE_F16) return (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 2;   // src1 as Half (Ggml.cs:3356-3357), padded
+    if (!is_q(type)) return 0;
     return act_bytes(K, pad_act(N));
 }
 
@@ -388,6 +397,11 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     if (!d_src1 || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
     if (!is_q(w->type)) {
+        if (dense16_serves(w, N) && d_work && work_bytes >= ggml_hip_mul_mat_work_size(w->type, w->K, N)) {
+            HIP_TRY(launch_dense16_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));       // INIT: src1 -> Half (Ggml.cs:6362-6379)
+            HIP_TRY(launch_dense16(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
+            return GGML_HIP_OK;
+        }
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }

@@ -55,6 +55,7 @@ struct ggml_hip_weight {
     uint8_t *q6b;     //   (element e at bits [6e, 6e+5]) and [nbk][NF][Mpad][8 B] = the last 8; NF = 1 (Q4_0, Q4_1: nib - 8)
                       //   or 2 (Q5_0, Q8_0: w = 16 * wh + wl, fragment 0 = wl, fragment 1 = wh) -- gemm_qmx.hip
     void    *dense;
+    uint8_t *p16;     // F16 only: k-panel-major copy [Kpad/8 + spare][Mpad][16 B] for dense16.hip
     size_t   bytes;
     int      device;
 };
@@ -125,6 +126,13 @@ hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t l
 hipError_t launch_add_q_f32(int type, const void *blocks_in, const float *x, int64_t nrows, int64_t k, void *blocks_out,
                             hipStream_t st);
 hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
+// dense16.hip: K padded to whole stages of 128, plus spare (zero) panels for the register look-ahead
+#define DENSE16_SPARE_PANELS 8
+static inline int64_t dense16_kpad(int64_t K) { return (K + 127) / 128 * 128; }
+hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st);
+bool dense16_serves(const ggml_hip_weight *w, int64_t N);
+hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st);
+hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,

@@ -1,0 +1,246 @@
+// dense16.hip -- K10b: dense f16 x f32 mul_mat (ggml_compute_forward_mul_mat_f16_f32, Ggml.cs:6180-6438) on the f16
+// matrix cores, for shapes that fill the chip.
+//
+// The reference's INIT phase rounds src1 to Half (Ggml.cs:6362-6379) and ggml_vec_dot_f16 (Ggml.cs:2642-2651) sums
+// (float)h * (float)h in f64.  Here: convert_act_f16 does the same rounding (round-to-nearest-even, as (Half)x) into a
+// panel image, v_mfma_f32_32x32x16_f16 forms the products exactly (22-bit significands) and accumulates in f32 --
+// the reference's sum with f32 instead of f64 accumulation, ~sqrt(K) * 2^-24 relative, inside the 1e-3 budget.
+// No scale work, no VALU in the loop: this is the one kernel of the path that the matrix pipe bounds.
+//
+// Layouts (both built once: the weights at upload, the activations by the INIT kernel below): k-panel-major,
+// [K/8][rows][8 x f16 = 16 B], K zero-padded to whole stages (128) -- panel p of row r is one 16-byte piece, 64 rows of a
+// panel are one contiguous 1-KiB DMA piece, and the MFMA fragment of lane (row l & 31, half h) for k-step ks is the
+// 16-byte entry of panel 2 ks + h: one conflict-free ds_read_b128 (activations, via LDS) or one buffer_load_dwordx4
+// straight into the B operand (weights, from L2, four k-steps ahead).
+// Structure as gemm_qmx.hip: 4 waves, wave tile 64 (m) x 128 (n) = 2 x 4 MFMA tiles, workgroup tile 256 x 128, two
+// workgroups per CU, activations by buffer_load ... lds DMA in double-buffered stages of 8 k-steps, one barrier per stage.
+#include "common.h"
+#include <hip/hip_fp16.h>
+#include <utility>
+
+namespace {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+typedef __attribute__((address_space(3))) void lds_void;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void blds16(rsrc_t r, void *l, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)l, 16, (int)voff, (int)soff, 0, 0);
+}
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- INIT: src1 f32 rows -> f16 panel image [Kpad/8][Npad][16 B]; lane = 8 * row_in_wave + t owns 4 consecutive floats ----
+#define CV_CH 4   // 128-byte chunks (32 floats = 4 panels) per lane group and workgroup column
+__global__ __launch_bounds__(256) void convert_act_f16_kernel(const float *__restrict__ x, int64_t N, int64_t K, int64_t Kpad, int64_t ld1,
+                                                             uint8_t *__restrict__ img, int64_t Npad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = lane & 7;
+    const int64_t n = (int64_t)blockIdx.y * 32 + wave * 8 + (lane >> 3);
+    const bool live = n < N;
+    const float *row = x + (live ? n : N - 1) * ld1;
+#pragma unroll
+    for (int j = 0; j < CV_CH; ++j) {
+        const int64_t k = ((int64_t)blockIdx.x * CV_CH + j) * 32 + 4 * t;
+        if (k >= Kpad) break;                                          // uniform per workgroup column
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 3 < K) v = *(const float4 *)(row + k);
+        else {
+            if (k + 0 < K) v.x = row[k + 0];
+            if (k + 1 < K) v.y = row[k + 1];
+            if (k + 2 < K) v.z = row[k + 2];
+        }
+        // (Half)x: round-to-nearest-even, overflow to infinity (Ggml.cs:6369)
+        const uint32_t h0 = __builtin_bit_cast(uint16_t, (_Float16)v.x), h1 = __builtin_bit_cast(uint16_t, (_Float16)v.y);
+        const uint32_t h2 = __builtin_bit_cast(uint16_t, (_Float16)v.z), h3 = __builtin_bit_cast(uint16_t, (_Float16)v.w);
+        if (live) *(uint2 *)(img + ((k >> 3) * Npad + n) * 16 + 8 * (t & 1)) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    }
+}
+
+// ---- weights: f16 rows -> panels [Kpad/8 + spare][Mpad][16 B] (zero past K and past M: the buffer is pre-zeroed) ----
+__global__ void f16_rows_to_panels_kernel(const uint16_t *__restrict__ rows, int64_t M, int64_t K, int64_t Mpad, uint8_t *__restrict__ pan) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (m >= M) return;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t k = p * 8 + e;
+        if (k < K) w[e >> 1] |= (uint32_t)rows[m * K + k] << (16 * (e & 1));
+    }
+    *(uint4 *)(pan + (p * Mpad + m) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+constexpr int KS = 8;       // k-steps of 16 per LDS stage (128 k)
+constexpr int RING = 4;     // weight fragments in flight, in k-steps
+
+template <int WMT, int WNT, int WGM, int WGN>
+struct Cfg {
+    static constexpr int TM = WGM * WMT * 32, TN = WGN * WNT * 32, NT = WGM * WGN * 64;
+    static constexpr int STAGE = KS * 2 * TN * 16;
+    static constexpr int TOTAL = 2 * STAGE;
+    static constexpr int P = NT / TN;
+    static_assert(NT % TN == 0 && (KS * 2) % P == 0, "chunk decomposition");
+    static constexpr int ROUNDS = KS * 2 * TN / NT;
+    static_assert(ROUNDS <= KS * WNT, "one DMA piece per n-tile step");
+};
+
+template <int WMT, int WNT, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64, 2)
+void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict__ apan, float *__restrict__ dst, int M, int N, int Mpad,
+                    int Npad, int nstages, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes) {
+    using C = Cfg<WMT, WNT, WGM, WGN>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave / WGM, wm_ = wave % WGM;
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (t_lin % tiles_m) * C::TM;
+    const int n0 = (t_lin / tiles_m) * C::TN;
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // activations: DMA, chunk c = tid + NT * i of a stage = [16 panels][TN rows] x 16 B
+    const uint32_t a_pan = (uint32_t)(Npad * 16);
+    const uint32_t voffA = (uint32_t)(((tid / C::TN) * Npad + n0 + tid % C::TN) * 16);
+    const rsrc_t rA = make_rsrc(apan, a_bytes);
+    auto dma_piece = [&](int s, auto pc) {
+        constexpr int i = decltype(pc)::value;
+        uint8_t *sp = smem + (s & 1) * C::STAGE;
+        blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voffA, ((uint32_t)s * KS * 2 + C::P * i) * a_pan);
+    };
+
+    // weights: registers, RING k-steps ahead
+    const uint32_t w_pan = (uint32_t)(Mpad * 16);
+    const uint32_t voffW = (uint32_t)((hh * Mpad + m0 + wm_ * WMT * 32 + l31) * 16);
+    const rsrc_t rW = make_rsrc(wpan, w_bytes);
+    u32x4 bq[RING][WMT];
+    auto load_b = [&](int gstep, auto rc) {                 // global k-step -> ring slot
+        constexpr int slot = decltype(rc)::value;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+            bq[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(voffW + 512u * i), (int)((uint32_t)gstep * 2 * w_pan), 0);
+    };
+
+    auto compute = [&](int s) {
+        const uint8_t *sA = smem + (s & 1) * C::STAGE + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
+        static_for<KS>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            static_for<WNT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (ks * WNT + j < C::ROUNDS) dma_piece(s + 1, std::integral_constant<int, ks * WNT + j>{});
+                const f16x8 af = *(const f16x8 *)(sA + (ks * 2 * C::TN + 32 * j) * 16);
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, bq[ks % RING][i]), acc[i][j], 0, 0, 0);
+            });
+            // the DMA pieces of the next stage must have landed before the barrier: drain where nothing is young
+            if constexpr (ks == KS - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_b(s * KS + ks + RING, std::integral_constant<int, ks % RING>{});
+        });
+    };
+
+    static_for<C::ROUNDS>([&](auto pc) { dma_piece(0, pc); });
+    static_for<RING>([&](auto rc) { load_b(decltype(rc)::value, rc); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < nstages; ++s) {
+        compute(s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // dst[n][m] (Ggml.cs:6692-6697): D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]
+    const rsrc_t rD = make_rsrc(dst + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
+    const bool full = n0 + C::TN <= N && m0 + C::TM <= M;
+    const uint32_t lane_off = (uint32_t)((4 * hh * ldd + l31) * 4);
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int mb = (wm_ * WMT + i) * 32, nb = (wn * WNT + j) * 32;
+            if (!full && (m0 + mb >= M || n0 + nb >= N)) continue;
+            const bool mok = full || m0 + mb + l31 < M;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nr = nb + (r & 3) + 8 * (r >> 2);
+                const float v = acc[i][j][r];     // (a bit_cast applied directly to the vector element stores element 0 every time)
+                if (full || (mok && n0 + nr + 4 * hh < N))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rD, (int)lane_off,
+                                                          (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+            }
+        }
+}
+
+template <int WMT, int WNT, int WGM, int WGN>
+hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
+    using C = Cfg<WMT, WNT, WGM, WGN>;
+    static bool attr_set = false;
+    auto kern = dense16_kernel<WMT, WNT, WGM, WGN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (w->Mpad % C::TM != 0 || Npad % C::TN != 0) return hipErrorInvalidValue;
+    const int64_t Kpad = dense16_kpad(w->K);
+    const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
+    const uint64_t w_bytes = (uint64_t)(Kpad / 8 + DENSE16_SPARE_PANELS) * w->Mpad * 16, a_bytes = (uint64_t)(Kpad / 8) * Npad * 16;
+    if (w_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull || (uint64_t)C::TN * ldd * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
+    kern<<<dim3((unsigned)(tiles_m * tiles_n)), C::NT, C::TOTAL, st>>>(w->p16, apan, dst, (int)w->M, (int)N, (int)w->Mpad, (int)Npad,
+                                                                     (int)(Kpad / (16 * KS)), (int)ldd, tiles_m, tiles_n, (uint32_t)w_bytes,
+                                                                     (uint32_t)a_bytes);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st) {
+    if (!w->p16 || w->M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)((w->K + 7) / 8));
+    f16_rows_to_panels_kernel<<<grid, 256, 0, st>>>((const uint16_t *)w->dense, w->M, w->K, w->Mpad, w->p16);
+    return hipGetLastError();
+}
+
+// true when the f16 MFMA kernel serves this shape (a full grid of its smaller tile); else dense.hip does
+bool dense16_serves(const ggml_hip_weight *w, int64_t N) {
+    if (w->type != GGML_TYPE_F16 || !w->p16) return false;
+    const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
+    if ((Kpad / 8 + DENSE16_SPARE_PANELS) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (Kpad / 8) * Npad * 16 > 0xFFFFFFFFull) return false;
+    return ((w->M + 127) / 128) * ((N + 127) / 128) >= 256;
+}
+
+hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st) {
+    const int64_t Kpad = dense16_kpad(K), Npad = pad_act(N);
+    dim3 grid((unsigned)((Kpad / 32 + CV_CH - 1) / CV_CH), (unsigned)((N + 31) / 32));
+    convert_act_f16_kernel<<<grid, 256, 0, st>>>(x, N, K, Kpad, ld1, (uint8_t *)work, Npad);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    const int64_t Npad = pad_act(N);
+    if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    return launch_cfg<2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+}

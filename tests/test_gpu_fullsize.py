@@ -63,6 +63,24 @@ def test_fullsize_matches_fp64_block_arithmetic(dev, name, t, M, K, N):
     W.free()
 
 
+@pytest.mark.parametrize("M,K,N", [(4096, 4096, 4096), (2048, 4096 + 40, 2048 + 17), (4096, 11008, 512)])
+def test_dense_f16_fullsize_matches_fp64(dev, M, K, N):
+    """ggml_compute_forward_mul_mat_f16_f32 (Ggml.cs:6180-6438) at sizes served by the f16 MFMA kernel (dense16.hip): src1 is
+    rounded to Half in INIT (:6362-6379), the products are exact, the sum is f32 here and f64 in the reference."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + N)
+    w = torch.randn((M, K), generator=g, device="cuda").half()
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    W = dev.Weight.from_device(1, w.contiguous().view(torch.uint8), K)
+    got = dev.mul_mat(W, x)
+    ref = x.half().double() @ w.double().T
+    err = (got.double() - ref).abs()
+    rms = ref.pow(2).mean().sqrt()
+    assert (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item() == 0, f"max err / rms = {(err.max() / rms).item():.3e}"
+    assert np.array_equal(W.download(), w.cpu().numpy().view(np.uint8).reshape(-1))      # the row-major copy still round-trips
+    W.free()
+
+
 def test_row_shard_and_column_subset_are_bitwise_slices(dev):
     M, K, N = 4096, 4096, 512
     rows, x = _make(dev, Q4_0, M, K, N, seed=3)

@@ -29,7 +29,28 @@ def ev_ms(fn, iters):
     return s.elapsed_time(e) / iters
 
 
+def run_f16(M, K, N, iters):
+    """dense f16 x f32 (ggml_compute_forward_mul_mat_f16_f32): the f16 MFMA kernel incl. its INIT (src1 -> Half)"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    w = torch.randn((M, K), generator=g, device="cuda").half()
+    x = torch.randn((N, K), generator=g, device="cuda")
+    W = device.Weight.from_device(1, w.contiguous().view(torch.uint8), K)
+    out = torch.empty((N, M), device="cuda")
+    work = device.alloc_work(1, K, N)
+    device.mul_mat(W, x, out=out, work=work)
+    ref = x.half().double() @ w.double().T
+    err = (out.double() - ref).abs()
+    rms = ref.pow(2).mean().sqrt()
+    t = ev_ms(lambda: device.mul_mat(W, x, out=out, work=work), iters)
+    print(f"f16 M{M} K{K} N{N}: init+compute {t * 1e3:8.1f} us  {2.0 * M * K * N / t / 1e9:9.1f} TFLOP/s  "
+          f"max_err/rms {err.max().item() / rms.item():.2e}", flush=True)
+    W.free()
+
+
 def run(tname, M, K, N, iters, check=True, copies=1):
+    if tname == "f16":
+        return run_f16(M, K, N, iters)
     t = TYPES[tname]
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
