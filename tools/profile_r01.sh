@@ -10,4 +10,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY
   tag=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc_r01_$tag -- python3 $R/tools/kbench.py --cfg q4_0:4096:4096:4096 q4_0:4096:4096:1:32 --iters 3 --no-check > $R/gpurun_out/pmc_r01_$tag.log 2>&1 || exit 3
 done
+# dense f16 path: MFMA utilisation of dense16_kernel (SQ_VALU_MFMA_BUSY_CYCLES / 4 SIMD-cycles vs SQ_BUSY...)
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmc_r01_dense16 -- python3 $R/tools/kbench.py --cfg f16:4096:4096:4096 --iters 5 > $R/gpurun_out/pmc_r01_dense16.log 2>&1 || exit 4
 echo ok

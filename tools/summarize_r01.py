@@ -7,7 +7,7 @@ import json
 import re
 import shutil
 
-PAT = re.compile("gemm_q|gemv_q|quantize_act")
+PAT = re.compile("gemm_q|gemv_q|quantize_act|dense16|convert_act")
 
 
 def short(n):
