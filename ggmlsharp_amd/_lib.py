@@ -108,6 +108,9 @@ SYMBOLS = {
     "ggml_hip_vec_dot": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "ggml_hip_compute_forward_cpy": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
     "ggml_hip_compute_forward_add": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
+    "ggml_hip_compute_forward_mul": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
+    "ggml_hip_compute_forward_scale": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
+    "ggml_hip_compute_forward_rms_norm": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
     "ggml_hip_quantize_rows_src_dev": (C.c_int, [C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_add_q_f32_rows_dev": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
@@ -136,6 +139,9 @@ SYMBOLS = {
     "ggml_dup_tensor": (_T, [_P, _T]),
     "ggml_cpy": (_T, [_P, _T, _T]),
     "ggml_add": (_T, [_P, _T, _T]),
+    "ggml_mul": (_T, [_P, _T, _T]),
+    "ggml_scale": (_T, [_P, _T, _T]),
+    "ggml_rms_norm": (_T, [_P, _T]),
     "ggml_build_forward": (None, [C.POINTER(ggml_cgraph), _T]),
     "ggml_build_forward_expand": (None, [C.POINTER(ggml_cgraph), _T]),
     "ggml_graph_compute": (C.c_int, [_P, C.POINTER(ggml_cgraph)]),

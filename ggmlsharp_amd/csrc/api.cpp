@@ -133,6 +133,50 @@ void *pool_take(size_t n) {
     g_resident[nullptr] = Resident{p, n};
     return p;
 }
+// ---- operands / results of the f32 element-wise seams: contiguous tensors, device-resident inside a graph scope ----
+bool contiguous_f32(const ggml_tensor *t) {
+    return t->type == GGML_TYPE_F32 && t->nb[0] == 4 && t->nb[1] == (uint64_t)t->ne[0] * 4 && t->nb[2] == t->nb[1] * (uint64_t)t->ne[1] &&
+           t->nb[3] == t->nb[2] * (uint64_t)t->ne[2];
+}
+int64_t nelem(const ggml_tensor *t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+// device pointer of a contiguous f32 operand: its resident copy if an earlier node of this graph produced it, else an upload
+int operand_f32(const ggml_tensor *t, Scratch &scratch, const float **out, hipStream_t st);
+int operand_f32(const ggml_tensor *t, Scratch &scratch, const float **out, hipStream_t st) {
+    const size_t bytes = (size_t)nelem(t) * 4;
+    if (g_graph_depth > 0) {
+        auto r = g_resident.find(t->data);
+        if (r != g_resident.end() && r->second.bytes >= bytes) { *out = (const float *)r->second.p; ++g_resident_hits; return 0; }
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;   // host memory may still be receiving an earlier node's result
+    }
+    if (scratch.ensure(bytes)) return -1;
+    if (hipMemcpyAsync(scratch.p, t->data, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    g_h2d_bytes += bytes;
+    *out = (const float *)scratch.p;
+    return 0;
+}
+// device buffer for a contiguous f32 result: kept resident inside a graph scope (in place when dst shares src's data)
+float *result_f32(const ggml_tensor *t, Scratch &scratch) {
+    const size_t bytes = (size_t)nelem(t) * 4;
+    if (g_graph_depth > 0) {
+        auto old = g_resident.find(t->data);
+        if (old != g_resident.end() && old->second.bytes >= bytes) return (float *)old->second.p;
+        if (old != g_resident.end()) { g_pool.push_back(old->second); g_resident.erase(old); }
+        void *p = pool_take(bytes);
+        if (!p) return nullptr;
+        g_resident[t->data] = g_resident[nullptr];
+        g_resident.erase(nullptr);
+        return (float *)p;
+    }
+    return scratch.ensure(bytes) ? nullptr : (float *)scratch.p;
+}
+int finish_f32(ggml_tensor *t, const float *dev, hipStream_t st) {
+    const size_t bytes = (size_t)nelem(t) * 4;
+    if (hipMemcpyAsync(t->data, dev, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    g_d2h_bytes += bytes;
+    if (g_graph_depth == 0 && hipStreamSynchronize(st) != hipSuccess) return -1;
+    return 0;
+}
+
 void pool_drain_locked(bool free_all) {
     for (auto &kv : g_resident) g_pool.push_back(kv.second);
     g_resident.clear();
@@ -570,14 +614,36 @@ int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const
     return GGML_HIP_OK;
 }
 
+/* ggml_compute_forward_add_f32 / _mul_f32 (Ggml.cs:4622-4682, 5007-5035): same-shape contiguous f32 operands */
+static int binary_f32_seam(int op, const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    const char *name = op == 0 ? "add_f32" : "mul_f32";
+    if (src0->type != GGML_TYPE_F32 || src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "%s: F32 operands only (Ggml.cs:5043-5056)", name);
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != src1->ne[i] || src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "%s: shapes differ (Ggml.cs:4628, 5014)", name);
+    if (!contiguous_f32(src0) || !contiguous_f32(src1) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "%s: contiguous operands only", name);
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const float *a = nullptr, *b = nullptr;
+    if (operand_f32(src0, g_src1, &a, g_stream) || operand_f32(src1, g_stage, &b, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "%s: operand staging failed", name);
+    float *z = result_f32(dst, g_dst);
+    if (!z) return fail(GGML_HIP_ERR_RUNTIME, "%s: hipMalloc failed", name);
+    HIP_TRY(launch_binary_f32(op, a, b, z, nelem(src0), g_stream));
+    if (finish_f32(dst, z, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "%s: copy back failed", name);
+    return GGML_HIP_OK;
+}
+
 /* ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906) */
 int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                  const struct ggml_tensor *src1, struct ggml_tensor *dst) {
     if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
     const int t = src0->type;
+    if (t == GGML_TYPE_F32) return binary_f32_seam(0, src0, src1, dst);      // ggml_compute_forward_add_f32 (Ggml.cs:4622-4682)
     if (!(t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q8_0))
-        return fail(GGML_HIP_ERR_TYPE, "add: only a quantized src0 (add_q_f32) is on this path, got type %d", t);
+        return fail(GGML_HIP_ERR_TYPE, "add: src0 must be F32 or quantized (add_q_f32), got type %d", t);
     if (dst->type != t || src1->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "add_q_f32: dst must have src0's type, src1 F32 (Ggml.cs:4863-4865)");
     for (int i = 0; i < 4; ++i)
         if (src0->ne[i] != src1->ne[i] || src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: shapes differ (Ggml.cs:4803)");
@@ -607,6 +673,66 @@ int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const
             HIP_TRY(hipStreamSynchronize(g_stream));
         }
     invalidate_locked(dst->data);
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_mul (Ggml.cs:5037-5056) */
+int ggml_hip_compute_forward_mul(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    return binary_f32_seam(1, src0, src1, dst);
+}
+
+/* ggml_compute_forward_scale_f32 (Ggml.cs:6746-6778): dst (a view of src0) *= *(float *)src1->data */
+int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                   const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (src0->type != GGML_TYPE_F32 || src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "scale: F32 only (Ggml.cs:6786-6799)");
+    if (nelem(src1) != 1) return fail(GGML_HIP_ERR_SHAPE, "scale: src1 must be a scalar (Ggml.cs:6755)");
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "scale: shapes differ (Ggml.cs:6754)");
+    if (!contiguous_f32(src0) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "scale: contiguous operands only (Ggml.cs:6752-6753)");
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_graph_depth > 0) HIP_TRY(hipStreamSynchronize(g_stream));           // the scalar is read from host memory
+    const float v = *(const float *)src1->data;
+    // the reference scales dst's own memory: when dst is not a view of src0 that memory is whatever it held before, and
+    // so it is here (the device form of "dst" is then an upload of dst->data, not of src0->data)
+    const float *cur = nullptr;
+    if (operand_f32(dst, g_src1, &cur, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "scale: operand staging failed");
+    float *z = result_f32(dst, g_dst);
+    if (!z) return fail(GGML_HIP_ERR_RUNTIME, "scale: hipMalloc failed");
+    if (z != cur) HIP_TRY(hipMemcpyAsync(z, cur, (size_t)nelem(dst) * 4, hipMemcpyDeviceToDevice, g_stream));
+    HIP_TRY(launch_scale_f32(z, nelem(dst), v, g_stream));
+    if (finish_f32(dst, z, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "scale: copy back failed");
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_rms_norm_f32 (Ggml.cs:5858-5920) */
+int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                      struct ggml_tensor *dst) {
+    if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (src0->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "rms_norm: F32 only (Ggml.cs:5927-5940)");
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "rms_norm: shapes differ (Ggml.cs:5863)");
+    if (!contiguous_f32(src0) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "rms_norm: contiguous operands only");
+    if (!src0->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const float *a = nullptr;
+    if (operand_f32(src0, g_src1, &a, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "rms_norm: operand staging failed");
+    float *z = result_f32(dst, g_dst);
+    if (!z) return fail(GGML_HIP_ERR_RUNTIME, "rms_norm: hipMalloc failed");
+    HIP_TRY(launch_rms_norm_f32(a, z, nelem(src0) / src0->ne[0], src0->ne[0], g_stream));
+    if (finish_f32(dst, z, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "rms_norm: copy back failed");
     return GGML_HIP_OK;
 }
 

@@ -133,6 +133,10 @@ hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st);
 bool dense16_serves(const ggml_hip_weight *w, int64_t N);
 hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st);
 hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+// eltwise.hip (op: 0 add, 1 mul; contiguous f32)
+hipError_t launch_binary_f32(int op, const float *x, const float *y, float *z, int64_t n, hipStream_t st);
+hipError_t launch_scale_f32(float *z, int64_t n, float v, hipStream_t st);
+hipError_t launch_rms_norm_f32(const float *x, float *y, int64_t nr, int64_t nc, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,

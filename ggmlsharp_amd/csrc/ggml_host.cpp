@@ -246,6 +246,47 @@ ggml_tensor *ggml_add(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
     return result;
 }
 
+// Ggml.cs:6878-6884 -> ggml_mul_impl 7918-7946 (not in place): result = dup(a); NULL unless same shape (:7924)
+ggml_tensor *ggml_mul(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
+    if (!ctx || !a || !b) return nullptr;
+    for (int i = 0; i < GGML_MAX_DIMS; ++i)
+        if (a->ne[i] != b->ne[i]) return nullptr;
+    const bool is_node = a->grad != nullptr || b->grad != nullptr;
+    ggml_tensor *result = ggml_dup_tensor(ctx, a);
+    if (!result) return nullptr;
+    result->op = GGML_OP_MUL;
+    result->grad = is_node ? ggml_dup_tensor(ctx, result) : nullptr;
+    result->src0 = a;
+    result->src1 = b;
+    return result;
+}
+
+// Ggml.cs:7153-7159 -> ggml_scale_impl 8248-8273: b must be a scalar (:8254); the result is a VIEW of a (:8265): in place
+ggml_tensor *ggml_scale(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
+    if (!ctx || !a || !b) return nullptr;
+    if (ggml_nelements(b) != 1) return nullptr;
+    const bool is_node = a->grad != nullptr || b->grad != nullptr;
+    ggml_tensor *result = ggml_view_tensor(ctx, a);
+    if (!result) return nullptr;
+    result->op = GGML_OP_SCALE;
+    result->grad = is_node ? ggml_dup_tensor(ctx, result) : nullptr;
+    result->src0 = a;
+    result->src1 = b;
+    return result;
+}
+
+// Ggml.cs:7123-7128 -> ggml_rms_norm_impl 8199-8220 (not in place): result = dup(a); backward is not implemented (:8208)
+ggml_tensor *ggml_rms_norm(ggml_context *ctx, ggml_tensor *a) {
+    if (!ctx || !a) return nullptr;
+    if (a->grad != nullptr) return nullptr;
+    ggml_tensor *result = ggml_dup_tensor(ctx, a);
+    if (!result) return nullptr;
+    result->op = GGML_OP_RMS_NORM;
+    result->src0 = a;
+    result->src1 = nullptr;
+    return result;
+}
+
 void ggml_build_forward_expand(ggml_cgraph *cgraph, ggml_tensor *tensor) { visit_parents(cgraph, tensor); }
 
 void ggml_build_forward(ggml_cgraph *out, ggml_tensor *tensor) {
@@ -264,7 +305,8 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
     for (int i = 0; i < cgraph->n_nodes; i++) {
         ggml_tensor *node = cgraph->nodes[i];
         if (node->op == GGML_OP_NONE) continue;
-        if (node->op != GGML_OP_MUL_MAT && node->op != GGML_OP_CPY && node->op != GGML_OP_ADD) {
+        if (node->op != GGML_OP_MUL_MAT && node->op != GGML_OP_CPY && node->op != GGML_OP_ADD && node->op != GGML_OP_MUL &&
+            node->op != GGML_OP_SCALE && node->op != GGML_OP_RMS_NORM) {
             fprintf(stderr, "ggml_graph_compute: op %d is outside the MI355X mul_mat path (SURVEY.md 2.2)\n", node->op);
             return GGML_HIP_ERR_TYPE;
         }
@@ -284,6 +326,9 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
             int rc;
             if (node->op == GGML_OP_MUL_MAT) rc = ggml_hip_compute_forward_mul_mat(&params, node->src0, node->src1, node);
             else if (node->op == GGML_OP_CPY) rc = ggml_hip_compute_forward_cpy(&params, node->src0, node);   // Ggml.cs:8659-8663
+            else if (node->op == GGML_OP_MUL) rc = ggml_hip_compute_forward_mul(&params, node->src0, node->src1, node);       // Ggml.cs:8569-8573
+            else if (node->op == GGML_OP_SCALE) rc = ggml_hip_compute_forward_scale(&params, node->src0, node->src1, node);   // Ggml.cs:8654-8658
+            else if (node->op == GGML_OP_RMS_NORM) rc = ggml_hip_compute_forward_rms_norm(&params, node->src0, node);         // Ggml.cs:8644-8648
             else rc = ggml_hip_compute_forward_add(&params, node->src0, node->src1, node);                    // Ggml.cs:8566-8570
             if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }
         }

@@ -65,6 +65,18 @@ def ggml_add(ctx, a, b):
     return _lib.lib().ggml_add(ctx, a, b)
 
 
+def ggml_mul(ctx, a, b):
+    return _lib.lib().ggml_mul(ctx, a, b)
+
+
+def ggml_scale(ctx, a, b):
+    return _lib.lib().ggml_scale(ctx, a, b)
+
+
+def ggml_rms_norm(ctx, a):
+    return _lib.lib().ggml_rms_norm(ctx, a)
+
+
 def ggml_build_forward(tensor):
     g = ggml_cgraph()
     _lib.lib().ggml_build_forward(C.byref(g), tensor)

@@ -118,6 +118,12 @@ struct ggml_tensor *ggml_dup_tensor(struct ggml_context *ctx, const struct ggml_
 struct ggml_tensor *ggml_cpy(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
 /* Ggml.cs:6846-6852 -> ggml_add_impl 7868-7891: result has a's type and shape; NULL unless same shape (:7874). */
 struct ggml_tensor *ggml_add(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
+/* Ggml.cs:6878-6884 -> ggml_mul_impl 7918-7946: result = dup(a); NULL unless same shape (:7924). */
+struct ggml_tensor *ggml_mul(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
+/* Ggml.cs:7153-7159 -> ggml_scale_impl 8248-8273: b a scalar (:8254); the result is a view of a -- the op works in place. */
+struct ggml_tensor *ggml_scale(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
+/* Ggml.cs:7123-7128 -> ggml_rms_norm_impl 8199-8220: result = dup(a). */
+struct ggml_tensor *ggml_rms_norm(struct ggml_context *ctx, struct ggml_tensor *a);
 
 /* Ggml.cs:7648-7673 */
 void ggml_build_forward(struct ggml_cgraph *out, struct ggml_tensor *tensor);

@@ -61,6 +61,8 @@ enum ggml_op {
     GGML_OP_NONE = 0,
     GGML_OP_DUP = 1,
     GGML_OP_ADD = 2,
+    GGML_OP_MUL = 4,
+    GGML_OP_RMS_NORM = 19,
     GGML_OP_MUL_MAT = 20,
     GGML_OP_SCALE = 21,
     GGML_OP_CPY = 22,
@@ -211,9 +213,23 @@ int ggml_hip_vec_dot(int type, int n, float *s, const void *vx, const void *vy);
 int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                  struct ggml_tensor *dst);
 /* ggml_compute_forward_add for a quantized src0 = ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906):
- * dst row = quantize_row_q(dequantize_row_q(src0 row) + src1 row); src1 F32, dst the type and shape of src0. */
+ * dst row = quantize_row_q(dequantize_row_q(src0 row) + src1 row); src1 F32, dst the type and shape of src0;
+ * for an F32 src0 = ggml_compute_forward_add_f32 (Ggml.cs:4622-4682), same-shape contiguous operands, bit-exact. */
 int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                  const struct ggml_tensor *src1, struct ggml_tensor *dst);
+/* The f32 element-wise neighbours of mul_mat in a transformer block; contiguous F32 tensors, same
+ * offload convention as Seam 1; inside a graph scope operands and results stay in HBM (see ggml_hip_graph_begin).
+ *   mul      ggml_compute_forward_mul_f32      Ggml.cs:5007-5035   dst = src0 * src1, same shape           (bit-exact)
+ *   scale    ggml_compute_forward_scale_f32    Ggml.cs:6746-6778   dst *= *(float *)src1->data, IN PLACE: dst is a view
+ *                                                                  of src0 (ggml_scale_impl Ggml.cs:8265)     (bit-exact)
+ *   rms_norm ggml_compute_forward_rms_norm_f32 Ggml.cs:5858-5920   y = x / sqrt(mean(x^2) + 1e-6), squares summed in f64
+ *                                                                  (only the order of the f64 additions differs) */
+int ggml_hip_compute_forward_mul(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 const struct ggml_tensor *src1, struct ggml_tensor *dst);
+int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                   const struct ggml_tensor *src1, struct ggml_tensor *dst);
+int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                      struct ggml_tensor *dst);
 /* Device forms.  src_type F32 or F16; source rows ld elements apart; blocks of all rows contiguous. */
 int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int64_t ld, int64_t nrows, int64_t k,
                                    void *d_blocks, void *stream);

@@ -787,3 +787,39 @@ uint32_t oracle_xrand(void) {
     lcg_next = lcg_next * 214013ULL + 2531011ULL;
     return (uint32_t)((lcg_next >> 16) & 0x7FFF);
 }
+
+/* ================= element-wise neighbours of mul_mat ================= */
+
+/* Ggml.cs:4622-4682, contiguous branch: ggml_vec_add_f32 z[i] = x[i] + y[i] per row */
+void oracle_add_f32(int64_t nr, int64_t nc, const float *x, const float *y, float *z) {
+    for (int64_t j = 0; j < nr; j++)
+        for (int64_t i = 0; i < nc; i++) z[j * nc + i] = x[j * nc + i] + y[j * nc + i];
+}
+
+/* Ggml.cs:5007-5035: ggml_vec_mul_f32 z[i] = x[i] * y[i] per row */
+void oracle_mul_f32(int64_t nr, int64_t nc, const float *x, const float *y, float *z) {
+    for (int64_t j = 0; j < nr; j++)
+        for (int64_t i = 0; i < nc; i++) z[j * nc + i] = x[j * nc + i] * y[j * nc + i];
+}
+
+/* Ggml.cs:6746-6778: v = *(float *)src1->data; ggml_vec_scale_f32(nc, dst row, v) -- dst is a view of src0 (:8265) */
+void oracle_scale_f32(int64_t nr, int64_t nc, float *z, float v) {
+    for (int64_t j = 0; j < nr; j++)
+        for (int64_t i = 0; i < nc; i++) z[j * nc + i] *= v;
+}
+
+/* Ggml.cs:5858-5920 */
+void oracle_rms_norm_f32(int64_t nr, int64_t nc, const float *x, float *y) {
+    const float eps = 1e-6f;                                  /* :5889 */
+    for (int64_t j = 0; j < nr; j++) {
+        const float *xr = x + j * nc;
+        double sum = 0.0;                                     /* :5900 */
+        for (int64_t i = 0; i < nc; i++) {
+            const float sq = xr[i] * xr[i];                   /* float product, then widened (:5903) */
+            sum += (double)sq;
+        }
+        const float mean = (float)(sum / (double)nc);         /* :5906 */
+        const float scale = 1.0f / sqrtf(mean + eps);         /* :5915 */
+        for (int64_t i = 0; i < nc; i++) y[j * nc + i] = xr[i] * scale;   /* copy + ggml_vec_scale_f32 (:5910-5917) */
+    }
+}

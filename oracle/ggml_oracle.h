@@ -131,6 +131,17 @@ int oracle_cpy_to_q(const oracle_tensor *src0, const oracle_tensor *dst);
 int oracle_add_q_f32(const oracle_tensor *src0, const oracle_tensor *src1, const oracle_tensor *dst);
 
 /* Test3's LCG (Test3/Program.cs:98-107): xsrand(seed); xrand() -> (next >> 16) & 0x7FFF. */
+/* Element-wise neighbours of mul_mat in a transformer block, contiguous f32 rows [nr][nc]:
+ *   add  : ggml_compute_forward_add_f32  Ggml.cs:4622-4682 (contiguous branch, ggml_vec_add_f32)
+ *   mul  : ggml_compute_forward_mul_f32  Ggml.cs:5007-5035 (ggml_vec_mul_f32)
+ *   scale: ggml_compute_forward_scale_f32 Ggml.cs:6746-6778: dst (a view of src0, ggml_scale_impl 8248-8273) *= v, IN PLACE
+ *   rms_norm: ggml_compute_forward_rms_norm_f32 Ggml.cs:5858-5920: f32 squares summed in f64, mean = (float)(sum / nc),
+ *             scale = 1.0f / sqrtf(mean + 1e-6f), y = x * scale */
+void oracle_add_f32(int64_t nr, int64_t nc, const float *x, const float *y, float *z);
+void oracle_mul_f32(int64_t nr, int64_t nc, const float *x, const float *y, float *z);
+void oracle_scale_f32(int64_t nr, int64_t nc, float *z, float v);
+void oracle_rms_norm_f32(int64_t nr, int64_t nc, const float *x, float *y);
+
 void     oracle_xsrand(uint64_t seed);
 uint32_t oracle_xrand(void);
 

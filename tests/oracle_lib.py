@@ -46,8 +46,35 @@ def lib():
         L.oracle_mul_mat_work_size.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor)]
         L.oracle_cpy_to_q.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor)]
         L.oracle_add_q_f32.argtypes = [C.POINTER(OTensor), C.POINTER(OTensor), C.POINTER(OTensor)]
+        fp = C.POINTER(C.c_float)
+        L.oracle_add_f32.argtypes = [C.c_int64, C.c_int64, fp, fp, fp]
+        L.oracle_mul_f32.argtypes = [C.c_int64, C.c_int64, fp, fp, fp]
+        L.oracle_scale_f32.argtypes = [C.c_int64, C.c_int64, fp, C.c_float]
+        L.oracle_rms_norm_f32.argtypes = [C.c_int64, C.c_int64, fp, fp]
         _lib = L
     return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def eltwise(op, x, y=None, v=None):
+    """add / mul / scale / rms_norm over contiguous f32 rows (oracle restatements of Ggml.cs:4622, 5007, 6746, 5858)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    nc = x.shape[-1]
+    nr = x.size // nc
+    if op == "scale":
+        z = x.copy()
+        lib().oracle_scale_f32(nr, nc, _fp(z), float(np.float32(v)))
+        return z
+    z = np.empty_like(x)
+    if op == "rms_norm":
+        lib().oracle_rms_norm_f32(nr, nc, _fp(x), _fp(z))
+        return z
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    getattr(lib(), "oracle_add_f32" if op == "add" else "oracle_mul_f32")(nr, nc, _fp(x), _fp(y), _fp(z))
+    return z
 
 
 def type_size(t):

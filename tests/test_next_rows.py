@@ -141,3 +141,76 @@ def test_ggml_program_cpy_then_mul_mat_then_add():
             assert np.all(np.abs(got2 - ref2) <= 1e-3 * np.abs(ref2) + 1e-5 * rms)
     finally:
         G.ggml_free(ctx)
+
+
+# ---------------------------------------------------------------- row 4: f32 neighbours of mul_mat, chained on the device
+@pytest.mark.gpu
+def test_transformer_style_chain_stays_on_device():
+    """cur = rms_norm(x); cur = mul(cur, g); y = mul_mat(W1, cur); y = scale(y, s) [in place]; out = add(mul_mat(W2, y), r)
+    in ONE graph: every intermediate is consumed from HBM, every node's data is in host memory afterwards, add / mul / scale
+    bit-exact against the oracle chain, rms_norm and mul_mat within their documented tolerances."""
+    pytest.importorskip("torch")
+    from ggmlsharp_amd import device
+    from ggmlsharp_amd._lib import lib
+    device.init(0)
+
+    def assert_close(got, ref, what=""):     # the mul_mat tolerance of tests/test_gpu_parity.py
+        got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+        rms = np.sqrt(np.mean(ref * ref))
+        assert not (np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-5 * rms).any(), what
+
+    K, M1, M2, N = 256, 128, 64, 20
+    rng = np.random.default_rng(5)
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    try:
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        Gn = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        W1 = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M1)
+        W2 = G.ggml_new_tensor_2d(ctx, G.Q8_0, M1, M2)
+        S = G.ggml_new_tensor_1d(ctx, G.F32, 1)
+        R = G.ggml_new_tensor_2d(ctx, G.F32, M2, N)
+        x = rng.standard_normal((N, K)).astype(np.float32) * 3
+        g = rng.standard_normal((N, K)).astype(np.float32)
+        r = rng.standard_normal((N, M2)).astype(np.float32)
+        w1q = O.quantize_row(O.Q4_0, rng.standard_normal((M1, K)).astype(np.float32))
+        w2q = O.quantize_row(O.Q8_0, rng.standard_normal((M2, M1)).astype(np.float32))
+        G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
+        G.tensor_f32(Gn)[:] = g.reshape(1, 1, N, K)
+        G.tensor_f32(R)[:] = r.reshape(1, 1, N, M2)
+        G.tensor_f32(S)[:] = 0.125
+        G.tensor_bytes(W1)[:] = w1q.reshape(-1)
+        G.tensor_bytes(W2)[:] = w2q.reshape(-1)
+        t_norm = G.ggml_rms_norm(ctx, X)
+        t_mul = G.ggml_mul(ctx, t_norm, Gn)
+        t_y1 = G.ggml_mul_mat(ctx, W1, t_mul)
+        t_sc = G.ggml_scale(ctx, t_y1, S)                   # a view of t_y1: in place
+        t_y2 = G.ggml_mul_mat(ctx, W2, t_sc)
+        t_out = G.ggml_add(ctx, t_y2, R)
+        assert t_norm and t_mul and t_y1 and t_sc and t_y2 and t_out
+        assert t_sc.contents.data == t_y1.contents.data
+        gf = G.ggml_build_forward(t_out)
+        assert gf.n_nodes == 6
+        c0 = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        c1 = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        lib().ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c0])
+        G.ggml_graph_compute(ctx, gf)
+        lib().ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c1])
+        # oracle chain
+        o_norm = O.eltwise("rms_norm", x)
+        got_norm = G.tensor_f32(t_norm)[0, 0]
+        assert np.allclose(got_norm, o_norm, rtol=2e-7, atol=0)                 # f64 summation order only
+        o_mul = O.eltwise("mul", got_norm, g)
+        assert np.array_equal(G.tensor_f32(t_mul)[0, 0], o_mul)                 # bit-exact given its input
+        o_y1 = O.mul_mat(O.Q4_0, w1q, o_mul, M1, K, N, nth=2)[0, 0]
+        o_sc = O.eltwise("scale", o_y1, v=0.125)
+        got_sc = G.tensor_f32(t_sc)[0, 0]
+        assert_close(got_sc, o_sc, "scale(mul_mat)")
+        o_y2 = O.mul_mat(O.Q8_0, w2q, np.ascontiguousarray(got_sc), M2, M1, N, nth=2)[0, 0]
+        got_y2 = G.tensor_f32(t_y2)[0, 0]
+        assert_close(got_y2, o_y2, "second mul_mat")
+        assert np.array_equal(G.tensor_f32(t_out)[0, 0], O.eltwise("add", got_y2, r))   # bit-exact given its input
+        # PCIe: only the four leaf activations go down (X, Gn, R; S is read on the host), every intermediate is a hit
+        assert c1[0].value - c0[0].value == (2 * N * K + N * M2) * 4
+        assert c1[2].value - c0[2].value >= 5
+    finally:
+        G.ggml_free(ctx)

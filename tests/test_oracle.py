@@ -276,3 +276,20 @@ def test_test0_layout_rule():
     assert t2.nb[1] == 10 * 2 and t2.nb[2] == 10 * 20 * 2
     t3 = O.make_tensor(O.I32, np.zeros(6000, dtype=np.int32), [10, 20, 30])
     assert t3.nb[1] == 40 and t3.nb[2] == 800 and t3.nb[3] == 24000
+
+
+# ---------------------------------------------------------------- element-wise neighbours
+def test_eltwise_restatements_match_numpy():
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((7, 96)).astype(np.float32)
+    y = rng.standard_normal((7, 96)).astype(np.float32)
+    assert np.array_equal(O.eltwise("add", x, y), x + y)                       # one IEEE f32 add per element
+    assert np.array_equal(O.eltwise("mul", x, y), x * y)
+    assert np.array_equal(O.eltwise("scale", x, v=0.3), x * np.float32(0.3))
+    # rms_norm (Ggml.cs:5858-5920): f32 squares, f64 sequential sum, mean cast to f32, 1 / sqrtf(mean + 1e-6f)
+    sq = (x * x).astype(np.float64)
+    mean = np.array([np.float32(sum(row.tolist()) / 96.0) for row in sq], dtype=np.float32)     # sequential f64 sum
+    scale = (np.float32(1.0) / np.sqrt(mean + np.float32(1e-6), dtype=np.float32)).astype(np.float32)
+    assert np.array_equal(O.eltwise("rms_norm", x), x * scale[:, None])
+    z = np.zeros((3, 32), np.float32)
+    assert np.array_equal(O.eltwise("rms_norm", z), z)                          # 0 * 1000 = 0, no NaN
