@@ -82,7 +82,10 @@ __global__ void f16_rows_to_panels_kernel(const uint16_t *__restrict__ rows, int
 }
 
 constexpr int KS = 8;       // k-steps of 16 per LDS stage (128 k)
-constexpr int RING = 4;     // weight fragments in flight, in k-steps
+#ifndef D16_RING
+#define D16_RING 4
+#endif
+constexpr int RING = D16_RING;   // weight fragments in flight, in k-steps (A/B: -DD16_RING=n)
 
 template <int WMT, int WNT, int WGM, int WGN>
 struct Cfg {
@@ -155,7 +158,9 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, bq[ks % RING][i]), acc[i][j], 0, 0, 0);
             });
             // the DMA pieces of the next stage must have landed before the barrier: drain where nothing is young
+#ifndef D16_NODRAIN   /* timing ablation only: without the drain the kernel races */
             if constexpr (ks == KS - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             load_b(s * KS + ks + RING, std::integral_constant<int, ks % RING>{});
         });
     };
