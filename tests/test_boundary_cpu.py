@@ -181,3 +181,25 @@ def test_argument_validation_without_touching_a_device():
     assert L.ggml_hip_weight_upload(G.Q4_0, None, 64, 1, 40, 0, 1, None, C.byref(h)) == _lib.ERR_ARG
     assert L.ggml_hip_mul_mat_work_size(G.Q4_0, 4096, 500) == 128 * 4 * 512 * 16 + 2 * 128 * 512 * 4   # rows padded to 256
     assert L.ggml_hip_mul_mat_work_size(G.F32, 4096, 512) == 0                                          # Ggml.cs:3360-3364
+
+
+def test_reference_style_c_program_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+    """include/*.h are valid C99 and the C-ABI links from plain C: tests/c/reference_style_program.c (the Test1-shaped
+    program of INTEGRATION.md 3).  Without a GPU ggml_graph_compute must report NO_DEVICE -- no CPU fallback."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "ggmlsharp_amd", "lib")
+    exe = str(tmp_path / "refprog")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "reference_style_program.c"), "-L" + libdir, "-lggml_hip",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert out.stdout.strip() == "no-device"
+    else:
+        assert out.stdout.startswith("ok ")

@@ -424,3 +424,18 @@ def test_relayout_gathered(dev):
     out = dev.relayout_gathered(torch.from_numpy(g).cuda(), G_, N, Ms, M).cpu().numpy()
     want = np.concatenate([g[r] for r in range(G_)], axis=1)[:, :M]
     assert np.array_equal(out, want)
+
+
+def test_reference_style_c_program_on_gpu(dev, tmp_path):
+    """tests/c/reference_style_program.c (Test1-shaped f32 mul_mat 64x128x256 through ggml_graph_compute) from plain C."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "ggmlsharp_amd", "lib")
+    exe = str(tmp_path / "refprog")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "reference_style_program.c"),
+                           "-L" + libdir, "-lggml_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
