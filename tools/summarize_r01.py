@@ -15,7 +15,22 @@ def short(n):
     return m.group(1) if m else n[:40]
 
 
-shutil.copy(glob.glob("gpurun_out/prof_r01/*/*_kernel_stats.csv")[0], "profiles/r01_bench_kernel_stats.csv")
+import os
+
+
+def newest(pattern):
+    """gpurun merges every run's files into gpurun_out/: take the latest of each kind"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+shutil.copy(newest("gpurun_out/prof_r01/*/*_kernel_stats.csv")[0], "profiles/r01_bench_kernel_stats.csv")
+# the JSON line bench.py printed while rocprofv3 --stats was attached (its own HIP-event timing of the dominant kernel is the
+# number to compare with the stats average: both are taken in the same, profiled, run) and the un-profiled line
+for src, dst in (("gpurun_out/prof_r01.log", "profiles/r01_bench_under_rocprof.json"), ("gpurun_out/bench_r01.json", "profiles/r01_bench.json")):
+    js = [ln for ln in open(src).read().splitlines() if ln.startswith('{"metric"')]
+    if js:
+        open(dst, "w").write(js[-1] + "\n")
 lines = ["# rocprofv3 --pmc summaries, round 1, MI355X (gfx950), ROCm 7.2.  Averages per dispatch, in millions.",
          "# Collected by tools/profile_r01.sh around tools/kbench.py --cfg q4_0:4096:4096:4096 q4_0:4096:4096:1:32 (separate passes",
          "# per counter set, --kernel-trace only).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles.",
@@ -25,14 +40,14 @@ traffic = {}
 for d in sorted(glob.glob("gpurun_out/pmc_r01_*/")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
-    for f in glob.glob(d + "*/*_counter_collection.csv"):
+    for f in newest(d + "*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if PAT.search(r["Kernel_Name"]):
                 k = short(r["Kernel_Name"])
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[k] = (r["VGPR_Count"], r.get("Accum_VGPR_Count", "?"), r["LDS_Block_Size"], r["Grid_Size"], r["Workgroup_Size"])
     dur = collections.defaultdict(list)
-    for f in glob.glob(d + "*/*_kernel_trace.csv"):
+    for f in newest(d + "*/*_kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             if PAT.search(r["Kernel_Name"]):
                 dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
