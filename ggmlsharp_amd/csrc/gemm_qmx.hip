@@ -85,8 +85,10 @@ struct Cfg {
 
 // FB = weight fragment buffers: 2 = fragments of k-block kb+2 are loaded into the buffer k-block kb has just released;
 // 1 = in place, for kb+1 (enough look-ahead when a wave has >= 4 m-tiles between two uses of a fragment)
-template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB>
-__global__ __launch_bounds__(WGM * WGN * 64, 2)
+// KSP = 1 | 2: with 2 the workgroup holds two wave groups that take alternate LDS stages of K (each with its own stage
+// buffers) and add their accumulators through LDS at the end -- twice the waves for grids too small to fill the chip.
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP>
+__global__ __launch_bounds__(WGM * WGN * 64 * KSP, 2)
 void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
                      const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
                      const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nstages,
@@ -98,10 +100,14 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     static_assert(KB % 2 == 0, "fragment buffers alternate by k-block parity");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave_all / (WGM * WGN);                 // K-split group (0 when KSP == 1)
+    const int wave = wave_all % (WGM * WGN);                // wave inside its group
+    const int tid = wave * 64 + lane;                       // thread inside its group
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wn = wave / WGM, wm_ = wave % WGM;           // waves of one workgroup: m fastest
+    const int wn = wave / WGM, wm_ = wave % WGM;           // waves of one group: m fastest
+    uint8_t *const gsm = smem + grp * C::TOTAL;             // this group's two stage buffers
 
     // XCD-aware tile order (speed only): workgroups b, b+8, b+16, ... share an XCD and its L2.  Each XCD gets a
     // contiguous run of the tile list ordered "m fastest".
@@ -130,9 +136,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     const uint32_t voffS = (uint32_t)(((tid / (C::TN / 4)) * Npad + n0 + 4 * (tid % (C::TN / 4))) * 4);
     const rsrc_t rA = make_rsrc(a6, a_bytes), rAd = make_rsrc(ad, ad_bytes), rAs = make_rsrc(asd, ad_bytes);
     // Pieces past the end of K are dropped by the descriptor's range check (they would fill a buffer nobody reads).
-    auto dma_piece = [&](int s, auto pc) {
+    auto dma_piece = [&](int s, int buf, auto pc) {             // stage s of K -> stage buffer buf of this group
         constexpr int i = decltype(pc)::value;
-        uint8_t *sp = smem + (s & 1) * C::STAGE;
+        uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         const uint32_t s0 = (uint32_t)s * KB * a_blk;
         if constexpr (i < C::A16_ROUNDS) {
             constexpr int u = P * i;
@@ -174,8 +180,8 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     Frag frag[FB];                                          // k-block kb uses frag[kb % FB]
     const int scale_a = hh ? 127 : 131;                     // E8M0: K group 0 (the ah digits) carries 2^4
 
-    auto compute = [&](int s) {
-        const uint8_t *sp = smem + (s & 1) * C::STAGE;
+    auto compute = [&](int s, int buf) {                         // stage s of K, resident in stage buffer buf
+        const uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         const uint8_t *sA16 = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         const uint8_t *sA8 = sp + C::A16_BYTES + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 8;
         const float *sDa = (const float *)(sp + C::A16_BYTES + C::A8_BYTES) + wn * WNT * 32 + 4 * hh;
@@ -222,7 +228,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             }
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 64))) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
-            if constexpr (j == WNT - 1 && !(GGML_MX_DBG & 4)) load_frag_one(kb0 + bb + FB, f, std::integral_constant<int, i>{});
+            // (this group's k-blocks: the stage after s is s + KSP)
+            if constexpr (j == WNT - 1 && !(GGML_MX_DBG & 4))
+                load_frag_one(bb + FB < KB ? kb0 + bb + FB : kb0 + KSP * KB + (bb + FB - KB), f, std::integral_constant<int, i>{});
         };
 
         fetch_af(std::integral_constant<int, 0>{});
@@ -234,7 +242,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             // this tile's weight scales, read before issue(t + 1) may replace them with the next block's (WMT == 1)
             const float dw = dcur[i];
             const float mw = TYPE == GGML_TYPE_Q4_1 ? mcur[i] : 0.0f;
-            if constexpr (t < C::NPIECE && !(GGML_MX_DBG & 1)) dma_piece(s + 1, tc);
+            if constexpr (t < C::NPIECE && !(GGML_MX_DBG & 1)) dma_piece(s + KSP, buf + 1, tc);
             // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
             // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
             // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
@@ -279,20 +287,46 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         });
     };
 
-    // ---- main loop: double-buffered LDS, one barrier per stage (vmcnt(0): see gemm_q16.hip) ----
-    static_for<C::NPIECE>([&](auto pc) { dma_piece(0, pc); });
+    // ---- main loop: double-buffered LDS, one barrier per stage (vmcnt(0): see gemm_q16.hip).  Group grp takes stages
+    //      grp, grp + KSP, ...; every wave passes the same number of barriers. ----
+    static_assert(FB <= KB, "fragment look-ahead stays within two stages");
+    static_for<C::NPIECE>([&](auto pc) { dma_piece(grp, 0, pc); });
     static_for<WMT>([&](auto ic) {
-        load_frag_one(0, frag[0], ic);
-        if constexpr (FB == 2) load_frag_one(1, frag[FB - 1], ic);
+        load_frag_one(grp * KB, frag[0], ic);
+        if constexpr (FB == 2) load_frag_one(grp * KB + 1, frag[FB - 1], ic);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
-    for (int s = 0; s < nstages; ++s) {
-        compute(s);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int niter = (nstages + KSP - 1) / KSP;
+    for (int it = 0; it < niter; ++it) {
+        const int s = it * KSP + grp;
+        if (KSP == 1 || s < nstages) compute(s, it);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the drain inside compute, again for a skipped stage)
         if (!(GGML_MX_DBG & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+
+    // ---- K split: group 1 hands its accumulators to group 0 through LDS (the stage buffers are free now) ----
+    if constexpr (KSP == 2) {
+        static_assert(WGM * WGN * WMT * WNT * 16 * 64 * 4 <= 2 * C::TOTAL, "K-split exchange fits the stage buffers");
+        float *xch = (float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * WNT + j) * 16 + r) * 64];
     }
 
     // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
@@ -331,13 +365,13 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     }
 }
 
-template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB>
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
     static bool attr_set = false;
-    auto kern = gemm_qmx_kernel<TYPE, WMT, WNT, WGM, WGN, KB, FB>;
+    auto kern = gemm_qmx_kernel<TYPE, WMT, WNT, WGM, WGN, KB, FB, KSP>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -353,7 +387,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     const uint64_t ad_bytes = nba * (uint64_t)p.Npad * 4, dst_bytes = ((uint64_t)(N - 1) * (uint64_t)ldd + (uint64_t)w->M) * 4;
     constexpr uint64_t LIM = 0xFFFFFFFFull;                  // 32-bit buffer offsets
     if (wq_bytes > LIM || a_bytes > LIM || (uint64_t)C::TN * (uint64_t)ldd * 4 > LIM) return hipErrorNotSupported;   // api.cpp routes such shapes to gemm_q.hip
-    kern<<<grid, C::NT, C::TOTAL, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
+    kern<<<grid, C::NT * KSP, C::TOTAL * KSP, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
                                         (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
                                         (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes);
     return hipGetLastError();
@@ -372,6 +406,11 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
             return launch_cfg<TYPE, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                 // 256 x 128, waves 64 x 128
         }
     }
+    // Prompt-sized batches (N <= 512) rarely fill the chip with one wave group per tile: two groups per 128 x 64 tile split K
+    // between them (4096 x 4096 x 512: 45.8 -> 31.9 us; 4096 x 11008 x 512: 107 -> 75 us; N = 1024 is 10 % slower that
+    // way, M = 32000 x N = 512 6 % slower).  The choice depends on N and K only -- never on M -- so a row shard still
+    // computes bit for bit what the unsplit matrix does (the summation tree of an element is a function of the kernel form).
+    if (N <= 512 && w->nbk >= 8 && var != 3) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
     if (tm128 * tn128 >= 384) return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);   // 128 x 128, 4 tiles per wave
     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
 }
