@@ -55,8 +55,8 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
 
 // Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat (measured on MI355X):
 //   gemm_qmx.hip (MX matrix path, bf6 digits, one exact MFMA per tile and block) -- Q4_0 / Q4_1,
-//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 when its 256 x 128 tile fills the chip,
-//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q8_0, and Q5_0 on small grids.
+//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q8_0 on prompt-sized batches (N <= 512, K split in the workgroup),
+//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q5_0 / Q8_0 otherwise.
 // GGML_HIP_GEMM=mx|f16|i8 forces one (developer A/B switch).  The MX kernel also has a two-digit form for Q5_0 / Q8_0
 // (two MFMAs per tile and block); it measured no faster than the kernels above, so its digit planes
 // (1.5 B / weight) are only built for weights uploaded while "mx" is forced.
@@ -81,8 +81,11 @@ int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     if ((nba + K_LOOKAHEAD) * (uint64_t)pad_rows(M) * 32 > 0xFFFFFFFFull || nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
     if (force == 2) return gemm_q16_image_kind(type);
     if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
-    const bool fills = ((M + 255) / 256) * ((N + 127) / 128) >= 384;
-    return (type == GGML_TYPE_Q5_0 && fills) ? gemm_q16_image_kind(type) : 0;
+    // Q5_0 / Q8_0: the f16 kernel's K-split form wins on prompt-sized batches (4096 x 11008 x 512: 104 / 113 us against 118 /
+    // 127 us), the int8 kernel on everything larger.  Decided from N and K only, like the K split itself: never from M, so
+    // a row shard runs the kernel form of the unsplit matrix.
+    (void)M;
+    return (N <= 512 && K / QK >= 8) ? gemm_q16_image_kind(type) : 0;
 }
 
 int ensure_init() {

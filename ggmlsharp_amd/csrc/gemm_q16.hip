@@ -132,8 +132,10 @@ struct Cfg {
     static constexpr int WPS = 2;                          // waves per SIMD aimed at (256 registers each)
 };
 
-template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
-__global__ __launch_bounds__(WGM * WGN * 64, (Cfg<TYPE, WMT, WNT, WGM, WGN, KB>::WPS))
+// KSP = 1 | 2: with 2 the workgroup holds two wave groups that take alternate LDS stages of K (each with its own stage
+// buffers) and add their accumulators through LDS at the end -- twice the waves for grids too small to fill the chip.
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int KSP>
+__global__ __launch_bounds__(WGM * WGN * 64 * KSP, (Cfg<TYPE, WMT, WNT, WGM, WGN, KB>::WPS))
 void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict__ wqh, const float *__restrict__ wd,
                      const float *__restrict__ wm, const uint8_t *__restrict__ a16, const float *__restrict__ ad,
                      const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nstages,
@@ -145,10 +147,14 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     static_assert(KB % 2 == 0, "fragment buffers alternate by k-block parity");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave_all / (WGM * WGN);                 // K-split group (0 when KSP == 1)
+    const int wave = wave_all % (WGM * WGN);                // wave inside its group
+    const int tid = wave * 64 + lane;                       // thread inside its group
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wn = wave / WGM, wm_ = wave % WGM;           // waves of one workgroup: m fastest
+    const int wn = wave / WGM, wm_ = wave % WGM;           // waves of one group: m fastest
+    uint8_t *const gsm = smem + grp * C::TOTAL;             // this group's two stage buffers
 
     // XCD-aware tile order (speed only): workgroups b, b+8, b+16, ... share an XCD and its L2.  Each XCD gets a
     // contiguous run of the tile list ordered "m fastest": its resident workgroups share few activation panels and
@@ -184,9 +190,9 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     // s+1 are spread over the first tiles of stage s (one per tile) instead of being issued as a burst.  Pieces past
     // the end of K are dropped by the descriptor's range check (they would only fill a buffer nobody reads).
     constexpr int NPIECE = C::A_ROUNDS + 1;
-    auto dma_piece = [&](int s, auto pc) {
+    auto dma_piece = [&](int s, int buf, auto pc) {             // stage s of K -> stage buffer buf of this group
         constexpr int i = decltype(pc)::value;
-        uint8_t *sp = smem + (s & 1) * C::STAGE;
+        uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         if constexpr (i < C::A_ROUNDS) {
             constexpr int bb = (P * i) >> 2, pan = (P * i) & 3;
             blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voffA, (uint32_t)s * KB * a_blk + bb * a_blk + pan * a_pan);
@@ -260,8 +266,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     //        current fragments of that m-tile, and the raw loads of kb+2 start right after.
     //      The scale-accumulate itself is inline asm, 4 accumulator registers at a time (mul into a temp, fmac): left
     //      to the scheduler, the 16 products of a tile are hoisted far above their fmacs and the kernel spills. ----
-    auto compute = [&](int s) {
-        const uint8_t *sp = smem + (s & 1) * C::STAGE;
+    auto compute = [&](int s, int buf) {                         // stage s of K, resident in stage buffer buf
+        const uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         const uint8_t *sA = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         const float *sDa = (const float *)(sp + C::A_BYTES) + wn * WNT * 32 + 4 * hh;
         const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
@@ -297,7 +303,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             if constexpr (j == WNT - 1) {
                 unpack_one(raw, frag[(bb + 1) & 1], std::integral_constant<int, i>{});
-                load_raw_one(kb0 + bb + 2, raw, std::integral_constant<int, i>{});
+                // (this group's k-blocks: the stage after s is s + KSP)
+                load_raw_one(bb + 2 < KB ? kb0 + bb + 2 : kb0 + KSP * KB + (bb + 2 - KB), raw, std::integral_constant<int, i>{});
             }
         };
 
@@ -308,7 +315,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
 
         static_for<KB * NTILE>([&](auto tc) {
             constexpr int t = decltype(tc)::value, bb = t / NTILE, tl = t % NTILE, j = tl / WMT, i = tl % WMT;
-            if constexpr (t < NPIECE) dma_piece(s + 1, tc);
+            if constexpr (t < NPIECE) dma_piece(s + KSP, buf + 1, tc);
             // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
             // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
             // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
@@ -360,17 +367,41 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     // ---- main loop: double-buffered LDS, one barrier per stage.  The DMA drain is a vmcnt(0) placed where it is free
     //      (see DRAIN in compute), not a counted wait at the barrier: hipcc may sink the weight loads (read-only buffer
     //      loads) below an asm wait, so "all but the youngest N" would not be a statement about the DMA pieces. ----
-    static_for<NPIECE>([&](auto pc) { dma_piece(0, pc); });
-    static_for<WMT>([&](auto ic) { load_raw_one(0, raw, ic); });
-    static_for<WMT>([&](auto ic) { unpack_one(raw, frag[0], ic); load_raw_one(1, raw, ic); });
+    static_for<NPIECE>([&](auto pc) { dma_piece(grp, 0, pc); });
+    static_for<WMT>([&](auto ic) { load_raw_one(grp * KB, raw, ic); });
+    static_for<WMT>([&](auto ic) { unpack_one(raw, frag[0], ic); load_raw_one(grp * KB + 1, raw, ic); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
-    for (int s = 0; s < nstages; ++s) {
-        compute(s);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int niter = (nstages + KSP - 1) / KSP;            // group grp takes stages grp, grp + KSP, ...; same barrier count for all
+    for (int it = 0; it < niter; ++it) {
+        const int s = it * KSP + grp;
+        if (KSP == 1 || s < nstages) compute(s, it);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the drain inside compute, again for a skipped stage)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+
+    // ---- K split: group 1 hands its accumulators to group 0 through LDS (the stage buffers are free now) ----
+    if constexpr (KSP == 2) {
+        static_assert(WGM * WGN * WMT * WNT * 16 * 64 * 4 <= 2 * C::TOTAL, "K-split exchange fits the stage buffers");
+        float *xch = (float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * WNT + j) * 16 + r) * 64];
     }
 
     // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
@@ -409,13 +440,13 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     }
 }
 
-template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
     static bool attr_set = false;
-    auto kern = gemm_q16_kernel<TYPE, WMT, WNT, WGM, WGN, KB>;
+    auto kern = gemm_q16_kernel<TYPE, WMT, WNT, WGM, WGN, KB, KSP>;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -430,7 +461,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     const uint64_t ad_bytes = nba * (uint64_t)p.Npad * 4, dst_bytes = ((uint64_t)(N - 1) * (uint64_t)ldd + (uint64_t)w->M) * 4;
     constexpr uint64_t LIM = 0xFFFFFFFFull;                  // 32-bit buffer offsets
     if (wq_bytes > LIM || a_bytes > LIM || (uint64_t)C::TN * (uint64_t)ldd * 4 > LIM) return hipErrorNotSupported;   // api.cpp routes such shapes to gemm_q.hip
-    kern<<<grid, C::NT, C::TOTAL, st>>>(w->qs, w->qh, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
+    kern<<<grid, C::NT * KSP, C::TOTAL * KSP, st>>>(w->qs, w->qh, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
                                         (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
                                         (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes);
     return hipGetLastError();
@@ -440,6 +471,8 @@ template <int TYPE>
 hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     // big tile (256 x 128, 8 tiles per wave) when it still fills the chip with >= 2 workgroups per CU; else 128 x 64
     const int64_t big = ((w->M + 255) / 256) * ((N + 127) / 128);
+    // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (chosen from N and K only, see gemm_qmx.hip)
+    if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
     if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
     return launch_cfg<TYPE, 2, 2, 2, 1, 4>(w, p, N, dst, ldd, st);
 }
