@@ -99,6 +99,21 @@ def test_row_shard_and_column_subset_are_bitwise_slices(dev):
     W.free()
 
 
+@pytest.mark.parametrize("t,N", [(Q5_0, 512), (Q8_0, 512), (Q8_0, 1024), (Q4_0, 2048), (Q4_0, 3)])
+def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
+    """The kernel form (MX / f16 with or without the K split / int8 / mat-vec) is chosen from the type, N and K -- never
+    from M -- so a row shard computes bit for bit the matching columns of the unsplit result, whatever serves the shape."""
+    M, K = 4096, 1024
+    rows, x = _make(dev, t, M, K, N, seed=11 + N)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((0, 512), (3584, 4096), (777, 2000)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, N, r0, r1)
+        Ws.free()
+    W.free()
+
+
 def test_fullsize_byte_roundtrips(dev):
     M, K = 4096, 4096
     for t in (Q4_0, Q5_0, Q8_0):
