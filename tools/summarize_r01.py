@@ -62,9 +62,12 @@ for d in sorted(glob.glob("gpurun_out/pmc_r01_*/")):
 open("profiles/r01_pmc_summary.txt", "w").write("\n".join(lines))
 out = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC (separate --pmc passes), round 1. bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: "
                    "FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream; the batch-1 kernel confirms it)."}
-names = {"gemm_qmx_kernel<2, 2, 4, 4, 1, 4, 2>": "gemm_qmx_kernel<Q4_0,2,4,4,1> M=4096 K=4096 N=4096",
-         "gemv_q_kernel<2, 1, true>": "gemv_q_kernel<Q4_0,1,fused> M=4096 K=4096 N=1",
-         "quantize_act_kernel<3>": "quantize_act_kernel<bf6 image> N=4096 K=4096"}
+# matched by prefix so that an added template parameter does not silently drop a kernel from the file
+prefixes = [("gemm_qmx_kernel<2, 2, 4, 4, 1,", "gemm_qmx_kernel<Q4_0,2,4,4,1> M=4096 K=4096 N=4096"),
+            ("gemv_q_kernel<2, 1, true", "gemv_q_kernel<Q4_0,1,fused> M=4096 K=4096 N=1"),
+            ("quantize_act_kernel<3>", "quantize_act_kernel<bf6 image> N=4096 K=4096")]
+names = {k: nm for k in traffic for (pre, nm) in prefixes if k.startswith(pre)}
+assert len(names) == len(prefixes), (sorted(traffic), names)
 for k, t in traffic.items():
     if k in names and "FETCH_SIZE_KB" in t and "WRITE_SIZE_KB" in t:
         out[names[k]] = dict(t, traffic_bytes=int((2 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024))
