@@ -40,15 +40,21 @@ int fail(int code, const char *fmt, ...) {
 const int BLCK[GGML_TYPE_COUNT] = {1, 1, 32, 32, 16, 16, 32, 32, 32, 32, 1, 1, 1};          // Ggml.cs:55-70
 const size_t TSIZE[GGML_TYPE_COUNT] = {4, 2, 20, 24, 10, 12, 22, 24, 36, 44, 1, 2, 4};      // Ggml.cs:72-87
 
-bool weight_type_ok(int t) {
-    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q8_0 ||
-           t == GGML_TYPE_F32 || t == GGML_TYPE_F16;
+// quantized types with working row functions and dot products.  Q4_2 and Q5_1 follow SURVEY D7's intent (their half
+// scales are IEEE bit patterns, as in the upstream scalar code the C# transcribes); Q4_3 / Q8_1 have null slots (D8).
+bool wq_ok(int t) {
+    return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q4_2 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1 ||
+           t == GGML_TYPE_Q8_0;
 }
+bool weight_type_ok(int t) { return wq_ok(t) || t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+bool has_min_plane(int t) { return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q4_2; }   // Q4_2: its second scale
+bool has_qh_plane(int t) { return t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
+size_t row_bytes_of(int t, int64_t k) { return TSIZE[t] * (size_t)(k / BLCK[t]); }
 bool is_q(int t) { return t >= GGML_TYPE_Q4_0 && t <= GGML_TYPE_Q8_1; }
 int vec_dot_type(int t) {  // Ggml.cs:219-290
     switch (t) {
-    case GGML_TYPE_Q4_0: case GGML_TYPE_Q5_0: case GGML_TYPE_Q8_0: return GGML_TYPE_Q8_0;
-    case GGML_TYPE_Q4_1: return GGML_TYPE_Q8_1;
+    case GGML_TYPE_Q4_0: case GGML_TYPE_Q4_2: case GGML_TYPE_Q5_0: case GGML_TYPE_Q8_0: return GGML_TYPE_Q8_0;
+    case GGML_TYPE_Q4_1: case GGML_TYPE_Q5_1: return GGML_TYPE_Q8_1;
     default: return -1;
     }
 }
@@ -76,6 +82,7 @@ int gemm_force() {
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
     if (N <= GEMV_MAX_N || force == 1) return 0;
+    if (type == GGML_TYPE_Q4_2 || type == GGML_TYPE_Q5_1) return 0;   // served by the int8 kernel only (outside BASELINE's configs)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
     if ((nba + K_LOOKAHEAD) * (uint64_t)pad_rows(M) * 32 > 0xFFFFFFFFull || nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
@@ -213,10 +220,10 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
         const size_t plane = (size_t)nba * w->Mpad * 4;
         off_qs = 0; total = qs_bytes;
         off_d = total; total += plane;
-        if (type == GGML_TYPE_Q4_1) { off_m = total; total += plane; }
-        if (type == GGML_TYPE_Q5_0) { off_qh = total; total += plane; }
+        if (has_min_plane(type)) { off_m = total; total += plane; }
+        if (has_qh_plane(type)) { off_qh = total; total += plane; }
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
-        with6 = q4 || gemm_force() == 3;
+        with6 = q4 || (gemm_force() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
             off_6a = total; total += (size_t)nba * nf * w->Mpad * 16;
@@ -234,8 +241,8 @@ int alloc_weight(int type, int64_t K, int64_t M, ggml_hip_weight **out) {
     } else {
         w->qs = (uint8_t *)base + off_qs;
         w->d = (float *)((uint8_t *)base + off_d);
-        if (type == GGML_TYPE_Q4_1) w->m = (float *)((uint8_t *)base + off_m);
-        if (type == GGML_TYPE_Q5_0) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
+        if (has_min_plane(type)) w->m = (float *)((uint8_t *)base + off_m);
+        if (has_qh_plane(type)) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
     }
     *out = w;
@@ -252,7 +259,8 @@ int make_weight(int type, const void *rows, bool rows_on_host, int64_t ne00, int
         return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type (Q4_3/Q8_1 have null slots, Ggml.cs:248,278-282)", type);
     if (!rows || ne00 <= 0 || ne01 < 0 || row_begin < 0 || row_end < row_begin || row_end > ne01)
         return fail(GGML_HIP_ERR_ARG, "bad weight arguments");
-    if (ne00 % BLCK[type] != 0) return fail(GGML_HIP_ERR_SHAPE, "ne00 %% %d != 0 (Ggml.cs:6694)", BLCK[type]);
+    if (ne00 % BLCK[type] != 0 || (is_q(type) && ne00 % QK != 0))   // every dot product runs against 32-element Q8 blocks
+        return fail(GGML_HIP_ERR_SHAPE, "ne00 %% %d != 0 (Ggml.cs:6694)", is_q(type) ? QK : BLCK[type]);
     const uint64_t row_bytes = (uint64_t)TSIZE[type] * (uint64_t)(ne00 / BLCK[type]);
     if (nb01 < row_bytes) return fail(GGML_HIP_ERR_SHAPE, "nb01 smaller than a row (transposed src0, Ggml.cs:8229)");
     int rc = ensure_init();
@@ -464,7 +472,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;  // empty input: nothing to do (buffers may be null)
     if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
-    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q8_1))
+    if (!(wq_ok(type) || type == GGML_TYPE_Q8_1))
         return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
     if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:336)");
     HIP_TRY(launch_quantize_rows(type, GGML_TYPE_F32, d_x, k, nrows, k, d_blocks, (hipStream_t)stream));
@@ -474,7 +482,7 @@ int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_
 int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, int64_t k, float *d_y, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;
     if (!d_y || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
-    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0))
+    if (!wq_ok(type))
         return fail(GGML_HIP_ERR_TYPE, "dequantize: unsupported type %d (Q8_1 slot is null, Ggml.cs:278)", type);
     if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:839)");
     HIP_TRY(launch_dequantize_rows(type, d_blocks, nrows, k, d_y, (hipStream_t)stream));
@@ -521,7 +529,7 @@ int ggml_hip_vec_dot(int type, int n, float *s, const void *vx, const void *vy) 
     int rc = ensure_init();
     if (rc) return rc;
     ggml_hip_weight *w = nullptr;
-    const uint64_t xb = (uint64_t)TSIZE[type] * (uint64_t)(n / QK);
+    const uint64_t xb = (uint64_t)row_bytes_of(type, n);
     rc = ggml_hip_weight_upload(type, vx, n, 1, xb, 0, 1, g_stream, &w);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -554,7 +562,7 @@ int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int6
                                    void *d_blocks, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;
     if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
-    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q8_1))
+    if (!(wq_ok(type) || type == GGML_TYPE_Q8_1))
         return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
     if (src_type != GGML_TYPE_F32 && src_type != GGML_TYPE_F16) return fail(GGML_HIP_ERR_TYPE, "quantize: source must be F32 or F16");
     if (k % QK != 0 || ld < k) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 or ld < k");
@@ -568,7 +576,7 @@ int ggml_hip_add_q_f32_rows_dev(int type, const void *d_blocks_in, const float *
                                 void *d_blocks_out, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;
     if (!d_blocks_in || !d_x || !d_blocks_out) return fail(GGML_HIP_ERR_ARG, "null argument");
-    if (!(type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0))
+    if (!wq_ok(type))
         return fail(GGML_HIP_ERR_TYPE, "add_q_f32: unsupported type %d", type);
     if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:4893)");
     HIP_TRY(launch_add_q_f32(type, d_blocks_in, d_x, nrows, k, d_blocks_out, (hipStream_t)stream));
@@ -582,14 +590,14 @@ int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
     const int st = src0->type, dt = dst->type;
     if (st != GGML_TYPE_F32 && st != GGML_TYPE_F16) return fail(GGML_HIP_ERR_TYPE, "cpy: src0 must be F32 or F16 (Ggml.cs:4602-4619)");
-    if (!(dt == GGML_TYPE_Q4_0 || dt == GGML_TYPE_Q4_1 || dt == GGML_TYPE_Q5_0 || dt == GGML_TYPE_Q8_0))
+    if (!wq_ok(dt))
         return fail(GGML_HIP_ERR_TYPE, "cpy: only the quantizing branch is on this path (dst type %d)", dt);
     const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
     const int64_t n_src = ne00 * ne01 * ne02 * ne03, n_dst = dst->ne[0] * dst->ne[1] * dst->ne[2] * dst->ne[3];
     if (n_src != n_dst) return fail(GGML_HIP_ERR_SHAPE, "cpy: element counts differ (Ggml.cs:8281)");
     const size_t es = st == GGML_TYPE_F32 ? 4 : 2;
     if (src0->nb[0] != es) return fail(GGML_HIP_ERR_SHAPE, "cpy: src0 rows must be contiguous");
-    if (dst->nb[0] != TSIZE[dt] || dst->nb[1] != dst->nb[0] * (uint64_t)(dst->ne[0] / QK) || dst->nb[2] != dst->nb[1] * (uint64_t)dst->ne[1] ||
+    if (dst->nb[0] != TSIZE[dt] || dst->nb[1] != dst->nb[0] * (uint64_t)(dst->ne[0] / BLCK[dt]) || dst->nb[2] != dst->nb[1] * (uint64_t)dst->ne[1] ||
         dst->nb[3] != dst->nb[2] * (uint64_t)dst->ne[2])
         return fail(GGML_HIP_ERR_SHAPE, "cpy: dst must be contiguous (Ggml.cs:4290)");
     if (ne00 % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "cpy: ne00 %% 32 != 0");
@@ -600,7 +608,7 @@ int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_graph_depth > 0) HIP_TRY(hipStreamSynchronize(g_stream));   // operands may be dst of an earlier node still on its way to the host
-    const size_t row_in = (size_t)ne00 * es, rs = TSIZE[dt] * (size_t)(ne00 / QK);   // rs as in Ggml.cs:4345
+    const size_t row_in = (size_t)ne00 * es, rs = row_bytes_of(dt, ne00);   // rs as in Ggml.cs:4345
     if (g_src1.ensure(row_in * ne01) || g_dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
     size_t id = 0;
     for (int64_t i03 = 0; i03 < ne03; ++i03)
@@ -645,7 +653,7 @@ int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
     const int t = src0->type;
     if (t == GGML_TYPE_F32) return binary_f32_seam(0, src0, src1, dst);      // ggml_compute_forward_add_f32 (Ggml.cs:4622-4682)
-    if (!(t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q8_0))
+    if (!wq_ok(t))
         return fail(GGML_HIP_ERR_TYPE, "add: src0 must be F32 or quantized (add_q_f32), got type %d", t);
     if (dst->type != t || src1->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "add_q_f32: dst must have src0's type, src1 F32 (Ggml.cs:4863-4865)");
     for (int i = 0; i < 4; ++i)
@@ -660,7 +668,7 @@ int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_graph_depth > 0) HIP_TRY(hipStreamSynchronize(g_stream));   // operands may be dst of an earlier node still on its way to the host
-    const size_t rs = TSIZE[t] * (size_t)(ne00 / QK), rx = (size_t)ne00 * 4;
+    const size_t rs = row_bytes_of(t, ne00), rx = (size_t)ne00 * 4;
     if (g_stage.ensure(rs * ne01) || g_src1.ensure(rx * ne01) || g_dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
     for (int64_t i03 = 0; i03 < ne03; ++i03)
         for (int64_t i02 = 0; i02 < ne02; ++i02) {

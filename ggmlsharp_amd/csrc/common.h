@@ -12,13 +12,17 @@
 #pragma pack(push, 1)
 struct block_q4_0 { float d; uint8_t qs[16]; };
 struct block_q4_1 { float d; float m; uint8_t qs[16]; };
+struct block_q4_2 { uint16_t d; uint8_t qs[8]; };               // 16 elements; d is an IEEE half (intent)
 struct block_q5_0 { uint16_t d; uint8_t qh[4]; uint8_t qs[16]; };
+struct block_q5_1 { uint16_t d; uint16_t m; uint8_t qh[4]; uint8_t qs[16]; };   // d, m IEEE halves (D7, intent)
 struct block_q8_0 { float d; int8_t qs[32]; };
 struct block_q8_1 { float d; float s0; float s1; int8_t qs[32]; };
 #pragma pack(pop)
 static_assert(sizeof(block_q4_0) == 20, "Ggml.cs:76");
 static_assert(sizeof(block_q4_1) == 24, "Ggml.cs:77");
+static_assert(sizeof(block_q4_2) == 10, "Ggml.cs:78");
 static_assert(sizeof(block_q5_0) == 22, "Ggml.cs:80");
+static_assert(sizeof(block_q5_1) == 24, "Ggml.cs:81");
 static_assert(sizeof(block_q8_0) == 36, "Ggml.cs:82");
 static_assert(sizeof(block_q8_1) == 44, "Ggml.cs:83");
 static_assert(sizeof(ggml_tensor) == 176, "TypeDefinitions.cs:65-99");
@@ -39,10 +43,13 @@ static inline int64_t pad_rows(int64_t n) { return (n + ROW_PAD - 1) / ROW_PAD *
 static inline int64_t pad_act(int64_t n) { return (n + ACT_PAD - 1) / ACT_PAD * ACT_PAD; }
 
 // ---- resident weight: planar (block-major) layout, see DESIGN.md "Data layout in HBM" ----
-//   Q4_0/Q4_1/Q5_0: qs [nbk][Mpad][16] bytes of nibbles exactly as in the reference block
+//   Q4_0/Q4_1/Q5_0/Q5_1: qs [nbk][Mpad][16] bytes of nibbles exactly as in the reference block
+//   Q4_2          : the same plane; k-block b = the reference's 16-element blocks 2b (bytes 0..7) and 2b+1 (bytes 8..15),
+//                   which is byte for byte the nibble order of a Q4_0 block (Ggml.cs:1217-1238 vs 1136-1150)
 //   Q8_0          : qs [nbk][2][Mpad][16] int8, plane 0 = even elements, plane 1 = odd elements of the block
-//   d   [nbk][Mpad] f32 (Q5_0: the half scale widened, exact)
-//   m   [nbk][Mpad] f32 (Q4_1 only);  qh [nbk][Mpad] u32 (Q5_0 only)
+//   d   [nbk][Mpad] f32 (Q5_0 / Q5_1 / Q4_2: the half scale widened, exact; Q4_2: of its first 16-element block)
+//   m   [nbk][Mpad] f32 (Q4_1, Q5_1: the min; Q4_2: the scale of its second 16-element block)
+//   qh  [nbk][Mpad] u32 (Q5_0, Q5_1)
 //   F32/F16: dense [Mpad][K] row-major copy
 struct ggml_hip_weight {
     int      type;

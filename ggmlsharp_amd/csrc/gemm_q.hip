@@ -2,7 +2,10 @@
 //
 // COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698):
 //   dst[n*ldd + m] = sum_b (dw[m,b] * da[n,b]) * sumi_b(m,n),   sumi_b = exact int32 dot of one 32-element block
-// (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159; _q5_0_q8_0 1270-1298; _q8_0_q8_0 1362-1378; _q4_1_q8_1 1176-1198).
+// (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159; _q5_0_q8_0 1270-1298; _q8_0_q8_0 1362-1378; _q4_1_q8_1 1176-1198;
+// _q5_1_q8_1 1318-1344: unsigned 5-bit values + the min term; _q4_2_q8_0 1216-1252: a k-block is two 16-element blocks
+// with their own scales, so its tile takes two v_mfma_i32_32x32x16_i8 -- bytes 0..7 of both operand halves are elements
+// 0..15, bytes 8..15 elements 16..31 -- and two scale-accumulates).
 // The reference's K-block of 32 is exactly one v_mfma_i32_32x32x32_i8 step, so each MFMA yields the 32x32 tile of
 // sumi_b for one k-block; the f32 scale-accumulate of Ggml.cs:1158 is then applied per tile on the VALU:
 //   acc[r] = fma((float)sumi[r], da[row(r)] * dw[col], acc[r]).
@@ -61,6 +64,12 @@ __device__ __forceinline__ uint32_t q5_hi(uint32_t qh, int i, int sel) {
     return (t * 0x00410410u) & 0x10101010u;
 }
 
+template <int TYPE> struct Traits {
+    static constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // second weight plane
+    static constexpr bool MIN = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1;                              // ... that is a min
+    static constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
+};
+
 template <int TYPE, int IT, int JT>
 struct Tile {
     static constexpr int TN = 64 * IT;  // src1 rows per workgroup
@@ -69,8 +78,8 @@ struct Tile {
     static constexpr int W_BYTES = BKB * 2 * TM * 16;
     static constexpr int DA_BYTES = BKB * TN * 4;
     static constexpr int DW_BYTES = BKB * TM * 4;
-    static constexpr int MW_BYTES = (TYPE == GGML_TYPE_Q4_1) ? BKB * TM * 4 : 0;
-    static constexpr int SA_BYTES = (TYPE == GGML_TYPE_Q4_1) ? BKB * TN * 4 : 0;
+    static constexpr int MW_BYTES = Traits<TYPE>::HAS_M ? BKB * TM * 4 : 0;
+    static constexpr int SA_BYTES = Traits<TYPE>::MIN ? BKB * TN * 4 : 0;
     static constexpr int STAGE = A_BYTES + W_BYTES + DA_BYTES + DW_BYTES + MW_BYTES + SA_BYTES;
     static constexpr int LDS = 2 * STAGE;
 };
@@ -84,6 +93,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
                                                        int tiles_m, int tiles_n) {
     using T = Tile<TYPE, IT, JT>;
     constexpr int TN = T::TN, TM = T::TM;
+    constexpr bool HAS_M = Traits<TYPE>::HAS_M, MIN = Traits<TYPE>::MIN, HAS_H = Traits<TYPE>::HAS_H;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
                 const int c = tid + 256 * i, bb = c / TM;
                 const bool dead = bb >= left;
                 wreg[i] = *(const uint4 *)(gW + (offW[i] - (dead ? (uint32_t)bb * w_blk : 0u)));
-                if (TYPE == GGML_TYPE_Q5_0)
+                if (HAS_H)
                     hreg[i] = *(const uint32_t *)((const uint8_t *)(wqh + kb0 * Mpad) + (offH[i] - (dead ? (uint32_t)(bb * Mpad * 4) : 0u)));
             }
         }
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
             const uint32_t off = offDa[k] - (ok ? 0u : (uint32_t)(bb * Npad * 4));   // dead block: re-read block 0 of the stage
             const float v = *(const float *)(gDa + off);
             dareg[k] = ok ? v : 0.0f;
-            if (TYPE == GGML_TYPE_Q4_1) { const int sv = *(const int32_t *)(gSa + off); sareg[k] = ok ? (float)sv : 0.0f; }
+            if (MIN) { const int sv = *(const int32_t *)(gSa + off); sareg[k] = ok ? (float)sv : 0.0f; }
         }
 #pragma unroll
         for (int k = 0; k < SW_PER_THREAD; ++k) {
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
             const uint32_t off = offDw[k] - (ok ? 0u : (uint32_t)(bb * Mpad * 4));
             const float v = *(const float *)(gDw + off);
             dwreg[k] = ok ? v : 0.0f;
-            if (TYPE == GGML_TYPE_Q4_1) { const float v2 = *(const float *)(gMw + off); mwreg[k] = ok ? v2 : 0.0f; }
+            if (HAS_M) { const float v2 = *(const float *)(gMw + off); mwreg[k] = ok ? v2 : 0.0f; }
         }
     };
     auto store_scales = [&](int s) {
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
             const int i = tid + 256 * k;
             if (i < BKB * TN) {
                 sDa[i] = dareg[k];
-                if (TYPE == GGML_TYPE_Q4_1) sSa[i] = sareg[k];
+                if (MIN) sSa[i] = sareg[k];
             }
         }
 #pragma unroll
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
             const int i = tid + 256 * k;
             if (i < BKB * TM) {
                 sDw[i] = dwreg[k];
-                if (TYPE == GGML_TYPE_Q4_1) sMw[i] = mwreg[k];
+                if (HAS_M) sMw[i] = mwreg[k];
             }
         }
     };
@@ -254,9 +264,12 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
             for (int k = 0; k < 4; ++k) {
                 lo[k] = q[k] & 0x0F0F0F0Fu;         // elements 8k+0,2,4,6
                 hi[k] = (q[k] >> 4) & 0x0F0F0F0Fu;  // elements 8k+1,3,5,7
-                if (TYPE == GGML_TYPE_Q4_0) {       // (nib - 8), Ggml.cs:1149-1150
+                if (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_2) {       // (nib - 8), Ggml.cs:1149-1150 / 1231-1235
                     lo[k] = sub_bytes(lo[k], 0x08080808u);
                     hi[k] = sub_bytes(hi[k], 0x08080808u);
+                } else if (TYPE == GGML_TYPE_Q5_1) {  // (nib | bit << 4), unsigned 0..31, Ggml.cs:1330-1334
+                    lo[k] |= q5_hi(hreg[i], k, 0);
+                    hi[k] |= q5_hi(hreg[i], k, 1);
                 } else if (TYPE == GGML_TYPE_Q5_0) {  // ((nib | bit << 4) - 16), Ggml.cs:1285-1289
                     lo[k] = sub_bytes(lo[k] | q5_hi(hreg[i], k, 0), 0x10101010u);
                     hi[k] = sub_bytes(hi[k] | q5_hi(hreg[i], k, 1), 0x10101010u);
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
         i32x4 af[RING][IT], bf[RING][JT];
         float dw[RING][JT], mw[RING][JT];
         f32x4 da[2][4], sa[2][4];
-        i32x16 tacc[2];
+        i32x16 tacc[2], tacc2[TYPE == GGML_TYPE_Q4_2 ? 2 : 1];   // Q4_2: the second 16-element block's sums
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
         auto load_block = [&](auto bbc) {   // operand fragments + per-lane weight scales of k-block bb
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
                 const int col = wm_ * 32 * JT + 32 * j + l31;
                 bf[p][j] = *(const i32x4 *)(sW + ((size_t)((bb * 2 + hh) * TM + col)) * 16);
                 dw[p][j] = sDw[bb * TM + col];
-                if (TYPE == GGML_TYPE_Q4_1) mw[p][j] = sMw[bb * TM + col];
+                if (HAS_M) mw[p][j] = sMw[bb * TM + col];
             }
         };
         auto load_group = [&](auto gc) {    // the 16 per-register row scales of group g = bb * IT + i
@@ -312,12 +325,20 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 da[p][k] = *(const f32x4 *)(sDa + bb * TN + row + 8 * k + 4 * hh);
-                if (TYPE == GGML_TYPE_Q4_1) sa[p][k] = *(const f32x4 *)(sSa + bb * TN + row + 8 * k + 4 * hh);
+                if (MIN) sa[p][k] = *(const f32x4 *)(sSa + bb * TN + row + 8 * k + 4 * hh);
             }
         };
         auto mfma_tile = [&](auto tc) {
             constexpr int t = decltype(tc)::value, bb = t / (IT * JT), i = (t / JT) % IT, j = t % JT;
-            tacc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[bb % RING][i], bf[bb % RING][j], zero, 0, 0, 0);
+            if constexpr (TYPE == GGML_TYPE_Q4_2) {
+                const i32x4 a = af[bb % RING][i], b = bf[bb % RING][j];
+                const long a0 = (long)(((uint64_t)(uint32_t)a[1] << 32) | (uint32_t)a[0]), a1 = (long)(((uint64_t)(uint32_t)a[3] << 32) | (uint32_t)a[2]);
+                const long b0 = (long)(((uint64_t)(uint32_t)b[1] << 32) | (uint32_t)b[0]), b1 = (long)(((uint64_t)(uint32_t)b[3] << 32) | (uint32_t)b[2]);
+                tacc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a0, b0, zero, 0, 0, 0);
+                tacc2[t & 1] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a1, b1, zero, 0, 0, 0);
+            } else {
+                tacc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[bb % RING][i], bf[bb % RING][j], zero, 0, 0, 0);
+            }
         };
 
         static_for<AHEAD>([&](auto bc) { load_block(bc); });
@@ -338,7 +359,16 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
                 const float sc = da[g & 1][r >> 2][r & 3] * dwj;
                 acc[i][j][r >> 2][r & 3] = fmaf((float)tt[r], sc, acc[i][j][r >> 2][r & 3]);
             }
-            if (TYPE == GGML_TYPE_Q4_1) {  // + m0 * d1 * sum(a)  (Ggml.cs:1190-1196 factorised)
+            if constexpr (TYPE == GGML_TYPE_Q4_2) {   // sumf += (d1 * yd) * sumi_1 (Ggml.cs:1250): the second block's scale rides in the m plane
+                const i32x16 t2 = tacc2[t & 1];
+                const float dw2 = mw[bb % RING][j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float sc = da[g & 1][r >> 2][r & 3] * dw2;
+                    acc[i][j][r >> 2][r & 3] = fmaf((float)t2[r], sc, acc[i][j][r >> 2][r & 3]);
+                }
+            }
+            if (MIN) {  // + m0 * d1 * sum(a)  (Ggml.cs:1190-1196 factorised; Q5_1: m * (s0 + s1), Ggml.cs:1344)
                 const float mwj = mw[bb % RING][j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -426,6 +456,8 @@ hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, floa
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }

@@ -3,7 +3,8 @@
 // Computes the COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698) for few src1 rows:
 //   dst[n*ldd + m] = sum_b dw[m,b] * da[n,b] * sum_{k in b} w[m,k] * a[n,k]
 // with the integer block sums exact (ggml_vec_dot_q4_0_q8_0 Ggml.cs:1136-1159, _q5_0_q8_0 1270-1298,
-// _q8_0_q8_0 1362-1378, _q4_1_q8_1 1176-1198) and the f32 scale-accumulate per block as in :1158.
+// _q8_0_q8_0 1362-1378, _q4_1_q8_1 1176-1198, _q5_1_q8_1 1318-1344, _q4_2_q8_0 1216-1252 -- the last two with IEEE-half
+// scales, SURVEY D7 intent) and the f32 scale-accumulate per block as in :1158.
 // Only the order of the f32 additions over blocks differs from the scalar loop.
 //
 // Mapping, chosen for the planar weight layout ([k-block][row][16 B]):
@@ -89,8 +90,10 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
 
         // 1. all of this lane's weight loads for the chunk go out first (8 x 16 B + scales in flight per lane)
         uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
-        float dw[BPL], mw[TYPE == GGML_TYPE_Q4_1 ? BPL : 1];
-        uint32_t hb[TYPE == GGML_TYPE_Q5_0 ? BPL : 1];
+        constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
+        constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
+        float dw[BPL], mw[HAS_M ? BPL : 1];
+        uint32_t hb[HAS_H ? BPL : 1];
 #pragma unroll
         for (int j = 0; j < BPL; ++j) {
             const int bl = u + GV_WORKERS * j;
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
                 q[j] = ld_w(qs + (b * Mpad + row) * 16);
             }
             dw[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
-            if (TYPE == GGML_TYPE_Q4_1) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
-            if (TYPE == GGML_TYPE_Q5_0) hb[j] = qh[b * Mpad + row];
+            if (HAS_M) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
+            if (HAS_H) hb[j] = qh[b * Mpad + row];
         }
 
         // 2. activations of the chunk -> LDS (int8 even/odd planes + scale + block sum); once per workgroup if K fits
@@ -182,9 +185,13 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
                 for (int i = 0; i < 4; ++i) {
                     lo[i] = qq[i] & 0x0F0F0F0Fu;          // elements 8i+0,2,4,6  (Ggml.cs:1149)
                     hi[i] = (qq[i] >> 4) & 0x0F0F0F0Fu;   // elements 8i+1,3,5,7  (Ggml.cs:1150)
-                    if (TYPE == GGML_TYPE_Q5_0) {         // Ggml.cs:1285-1289
+                    if (HAS_H) {                          // Ggml.cs:1285-1289 / 1330-1334
                         lo[i] |= q5_high_bits(hb[j], i, 0);
                         hi[i] |= q5_high_bits(hb[j], i, 1);
+                    }
+                    if (TYPE == GGML_TYPE_Q4_2) {         // (nib - 8) bytewise: the two half-block sums need their own offsets
+                        lo[i] = ((lo[i] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+                        hi[i] = ((hi[i] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
                     }
                 }
             }
@@ -192,15 +199,25 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
             for (int c = 0; c < NC; ++c) {
                 const uint4 a0 = sA[(bl * 2 + 0) * NC + c];
                 const uint4 a1 = sA[(bl * 2 + 1) * NC + c];
+                const float da = sD[bl * NC + c];
+                const int sa = sS[bl * NC + c];
+                if (TYPE == GGML_TYPE_Q4_2) {
+                    // elements 0..15 (the first 16-element block, scale dw) are words 0, 1 of both planes, 16..31 (scale
+                    // mw) words 2, 3: sumf += (d0 * yd) * sumi_0; sumf += (d1 * yd) * sumi_1 (Ggml.cs:1249-1250)
+                    int s0 = 0, s1 = 0;
+                    s0 = dot4(lo[0], a0.x, s0); s0 = dot4(lo[1], a0.y, s0); s0 = dot4(hi[0], a1.x, s0); s0 = dot4(hi[1], a1.y, s0);
+                    s1 = dot4(lo[2], a0.z, s1); s1 = dot4(lo[3], a0.w, s1); s1 = dot4(hi[2], a1.z, s1); s1 = dot4(hi[3], a1.w, s1);
+                    acc[c] = fmaf(dw[j] * da, (float)s0, acc[c]);
+                    acc[c] = fmaf(mw[j] * da, (float)s1, acc[c]);
+                    continue;
+                }
                 int s = 0;
                 s = dot4(lo[0], a0.x, s); s = dot4(lo[1], a0.y, s); s = dot4(lo[2], a0.z, s); s = dot4(lo[3], a0.w, s);
                 s = dot4(hi[0], a1.x, s); s = dot4(hi[1], a1.y, s); s = dot4(hi[2], a1.z, s); s = dot4(hi[3], a1.w, s);
-                const float da = sD[bl * NC + c];
-                const int sa = sS[bl * NC + c];
                 if (TYPE == GGML_TYPE_Q4_0) s -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
                 if (TYPE == GGML_TYPE_Q5_0) s -= 16 * sa;
                 acc[c] = fmaf(dw[j] * da, (float)s, acc[c]);
-                if (TYPE == GGML_TYPE_Q4_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);
+                if (TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);   // + m * (s0 + s1)
             }
         }
     }
@@ -254,6 +271,8 @@ hipError_t launch_any(const ggml_hip_weight *w, const float *x, int64_t ld1, act
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1, FUSED>(w, x, ld1, p, N, dst, ldd, st);
     case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2, FUSED>(w, x, ld1, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1, FUSED>(w, x, ld1, p, N, dst, ldd, st);
     case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }

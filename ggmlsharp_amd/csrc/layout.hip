@@ -72,6 +72,21 @@ __global__ void repack_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = (uint32_t)s[3 + 2 * i] | ((uint32_t)s[4 + 2 * i] << 16);
         *(uint4 *)(qs + pi * 16) = make_uint4(q[0], q[1], q[2], q[3]);
+    } else if (TYPE == GGML_TYPE_Q5_1) {
+        const uint16_t *s = (const uint16_t *)(src + b * 24);
+        d[pi] = half_bits_to_float(s[0]);
+        mm[pi] = half_bits_to_float(s[1]);
+        const uint32_t *s4 = (const uint32_t *)(src + b * 24);
+        qh[pi] = s4[1];
+        *(uint4 *)(qs + pi * 16) = make_uint4(s4[2], s4[3], s4[4], s4[5]);
+    } else if (TYPE == GGML_TYPE_Q4_2) {
+        const uint16_t *s = (const uint16_t *)(src + b * 20);              // two 10-byte blocks: {d, qs[8]} {d, qs[8]}
+        d[pi] = half_bits_to_float(s[0]);
+        mm[pi] = half_bits_to_float(s[5]);
+        uint32_t q[4];
+        q[0] = (uint32_t)s[1] | ((uint32_t)s[2] << 16); q[1] = (uint32_t)s[3] | ((uint32_t)s[4] << 16);
+        q[2] = (uint32_t)s[6] | ((uint32_t)s[7] << 16); q[3] = (uint32_t)s[8] | ((uint32_t)s[9] << 16);
+        *(uint4 *)(qs + pi * 16) = make_uint4(q[0], q[1], q[2], q[3]);
     } else if (TYPE == GGML_TYPE_Q8_0) {
         const uint32_t *s = (const uint32_t *)(src + b * 36);
         d[pi] = __uint_as_float(s[0]);
@@ -115,6 +130,20 @@ __global__ void planar_to_aos_kernel(uint8_t *__restrict__ aos, uint64_t nb01, i
         const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s[3 + 2 * i] = (uint16_t)qq[i]; s[4 + 2 * i] = (uint16_t)(qq[i] >> 16); }
+    } else if (TYPE == GGML_TYPE_Q5_1) {
+        uint16_t *s = (uint16_t *)(dst + b * 24);
+        uint32_t *s4 = (uint32_t *)(dst + b * 24);
+        const uint4 q = *(const uint4 *)(qs + pi * 16);
+        s[0] = float_to_half_bits_exact(d[pi]);
+        s[1] = float_to_half_bits_exact(mm[pi]);
+        s4[1] = qh[pi]; s4[2] = q.x; s4[3] = q.y; s4[4] = q.z; s4[5] = q.w;
+    } else if (TYPE == GGML_TYPE_Q4_2) {
+        uint16_t *s = (uint16_t *)(dst + b * 20);
+        const uint4 q = *(const uint4 *)(qs + pi * 16);
+        s[0] = float_to_half_bits_exact(d[pi]);
+        s[1] = (uint16_t)q.x; s[2] = (uint16_t)(q.x >> 16); s[3] = (uint16_t)q.y; s[4] = (uint16_t)(q.y >> 16);
+        s[5] = float_to_half_bits_exact(mm[pi]);
+        s[6] = (uint16_t)q.z; s[7] = (uint16_t)(q.z >> 16); s[8] = (uint16_t)q.w; s[9] = (uint16_t)(q.w >> 16);
     } else if (TYPE == GGML_TYPE_Q8_0) {
         uint32_t *s = (uint32_t *)(dst + b * 36);
         const uint4 e4 = *(const uint4 *)(qs + ((b * 2 + 0) * Mpad + m) * 16);
@@ -235,6 +264,8 @@ hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, 
     case GGML_TYPE_Q4_0: repack_to_planar_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     case GGML_TYPE_Q4_1: repack_to_planar_kernel<GGML_TYPE_Q4_1><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     case GGML_TYPE_Q5_0: repack_to_planar_kernel<GGML_TYPE_Q5_0><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q5_1: repack_to_planar_kernel<GGML_TYPE_Q5_1><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q4_2: repack_to_planar_kernel<GGML_TYPE_Q4_2><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     case GGML_TYPE_Q8_0: repack_to_planar_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     default: return hipErrorInvalidValue;
     }
@@ -250,12 +281,15 @@ hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStrea
                                                w->M, row_bytes);
         return hipGetLastError();
     }
-    const uint64_t nb01 = (uint64_t)ggml_hip_type_size(w->type) * (uint64_t)w->nbk;
+    // bytes of one row of blocks; Q4_2's blocks hold 16 elements, so a 32-element k-block is two of them
+    const uint64_t nb01 = (uint64_t)ggml_hip_type_size(w->type) * (uint64_t)w->nbk * (w->type == GGML_TYPE_Q4_2 ? 2 : 1);
     dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)w->nbk);
     switch (w->type) {
     case GGML_TYPE_Q4_0: planar_to_aos_kernel<GGML_TYPE_Q4_0><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     case GGML_TYPE_Q4_1: planar_to_aos_kernel<GGML_TYPE_Q4_1><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     case GGML_TYPE_Q5_0: planar_to_aos_kernel<GGML_TYPE_Q5_0><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q5_1: planar_to_aos_kernel<GGML_TYPE_Q5_1><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
+    case GGML_TYPE_Q4_2: planar_to_aos_kernel<GGML_TYPE_Q4_2><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     case GGML_TYPE_Q8_0: planar_to_aos_kernel<GGML_TYPE_Q8_0><<<grid, 256, 0, st>>>(aos, nb01, w->M, w->Mpad, w->nbk, w->qs, w->qh, w->d, w->m); break;
     default: return hipErrorInvalidValue;
     }

@@ -113,7 +113,7 @@ def quantize_rows(type, x):
     """x f32 [nrows, k] on the device -> uint8 [nrows, k/32*type_size] reference-format blocks."""
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
     nrows, k = x.shape
-    out = torch.empty((nrows, k // 32 * TYPE_SIZE[type]), dtype=torch.uint8, device=x.device)
+    out = torch.empty((nrows, k // BLCK_SIZE[type] * TYPE_SIZE[type]), dtype=torch.uint8, device=x.device)
     check(lib().ggml_hip_quantize_rows_dev(type, C.c_void_p(x.data_ptr()), nrows, k, C.c_void_p(out.data_ptr()),
                                            _stream()), "ggml_hip_quantize_rows_dev")
     return out
@@ -123,7 +123,7 @@ def quantize_rows_from(type, x):
     """x f32 or f16 [nrows, k] on the device (row stride may exceed k) -> reference-format blocks."""
     assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, torch.float16)
     nrows, k = x.shape
-    out = torch.empty((nrows, k // 32 * TYPE_SIZE[type]), dtype=torch.uint8, device=x.device)
+    out = torch.empty((nrows, k // BLCK_SIZE[type] * TYPE_SIZE[type]), dtype=torch.uint8, device=x.device)
     check(lib().ggml_hip_quantize_rows_src_dev(type, 0 if x.dtype == torch.float32 else 1, C.c_void_p(x.data_ptr()),
                                                x.stride(0), nrows, k, C.c_void_p(out.data_ptr()), _stream()),
           "ggml_hip_quantize_rows_src_dev")
@@ -142,7 +142,7 @@ def add_q_f32_rows(type, blocks, x):
 
 def dequantize_rows(type, blocks, k):
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
-    nrows = blocks.numel() // (k // 32 * TYPE_SIZE[type])
+    nrows = blocks.numel() // (k // BLCK_SIZE[type] * TYPE_SIZE[type])
     out = torch.empty((nrows, k), dtype=torch.float32, device=blocks.device)
     check(lib().ggml_hip_dequantize_rows_dev(type, C.c_void_p(blocks.data_ptr()), nrows, k,
                                              C.c_void_p(out.data_ptr()), _stream()), "ggml_hip_dequantize_rows_dev")

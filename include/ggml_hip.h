@@ -147,7 +147,9 @@ typedef struct ggml_hip_weight ggml_hip_weight;      /* opaque: one 2-D weight m
 /* Upload rows [row_begin, row_end) of a [K = ne00, M = ne01] weight matrix whose rows are nb01 bytes apart
  * in reference block format (TypeDefs:236-290) from HOST memory.  A sub-range is a row shard
  * (the reference's own thread split is a contiguous row partition, Ggml.cs:6665-6672).
- * type: Q4_0, Q4_1, Q5_0, Q8_0, F32 or F16. */
+ * type: Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0, F32 or F16.  (Q4_2 / Q5_1: half scales as IEEE bit patterns -- the intent
+ * policy of SURVEY D7; the C# as written stores them through numeric casts.  ne00 is a multiple of 32 for every
+ * quantized type: the dot products run against 32-element Q8 blocks, Ggml.cs:1209-1211.) */
 int  ggml_hip_weight_upload(int type, const void *host_rows, int64_t ne00, int64_t ne01, uint64_t nb01,
                             int64_t row_begin, int64_t row_end, void *stream, ggml_hip_weight **out);
 /* Same, from DEVICE memory holding reference-format rows (no host round trip). */
@@ -206,7 +208,7 @@ int ggml_hip_vec_dot(int type, int n, float *s, const void *vx, const void *vy);
 
 /* ---------------- neighbours of the path (SURVEY.md 8(f) "next") ----------------
  * ggml_compute_forward_cpy -> ggml_compute_forward_dup_f32 / _dup_f16, quantizing branch (Ggml.cs:8659-8663,
- * 4339-4363, 3935-3966): src0 F32 or F16 with contiguous rows, dst a contiguous Q4_0 / Q4_1 / Q5_0 / Q8_0 tensor with
+ * 4339-4363, 3935-3966): src0 F32 or F16 with contiguous rows, dst a contiguous Q4_0 / Q4_1 / Q4_2 / Q5_0 / Q5_1 / Q8_0 tensor with
  * the same element count.  This is the only public way to produce a quantized tensor in the reference; on the device
  * it uses the intended quantize_row_q4_0 (== _reference), not the broken AVX packNibbles path.
  * Same offload convention as Seam 1 (acts for ith == 0, COMPUTE phase). */

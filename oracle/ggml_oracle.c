@@ -730,7 +730,11 @@ int oracle_mul_mat(const oracle_tensor *src0, const oracle_tensor *src1, const o
 
 /* ================= neighbours of the path: cpy (f32/f16 -> Q) and add_q_f32 ================= */
 
-static int q_rw_ok(int t) { return t == ORACLE_TYPE_Q4_0 || t == ORACLE_TYPE_Q4_1 || t == ORACLE_TYPE_Q5_0 || t == ORACLE_TYPE_Q8_0; }
+/* every type with both a quantize_row_q and a dequantize_row_q slot (Ggml.cs:219-290; Q4_2 / Q5_1 per D7) */
+static int q_rw_ok(int t) {
+    return t == ORACLE_TYPE_Q4_0 || t == ORACLE_TYPE_Q4_1 || t == ORACLE_TYPE_Q4_2 || t == ORACLE_TYPE_Q5_0 || t == ORACLE_TYPE_Q5_1 ||
+           t == ORACLE_TYPE_Q8_0;
+}
 
 /* Ggml.cs:4339-4363 (dup_f32) and 3935-3966 (dup_f16): rows of src0 in (i03, i02, i01) order, dst written densely */
 int oracle_cpy_to_q(const oracle_tensor *src0, const oracle_tensor *dst) {

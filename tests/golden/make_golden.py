@@ -41,6 +41,15 @@ def main():
     out["mulmat_f16"] = O.mul_mat(O.F16, w.astype(np.float16).view(np.uint16), a, M, K, N)[0, 0]
     np.savez_compressed(os.path.join(HERE, "qpath_v1.npz"), **out)
     print("wrote", os.path.join(HERE, "qpath_v1.npz"), {k: v.shape for k, v in out.items()})
+    # Q4_2 / Q5_1 (built to the intent): same inputs, their own file so that v1 stays byte-stable
+    d7 = {}
+    for name, t in (("q4_2", O.Q4_2), ("q5_1", O.Q5_1)):
+        q = O.quantize_row(t, x)
+        d7[f"quant_{name}"] = q
+        d7[f"dequant_{name}"] = O.dequantize_row(t, q, K)
+        d7[f"mulmat_{name}"] = O.mul_mat(t, O.quantize_row(t, w), a, M, K, N)[0, 0]
+    np.savez_compressed(os.path.join(HERE, "qpath_d7_v1.npz"), **d7)
+    print("wrote", os.path.join(HERE, "qpath_d7_v1.npz"), {k: v.shape for k, v in d7.items()})
 
 
 if __name__ == "__main__":

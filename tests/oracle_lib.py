@@ -85,6 +85,11 @@ def blck_size(t):
     return int(lib().oracle_blck_size(t))
 
 
+def row_bytes(t, k):
+    """bytes of one row of k elements in the reference's block format (Q4_2 blocks hold 16 elements, the others 32)"""
+    return k // blck_size(t) * type_size(t)
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

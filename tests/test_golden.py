@@ -7,8 +7,10 @@ import pytest
 
 import oracle_lib as O
 
-G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qpath_v1.npz"))
-QT = (("q4_0", O.Q4_0), ("q4_1", O.Q4_1), ("q5_0", O.Q5_0), ("q8_0", O.Q8_0))
+_HERE = os.path.dirname(os.path.abspath(__file__))
+G = dict(np.load(os.path.join(_HERE, "golden", "qpath_v1.npz")))
+G.update(np.load(os.path.join(_HERE, "golden", "qpath_d7_v1.npz")))      # Q4_2 / Q5_1 (intent) on the same inputs
+QT = (("q4_0", O.Q4_0), ("q4_1", O.Q4_1), ("q5_0", O.Q5_0), ("q8_0", O.Q8_0), ("q4_2", O.Q4_2), ("q5_1", O.Q5_1))
 
 
 def test_oracle_reproduces_golden():

@@ -11,7 +11,7 @@ from ggmlsharp_amd import _lib
 from ggmlsharp_amd import ggml as G
 
 RNG = np.random.default_rng(77)
-QT = [O.Q4_0, O.Q4_1, O.Q5_0, O.Q8_0]
+QT = [O.Q4_0, O.Q4_1, O.Q5_0, O.Q8_0, O.Q4_2, O.Q5_1]
 
 
 def _rand(shape, scale=1.0):

@@ -139,7 +139,7 @@ def test_half_conversion_exhaustive_f16_and_sampled_f32():
 
 # ---------------- C oracle == numpy restatement, bit for bit ----------------
 @pytest.mark.parametrize("name,t", [("q4_0", O.Q4_0), ("q4_1", O.Q4_1), ("q5_0", O.Q5_0), ("q8_0", O.Q8_0),
-                                    ("q8_1", O.Q8_1)])
+                                    ("q8_1", O.Q8_1), ("q4_2", O.Q4_2), ("q5_1", O.Q5_1)])
 def test_quantize_matches_numpy(name, t):
     for scale in (1.0, 1e-3, 37.5):
         x = _rand((64, 256), scale)
@@ -151,18 +151,20 @@ def test_quantize_matches_numpy(name, t):
         assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("name,t", [("q4_0", O.Q4_0), ("q4_1", O.Q4_1), ("q5_0", O.Q5_0), ("q8_0", O.Q8_0)])
+@pytest.mark.parametrize("name,t", [("q4_0", O.Q4_0), ("q4_1", O.Q4_1), ("q5_0", O.Q5_0), ("q8_0", O.Q8_0),
+                                    ("q4_2", O.Q4_2), ("q5_1", O.Q5_1)])
 def test_dequantize_matches_numpy_and_roundtrip_idempotent(name, t):
     x = _rand((32, 128), 3.0)
     q = O.quantize_row(t, x)
     y = O.dequantize_row(t, q, 128)
     want = R.DEQUANT[name](q.reshape(-1, O.type_size(t))).reshape(32, 128)
     assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
-    # quantisation error bound: half a step
-    if name in ("q4_0", "q8_0", "q5_0"):
-        amax = np.abs(x.reshape(-1, 32)).max(axis=1)
-        step = amax / {"q4_0": 8, "q5_0": 16, "q8_0": 127}[name]
-        err = np.abs(y - x).reshape(-1, 32).max(axis=1)
+    # quantisation error bound: half a step (the half-precision scale of Q4_2 adds 2^-11 relative)
+    if name in ("q4_0", "q8_0", "q5_0", "q4_2"):
+        bs = O.blck_size(t)
+        amax = np.abs(x.reshape(-1, bs)).max(axis=1)
+        step = amax / {"q4_0": 8, "q5_0": 16, "q8_0": 127, "q4_2": 8}[name] * (1.001 if name == "q4_2" else 1.0)
+        err = np.abs(y - x).reshape(-1, bs).max(axis=1)
         assert np.all(err <= step * (1.0 if name != "q8_0" else 0.5) + 1e-6)
     # dequantize . quantize is idempotent on representable rows for the symmetric 8-bit format
     if name == "q8_0":
@@ -172,13 +174,18 @@ def test_dequantize_matches_numpy_and_roundtrip_idempotent(name, t):
 
 
 @pytest.mark.parametrize("t,fn", [(O.Q4_0, R.vec_dot_q4_0_q8_0), (O.Q5_0, R.vec_dot_q5_0_q8_0),
-                                  (O.Q8_0, R.vec_dot_q8_0_q8_0)])
+                                  (O.Q8_0, R.vec_dot_q8_0_q8_0), (O.Q4_2, R.vec_dot_q4_2_q8_0),
+                                  (O.Q5_1, R.vec_dot_q5_1_q8_1)])
 def test_vec_dot_matches_numpy(t, fn):
     for n in (64, 256, 4096):
         w = _rand(n)
         a = _rand(n, 2.0)
         wq = O.quantize_row(t, w)
-        aq = O.quantize_row(O.Q8_0, a)
+        aq = O.quantize_row(O.lib().oracle_vec_dot_type(t), a)
+        if t == O.Q5_1:      # Q8_1 activations: checked bit for bit against the numpy form, exactness bound below is Q8_0's
+            got = O.vec_dot(t, n, wq, aq)
+            assert np.float32(got).view(np.uint32) == np.float32(fn(wq, aq)).view(np.uint32)
+            continue
         got = O.vec_dot(t, n, wq, aq)
         want = fn(wq, aq)
         assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32)
@@ -215,7 +222,7 @@ def test_vec_dot_f32_f64_accumulate():
 
 
 # ---------------- mul_mat driver ----------------
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q5_0, O.Q8_0, O.Q4_1])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q5_0, O.Q8_0, O.Q4_1, O.Q4_2, O.Q5_1])
 @pytest.mark.parametrize("nth", [1, 3])
 def test_mul_mat_q_composes_row_functions(t, nth):
     M, K, N = 24, 128, 5

@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage: tools/build_variant.sh NAME FILE.hip "-DFOO=1 ..."   -> ggmlsharp_amd/lib/dbg/libggml_hip_NAME.so
+# Developer A/B builds: the product objects with ONE source recompiled under extra flags (select with GGML_HIP_LIB).
+set -e
+cd "$(dirname "$0")/../ggmlsharp_amd/csrc"
+NAME=$1; FILE=$2; EXTRA=$3
+make -s all
+mkdir -p ../lib/dbg ../lib/obj_dbg
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Wno-unused-variable"
+case $FILE in gemm_q16.hip|gemm_qmx.hip) FL="$FL -fno-slp-vectorize";; esac
+/opt/rocm/bin/hipcc $FL $EXTRA -c $FILE -o ../lib/obj_dbg/$NAME.o
+OBJS=$(ls ../lib/obj/*.o | grep -v "/$FILE.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS ../lib/obj_dbg/$NAME.o -o ../lib/dbg/libggml_hip_$NAME.so
+echo built $NAME
