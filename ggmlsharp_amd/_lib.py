@@ -25,6 +25,7 @@ TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 20, Q4_1: 24, Q4_2: 10, Q4_3: 12, Q5_0: 22, Q
              I8: 1, I16: 2, I32: 4}
 
 GGML_OP_NONE, GGML_OP_ADD, GGML_OP_MUL_MAT, GGML_OP_CPY = 0, 2, 20, 22
+GGML_OP_SILU = 17
 GGML_TASK_INIT, GGML_TASK_COMPUTE, GGML_TASK_FINALIZE = 0, 1, 2
 
 OK, ERR_NO_DEVICE, ERR_TYPE, ERR_SHAPE, ERR_ARG, ERR_RUNTIME = 0, -1, -2, -3, -4, -5
@@ -111,6 +112,7 @@ SYMBOLS = {
     "ggml_hip_compute_forward_mul": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
     "ggml_hip_compute_forward_scale": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
     "ggml_hip_compute_forward_rms_norm": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
+    "ggml_hip_compute_forward_silu": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
     "ggml_hip_quantize_rows_src_dev": (C.c_int, [C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_add_q_f32_rows_dev": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
@@ -142,6 +144,8 @@ SYMBOLS = {
     "ggml_mul": (_T, [_P, _T, _T]),
     "ggml_scale": (_T, [_P, _T, _T]),
     "ggml_rms_norm": (_T, [_P, _T]),
+    "ggml_silu": (_T, [_P, _T]),
+    "ggml_silu_inplace": (_T, [_P, _T]),
     "ggml_build_forward": (None, [C.POINTER(ggml_cgraph), _T]),
     "ggml_build_forward_expand": (None, [C.POINTER(ggml_cgraph), _T]),
     "ggml_graph_compute": (C.c_int, [_P, C.POINTER(ggml_cgraph)]),

@@ -747,6 +747,29 @@ int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, 
     return GGML_HIP_OK;
 }
 
+/* ggml_compute_forward_silu_f32 (Ggml.cs:5705-5748) */
+int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                  struct ggml_tensor *dst) {
+    if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (src0->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "silu: F32 only (Ggml.cs:5755-5768)");
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "silu: shapes differ (Ggml.cs:5712)");
+    if (!contiguous_f32(src0) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "silu: contiguous operands only (Ggml.cs:5710-5711)");
+    if (!src0->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const float *a = nullptr;
+    if (operand_f32(src0, g_src1, &a, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "silu: operand staging failed");
+    float *z = result_f32(dst, g_dst);
+    if (!z) return fail(GGML_HIP_ERR_RUNTIME, "silu: hipMalloc failed");
+    HIP_TRY(launch_silu_f32(a, z, nelem(src0), g_stream));
+    if (finish_f32(dst, z, g_stream)) return fail(GGML_HIP_ERR_RUNTIME, "silu: copy back failed");
+    return GGML_HIP_OK;
+}
+
 void ggml_hip_invalidate(const void *host_ptr) {
     std::lock_guard<std::mutex> lk(g_mu);
     invalidate_locked(host_ptr);

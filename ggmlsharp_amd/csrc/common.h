@@ -144,6 +144,7 @@ hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N,
 hipError_t launch_binary_f32(int op, const float *x, const float *y, float *z, int64_t n, hipStream_t st);
 hipError_t launch_scale_f32(float *z, int64_t n, float v, hipStream_t st);
 hipError_t launch_rms_norm_f32(const float *x, float *y, int64_t nr, int64_t nc, hipStream_t st);
+hipError_t launch_silu_f32(const float *x, float *y, int64_t n, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,

@@ -3,6 +3,7 @@
 //   mul      ggml_compute_forward_mul_f32      Ggml.cs:5007-5035 (ggml_vec_mul_f32)
 //   scale    ggml_compute_forward_scale_f32    Ggml.cs:6746-6778 (in place: dst is a view of src0, ggml_scale_impl :8265)
 //   rms_norm ggml_compute_forward_rms_norm_f32 Ggml.cs:5858-5920 (f32 squares summed in f64, eps = 1e-6)
+//   silu     ggml_compute_forward_silu_f32     Ggml.cs:5705-5748 (half-table form, see silu_f32_kernel)
 // One IEEE operation per reference operator (built with -ffp-contract=off, correctly rounded divide / sqrt), so add, mul and
 // scale are bit-exact; rms_norm differs from the reference only in the order of its f64 additions (a wave-wide tree
 // instead of a sequential loop), which reaches the f32 result only when the f64 sum sits on a float rounding boundary.
@@ -26,6 +27,19 @@ __global__ __launch_bounds__(256) void binary_f32_kernel(const float4 *__restric
 __global__ __launch_bounds__(256) void scale_f32_kernel(float *__restrict__ z, int64_t n, float v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) z[i] *= v;                               // ggml_vec_scale_f32
+}
+
+// silu in the reference's GGML_SILU_FP16 form (Ggml.cs:2737-2746): the argument is rounded to half, the result is the half
+// table entry silu(f) = f / (1 + exp(-f)) rounded to half (table built at Ggml.cs:1455-1471; indexed by bit pattern, SURVEY
+// A2 intent).  65536 possible results: computed here instead of looked up -- exp in f64 and rounded to f32 (= the
+// correctly rounded expf), then the reference's own f32 add and divide, then the round to half.  tests/ checks all 65536.
+__global__ __launch_bounds__(256) void silu_f32_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float f = (float)(_Float16)x[i];
+    const float e = (float)exp(-(double)f);
+    const float s = f / (1.0f + e);
+    y[i] = (float)(_Float16)s;
 }
 
 // one wave per row
@@ -61,6 +75,12 @@ hipError_t launch_binary_f32(int op, const float *x, const float *y, float *z, i
 hipError_t launch_scale_f32(float *z, int64_t n, float v, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     scale_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(z, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_silu_f32(const float *x, float *y, int64_t n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    silu_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, st>>>(x, y, n);
     return hipGetLastError();
 }
 

@@ -287,6 +287,21 @@ ggml_tensor *ggml_rms_norm(ggml_context *ctx, ggml_tensor *a) {
     return result;
 }
 
+// Ggml.cs:7095-7107 -> ggml_silu_impl 8154-8174
+static ggml_tensor *silu_impl(ggml_context *ctx, ggml_tensor *a, bool inplace) {
+    if (!ctx || !a) return nullptr;
+    const bool is_node = !inplace && a->grad != nullptr;
+    ggml_tensor *result = inplace ? ggml_view_tensor(ctx, a) : ggml_dup_tensor(ctx, a);
+    if (!result) return nullptr;
+    result->op = GGML_OP_SILU;
+    result->grad = is_node ? ggml_dup_tensor(ctx, result) : nullptr;
+    result->src0 = a;
+    result->src1 = nullptr;
+    return result;
+}
+ggml_tensor *ggml_silu(ggml_context *ctx, ggml_tensor *a) { return silu_impl(ctx, a, false); }
+ggml_tensor *ggml_silu_inplace(ggml_context *ctx, ggml_tensor *a) { return silu_impl(ctx, a, true); }
+
 void ggml_build_forward_expand(ggml_cgraph *cgraph, ggml_tensor *tensor) { visit_parents(cgraph, tensor); }
 
 void ggml_build_forward(ggml_cgraph *out, ggml_tensor *tensor) {
@@ -306,7 +321,7 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         ggml_tensor *node = cgraph->nodes[i];
         if (node->op == GGML_OP_NONE) continue;
         if (node->op != GGML_OP_MUL_MAT && node->op != GGML_OP_CPY && node->op != GGML_OP_ADD && node->op != GGML_OP_MUL &&
-            node->op != GGML_OP_SCALE && node->op != GGML_OP_RMS_NORM) {
+            node->op != GGML_OP_SCALE && node->op != GGML_OP_RMS_NORM && node->op != GGML_OP_SILU) {
             fprintf(stderr, "ggml_graph_compute: op %d is outside the MI355X mul_mat path (SURVEY.md 2.2)\n", node->op);
             return GGML_HIP_ERR_TYPE;
         }
@@ -328,6 +343,7 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
             else if (node->op == GGML_OP_CPY) rc = ggml_hip_compute_forward_cpy(&params, node->src0, node);   // Ggml.cs:8659-8663
             else if (node->op == GGML_OP_MUL) rc = ggml_hip_compute_forward_mul(&params, node->src0, node->src1, node);       // Ggml.cs:8569-8573
             else if (node->op == GGML_OP_SCALE) rc = ggml_hip_compute_forward_scale(&params, node->src0, node->src1, node);   // Ggml.cs:8654-8658
+            else if (node->op == GGML_OP_SILU) rc = ggml_hip_compute_forward_silu(&params, node->src0, node);                 // Ggml.cs:8634-8638
             else if (node->op == GGML_OP_RMS_NORM) rc = ggml_hip_compute_forward_rms_norm(&params, node->src0, node);         // Ggml.cs:8644-8648
             else rc = ggml_hip_compute_forward_add(&params, node->src0, node->src1, node);                    // Ggml.cs:8566-8570
             if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }

@@ -77,6 +77,14 @@ def ggml_rms_norm(ctx, a):
     return _lib.lib().ggml_rms_norm(ctx, a)
 
 
+def ggml_silu(ctx, a):
+    return _lib.lib().ggml_silu(ctx, a)
+
+
+def ggml_silu_inplace(ctx, a):
+    return _lib.lib().ggml_silu_inplace(ctx, a)
+
+
 def ggml_build_forward(tensor):
     g = ggml_cgraph()
     _lib.lib().ggml_build_forward(C.byref(g), tensor)

@@ -124,6 +124,9 @@ struct ggml_tensor *ggml_mul(struct ggml_context *ctx, struct ggml_tensor *a, st
 struct ggml_tensor *ggml_scale(struct ggml_context *ctx, struct ggml_tensor *a, struct ggml_tensor *b);
 /* Ggml.cs:7123-7128 -> ggml_rms_norm_impl 8199-8220: result = dup(a). */
 struct ggml_tensor *ggml_rms_norm(struct ggml_context *ctx, struct ggml_tensor *a);
+/* Ggml.cs:7095-7107 -> ggml_silu_impl 8154-8174: result = dup(a), or a view of a for the in-place form. */
+struct ggml_tensor *ggml_silu(struct ggml_context *ctx, struct ggml_tensor *a);
+struct ggml_tensor *ggml_silu_inplace(struct ggml_context *ctx, struct ggml_tensor *a);
 
 /* Ggml.cs:7648-7673 */
 void ggml_build_forward(struct ggml_cgraph *out, struct ggml_tensor *tensor);

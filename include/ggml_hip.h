@@ -62,6 +62,7 @@ enum ggml_op {
     GGML_OP_DUP = 1,
     GGML_OP_ADD = 2,
     GGML_OP_MUL = 4,
+    GGML_OP_SILU = 17,
     GGML_OP_RMS_NORM = 19,
     GGML_OP_MUL_MAT = 20,
     GGML_OP_SCALE = 21,
@@ -232,6 +233,13 @@ int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, con
                                    const struct ggml_tensor *src1, struct ggml_tensor *dst);
 int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                       struct ggml_tensor *dst);
+/*   silu     ggml_compute_forward_silu_f32     Ggml.cs:5705-5748   the GGML_SILU_FP16 build (GGMLSharp.csproj:9): argument
+ *                                                                  rounded to half, y = half(silu(x)) widened; the table
+ *                                                                  of Ggml.cs:1455-1471 indexed by bit pattern (SURVEY A2,
+ *                                                                  intent).  In-place form (ggml_silu_inplace): dst is a
+ *                                                                  view of src0.                              (bit-exact) */
+int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                  struct ggml_tensor *dst);
 /* Device forms.  src_type F32 or F16; source rows ld elements apart; blocks of all rows contiguous. */
 int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int64_t ld, int64_t nrows, int64_t k,
                                    void *d_blocks, void *stream);

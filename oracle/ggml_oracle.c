@@ -784,6 +784,15 @@ int oracle_add_q_f32(const oracle_tensor *src0, const oracle_tensor *src1, const
     return 0;
 }
 
+/* Ggml.cs:5705-5748, 2737-2746, 2723-2726, table 1455-1471 (A2: indexed by bit pattern) */
+void oracle_silu_f32(int64_t nr, int64_t nc, const float *x, float *y) {
+    for (int64_t i = 0; i < nr * nc; i++) {
+        const float f = oracle_f16_to_f32(oracle_f32_to_f16(x[i]));      /* Half fp16 = (Half)x[i]; f = table_f32_f16[bits] */
+        const float s = f / (1.0f + expf(-f));                          /* ggml_silu_f32 */
+        y[i] = oracle_f16_to_f32(oracle_f32_to_f16(s));                  /* (float)table_silu_f16[bits] */
+    }
+}
+
 /* ================= Test3 LCG (Test3/Program.cs:98-107) ================= */
 static uint64_t lcg_next = 1;
 void oracle_xsrand(uint64_t seed) { lcg_next = seed; }

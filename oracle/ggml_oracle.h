@@ -141,6 +141,11 @@ void oracle_add_f32(int64_t nr, int64_t nc, const float *x, const float *y, floa
 void oracle_mul_f32(int64_t nr, int64_t nc, const float *x, const float *y, float *z);
 void oracle_scale_f32(int64_t nr, int64_t nc, float *z, float v);
 void oracle_rms_norm_f32(int64_t nr, int64_t nc, const float *x, float *y);
+/*   silu : ggml_compute_forward_silu_f32 Ggml.cs:5705-5748 -> ggml_vec_silu_f32 2737-2746 (the GGML_SILU_FP16 build,
+ *          GGMLSharp.csproj:9): y = (float)table_silu_f16[bits((Half)x)], table_silu_f16[i] = (Half)silu(f(i)),
+ *          silu(f) = f / (1.0f + expf(-f)) (:2723-2726).  A2 (I): the table is indexed by the half's BIT PATTERN, f(i) =
+ *          the half with bits i (the C# builds it from the numeric value of i, :1467 + 8446-8449). */
+void oracle_silu_f32(int64_t nr, int64_t nc, const float *x, float *y);
 
 void     oracle_xsrand(uint64_t seed);
 uint32_t oracle_xrand(void);

@@ -51,6 +51,7 @@ def lib():
         L.oracle_mul_f32.argtypes = [C.c_int64, C.c_int64, fp, fp, fp]
         L.oracle_scale_f32.argtypes = [C.c_int64, C.c_int64, fp, C.c_float]
         L.oracle_rms_norm_f32.argtypes = [C.c_int64, C.c_int64, fp, fp]
+        L.oracle_silu_f32.argtypes = [C.c_int64, C.c_int64, fp, fp]
         _lib = L
     return _lib
 
@@ -71,6 +72,9 @@ def eltwise(op, x, y=None, v=None):
     z = np.empty_like(x)
     if op == "rms_norm":
         lib().oracle_rms_norm_f32(nr, nc, _fp(x), _fp(z))
+        return z
+    if op == "silu":
+        lib().oracle_silu_f32(nr, nc, _fp(x), _fp(z))
         return z
     y = np.ascontiguousarray(y, dtype=np.float32)
     getattr(lib(), "oracle_add_f32" if op == "add" else "oracle_mul_f32")(nr, nc, _fp(x), _fp(y), _fp(z))

@@ -143,6 +143,65 @@ def test_ggml_program_cpy_then_mul_mat_then_add():
         G.ggml_free(ctx)
 
 
+@pytest.mark.gpu
+def test_silu_bit_exact_for_every_half_and_swiglu_graph():
+    """silu (Ggml.cs:5705-5748, half-table form): all 63488 finite halves through the device kernel, bit for bit; then the
+    gate of a LLaMA-style FFN, out = mul_mat(W2, mul(silu(mul_mat(W1, x)), mul_mat(W3, x))), as one graph."""
+    pytest.importorskip("torch")
+    from ggmlsharp_amd import device
+    device.init(0)
+    h = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    f = h[np.isfinite(h)].astype(np.float32)
+    n = f.size
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    try:
+        A = G.ggml_new_tensor_1d(ctx, G.F32, n)
+        G.tensor_f32(A)[:] = f.reshape(1, 1, 1, n)
+        Sn = G.ggml_silu(ctx, A)
+        assert Sn and Sn.contents.op == _lib.GGML_OP_SILU and Sn.contents.data != A.contents.data
+        G.ggml_graph_compute(ctx, G.ggml_build_forward(Sn))
+        got = G.tensor_f32(Sn).reshape(-1)
+        want = O.eltwise("silu", f.reshape(1, -1)).reshape(-1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # in-place form: the result is a view of its argument
+        B = G.ggml_new_tensor_2d(ctx, G.F32, 96, 7)
+        xb = _rand((7, 96), 3.0)
+        G.tensor_f32(B)[:] = xb.reshape(1, 1, 7, 96)
+        Si = G.ggml_silu_inplace(ctx, B)
+        assert Si.contents.data == B.contents.data
+        G.ggml_graph_compute(ctx, G.ggml_build_forward(Si))
+        assert np.array_equal(G.tensor_f32(B)[0, 0], O.eltwise("silu", xb))
+        # SwiGLU gate
+        K, F, N = 128, 256, 9
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        W1 = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, F)
+        W3 = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, F)
+        W2 = G.ggml_new_tensor_2d(ctx, G.Q4_0, F, K)
+        x = _rand((N, K))
+        w1, w3, w2 = (O.quantize_row(O.Q4_0, _rand(s)) for s in ((F, K), (F, K), (K, F)))
+        G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
+        for T, w in ((W1, w1), (W3, w3), (W2, w2)):
+            G.tensor_bytes(T)[:] = w.reshape(-1)
+        gate = G.ggml_silu(ctx, G.ggml_mul_mat(ctx, W1, X))
+        up = G.ggml_mul_mat(ctx, W3, X)
+        out = G.ggml_mul_mat(ctx, W2, G.ggml_mul(ctx, gate, up))
+        gf = G.ggml_build_forward(out)
+        assert gf.n_nodes == 5
+        G.ggml_graph_compute(ctx, gf)
+        got_gate = G.tensor_f32(gate)[0, 0]
+        h1 = np.ascontiguousarray(G.tensor_f32(gate.contents.src0)[0, 0])
+        assert np.array_equal(got_gate, O.eltwise("silu", h1))                       # bit-exact given its input
+        ref_h1 = O.mul_mat(O.Q4_0, w1, x, F, K, N)[0, 0]
+        rms = np.sqrt(np.mean(ref_h1.astype(np.float64) ** 2))
+        assert np.all(np.abs(h1 - ref_h1) <= 1e-3 * np.abs(ref_h1) + 1e-5 * rms)
+        prod = O.eltwise("mul", got_gate, np.ascontiguousarray(G.tensor_f32(up)[0, 0]))
+        ref_out = O.mul_mat(O.Q4_0, w2, prod, K, F, N)[0, 0]
+        rms = np.sqrt(np.mean(ref_out.astype(np.float64) ** 2))
+        assert np.all(np.abs(G.tensor_f32(out)[0, 0] - ref_out) <= 1e-3 * np.abs(ref_out) + 1e-5 * rms)
+    finally:
+        G.ggml_free(ctx)
+
+
 # ---------------------------------------------------------------- row 4: f32 neighbours of mul_mat, chained on the device
 @pytest.mark.gpu
 def test_transformer_style_chain_stays_on_device():

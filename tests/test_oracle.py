@@ -300,3 +300,27 @@ def test_eltwise_restatements_match_numpy():
     assert np.array_equal(O.eltwise("rms_norm", x), x * scale[:, None])
     z = np.zeros((3, 32), np.float32)
     assert np.array_equal(O.eltwise("rms_norm", z), z)                          # 0 * 1000 = 0, no NaN
+
+
+def _all_halves_as_f32():
+    h = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    return h[np.isfinite(h)].astype(np.float32)
+
+
+def test_silu_half_table_matches_numpy_for_every_half():
+    """silu in the GGML_SILU_FP16 build (Ggml.cs:2737-2746 + table 1455-1471, A2 intent): 65536 possible arguments after the
+    round to half -- every finite one is checked against an independent numpy evaluation (exp in f64 rounded to f32)."""
+    f = _all_halves_as_f32()
+    with np.errstate(over="ignore"):
+        e = np.exp(-f.astype(np.float64)).astype(np.float32)
+        s = (f / (np.float32(1.0) + e)).astype(np.float32)
+    want = s.astype(np.float16).astype(np.float32)
+    got = O.eltwise("silu", f.reshape(1, -1)).reshape(-1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # an f32 argument is rounded to half first: same result as its half neighbour
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((5, 64)) * 4).astype(np.float32)
+    assert np.array_equal(O.eltwise("silu", x), O.eltwise("silu", x.astype(np.float16).astype(np.float32)))
+    # known values: silu(0) = 0, silu(large) = x (as a half), silu(-large) = -0
+    k = O.eltwise("silu", np.array([[0.0, 20.0, -20.0, 1.0]], np.float32))[0]
+    assert k[0] == 0.0 and k[1] == 20.0 and abs(k[2]) < 1e-7 and abs(k[3] - 0.7310586) < 5e-4
