@@ -12,6 +12,7 @@
 // All float arithmetic here must round exactly like the C# scalar code: one IEEE operation per C# operator,
 // no fused multiply-add, correctly rounded division.  Built with -ffp-contract=off.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -101,16 +102,6 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
 #pragma unroll
     for (int j = 0; j < K1_BPB; ++j) {
         const int64_t b = b0 + j;
-#if defined(K1_ABL) && K1_ABL == 2
-        if (IMG == 3) {     // timing ablation: loads + the same stores, no arithmetic
-            const uint32_t soff = (uint32_t)b * (uint32_t)(Npad * 48);
-            if (live && (t & 3) < 3) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].x) ^ __float_as_uint(v[j].z), rImg, (int)off6, (int)soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j].y) ^ __float_as_uint(v[j].w), rImg, (int)(off6 + half6), (int)soff, 0);
-            }
-            continue;
-        }
-#endif
         float amax = fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
         amax = group8_max(amax);
         const float d = amax / 127.0f;                      // Ggml.cs:751
@@ -147,11 +138,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
             const bool pad = !(b < nbk);
             if (b < pad_kblocks(nbk)) {
                 const uint32_t soff = (uint32_t)b * (uint32_t)(Npad * 48);
-#ifdef K1_ABL
-                if (live && u < 3 && (K1_ABL != 1 || dh == 0x12345678u)) {
-#else
                 if (live && u < 3) {
-#endif
                     __builtin_amdgcn_raw_buffer_store_b32(pad ? 0u : dh, rImg, (int)off6, (int)soff, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(pad ? 0u : dl, rImg, (int)(off6 + half6), (int)soff, 0);
                 }
@@ -226,6 +213,103 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1, bf6 image (gemm_qmx.hip), lane-per-block form.  One wave = 64 src1 rows x one k-block:
+//   global -> LDS by DMA, eight 1-KiB pieces (8 rows x 128 B each, coalesced 128-byte lines), laid out so that the
+//   transposed read -- lane = row, eight ds_read_b128 = the row's 32 floats -- is conflict-free (piece stride 1152 B);
+//   one division pair per BLOCK instead of per 8 lanes, 5 VALU per element for the two digits, and the 64 bf6 codes of a
+//   lane from two v_cvt_scalef32_2xpk16_bf6_f32 (it packs a[i] at position 2i, b[i] at 2i+1: tools/cvt_probe.hip);
+//   stores are lane-contiguous (1 KiB / 512 B runs per wave).  Same arithmetic as quantize_act_kernel<3>, bit for bit
+//   (Ggml.cs:751-759), ~1/4 of its VALU work.  Waves are independent (each reads only what it loaded): no barrier.
+// ---------------------------------------------------------------------------------------------------------
+#define K1V_PIECE 1152      // 8 rows x 128 B + 128 B: consecutive row groups land in opposite halves of the 64 LDS banks
+
+using f32x16q = __attribute__((ext_vector_type(16))) float;
+using u32x6q = __attribute__((ext_vector_type(6))) uint32_t;
+using u32x4q = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2q = __attribute__((ext_vector_type(2))) uint32_t;
+typedef __attribute__((address_space(3))) void lds_void_q;
+
+__global__ __launch_bounds__(256) void quantize_act_bf6_kernel(const float *__restrict__ x, int N, int nbk, uint32_t ld1_bytes,
+                                                               uint32_t x_bytes, int8_t *__restrict__ a8, float *__restrict__ ad,
+                                                               int32_t *__restrict__ as, int Npad) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 8 * K1V_PIECE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x * 4 + wave;                     // this wave's k-block (< pad_kblocks(nbk) by the grid)
+    const int n0 = blockIdx.y * 64;
+    uint8_t *wl = lds + wave * (8 * K1V_PIECE);
+
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    // piece g = rows n0 + 8g .. +7: lane L fetches 16 B chunk L / 8 of row 8g + L % 8 -> LDS [chunk][row][16 B].
+    // A ragged last row group re-reads row N - 1 for the rows past N (their lanes store nothing); pad k-blocks load nothing.
+    if (b < nbk) {
+        if (n0 + 64 <= N) {                                  // uniform
+            const uint32_t voff = (uint32_t)(n0 + (lane & 7)) * ld1_bytes + (uint32_t)(lane >> 3) * 16u;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void_q *)(wl + g * K1V_PIECE), 16, (int)voff,
+                                                         (int)((uint32_t)(8 * g) * ld1_bytes + (uint32_t)b * 128u), 0, 0);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int row = min(n0 + 8 * g + (lane & 7), N - 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void_q *)(wl + g * K1V_PIECE), 16,
+                                                         (int)((uint32_t)row * ld1_bytes + (uint32_t)(lane >> 3) * 16u), (int)((uint32_t)b * 128u), 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float v[32];
+    {
+        const uint8_t *rp = wl + (lane >> 3) * K1V_PIECE + (lane & 7) * 16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 t = *(const float4 *)(rp + c * 128);
+            v[4 * c + 0] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+        }
+    }
+    const bool pad = !(b < nbk);
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    const float d = amax / 127.0f;                          // Ggml.cs:751
+    const float id = d != 0.0f ? 1.0f / d : 0.0f;           // Ggml.cs:752
+    float sum = 0.0f;                                       // exact: |sum| <= 32 * 127
+    f32x16q he, ho, le, lo;                                  // digits of the even / odd elements
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const float q = rintf(v[e] * id);                   // Ggml.cs:758-759 (D1, D2)
+        sum += q;
+        const float ah = floorf(fmaf(q, 0.0625f, 0.5f));    // a = 16 ah + al, ah = floor((a + 8) / 16) in [-8, 8]
+        const float al = fmaf(ah, -16.0f, q);               // in [-8, 7]
+        if (e & 1) { ho[e >> 1] = ah; lo[e >> 1] = al; } else { he[e >> 1] = ah; le[e >> 1] = al; }
+    }
+    // Through asm with an early-clobber result: hipcc's builtin lets the 6-register result overlap the 32 source registers,
+    // and the instruction writes its result before it has read all of them (seen as garbage digits at elements 12..16).
+    u32x6q fh, fl;
+    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, 1.0" : "=&v"(fh) : "v"(he), "v"(ho));
+    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, 1.0" : "=&v"(fl) : "v"(le), "v"(lo));
+    float dv = d, sv = d * sum;                             // the Q8_1 s0 + s1 of Ggml.cs:820-821 (intent D3)
+    if (pad) {                                              // uniform: pad k-blocks are zero quants with zero scales
+        fh = (u32x6q){0, 0, 0, 0, 0, 0}; fl = fh; dv = 0.0f; sv = 0.0f;
+    }
+    const int n = n0 + lane;
+    if (n >= N) return;
+    const uint32_t img_bytes = (uint32_t)pad_kblocks(nbk) * (uint32_t)Npad * 48u, sc_bytes = (uint32_t)pad_kblocks(nbk) * (uint32_t)Npad * 4u;
+    const __amdgpu_buffer_rsrc_t rImg = __builtin_amdgcn_make_buffer_rsrc((void *)a8, 0, (int)img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rAd = __builtin_amdgcn_make_buffer_rsrc((void *)ad, 0, (int)sc_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rAs = __builtin_amdgcn_make_buffer_rsrc((void *)as, 0, (int)sc_bytes, 0x00020000);
+    const uint32_t blk = (uint32_t)b * (uint32_t)Npad * 48u;
+    // image per k-block: [half][Npad][16 B] then [half][Npad][8 B] (half 0 = ah, half 1 = al)
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4q){fh[0], fh[1], fh[2], fh[3]}, rImg, n * 16, (int)blk, 0);
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4q){fl[0], fl[1], fl[2], fl[3]}, rImg, n * 16, (int)(blk + (uint32_t)Npad * 16u), 0);
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2q){fh[4], fh[5]}, rImg, n * 8, (int)(blk + (uint32_t)Npad * 32u), 0);
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2q){fl[4], fl[5]}, rImg, n * 8, (int)(blk + (uint32_t)Npad * 40u), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rAd, n * 4, (int)((uint32_t)b * (uint32_t)Npad * 4u), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv), rAs, n * 4, (int)((uint32_t)b * (uint32_t)Npad * 4u), 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -547,8 +631,18 @@ hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1
         quantize_act_kernel<1><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     else if (image == 2)
         quantize_act_kernel<2><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
-    else if (image == 3)
-        quantize_act_kernel<3><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+    else if (image == 3) {
+        // lane-per-block form when the 32-bit buffer offsets reach (they do for every shape whose image does); rows must
+        // be 16-byte aligned for the DMA (ld1 % 4, checked by the callers for every device entry)
+        static const bool old_k1 = getenv("GGML_HIP_K1_OLD") != nullptr;   // developer A/B switch
+        const uint64_t xb = ((uint64_t)(N - 1) * (uint64_t)ld1 + (uint64_t)K) * 4;
+        if (!old_k1 && xb <= 0xFFFFFFFFull && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0) {
+            dim3 g2((unsigned)(pad_kblocks(nbk) / 4), (unsigned)((N + 63) / 64));
+            quantize_act_bf6_kernel<<<g2, 256, 0, st>>>(x, (int)N, (int)nbk, (uint32_t)(ld1 * 4), (uint32_t)xb, p.a8, p.ad, p.as, (int)p.Npad);
+        } else {
+            quantize_act_kernel<3><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        }
+    }
     else
         quantize_act_kernel<0><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     return hipGetLastError();
