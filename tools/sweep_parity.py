@@ -13,13 +13,13 @@ from ggmlsharp_amd._lib import lib  # noqa: E402
 
 device.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-TYPES = {2: "q4_0", 3: "q4_1", 6: "q5_0", 8: "q8_0"}
+TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
 edges = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640]
 nbad = ntot = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     t = int(rng.choice(list(TYPES)))
     M = int(rng.choice(edges))
-    N = int(rng.choice([9, 16, 31, 32, 33, 64, 65, 127, 128, 129, 200, 255, 256, 257, 384, 513]))
+    N = int(rng.choice([1, 2, 5, 8, 9, 16, 31, 32, 33, 64, 65, 127, 128, 129, 200, 255, 256, 257, 384, 513]))
     K = 32 * int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 33]))
     kernel = int(rng.choice([0, 1, 2, 3]))
     lib().ggml_hip_debug_force_gemm(kernel)
