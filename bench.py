@@ -48,13 +48,18 @@ def event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
-def make_weights_q4_0(M, K, seed):
-    """f32 N(0,1) weights quantized on the device with the bit-exact K9 kernel -> reference Q4_0 rows (device)."""
+Q5_0, Q8_0 = 6, 8
+BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36}          # Ggml.cs:76-82
+TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0"}
+
+
+def make_weights_q4_0(M, K, seed, qtype=Q4_0):
+    """f32 N(0,1) weights quantized on the device with the bit-exact K9 kernel -> reference block rows (device)."""
     from ggmlsharp_amd import device
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     w = torch.randn((M, K), generator=g, device="cuda", dtype=torch.float32)
-    return device.quantize_rows(Q4_0, w)
+    return device.quantize_rows(qtype, w)
 
 
 def cpu_baseline(M, K, n_cols, threads):
@@ -74,17 +79,17 @@ def cpu_baseline(M, K, n_cols, threads):
                       f"oracle/ggml_oracle.c scalar path, host has {os.cpu_count()} logical CPUs"}
 
 
-def side_config(device, M, K, N, copies, iters):
-    """Extra measured configs (BASELINE.json configs[1], configs[2]); weights rotate over `copies` distinct
-    matrices so a 10 MB matrix is not served from the 256 MB Infinity Cache."""
+def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
+    """Extra measured configs (the other single-GPU configs of BASELINE.json); weights rotate over `copies` distinct
+    matrices so that the weight stream is not served from the 256 MB Infinity Cache."""
     ws = []
     for c in range(copies):
-        rows = make_weights_q4_0(M, K, 100 + c)
-        ws.append(device.Weight.from_device(Q4_0, rows, K))
+        rows = make_weights_q4_0(M, K, 100 + c, qtype)
+        ws.append(device.Weight.from_device(qtype, rows, K))
         del rows
     x = torch.randn((N, K), device="cuda", dtype=torch.float32)
     out = torch.empty((N, M), device="cuda", dtype=torch.float32)
-    work = device.alloc_work(Q4_0, K, N)
+    work = device.alloc_work(qtype, K, N)
     if N > 8:
         device.mul_mat_init(ws[0], x, work)   # so that the compute-only timing has valid scratch
     stream = torch.cuda.current_stream()
@@ -111,9 +116,9 @@ def side_config(device, M, K, N, copies, iters):
             step()
     t_step = event_time_ms(graph.replay, max(3, iters // copies), stream) / copies
     t_comp = event_time_ms(compute_only, iters, stream) if N > 8 else None
-    ab = algorithmic_bytes(M, K, N)
+    ab = algorithmic_bytes(M, K, N, BLOCK_BYTES[qtype])
     flops = 2.0 * M * K * N
-    res = {"workload": f"Q4_0 mul_mat M={M} K={K} N={N}", "ms_per_step": round(t_step, 5),
+    res = {"workload": f"{TYPE_NAME[qtype]} mul_mat M={M} K={K} N={N}", "ms_per_step": round(t_step, 5),
            "gflops": round(flops / t_step / 1e6, 1), "algorithmic_GBs": round(ab / t_step / 1e6, 1),
            "hbm_frac": round(ab / t_step / 1e6 / HBM_PEAK_GBS, 4), "weight_copies_rotated": copies,
            "timing": "hipGraph replay of one call per weight copy"}
@@ -234,6 +239,11 @@ def main():
                 "batch1": side_config(device, 4096, 4096, 1, copies=32, iters=200),
                 "prompt512": side_config(device, 4096, 4096, 512, copies=32, iters=50),
                 "batch1_M32000": side_config(device, 32000, 4096, 1, copies=8, iters=100),   # the same mat-vec kernel on an 82 MB matrix
+                # BASELINE.json configs[3] (the reference has no k-quants: its 5-bit type Q5_0 stands in) and
+                # configs[4] on ONE GPU (the 8-GPU row split is `--gpus 8` of the headline shape)
+                "q8_0_ffn512": side_config(device, 4096, 11008, 512, copies=6, iters=30, qtype=Q8_0),
+                "q5_0_ffn512": side_config(device, 4096, 11008, 512, copies=8, iters=30, qtype=Q5_0),
+                "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=20),
             }
             for k in ("batch1_M32000",):
                 out["other_configs"][k]["roofline"] = {"bound": "hbm", "achieved": out["other_configs"][k]["algorithmic_GBs"],

@@ -65,7 +65,7 @@ out = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC (separate --p
 # matched by prefix so that an added template parameter does not silently drop a kernel from the file
 prefixes = [("gemm_qmx_kernel<2, 2, 4, 4, 1,", "gemm_qmx_kernel<Q4_0,2,4,4,1> M=4096 K=4096 N=4096"),
             ("gemv_q_kernel<2, 1, true", "gemv_q_kernel<Q4_0,1,fused> M=4096 K=4096 N=1"),
-            ("quantize_act_kernel<3>", "quantize_act_kernel<bf6 image> N=4096 K=4096")]
+            ("quantize_act_bf6_kernel", "quantize_act_bf6_kernel N=4096 K=4096")]
 names = {k: nm for k in traffic for (pre, nm) in prefixes if k.startswith(pre)}
 assert len(names) == len(prefixes), (sorted(traffic), names)
 for k, t in traffic.items():
