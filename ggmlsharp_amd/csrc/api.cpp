@@ -422,6 +422,9 @@ int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t
     if (K <= 0 || K % QK != 0 || ld1 < K) return fail(GGML_HIP_ERR_SHAPE, "K %% 32 != 0 or ld1 < K");
     if (image_kind < 0 || image_kind > 3) return fail(GGML_HIP_ERR_ARG, "image kind %d", image_kind);
     if (work_bytes < act_bytes(K, pad_act(N))) return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", act_bytes(K, pad_act(N)));
+    // the MFMA images are written (and read) through 32-bit buffer offsets: 64 image bytes per row and k-block
+    if (image_kind != 0 && (uint64_t)pad_kblocks(K / QK) * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull)
+        return fail(GGML_HIP_ERR_SHAPE, "image kind %d needs K/32 * 64 * Npad < 4 GiB (ggml_hip_act_image_kind never selects it beyond that)", image_kind);
     HIP_TRY(launch_quantize_act(d_src1, N, K, ld1, act_carve(d_work, K, pad_act(N)), image_kind, (hipStream_t)stream));
     return GGML_HIP_OK;
 }

@@ -261,7 +261,10 @@ __global__ __launch_bounds__(256) void quantize_act_bf6_kernel(const float *__re
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The DMA's LDS write is only complete for a reader after vmcnt(0) AND lgkmcnt(0) (with vmcnt(0) alone, now and then the
+    // upper 64 bytes of every 128-byte line of a piece were still the previous contents -- found with tools/stress_k1b.py).
+    // The barrier is the customary third part of this wait; it costs nothing here.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float v[32];
     {
         const uint8_t *rp = wl + (lane >> 3) * K1V_PIECE + (lane & 7) * 16;
@@ -289,9 +292,15 @@ __global__ __launch_bounds__(256) void quantize_act_bf6_kernel(const float *__re
     }
     // Through asm with an early-clobber result: hipcc's builtin lets the 6-register result overlap the 32 source registers,
     // and the instruction writes its result before it has read all of them (seen as garbage digits at elements 12..16).
+    // Both converts in ONE statement, so that no result shares a register with ANY of the 64 sources.  As two statements
+    // hipcc gave the second result the first convert's source registers and, in 22 of 100 launches, some rows came out with
+    // wrong quants 0..4 (tools/dbg_k1b.py; 8 wait states between the two did not help, distinct registers did: 0 of 250).
+    // The instruction evidently reads its sources for many cycles after issue with no interlock; the trailing nops keep
+    // whatever the compiler puts into the source registers next at a distance as well.
     u32x6q fh, fl;
-    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, 1.0" : "=&v"(fh) : "v"(he), "v"(ho));
-    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, 1.0" : "=&v"(fl) : "v"(le), "v"(lo));
+    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %2, %3, 1.0\n\ts_nop 7\n\tv_cvt_scalef32_2xpk16_bf6_f32 %1, %4, %5, 1.0\n\t"
+                 "s_nop 15\n\ts_nop 15"
+                 : "=&v"(fh), "=&v"(fl) : "v"(he), "v"(ho), "v"(le), "v"(lo));
     float dv = d, sv = d * sum;                             // the Q8_1 s0 + s1 of Ggml.cs:820-821 (intent D3)
     if (pad) {                                              // uniform: pad k-blocks are zero quants with zero scales
         fh = (u32x6q){0, 0, 0, 0, 0, 0}; fl = fh; dv = 0.0f; sv = 0.0f;

@@ -210,6 +210,31 @@ def test_quantize_act_planes_match_oracle(dev, t, force):
         assert lib().ggml_hip_mul_mat_work_size(t, K, N) == raw.size
 
 
+def test_bf6_image_is_reproducible_over_many_launches(dev):
+    """Regression: the lane-per-block INIT kernel once produced wrong quants in a few rows of a ragged last row group in
+    ~1 of 5 launches (a register-overlap hazard of v_cvt_scalef32_2xpk16_bf6_f32, quantize.hip).  40 launches with other
+    kernels in between, every image decoded and compared with the bit-exact row quantizer."""
+    from ggmlsharp_amd._lib import lib, check
+    N, K = 2000, 1024
+    nbk, Npad = K // 32, 2048
+    x = torch.randn((N, K), device="cuda") * 2
+    ref = dev.quantize_rows(O.Q8_0, x).view(N, nbk, 36)[:, :, 4:].contiguous().view(torch.int8).to(torch.int32)
+    mag = torch.tensor([0] * 12 + [1, 99, 99, 99, 2, 99, 3, 99, 4, 5, 6, 7, 8] + [99] * 7, device="cuda")
+    sh6 = torch.arange(6, device="cuda")
+    for it in range(40):
+        work = dev.alloc_work(O.Q4_0, K, N)
+        work.zero_()
+        torch.randn((1 + it % 5) * 200000, device="cuda").sum()
+        check(lib().ggml_hip_quantize_act_dev(C.c_void_p(x.data_ptr()), N, K, K, C.c_void_p(work.data_ptr()), work.numel(), 3, None), "quantize_act")
+        img = work[: nbk * 48 * Npad].view(nbk, 48 * Npad)
+        frag = torch.cat([img[:, : 32 * Npad].view(nbk, 2, Npad, 16), img[:, 32 * Npad:].view(nbk, 2, Npad, 8)], dim=-1)[:, :, :N, :]
+        bits = ((frag.to(torch.int64).unsqueeze(-1) >> torch.arange(8, device="cuda")) & 1).view(nbk, 2, N, 32, 6)
+        code = (bits * (1 << sh6)).sum(-1)
+        dig = torch.where((code & 32) != 0, -mag[code & 31], mag[code & 31])
+        q = (16 * dig[:, 0] + dig[:, 1]).permute(1, 0, 2)
+        assert torch.equal(q, ref), f"launch {it}: {int((q != ref).sum())} wrong quants"
+
+
 # ---------------------------------------------------------------- mul_mat vs oracle
 SHAPES = [  # (M, K, N): ragged M / N, both kernels (N <= 8 mat-vec, N > 8 MFMA), tail stage (K/32 % 4 != 0)
     (1, 32, 1), (16, 64, 1), (17, 96, 2), (200, 256, 3), (128, 4096, 1), (130, 352, 8),

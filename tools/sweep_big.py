@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggmlsharp_amd import device  # noqa: E402
 from ggmlsharp_amd._lib import lib  # noqa: E402
 device.init(0)
-TYPES = {2: "q4_0", 3: "q4_1", 6: "q5_0", 8: "q8_0"}
+TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
 nbad = 0
 for (M, K, N) in ((4096, 288, 1537), (5000, 4096, 2000), (2048, 1056, 3073), (8192, 512, 4096), (4097, 32, 1600)):
     for t in TYPES:
@@ -15,7 +15,9 @@ for (M, K, N) in ((4096, 288, 1537), (5000, 4096, 2000), (2048, 1056, 3073), (81
             lib().ggml_hip_debug_force_gemm(kernel)
             g = torch.Generator(device="cuda"); g.manual_seed(M + N + t)
             w = torch.randn((M, K), generator=g, device="cuda")
-            x = torch.randn((N, K), generator=g, device="cuda") * 2
+            # src1 as a strided view (row stride K + 64 elements): the INIT kernels take ld1 != K
+            xbig = torch.randn((N, K + 64), generator=g, device="cuda") * 2
+            x = xbig[:, :K]
             rows = device.quantize_rows(t, w)
             W = device.Weight.from_device(t, rows, K)
             got = device.mul_mat(W, x)
