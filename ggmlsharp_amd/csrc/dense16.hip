@@ -167,7 +167,7 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
 
     static_for<C::ROUNDS>([&](auto pc) { dma_piece(0, pc); });
     static_for<RING>([&](auto rc) { load_b(decltype(rc)::value, rc); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     for (int s = 0; s < nstages; ++s) {

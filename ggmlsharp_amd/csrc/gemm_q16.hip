@@ -370,7 +370,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     static_for<NPIECE>([&](auto pc) { dma_piece(grp, 0, pc); });
     static_for<WMT>([&](auto ic) { load_raw_one(grp * KB, raw, ic); });
     static_for<WMT>([&](auto ic) { unpack_one(raw, frag[0], ic); load_raw_one(grp * KB + 1, raw, ic); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
     const int niter = (nstages + KSP - 1) / KSP;            // group grp takes stages grp, grp + KSP, ...; same barrier count for all

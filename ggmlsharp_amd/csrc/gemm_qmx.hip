@@ -295,7 +295,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         load_frag_one(grp * KB, frag[0], ic);
         if constexpr (FB == 2) load_frag_one(grp * KB + 1, frag[FB - 1], ic);
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
     const int niter = (nstages + KSP - 1) / KSP;

@@ -46,5 +46,31 @@ for (M, K, N) in SHAPES:
             W.free()
             del wd, xs, first
 lib().ggml_hip_debug_force_gemm(0)
+# dense weights: F16 (dense16.hip on full grids, dense.hip otherwise) and F32 (dense.hip)
+for (M, K, N) in ((4096, 4096, 4096), (2048, 1000, 300), (512, 4096, 7)):
+    for t, dt in ((1, torch.float16), (0, torch.float32)):
+        g = torch.Generator(device="cuda"); g.manual_seed(M + N + t)
+        w = torch.randn((M, K), generator=g, device="cuda").to(dt)
+        W = device.Weight.from_device(t, w.view(torch.uint8).view(M, -1), K)
+        xs = [torch.randn((N, K), generator=g, device="cuda") * (1 + i) for i in range(2)]
+        first = [None, None]
+        fails = 0
+        for it in range(iters):
+            i = it & 1
+            torch.randn((1 + it % 5) * 150000, device="cuda").sum()
+            got = device.mul_mat(W, xs[i])
+            if first[i] is None:
+                first[i] = got.clone()
+                xr = xs[i].to(dt).double() if t == 1 else xs[i].double()     # INIT rounds src1 to half for F16 weights
+                ref = xr @ w.double().T
+                err = (got.double() - ref).abs(); rms = ref.pow(2).mean().sqrt()
+                if int((err > 1e-3 * ref.abs() + 2e-5 * rms).sum().item()):
+                    fails += 1
+                    print(f"WRONG dense type {t} M{M} K{K} N{N} input {i}: max err/rms {(err.max() / rms).item():.2e}", flush=True)
+            elif not torch.equal(got, first[i]):
+                fails += 1
+                print(f"DIFF dense type {t} M{M} K{K} N{N} launch {it}", flush=True)
+        nbad += fails
+        W.free()
 print("determinism stress: failures", nbad)
 sys.exit(1 if nbad else 0)
