@@ -81,7 +81,7 @@ int gemm_force() {
 
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
-    if (N <= GEMV_MAX_N || force == 1) return 0;
+    if (N <= GEMV_WIDE_MAX_N || force == 1) return 0;
     if (type == GGML_TYPE_Q4_2 || type == GGML_TYPE_Q5_1) return 0;   // served by the int8 kernel only (outside BASELINE's configs)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
@@ -437,7 +437,7 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     if (ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ldd < M");
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N)) return fail(GGML_HIP_ERR_ARG, "work buffer too small");
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
-    if (N <= GEMV_MAX_N)
+    if (N <= GEMV_WIDE_MAX_N)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else if (act_image_kind(w->type, w->M, w->K, N) == 3)
         HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));

@@ -23,7 +23,9 @@ namespace {
 #endif
 #define GV_NKQ (64 / GV_ROWS)          // k-lanes per wave
 #define GV_WORKERS (4 * GV_NKQ)       // k-workers per workgroup
-#define GV_CHUNK 128  // k-blocks of activations staged in LDS at a time
+#define GV_CHUNK 128  // k-blocks of activations staged in LDS at a time (N <= 8)
+// wider batches (9..16 src1 rows, two-step form only) stage fewer k-blocks at a time so that the image still fits 64 KB of LDS
+template <int NC> struct GvChunk { static constexpr int value = NC <= 8 ? GV_CHUNK : 64; };
 #ifndef GV_NT
 #define GV_NT 1       // non-temporal weight loads (A/B: -DGV_NT=0)
 #endif
@@ -60,19 +62,21 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
                                                     const int8_t *__restrict__ a8, const float *__restrict__ ad,
                                                     const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
                                                     int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd, int N, int ntiles) {
-    __shared__ uint4 sA[GV_CHUNK * 2 * NC];
-    __shared__ float sD[GV_CHUNK * NC];
-    __shared__ int sS[GV_CHUNK * NC];
+    constexpr int CH = GvChunk<NC>::value;
+    static_assert(!FUSED || NC <= 8, "the fused form quantizes N columns per workgroup: N <= 8 only");
+    __shared__ uint4 sA[CH * 2 * NC];
+    __shared__ float sD[CH * NC];
+    __shared__ int sS[CH * NC];
     __shared__ float sRed[4][NC][GV_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane % GV_ROWS, kq = lane / GV_ROWS, u = wave * GV_NKQ + kq;
-    constexpr int BPL = GV_CHUNK / GV_WORKERS;               // k-blocks per lane per chunk
+    constexpr int BPL = GvChunk<NC>::value / GV_WORKERS;     // k-blocks per lane per chunk
     // Persistent over row tiles: virtual block vb = blockIdx.x, + gridDim.x, ... takes tile f(vb).  When all of K fits one
     // LDS chunk the activations are quantized / staged ONCE per workgroup instead of once per 16 rows (at M = 32000 the
     // 2000 redundant quantizations were ~8 % of the kernel).  Per-row arithmetic and summation tree are unchanged.
     // (Also loading the next tile's weights a tile ahead measured 10 % SLOWER: 19.3 vs 17.3 us at M = 32000.)
-    const bool single_chunk = nbk <= GV_CHUNK;
+    const bool single_chunk = nbk <= GvChunk<NC>::value;
     bool staged = false;
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
     // XCD-aware tile order: virtual blocks b and b+8 share an XCD (and its L2) in the first round, so give each XCD a
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
 
-    for (int64_t cb = 0; cb < nbk; cb += GV_CHUNK) {
-        const int nbc = (int)((nbk - cb) < GV_CHUNK ? (nbk - cb) : GV_CHUNK);
+    for (int64_t cb = 0; cb < nbk; cb += CH) {
+        const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
 
         // 1. all of this lane's weight loads for the chunk go out first (8 x 16 B + scales in flight per lane)
         uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
         // 2. activations of the chunk -> LDS (int8 even/odd planes + scale + block sum); once per workgroup if K fits
         if (!(single_chunk && staged)) {
         __syncthreads();  // previous chunk fully consumed
-        if (FUSED) {
+        if constexpr (FUSED) {
             const int t = tid & 7, grp = tid >> 3;             // 8 lanes per 32-element block, 32 groups
             constexpr int ITEMS = GV_CHUNK * NC / 32;         // (column, k-block) items per group: 4 * NC
             constexpr int UNR = 4;                              // loads in flight per lane
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
         if (kq == 0) sRed[wave][c][r] = v;
     }
     __syncthreads();
-    if (tid < GV_ROWS * NC) {
-        const int c = tid / GV_ROWS, rr = tid % GV_ROWS;
+    for (int o = tid; o < GV_ROWS * NC; o += 256) {
+        const int c = o / GV_ROWS, rr = o % GV_ROWS;
         const int64_t m = (int64_t)tile * GV_ROWS + rr;
         if (m < M && c < N) dst[(int64_t)c * ldd + m] = (sRed[0][c][rr] + sRed[1][c][rr]) + (sRed[2][c][rr] + sRed[3][c][rr]);
     }
@@ -248,7 +252,8 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
     else if (N <= 4) GV_LAUNCH(4);
-    else GV_LAUNCH(8);
+    else if (N <= 8) GV_LAUNCH(8);
+    else if constexpr (!FUSED) GV_LAUNCH(16);   // 9..16 rows: the weights are still streamed once, 16 dot products per block
 #undef GV_LAUNCH
     return hipGetLastError();
 }
@@ -266,7 +271,7 @@ template <bool FUSED>
 hipError_t launch_any(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
                       int64_t ldd, hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
-    if (N > GEMV_MAX_N) return hipErrorInvalidValue;
+    if (N > (FUSED ? GEMV_MAX_N : GEMV_WIDE_MAX_N)) return hipErrorInvalidValue;
     switch (w->type) {
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1, FUSED>(w, x, ld1, p, N, dst, ldd, st);

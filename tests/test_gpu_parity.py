@@ -56,7 +56,9 @@ def assert_close(got, ref, what=""):
     bad = err > bound
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} beyond 1e-3 rel; max err {err.max():.3e}, rms {rms:.3e}"
     if ref.size and np.linalg.norm(ref) > 0:
-        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-5, what
+        # norm-wise: 1e-5 over a matrix; a handful of elements can sit on a cancellation (Q4_1 / Q5_1 add a scale term and a
+        # min term of opposite sign), where the 1e-6-level reordering differences are larger relative to the result
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= (1e-5 if ref.size >= 256 else 1e-4), what
 
 
 # ---------------------------------------------------------------- K9 / K8 bit-exact
@@ -236,11 +238,12 @@ def test_bf6_image_is_reproducible_over_many_launches(dev):
 
 
 # ---------------------------------------------------------------- mul_mat vs oracle
-SHAPES = [  # (M, K, N): ragged M / N, both kernels (N <= 8 mat-vec, N > 8 MFMA), tail stage (K/32 % 4 != 0)
+SHAPES = [  # (M, K, N): ragged M / N, all kernels (N <= 8 fused mat-vec, N <= 16 two-step mat-vec, above that MFMA), tail stage (K/32 % 4 != 0)
     (1, 32, 1), (16, 64, 1), (17, 96, 2), (200, 256, 3), (128, 4096, 1), (130, 352, 8),
     (64, 128, 9), (33, 160, 17), (200, 256, 64), (128, 512, 128), (257, 1024, 130), (64, 11008, 40),
     (600, 288, 300),    # several workgroup tiles in both directions, ragged edges, K/32 = 9 (pad k-blocks)
     (1, 32, 9), (31, 64, 33), (257, 96, 257), (129, 32, 65),   # one k-block (three pad blocks per stage), one-row weights
+    (128, 4096, 16), (130, 4096 + 64, 13), (200, 288, 10), (17, 2080, 12),   # 9..16 rows: the wide mat-vec form, several LDS chunks of K
 ]
 
 
@@ -253,8 +256,8 @@ def test_mul_mat_q_matches_oracle(dev, t, kernel):
     lib().ggml_hip_debug_force_gemm(kernel)
     try:
         for (M, K, N) in SHAPES:
-            if kernel and N <= 8:
-                continue          # the mat-vec kernel serves N <= 8 whatever is forced
+            if kernel and N <= 16:
+                continue          # the mat-vec kernel serves N <= 16 whatever is forced
             w = _rand((M, K))
             x = _rand((N, K), 2.0)
             wq = O.quantize_row(t, w)
