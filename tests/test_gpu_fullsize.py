@@ -51,6 +51,14 @@ CONFIGS = [  # BASELINE.json configs (M, K, N), Q5_0 standing in for the absent 
     ("c4b", Q5_0, 4096, 11008, 512),
     ("c4a transposed reading", Q8_0, 11008, 4096, 512),
     ("c5 single-GPU total", Q4_0, 32000, 4096, 512),
+    # the other forms at full size: Q4_1 (MX + min term), the SURVEY-D7 types on the int8 kernel and the mat-vec kernel,
+    # a 16-row decode batch (two-step mat-vec form)
+    ("q4_1 prompt-512", 3, 4096, 4096, 512),
+    ("q4_2 prompt-512", 4, 4096, 4096, 512),
+    ("q5_1 ffn-512", 7, 4096, 11008, 512),
+    ("q5_1 batch-1", 7, 11008, 4096, 1),
+    ("q4_2 batch-8", 4, 4096, 4096, 8),
+    ("decode batch of 16", Q4_0, 11008, 4096, 16),
 ]
 
 

@@ -273,3 +273,20 @@ def test_transformer_style_chain_stays_on_device():
         assert c1[2].value - c0[2].value >= 5
     finally:
         G.ggml_free(ctx)
+
+
+def test_host_mirror_silu_nodes():
+    """ggml_silu / ggml_silu_inplace node construction (Ggml.cs:8154-8174): dup vs view, op id, graph order."""
+    ctx = G.ggml_init(4 * 1024 * 1024)
+    try:
+        a = G.ggml_new_tensor_2d(ctx, G.F32, 64, 3)
+        s = G.ggml_silu(ctx, a)
+        si = G.ggml_silu_inplace(ctx, a)
+        assert s.contents.op == _lib.GGML_OP_SILU and si.contents.op == _lib.GGML_OP_SILU
+        assert s.contents.data != a.contents.data and si.contents.data == a.contents.data          # dup vs view (:8166)
+        assert C.addressof(s.contents.src0.contents) == C.addressof(a.contents) and not s.contents.src1
+        assert tuple(s.contents.ne) == tuple(a.contents.ne) and tuple(s.contents.nb) == tuple(a.contents.nb)
+        gf = G.ggml_build_forward(G.ggml_mul(ctx, s, G.ggml_silu(ctx, s)))
+        assert (gf.n_nodes, gf.n_leafs) == (3, 1)                                                   # silu, silu, mul ; a
+    finally:
+        G.ggml_free(ctx)
