@@ -80,12 +80,16 @@ struct Cfg {
     static constexpr int SC_CHUNKS = KB * TN / 4;          // 16-byte pieces per plane
     static_assert(SC_CHUNKS % 64 == 0 && SC_CHUNKS <= NT, "scale DMA is whole waves");
     static constexpr int NPIECE = A16_ROUNDS + A8_ROUNDS + 1;
-    static_assert(NPIECE <= KB * WMT * WNT, "one DMA piece per tile");
+    // DMA pieces per tile: one where the stage has enough tiles (the pieces must all be issued before the drain point in the
+    // middle of the stage's last k-block), two for the small wave tiles
+    static constexpr int DRAIN_T = (KB - 1) * WMT * WNT + WMT * WNT / 2;
+    static constexpr int PP = (NPIECE + DRAIN_T - 1) / DRAIN_T;
+    static_assert(PP <= 2, "at most two DMA pieces per tile");
 };
 
 // FB = weight fragment buffers: 2 = fragments of k-block kb+2 are loaded into the buffer k-block kb has just released;
 // 1 = in place, for kb+1 (enough look-ahead when a wave has >= 4 m-tiles between two uses of a fragment)
-// KSP = 1 | 2: with 2 the workgroup holds two wave groups that take alternate LDS stages of K (each with its own stage
+// KSP = 1 | 2 | 4: with 2 (4) the workgroup holds two (four) wave groups that take alternate LDS stages of K (each with its own stage
 // buffers) and add their accumulators through LDS at the end -- twice the waves for grids too small to fill the chip.
 template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP>
 __global__ __launch_bounds__(WGM * WGN * 64 * KSP, 2)
@@ -188,7 +192,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
         const int kb0 = s * KB;
         constexpr int LAST = KB * NTILE - 1, DRAIN = (KB - 1) * NTILE + NTILE / 2;
-        static_assert(C::NPIECE <= DRAIN, "all DMA pieces are issued before the drain point");
+        static_assert(DRAIN == C::DRAIN_T && C::NPIECE <= C::PP * DRAIN, "all DMA pieces are issued before the drain point");
 
         u32x4 af_lo;
         u32x2 af_hi;
@@ -242,7 +246,10 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             // this tile's weight scales, read before issue(t + 1) may replace them with the next block's (WMT == 1)
             const float dw = dcur[i];
             const float mw = TYPE == GGML_TYPE_Q4_1 ? mcur[i] : 0.0f;
-            if constexpr (t < C::NPIECE && !(GGML_MX_DBG & 1)) dma_piece(s + KSP, buf + 1, tc);
+            if constexpr (!(GGML_MX_DBG & 1)) {
+                if constexpr (C::PP * t < C::NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, C::PP * t>{});
+                if constexpr (C::PP == 2 && 2 * t + 1 < C::NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, 2 * t + 1>{});
+            }
             // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
             // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
             // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
@@ -307,26 +314,30 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         asm volatile("" ::: "memory");
     }
 
-    // ---- K split: group 1 hands its accumulators to group 0 through LDS (the stage buffers are free now) ----
-    if constexpr (KSP == 2) {
-        static_assert(WGM * WGN * WMT * WNT * 16 * 64 * 4 <= 2 * C::TOTAL, "K-split exchange fits the stage buffers");
+    // ---- K split: groups 1 .. KSP-1 hand their accumulators to group 0 through LDS (the stage buffers are free now); group 0
+    //      adds them in group order, so the summation tree is fixed ----
+    if constexpr (KSP > 1) {
+        constexpr int GRP_FLOATS = WGM * WGN * NTILE * 16 * 64;           // one group's accumulators
+        static_assert((KSP - 1) * GRP_FLOATS * 4 <= KSP * C::TOTAL, "K-split exchange fits the stage buffers");
         float *xch = (float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
-        if (grp == 1) {
+        if (grp != 0) {
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int j = 0; j < WNT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) xch[(size_t)(grp - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
         }
         __syncthreads();
-        if (grp == 1) return;
+        if (grp != 0) return;
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
+        for (int g = 1; g < KSP; ++g)
 #pragma unroll
-            for (int j = 0; j < WNT; ++j)
+            for (int i = 0; i < WMT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * WNT + j) * 16 + r) * 64];
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[(size_t)(g - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64];
     }
 
     // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
@@ -410,6 +421,9 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // between them (4096 x 4096 x 512: 45.8 -> 31.9 us; 4096 x 11008 x 512: 107 -> 75 us; N = 1024 is 10 % slower that
     // way, M = 32000 x N = 512 6 % slower).  The choice depends on N and K only -- never on M -- so a row shard still
     // computes bit for bit what the unsplit matrix does (the summation tree of an element is a function of the kernel form).
+    // Batches up to 128 rows: 32-row weight tiles with K split four ways inside the workgroup -- M / 32 x N / 64 workgroups of
+    // 4 waves instead of M / 128 x N / 64 of 8 (4096 x 4096 x 64 covered 32 CUs).
+    if (N <= 128 && w->nbk >= 16 && var != 3 && var != 9) return launch_cfg<TYPE, 1, 2, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
     if (N <= 512 && w->nbk >= 8 && var != 3) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
     if (tm128 * tn128 >= 384) return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);   // 128 x 128, 4 tiles per wave
     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
