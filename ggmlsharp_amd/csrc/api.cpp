@@ -47,6 +47,9 @@ bool wq_ok(int t) {
            t == GGML_TYPE_Q8_0;
 }
 bool weight_type_ok(int t) { return wq_ok(t) || t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
+// src1 rows up to which the mat-vec kernel serves a type (two-step form above GEMV_MAX_N): the types with small-batch MFMA
+// configurations leave it at 8, the two that only have the int8 kernel's 64 x 64 tiles behind them stay on it up to 16
+int64_t gemv_rows_max(int t) { return (t == GGML_TYPE_Q4_2 || t == GGML_TYPE_Q5_1) ? GEMV_WIDE_MAX_N : GEMV_MAX_N; }
 bool has_min_plane(int t) { return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q4_2; }   // Q4_2: its second scale
 bool has_qh_plane(int t) { return t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
 size_t row_bytes_of(int t, int64_t k) { return TSIZE[t] * (size_t)(k / BLCK[t]); }
@@ -81,8 +84,8 @@ int gemm_force() {
 
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
-    if (N <= GEMV_WIDE_MAX_N || force == 1) return 0;
-    if (type == GGML_TYPE_Q4_2 || type == GGML_TYPE_Q5_1) return 0;   // served by the int8 kernel only (outside BASELINE's configs)
+    if (N <= GEMV_MAX_N || force == 1) return 0;
+    if (type == GGML_TYPE_Q4_2 || type == GGML_TYPE_Q5_1) return 0;   // served by the mat-vec and int8 kernels only (outside BASELINE's configs)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
     if ((nba + K_LOOKAHEAD) * (uint64_t)pad_rows(M) * 32 > 0xFFFFFFFFull || nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
@@ -437,7 +440,7 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     if (ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ldd < M");
     if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N)) return fail(GGML_HIP_ERR_ARG, "work buffer too small");
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
-    if (N <= GEMV_WIDE_MAX_N)
+    if (N <= gemv_rows_max(w->type))
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else if (act_image_kind(w->type, w->M, w->K, N) == 3)
         HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));

@@ -132,7 +132,7 @@ struct Cfg {
     static constexpr int WPS = 2;                          // waves per SIMD aimed at (256 registers each)
 };
 
-// KSP = 1 | 2: with 2 the workgroup holds two wave groups that take alternate LDS stages of K (each with its own stage
+// KSP = 1 | 2 | 4: with 2 (4) the workgroup holds two (four) wave groups that take alternate LDS stages of K (each with its own stage
 // buffers) and add their accumulators through LDS at the end -- twice the waves for grids too small to fill the chip.
 template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int KSP>
 __global__ __launch_bounds__(WGM * WGN * 64 * KSP, (Cfg<TYPE, WMT, WNT, WGM, WGN, KB>::WPS))
@@ -273,7 +273,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
         const int kb0 = s * KB;
         constexpr int LAST = KB * NTILE - 1, DRAIN = (KB - 1) * NTILE + NTILE / 2;
-        static_assert(NPIECE <= DRAIN, "all DMA pieces are issued before the drain point");
+        constexpr int PP = (NPIECE + DRAIN - 1) / DRAIN;                // DMA pieces per tile (1 unless a stage has few tiles)
+        static_assert(PP <= 3 && NPIECE <= PP * DRAIN, "all DMA pieces are issued before the drain point");
 
         f16x8 af[2];
         f32x4 da[4], sa[4];
@@ -315,7 +316,10 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
 
         static_for<KB * NTILE>([&](auto tc) {
             constexpr int t = decltype(tc)::value, bb = t / NTILE, tl = t % NTILE, j = tl / WMT, i = tl % WMT;
-            if constexpr (t < NPIECE) dma_piece(s + KSP, buf + 1, tc);
+            static_for<PP>([&](auto uc) {
+                constexpr int pc = PP * t + decltype(uc)::value;
+                if constexpr (pc < NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, pc>{});
+            });
             // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
             // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
             // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
@@ -382,26 +386,30 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         asm volatile("" ::: "memory");
     }
 
-    // ---- K split: group 1 hands its accumulators to group 0 through LDS (the stage buffers are free now) ----
-    if constexpr (KSP == 2) {
-        static_assert(WGM * WGN * WMT * WNT * 16 * 64 * 4 <= 2 * C::TOTAL, "K-split exchange fits the stage buffers");
+    // ---- K split: groups 1 .. KSP-1 hand their accumulators to group 0 through LDS (the stage buffers are free now); group 0
+    //      adds them in group order, so the summation tree is fixed ----
+    if constexpr (KSP > 1) {
+        constexpr int GRP_FLOATS = WGM * WGN * NTILE * 16 * 64;           // one group's accumulators
+        static_assert((KSP - 1) * GRP_FLOATS * 4 <= KSP * C::TOTAL, "K-split exchange fits the stage buffers");
         float *xch = (float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
-        if (grp == 1) {
+        if (grp != 0) {
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int j = 0; j < WNT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) xch[(size_t)(grp - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
         }
         __syncthreads();
-        if (grp == 1) return;
+        if (grp != 0) return;
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
+        for (int g = 1; g < KSP; ++g)
 #pragma unroll
-            for (int j = 0; j < WNT; ++j)
+            for (int i = 0; i < WMT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * WNT + j) * 16 + r) * 64];
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[(size_t)(g - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64];
     }
 
     // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
@@ -472,6 +480,9 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // big tile (256 x 128, 8 tiles per wave) when it still fills the chip with >= 2 workgroups per CU; else 128 x 64
     const int64_t big = ((w->M + 255) / 256) * ((N + 127) / 128);
     // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (chosen from N and K only, see gemm_qmx.hip)
+    // batches up to 128 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip)
+    static const bool old128 = getenv("GGML_HIP_Q16_OLD128") != nullptr;   // developer A/B switch
+    if (N <= 128 && w->nbk >= 16 && !old128) return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
     if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
     if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
     return launch_cfg<TYPE, 2, 2, 2, 1, 4>(w, p, N, dst, ldd, st);

@@ -238,12 +238,13 @@ def test_bf6_image_is_reproducible_over_many_launches(dev):
 
 
 # ---------------------------------------------------------------- mul_mat vs oracle
-SHAPES = [  # (M, K, N): ragged M / N, all kernels (N <= 8 fused mat-vec, N <= 16 two-step mat-vec, above that MFMA), tail stage (K/32 % 4 != 0)
+SHAPES = [  # (M, K, N): ragged M / N, all kernels (N <= 8 fused mat-vec, above that MFMA -- 32-row K-split tiles up to 128 rows; Q4_2 / Q5_1: two-step mat-vec up to 16), tail stage (K/32 % 4 != 0)
     (1, 32, 1), (16, 64, 1), (17, 96, 2), (200, 256, 3), (128, 4096, 1), (130, 352, 8),
     (64, 128, 9), (33, 160, 17), (200, 256, 64), (128, 512, 128), (257, 1024, 130), (64, 11008, 40),
     (600, 288, 300),    # several workgroup tiles in both directions, ragged edges, K/32 = 9 (pad k-blocks)
     (1, 32, 9), (31, 64, 33), (257, 96, 257), (129, 32, 65),   # one k-block (three pad blocks per stage), one-row weights
-    (128, 4096, 16), (130, 4096 + 64, 13), (200, 288, 10), (17, 2080, 12),   # 9..16 rows: the wide mat-vec form, several LDS chunks of K
+    (128, 4096, 16), (130, 4096 + 64, 13), (200, 288, 10), (17, 2080, 12),   # 9..16 rows: wide mat-vec form (Q4_2 / Q5_1), several LDS chunks of K
+    (100, 512, 70), (96, 1056, 128), (40, 4096, 100),                       # 32-row tiles with the four-way K split (nbk >= 16, N <= 128)
 ]
 
 
@@ -256,8 +257,8 @@ def test_mul_mat_q_matches_oracle(dev, t, kernel):
     lib().ggml_hip_debug_force_gemm(kernel)
     try:
         for (M, K, N) in SHAPES:
-            if kernel and N <= 16:
-                continue          # the mat-vec kernel serves N <= 16 whatever is forced
+            if kernel and N <= 8:
+                continue          # the mat-vec kernel serves N <= 8 whatever is forced
             w = _rand((M, K))
             x = _rand((N, K), 2.0)
             wq = O.quantize_row(t, w)

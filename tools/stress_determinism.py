@@ -11,11 +11,11 @@ from ggmlsharp_amd._lib import lib  # noqa: E402
 device.init(0)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
-SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29)]
+SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29), (4096, 4096, 64), (777, 11008, 128)]
 nbad = 0
 for (M, K, N) in SHAPES:
     for t in TYPES:
-        for kernel in ((0,) if N <= 16 or t in (4, 7) else (0, 1, 2, 3)):
+        for kernel in ((0,) if N <= 8 or t in (4, 7) else (0, 1, 2, 3)):
             lib().ggml_hip_debug_force_gemm(kernel)
             g = torch.Generator(device="cuda"); g.manual_seed(M + 3 * N + t)
             w = torch.randn((M, K), generator=g, device="cuda")
