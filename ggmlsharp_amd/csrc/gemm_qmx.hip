@@ -84,7 +84,7 @@ struct Cfg {
     // middle of the stage's last k-block), two for the small wave tiles
     static constexpr int DRAIN_T = (KB - 1) * WMT * WNT + WMT * WNT / 2;
     static constexpr int PP = (NPIECE + DRAIN_T - 1) / DRAIN_T;
-    static_assert(PP <= 2, "at most two DMA pieces per tile");
+    static_assert(PP <= 3, "at most three DMA pieces per tile");
 };
 
 // FB = weight fragment buffers: 2 = fragments of k-block kb+2 are loaded into the buffer k-block kb has just released;
@@ -247,8 +247,10 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             const float dw = dcur[i];
             const float mw = TYPE == GGML_TYPE_Q4_1 ? mcur[i] : 0.0f;
             if constexpr (!(GGML_MX_DBG & 1)) {
-                if constexpr (C::PP * t < C::NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, C::PP * t>{});
-                if constexpr (C::PP == 2 && 2 * t + 1 < C::NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, 2 * t + 1>{});
+                static_for<C::PP>([&](auto uc) {
+                    constexpr int pc = C::PP * t + decltype(uc)::value;
+                    if constexpr (pc < C::NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, pc>{});
+                });
             }
             // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
             // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
