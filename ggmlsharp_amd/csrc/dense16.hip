@@ -202,13 +202,10 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
 template <int WMT, int WNT, int WGM, int WGN>
 hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<WMT, WNT, WGM, WGN>;
-    static bool attr_set = false;
     auto kern = dense16_kernel<WMT, WNT, WGM, WGN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
+    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+    if (attr != hipSuccess) return attr;
     if (w->Mpad % C::TM != 0 || Npad % C::TN != 0) return hipErrorInvalidValue;
     const int64_t Kpad = dense16_kpad(w->K);
     const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);

@@ -423,13 +423,10 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
 template <int TYPE, int IT, int JT>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using T = Tile<TYPE, IT, JT>;
-    static bool attr_set = false;
     auto kern = gemm_q_kernel<TYPE, IT, JT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
+    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS);
+    if (attr != hipSuccess) return attr;
     const int tiles_m = (int)((w->M + T::TM - 1) / T::TM), tiles_n = (int)((N + T::TN - 1) / T::TN);
     dim3 grid((unsigned)(tiles_m * tiles_n));
     kern<<<grid, 256, T::LDS, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad, w->nbk, ldd,

@@ -451,13 +451,10 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
 template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
-    static bool attr_set = false;
     auto kern = gemm_q16_kernel<TYPE, WMT, WNT, WGM, WGN, KB, KSP>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
+    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
+    if (attr != hipSuccess) return attr;
     if (w->Mpad % C::TM != 0 || p.Npad % C::TN != 0) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
     dim3 grid((unsigned)(tiles_m * tiles_n));
