@@ -8,8 +8,8 @@
 // Only the order of the f32 additions over blocks differs from the scalar loop.
 //
 // Mapping, chosen for the planar weight layout ([k-block][row][16 B]):
-//   workgroup = 16 weight rows x all K; lane = (row r = lane & 15, k-lane kq = lane >> 4); the 4 waves x 4 k-lanes
-//   are 16 "k-workers", worker u takes blocks u, u+16, u+32, ...  A wave-wide 16-byte load therefore touches four
+//   workgroup = 16 weight rows x all K; lane = (row r = lane & 15, k-lane kq = lane >> 4); the 8 waves x 4 k-lanes
+//   are 32 "k-workers", worker u takes blocks u, u+32, u+64, ...  A wave-wide 16-byte load therefore touches four
 //   256-byte contiguous segments, every lane keeps 4 independent loads in flight, and a row's dot product needs
 //   only two xor-shuffles plus one LDS pass to combine -- no atomics, fixed summation tree (deterministic).
 //   The Q8 activation vector (written by K1) is staged into LDS once per 128 k-blocks and read as broadcasts.
@@ -21,8 +21,13 @@ namespace {
 #ifndef GV_MAX_WGS
 #define GV_MAX_WGS 512              // persistent grid: 2 workgroups per CU (A/B at M = 32000: 512 -> 17.3 us, 1024 -> 18.5, 2048 -> 19.2)
 #endif
+#ifndef GV_WAVES
+#define GV_WAVES 8                     // waves per workgroup (A/B: 4 -> 8 waves: 4096^2 batch-1 5.81 -> 5.40 us, 4096 x 11008 12.1 -> 10.6,
+                                       // N = 8 14.8 -> 12.0, M = 32000 17.25 -> 17.1; 16 waves gain another 3 % on Q4_0 and lose 10 % on Q8_0)
+#endif
+#define GV_THREADS (64 * GV_WAVES)
 #define GV_NKQ (64 / GV_ROWS)          // k-lanes per wave
-#define GV_WORKERS (4 * GV_NKQ)       // k-workers per workgroup
+#define GV_WORKERS (GV_WAVES * GV_NKQ) // k-workers per workgroup
 #define GV_CHUNK 128  // k-blocks of activations staged in LDS at a time (N <= 8)
 // wider batches (9..16 src1 rows, two-step form only) stage fewer k-blocks at a time so that the image still fits 64 KB of LDS
 template <int NC> struct GvChunk { static constexpr int value = NC <= 8 ? GV_CHUNK : 64; };
@@ -56,7 +61,7 @@ __device__ __forceinline__ uint32_t q5_high_bits(uint32_t qh, int i, int sel) {
 // FUSED = false: src1 was quantized earlier (K1 planes, or reference Q8 blocks through ggml_hip_vec_dot).
 // The weight loads of a chunk are issued before the activations are staged, so both latencies overlap.
 template <int TYPE, int NC, bool FUSED, int GV_ROWS>
-__global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
+__global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
                                                     const float *__restrict__ wd, const float *__restrict__ wm,
                                                     const float *__restrict__ x, int64_t ld1,
                                                     const int8_t *__restrict__ a8, const float *__restrict__ ad,
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
     __shared__ uint4 sA[CH * 2 * NC];
     __shared__ float sD[CH * NC];
     __shared__ int sS[CH * NC];
-    __shared__ float sRed[4][NC][GV_ROWS];
+    __shared__ float sRed[GV_WAVES][NC][GV_ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane % GV_ROWS, kq = lane / GV_ROWS, u = wave * GV_NKQ + kq;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
     for (int64_t cb = 0; cb < nbk; cb += CH) {
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
 
-        // 1. all of this lane's weight loads for the chunk go out first (8 x 16 B + scales in flight per lane)
+        // 1. all of this lane's weight loads for the chunk go out first (4 x 16 B + scales in flight per lane, 512 lanes)
         uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
         constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
         constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
@@ -119,15 +124,16 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
         if (!(single_chunk && staged)) {
         __syncthreads();  // previous chunk fully consumed
         if constexpr (FUSED) {
-            const int t = tid & 7, grp = tid >> 3;             // 8 lanes per 32-element block, 32 groups
-            constexpr int ITEMS = GV_CHUNK * NC / 32;         // (column, k-block) items per group: 4 * NC
-            constexpr int UNR = 4;                              // loads in flight per lane
+            const int t = tid & 7, grp = tid >> 3;             // 8 lanes per 32-element block, GV_THREADS / 8 groups
+            constexpr int NGRP = GV_THREADS / 8;
+            constexpr int ITEMS = GV_CHUNK * NC / NGRP;       // (column, k-block) items per group
+            constexpr int UNR = ITEMS < 4 ? ITEMS : 4;          // loads in flight per lane
 #pragma unroll 1
             for (int it0 = 0; it0 < ITEMS; it0 += UNR) {
                 float4 v[UNR];
 #pragma unroll
                 for (int k = 0; k < UNR; ++k) {
-                    const int w0 = grp + 32 * (it0 + k);
+                    const int w0 = grp + NGRP * (it0 + k);
                     const int c = w0 / GV_CHUNK, bl = w0 % GV_CHUNK;
                     const int cc = c < N ? c : N - 1;
                     const int blc = bl < nbc ? bl : nbc - 1;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
                 }
 #pragma unroll
                 for (int k = 0; k < UNR; ++k) {
-                    const int w0 = grp + 32 * (it0 + k);
+                    const int w0 = grp + NGRP * (it0 + k);
                     const int c = w0 / GV_CHUNK, bl = w0 % GV_CHUNK;
                     const bool live = c < N && bl < nbc;       // uniform over the 8 lanes of the group
                     float amax = fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
@@ -159,12 +165,12 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
                 }
             }
         } else {
-            for (int i = tid; i < nbc * 2 * NC; i += 256) {
+            for (int i = tid; i < nbc * 2 * NC; i += GV_THREADS) {
                 const int c = i % NC, bh = i / NC;  // bh = b_local*2 + h
                 const int cc = c < N ? c : N - 1;
                 sA[i] = *(const uint4 *)(a8 + (((cb * 2 + bh) * Npad) + cc) * 16);
             }
-            for (int i = tid; i < nbc * NC; i += 256) {
+            for (int i = tid; i < nbc * NC; i += GV_THREADS) {
                 const int c = i % NC, bl = i / NC;
                 const int cc = c < N ? c : N - 1;
                 sD[i] = ad[(cb + bl) * Npad + cc];
@@ -234,10 +240,16 @@ __global__ __launch_bounds__(256) void gemv_q_kernel(const uint8_t *__restrict__
         if (kq == 0) sRed[wave][c][r] = v;
     }
     __syncthreads();
-    for (int o = tid; o < GV_ROWS * NC; o += 256) {
+    for (int o = tid; o < GV_ROWS * NC; o += GV_THREADS) {
         const int c = o / GV_ROWS, rr = o % GV_ROWS;
         const int64_t m = (int64_t)tile * GV_ROWS + rr;
-        if (m < M && c < N) dst[(int64_t)c * ldd + m] = (sRed[0][c][rr] + sRed[1][c][rr]) + (sRed[2][c][rr] + sRed[3][c][rr]);
+        float quad[GV_WAVES / 4];                                                                   // fixed tree over the waves
+#pragma unroll
+        for (int q = 0; q < GV_WAVES / 4; ++q)
+            quad[q] = (sRed[4 * q][c][rr] + sRed[4 * q + 1][c][rr]) + (sRed[4 * q + 2][c][rr] + sRed[4 * q + 3][c][rr]);
+        const float tot = GV_WAVES == 4 ? quad[0] : GV_WAVES == 8 ? quad[0] + quad[1 % (GV_WAVES / 4)]
+                                        : (quad[0] + quad[1 % (GV_WAVES / 4)]) + (quad[2 % (GV_WAVES / 4)] + quad[3 % (GV_WAVES / 4)]);
+        if (m < M && c < N) dst[(int64_t)c * ldd + m] = tot;
     }
     __syncthreads();   // sRed is rewritten by the next tile
     }
@@ -248,7 +260,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
                        int64_t ldd, hipStream_t st) {
     const int ntiles = (int)((w->M + ROWS - 1) / ROWS);
     dim3 grid((unsigned)(ntiles < GV_MAX_WGS ? ntiles : GV_MAX_WGS));
-#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, 256, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
+#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
     else if (N <= 4) GV_LAUNCH(4);
