@@ -23,7 +23,8 @@ namespace {
 #endif
 #ifndef GV_WAVES
 #define GV_WAVES 8                     // waves per workgroup (A/B: 4 -> 8 waves: 4096^2 batch-1 5.81 -> 5.40 us, 4096 x 11008 12.1 -> 10.6,
-                                       // N = 8 14.8 -> 12.0, M = 32000 17.25 -> 17.1; 16 waves gain another 3 % on Q4_0 and lose 10 % on Q8_0)
+                                       // N = 8 14.8 -> 12.0, M = 32000 17.25 -> 17.1; 16 waves: 5.23 us at 4096^2 but 19.9 us at M = 32000 with
+                                       // one resident workgroup per CU, and 10 % slower on Q8_0 -- and the choice must not depend on M)
 #endif
 #define GV_THREADS (64 * GV_WAVES)
 #define GV_NKQ (64 / GV_ROWS)          // k-lanes per wave
