@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 flow on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,11 +146,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if "GGML_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N > 1 flow with every rank on one GPU
+        local_rank = int(os.environ["GGML_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from ggmlsharp_amd import device, dist as gdist
     device.init(local_rank)

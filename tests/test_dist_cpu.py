@@ -101,3 +101,58 @@ def test_row_split_all_gather_world2(M, K, N, chunks):
     for rank, ok, shape in results:
         assert ok, f"rank {rank} result differs from the unsplit oracle"
         assert shape == (N, M)
+
+
+# ---------------------------------------------------------------- two ranks on ONE GPU: the real HIP shard kernels and the
+# real re-layout kernel, gloo standing in for RCCL (the driver runs the RCCL form on a whole node at round end)
+def _gpu_worker(rank, world, port, M, K, N, chunks, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ggmlsharp_amd import device
+        torch.cuda.set_device(0)
+        device.init(0)
+        rng = np.random.default_rng(9)          # same data on every rank
+        w = rng.standard_normal((M, K)).astype(np.float32)
+        x = rng.standard_normal((N, K)).astype(np.float32)
+        wq = O.quantize_row(O.Q4_0, w)
+        r0, r1 = gdist.shard_rows(M, world, rank)
+        rows_dev = torch.from_numpy(wq).cuda()
+        shard = device.Weight.from_device(O.Q4_0, rows_dev, K, row_begin=r0, row_end=r1)
+        runner = gdist.RowSplitMulMat(shard, N, world, rank, M_total=M, chunks=chunks)   # HIP compute + HIP re-layout
+        xd = torch.from_numpy(x).cuda()
+        got = runner.step(xd).clone()
+        got2 = runner.step(xd)                  # second step reuses the buffers
+        # the unsplit matrix on this GPU, over the same column chunks (the kernel form is a function of a call's N and K,
+        # never of M: a row shard is bitwise a column slice of the unsplit result of the same call)
+        Wfull = device.Weight.from_device(O.Q4_0, rows_dev, K)
+        full = torch.cat([device.mul_mat(Wfull, xd[a:b]) for (a, b) in runner._chunk_bounds()], dim=0)
+        ref = O.mul_mat(O.Q4_0, wq, x, M, K, N)[0, 0]
+        rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+        close = bool(np.all(np.abs(got.cpu().numpy() - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms))
+        out_q.put((rank, bool(torch.equal(got, full)) and bool(torch.equal(got2, full)), close, tuple(got.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,chunks", [(300, 256, 70, 1), (515, 512, 130, 4), (1000, 128, 1, 1)])
+def test_row_split_world2_on_one_gpu_is_bitwise_the_unsplit_result(M, K, N, chunks):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, M, K, N, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, same, close, shape in results:
+        assert shape == (N, M)
+        assert close, f"rank {rank}: gathered result is off the oracle"
+        assert same, f"rank {rank}: gathered result is not bitwise the unsplit HIP result"
