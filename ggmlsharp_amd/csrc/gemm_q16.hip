@@ -479,7 +479,13 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (chosen from N and K only, see gemm_qmx.hip)
     // batches up to 128 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip)
     static const bool old128 = getenv("GGML_HIP_Q16_OLD128") != nullptr;   // developer A/B switch
-    if (N <= 128 && w->nbk >= 16 && !old128) return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
+    if (N <= 128 && w->nbk >= 16 && !old128) {
+        // same split on 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip); not for Q4_1 (registers)
+        static const int tile = [] { const char *e = getenv("GGML_HIP_Q16_TILE"); return e ? atoi(e) : 0; }();   // A/B: 1 = 128-row, 2 = 32-row
+        if constexpr (TYPE != GGML_TYPE_Q4_1)
+            if (tile == 1 || (tile != 2 && ((w->M + 127) / 128) * ((N + 63) / 64) >= 80)) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st);
+        return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
+    }
     if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
     if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
     return launch_cfg<TYPE, 2, 2, 2, 1, 4>(w, p, N, dst, ldd, st);

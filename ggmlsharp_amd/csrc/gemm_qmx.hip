@@ -422,7 +422,15 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // computes bit for bit what the unsplit matrix does (the summation tree of an element is a function of the kernel form).
     // Batches up to 128 rows: 32-row weight tiles with K split four ways inside the workgroup -- M / 32 x N / 64 workgroups of
     // 4 waves instead of M / 128 x N / 64 of 8 (4096 x 4096 x 64 covered 32 CUs).
-    if (N <= 128 && w->nbk >= 16 && var != 3 && var != 9) return launch_cfg<TYPE, 1, 2, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+    if (N <= 128 && w->nbk >= 16 && var != 3 && var != 9) {
+        // The same four-way split -- hence the same summation tree, bit for bit -- on 128-row tiles of 16 waves where those
+        // cover the chip (M = 32000, N = 64: 55 -> 35 us; M = 4096: 13 us on 32-row tiles, 23 us on these).  Q4_0 only: the
+        // 128 registers of a 1024-thread workgroup do not hold Q4_1's min-term operands.
+        const int64_t tn64 = (N + 63) / 64;
+        if constexpr (TYPE == GGML_TYPE_Q4_0)
+            if ((var == 12 || (var != 13 && tm128 * tn64 >= 80))) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+        return launch_cfg<TYPE, 1, 2, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+    }
     if (N <= 512 && w->nbk >= 8 && var != 3) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
     if (tm128 * tn128 >= 384) return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);   // 128 x 128, 4 tiles per wave
     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
