@@ -458,7 +458,8 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     if (!d_src1 || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
     if (!is_q(w->type)) {
-        if (dense16_serves(w, N) && d_work && work_bytes >= ggml_hip_mul_mat_work_size(w->type, w->K, N)) {
+        if (dense16_serves(w, N) && d_work && work_bytes >= ggml_hip_mul_mat_work_size(w->type, w->K, N) && ld1 % 4 == 0 &&
+            ((uintptr_t)d_src1 & 15) == 0) {      // (the INIT kernel reads src1 rows in 16-byte pieces)
             HIP_TRY(launch_dense16_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));       // INIT: src1 -> Half (Ggml.cs:6362-6379)
             HIP_TRY(launch_dense16(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
             return GGML_HIP_OK;

@@ -75,11 +75,80 @@ __global__ __launch_bounds__(256) void dense_kernel(const void *__restrict__ wv,
     }
 }
 
+// ---- N <= 8: mat-vec, bandwidth-bound.  One wave per weight row: lanes stride K in 16-byte pieces, f32 products and f32
+//      partial sums per lane (the reference sums the same products in f64, Ggml.cs:2633 / 2644: ~1e-6 relative at these
+//      K), a fixed xor-shuffle tree across the wave.  F16 weights: src1 is rounded to Half first (Ggml.cs:6369).  4 rows per
+//      workgroup; the src1 rows are re-read from L2 by every wave (N * K * 4 bytes, small next to the weight stream). ----
+template <bool W_F16, int NC>
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const void *__restrict__ wv, const float *__restrict__ x, float *__restrict__ dst,
+                                                        int64_t M, int N, int64_t K, int64_t ld1, int64_t ldd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;                                      // uniform per wave
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+    constexpr int E = W_F16 ? 8 : 4;                         // weight elements per 16-byte piece
+    const int64_t Kv = K / E * E;
+    for (int64_t k = (int64_t)lane * E; k < Kv; k += 64 * E) {
+        float wf[E];
+        if (W_F16) {
+            const uint4 q = *(const uint4 *)((const __half *)wv + m * K + k);
+            const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wf[2 * e + 0] = __half2float(__ushort_as_half((unsigned short)(u[e] & 0xFFFFu)));
+                wf[2 * e + 1] = __half2float(__ushort_as_half((unsigned short)(u[e] >> 16)));
+            }
+        } else {
+            const float4 q = *(const float4 *)((const float *)wv + m * K + k);
+            wf[0] = q.x; wf[1] = q.y; wf[2] = q.z; wf[3] = q.w;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float *xp = x + (int64_t)(c < N ? c : N - 1) * ld1 + k;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float xe = xp[e];
+                if (W_F16) xe = __half2float(__float2half_rn(xe));
+                acc[c] = fmaf(wf[e], xe, acc[c]);
+            }
+        }
+    }
+    if (lane == 0)                                           // K tail (K not a multiple of the piece)
+        for (int64_t k = Kv; k < K; ++k) {
+            const float we = W_F16 ? __half2float(((const __half *)wv)[m * K + k]) : ((const float *)wv)[m * K + k];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float xe = x[(int64_t)(c < N ? c : N - 1) * ld1 + k];
+                if (W_F16) xe = __half2float(__float2half_rn(xe));
+                acc[c] = fmaf(we, xe, acc[c]);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float v = acc[c];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if (lane == 0 && c < N) dst[(int64_t)c * ldd + m] = v;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
+    // mat-vec form: rows of the resident copy are K elements apart, so 16-byte pieces need K % 8 (f16) / K % 4 (f32) == 0
+    const bool f16 = w->type == GGML_TYPE_F16;
+    if (N <= 8 && w->K % (f16 ? 8 : 4) == 0 && w->K >= 512) {
+        dim3 g((unsigned)((w->M + 3) / 4));
+#define DG(F, NC) dense_gemv_kernel<F, NC><<<g, 256, 0, st>>>(w->dense, x, dst, w->M, (int)N, w->K, ld1, ldd)
+        if (f16) { if (N <= 1) DG(true, 1); else if (N <= 2) DG(true, 2); else if (N <= 4) DG(true, 4); else DG(true, 8); }
+        else { if (N <= 1) DG(false, 1); else if (N <= 2) DG(false, 2); else if (N <= 4) DG(false, 4); else DG(false, 8); }
+#undef DG
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
     if (w->type == GGML_TYPE_F16)
         dense_kernel<true><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);

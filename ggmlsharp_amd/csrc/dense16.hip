@@ -231,7 +231,9 @@ bool dense16_serves(const ggml_hip_weight *w, int64_t N) {
     if (w->type != GGML_TYPE_F16 || !w->p16) return false;
     const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
     if ((Kpad / 8 + DENSE16_SPARE_PANELS) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (Kpad / 8) * Npad * 16 > 0xFFFFFFFFull) return false;
-    return ((w->M + 127) / 128) * ((N + 127) / 128) >= 256;
+    // the small-tile kernel of dense.hip reaches ~30 TFLOP/s: from 8 tiles of 128 x 128 on the matrix-core kernel is ahead even
+    // on a partly filled chip (4096 x 4096 x 512: 588 us there); batches of up to 8 rows go to the mat-vec form of dense.hip
+    return N > 8 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 8;
 }
 
 hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st) {
