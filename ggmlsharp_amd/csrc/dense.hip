@@ -17,7 +17,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #define DK 32    // k per stage
 #define DLD 33   // padded LDS row (floats): column reads hit 32 distinct banks
 
-template <bool W_F16>
+// VEC: K % 8 == 0, ld1 % 4 == 0 and src1 16-byte aligned -- a thread's 8 consecutive k are two 16-byte loads per operand
+// (one for f16 weights) instead of 8 scalar ones (the scalar form spends its time in the texture addresser: 28 -> 70 TFLOP/s)
+template <bool W_F16, bool VEC>
 __global__ __launch_bounds__(256) void dense_kernel(const void *__restrict__ wv, const float *__restrict__ x,
                                                    float *__restrict__ dst, int64_t M, int64_t N, int64_t K, int64_t ld1,
                                                    int64_t ldd) {
@@ -37,6 +39,24 @@ __global__ __launch_bounds__(256) void dense_kernel(const void *__restrict__ wv,
 
     for (int64_t k0 = 0; k0 < K; k0 += DK) {
         float xv[8], wv8[8];
+        if constexpr (VEC) {
+            const float4 x0 = *(const float4 *)(xp + k0 + sk), x1 = *(const float4 *)(xp + k0 + sk + 4);
+            xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+            if (W_F16) {
+                const uint4 q = *(const uint4 *)((const __half *)wv + wr * K + k0 + sk);
+                const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wv8[2 * e + 0] = __half2float(__ushort_as_half((unsigned short)(u[e] & 0xFFFFu)));
+                    wv8[2 * e + 1] = __half2float(__ushort_as_half((unsigned short)(u[e] >> 16)));
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = __half2float(__float2half_rn(xv[e]));   // (Half)src1, Ggml.cs:6369
+            } else {
+                const float4 w0 = *(const float4 *)((const float *)wv + wr * K + k0 + sk), w1 = *(const float4 *)((const float *)wv + wr * K + k0 + sk + 4);
+                wv8[0] = w0.x; wv8[1] = w0.y; wv8[2] = w0.z; wv8[3] = w0.w; wv8[4] = w1.x; wv8[5] = w1.y; wv8[6] = w1.z; wv8[7] = w1.w;
+            }
+        } else
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t k = k0 + sk + e;
@@ -141,18 +161,30 @@ hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int
     if (N <= 0 || w->M <= 0) return hipSuccess;
     // mat-vec form: rows of the resident copy are K elements apart, so 16-byte pieces need K % 8 (f16) / K % 4 (f32) == 0
     const bool f16 = w->type == GGML_TYPE_F16;
-    if (N <= 8 && w->K % (f16 ? 8 : 4) == 0 && w->K >= 512) {
+    // up to 16 rows: passes of 8 columns over the weights (4096 x 4096 x 16: two passes 53 us, the tile kernel below 121 us;
+    // at 32 rows and M = 11008 the tile kernel is ahead, 121 against 243 us)
+    if (N <= 16 && w->K % (f16 ? 8 : 4) == 0 && w->K >= 512) {
         dim3 g((unsigned)((w->M + 3) / 4));
-#define DG(F, NC) dense_gemv_kernel<F, NC><<<g, 256, 0, st>>>(w->dense, x, dst, w->M, (int)N, w->K, ld1, ldd)
-        if (f16) { if (N <= 1) DG(true, 1); else if (N <= 2) DG(true, 2); else if (N <= 4) DG(true, 4); else DG(true, 8); }
-        else { if (N <= 1) DG(false, 1); else if (N <= 2) DG(false, 2); else if (N <= 4) DG(false, 4); else DG(false, 8); }
+        for (int64_t c0 = 0; c0 < N; c0 += 8) {
+            const int n = (int)(N - c0 < 8 ? N - c0 : 8);
+            const float *xc = x + c0 * ld1;
+            float *dc = dst + c0 * ldd;
+#define DG(F, NC) dense_gemv_kernel<F, NC><<<g, 256, 0, st>>>(w->dense, xc, dc, w->M, n, w->K, ld1, ldd)
+            if (f16) { if (n <= 1) DG(true, 1); else if (n <= 2) DG(true, 2); else if (n <= 4) DG(true, 4); else DG(true, 8); }
+            else { if (n <= 1) DG(false, 1); else if (n <= 2) DG(false, 2); else if (n <= 4) DG(false, 4); else DG(false, 8); }
 #undef DG
+        }
         return hipGetLastError();
     }
     dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
-    if (w->type == GGML_TYPE_F16)
-        dense_kernel<true><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
-    else
-        dense_kernel<false><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+    // K % 32 == 0 keeps every 8-element piece of a stage inside the row
+    const bool vec = w->K % DK == 0 && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    if (w->type == GGML_TYPE_F16) {
+        if (vec) dense_kernel<true, true><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+        else dense_kernel<true, false><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+    } else {
+        if (vec) dense_kernel<false, true><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+        else dense_kernel<false, false><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
+    }
     return hipGetLastError();
 }

@@ -321,7 +321,7 @@ def test_mul_mat_extreme_block_values(dev):
 @pytest.mark.parametrize("t", [O.F32, O.F16])
 def test_mul_mat_dense_matches_oracle(dev, t):
     for (M, K, N) in ((64, 128, 256), (1, 32, 1), (70, 100, 33), (256, 4096, 1),  # first = BASELINE config 1
-                      (300, 4096, 3), (129, 1024, 8), (100, 520, 5), (77, 516, 2),     # mat-vec form (K % 8 / K % 4, K >= 512), else the tile kernel
+                      (300, 4096, 3), (129, 1024, 8), (100, 520, 5), (77, 516, 2), (90, 1024, 19), (64, 512, 32),     # mat-vec form (K % 8 / K % 4, K >= 512), else the tile kernel
                       (1024, 512, 200), (1000, 520, 130), (2050, 96, 64)):             # F16: the matrix-core kernel on partly filled grids, ragged M / N / K
         w = _rand((M, K))
         x = _rand((N, K))
