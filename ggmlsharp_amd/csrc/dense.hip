@@ -95,34 +95,41 @@ __global__ __launch_bounds__(256) void dense_kernel(const void *__restrict__ wv,
     }
 }
 
-// ---- N <= 8: mat-vec, bandwidth-bound.  One wave per weight row: lanes stride K in 16-byte pieces, f32 products and f32
-//      partial sums per lane (the reference sums the same products in f64, Ggml.cs:2633 / 2644: ~1e-6 relative at these
-//      K), a fixed xor-shuffle tree across the wave.  F16 weights: src1 is rounded to Half first (Ggml.cs:6369).  4 rows per
-//      workgroup; the src1 rows are re-read from L2 by every wave (N * K * 4 bytes, small next to the weight stream). ----
-template <bool W_F16, int NC>
+// ---- N <= 8 (more rows in passes of 8): mat-vec, bandwidth-bound.  One wave per DGR weight rows: lanes stride K in 16-byte
+//      pieces, f32 products and f32 partial sums per lane (the reference sums the same products in f64, Ggml.cs:2633 / 2644:
+//      ~1e-6 relative at these K), a fixed xor-shuffle tree across the wave.  F16 weights: src1 is rounded to Half first
+//      (Ggml.cs:6369).  A piece of src1 is loaded once for the wave's DGR rows (with one row per wave the L2 reads of src1
+//      were 2 .. 16 x the weight stream: 32000 x 4096 f16, N = 8: 146 us). ----
+template <bool W_F16, int NC, int DGR>                       // DGR rows per wave: 1 for one or two columns (more waves in flight), 4 above
 __global__ __launch_bounds__(256) void dense_gemv_kernel(const void *__restrict__ wv, const float *__restrict__ x, float *__restrict__ dst,
                                                         int64_t M, int N, int64_t K, int64_t ld1, int64_t ldd) {
     const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;                                      // uniform per wave
-    float acc[NC];
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * DGR;
+    if (m0 >= M) return;                                     // uniform per wave
+    float acc[DGR][NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+    for (int r = 0; r < DGR; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[r][c] = 0.0f;
     constexpr int E = W_F16 ? 8 : 4;                         // weight elements per 16-byte piece
     const int64_t Kv = K / E * E;
     for (int64_t k = (int64_t)lane * E; k < Kv; k += 64 * E) {
-        float wf[E];
-        if (W_F16) {
-            const uint4 q = *(const uint4 *)((const __half *)wv + m * K + k);
-            const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+        float wf[DGR][E];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                wf[2 * e + 0] = __half2float(__ushort_as_half((unsigned short)(u[e] & 0xFFFFu)));
-                wf[2 * e + 1] = __half2float(__ushort_as_half((unsigned short)(u[e] >> 16)));
+        for (int r = 0; r < DGR; ++r) {
+            const int64_t m = m0 + r < M ? m0 + r : M - 1;   // rows past the end repeat the last one (not stored)
+            if (W_F16) {
+                const uint4 q = *(const uint4 *)((const __half *)wv + m * K + k);
+                const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wf[r][2 * e + 0] = __half2float(__ushort_as_half((unsigned short)(u[e] & 0xFFFFu)));
+                    wf[r][2 * e + 1] = __half2float(__ushort_as_half((unsigned short)(u[e] >> 16)));
+                }
+            } else {
+                const float4 q = *(const float4 *)((const float *)wv + m * K + k);
+                wf[r][0] = q.x; wf[r][1] = q.y; wf[r][2] = q.z; wf[r][3] = q.w;
             }
-        } else {
-            const float4 q = *(const float4 *)((const float *)wv + m * K + k);
-            wf[0] = q.x; wf[1] = q.y; wf[2] = q.z; wf[3] = q.w;
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -131,27 +138,33 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const void *__restrict_
             for (int e = 0; e < E; ++e) {
                 float xe = xp[e];
                 if (W_F16) xe = __half2float(__float2half_rn(xe));
-                acc[c] = fmaf(wf[e], xe, acc[c]);
+#pragma unroll
+                for (int r = 0; r < DGR; ++r) acc[r][c] = fmaf(wf[r][e], xe, acc[r][c]);
             }
         }
     }
     if (lane == 0)                                           // K tail (K not a multiple of the piece)
-        for (int64_t k = Kv; k < K; ++k) {
-            const float we = W_F16 ? __half2float(((const __half *)wv)[m * K + k]) : ((const float *)wv)[m * K + k];
+        for (int64_t k = Kv; k < K; ++k)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float xe = x[(int64_t)(c < N ? c : N - 1) * ld1 + k];
-                if (W_F16) xe = __half2float(__float2half_rn(xe));
-                acc[c] = fmaf(we, xe, acc[c]);
+            for (int r = 0; r < DGR; ++r) {
+                const int64_t m = m0 + r < M ? m0 + r : M - 1;
+                const float we = W_F16 ? __half2float(((const __half *)wv)[m * K + k]) : ((const float *)wv)[m * K + k];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float xe = x[(int64_t)(c < N ? c : N - 1) * ld1 + k];
+                    if (W_F16) xe = __half2float(__float2half_rn(xe));
+                    acc[r][c] = fmaf(we, xe, acc[r][c]);
+                }
             }
+#pragma unroll
+    for (int r = 0; r < DGR; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float v = acc[r][c];
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+            if (lane == 0 && c < N && m0 + r < M) dst[(int64_t)c * ldd + m0 + r] = v;
         }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        float v = acc[c];
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-        if (lane == 0 && c < N) dst[(int64_t)c * ldd + m] = v;
-    }
 }
 
 }  // namespace
@@ -164,12 +177,11 @@ hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int
     // up to 16 rows: passes of 8 columns over the weights (4096 x 4096 x 16: two passes 53 us, the tile kernel below 121 us;
     // at 32 rows and M = 11008 the tile kernel is ahead, 121 against 243 us)
     if (N <= 16 && w->K % (f16 ? 8 : 4) == 0 && w->K >= 512) {
-        dim3 g((unsigned)((w->M + 3) / 4));
         for (int64_t c0 = 0; c0 < N; c0 += 8) {
             const int n = (int)(N - c0 < 8 ? N - c0 : 8);
             const float *xc = x + c0 * ld1;
             float *dc = dst + c0 * ldd;
-#define DG(F, NC) dense_gemv_kernel<F, NC><<<g, 256, 0, st>>>(w->dense, xc, dc, w->M, n, w->K, ld1, ldd)
+#define DG(F, NC) dense_gemv_kernel<F, NC, (NC <= 2 ? 1 : 4)><<<dim3((unsigned)((w->M + 4 * (NC <= 2 ? 1 : 4) - 1) / (4 * (NC <= 2 ? 1 : 4)))), 256, 0, st>>>(w->dense, xc, dc, w->M, n, w->K, ld1, ldd)
             if (f16) { if (n <= 1) DG(true, 1); else if (n <= 2) DG(true, 2); else if (n <= 4) DG(true, 4); else DG(true, 8); }
             else { if (n <= 1) DG(false, 1); else if (n <= 2) DG(false, 2); else if (n <= 4) DG(false, 4); else DG(false, 8); }
 #undef DG

@@ -7,7 +7,8 @@ TYPES = {"q4_0": 2, "q4_1": 3, "q5_0": 6, "q8_0": 8, "q4_2": 4, "q5_1": 7, "f16"
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(TYPES)
 for name in names:
     t = TYPES[name]
-    for (M, K) in ((4096, 4096), (11008, 4096)):
+    shapes = [tuple(int(v) for v in s.split("x")) for s in sys.argv[2].split(",")] if len(sys.argv) > 2 else [(4096, 4096), (11008, 4096)]
+    for (M, K) in shapes:
         w = torch.randn((M, K), device="cuda")
         if t == 1:
             W = device.Weight.from_device(t, w.half().view(torch.uint8).view(M, -1), K)
