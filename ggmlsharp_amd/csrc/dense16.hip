@@ -16,6 +16,7 @@
 // workgroups per CU, activations by buffer_load ... lds DMA in double-buffered stages of 8 k-steps, one barrier per stage.
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -95,19 +96,26 @@ struct Cfg {
     static constexpr int P = NT / TN;
     static_assert(NT % TN == 0 && (KS * 2) % P == 0, "chunk decomposition");
     static constexpr int ROUNDS = KS * 2 * TN / NT;
-    static_assert(ROUNDS <= KS * WNT, "one DMA piece per n-tile step");
+    // DMA pieces per n-tile step: all of them are issued before the drain point (k-step KS - 2)
+    static constexpr int PP = (ROUNDS + (KS - 2) * WNT - 1) / ((KS - 2) * WNT);
+    static_assert(PP <= 2, "at most two DMA pieces per n-tile step");
 };
 
-template <int WMT, int WNT, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64, 2)
+// KSP = 1 | 2 | 4: K split inside the workgroup as in gemm_qmx.hip -- KSP wave groups take alternate stages (own stage buffers)
+// and add their tiles through LDS in group order at the end; for batches that leave most of the chip idle otherwise.
+template <int WMT, int WNT, int WGM, int WGN, int KSP>
+__global__ __launch_bounds__(WGM * WGN * 64 * KSP, 2)
 void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict__ apan, float *__restrict__ dst, int M, int N, int Mpad,
                     int Npad, int nstages, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes) {
     using C = Cfg<WMT, WNT, WGM, WGN>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave_all / (WGM * WGN), wave = wave_all % (WGM * WGN);   // K-split group, wave inside it
+    const int tid = wave * 64 + lane;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wn = wave / WGM, wm_ = wave % WGM;
+    uint8_t *const gsm = smem + grp * C::TOTAL;
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
@@ -127,9 +135,9 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
     const uint32_t a_pan = (uint32_t)(Npad * 16);
     const uint32_t voffA = (uint32_t)(((tid / C::TN) * Npad + n0 + tid % C::TN) * 16);
     const rsrc_t rA = make_rsrc(apan, a_bytes);
-    auto dma_piece = [&](int s, auto pc) {
+    auto dma_piece = [&](int s, int buf, auto pc) {           // stage s of K -> stage buffer buf of this group
         constexpr int i = decltype(pc)::value;
-        uint8_t *sp = smem + (s & 1) * C::STAGE;
+        uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voffA, ((uint32_t)s * KS * 2 + C::P * i) * a_pan);
     };
 
@@ -145,13 +153,16 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
             bq[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(voffW + 512u * i), (int)((uint32_t)gstep * 2 * w_pan), 0);
     };
 
-    auto compute = [&](int s) {
-        const uint8_t *sA = smem + (s & 1) * C::STAGE + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
+    auto compute = [&](int s, int buf) {
+        const uint8_t *sA = gsm + (buf & 1) * C::STAGE + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         static_for<KS>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
             static_for<WNT>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (ks * WNT + j < C::ROUNDS) dma_piece(s + 1, std::integral_constant<int, ks * WNT + j>{});
+                static_for<C::PP>([&](auto uc) {
+                    constexpr int pc = C::PP * (ks * WNT + j) + decltype(uc)::value;
+                    if constexpr (pc < C::ROUNDS) dma_piece(s + KSP, buf + 1, std::integral_constant<int, pc>{});
+                });
                 const f16x8 af = *(const f16x8 *)(sA + (ks * 2 * C::TN + 32 * j) * 16);
 #pragma unroll
                 for (int i = 0; i < WMT; ++i)
@@ -161,20 +172,52 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
 #ifndef D16_NODRAIN   /* timing ablation only: without the drain the kernel races */
             if constexpr (ks == KS - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            load_b(s * KS + ks + RING, std::integral_constant<int, ks % RING>{});
+            // this group's next k-steps: the rest of the stage, then its next stage s + KSP
+            load_b(ks + RING < KS ? s * KS + ks + RING : (s + KSP) * KS + (ks + RING - KS), std::integral_constant<int, ks % RING>{});
         });
     };
 
-    static_for<C::ROUNDS>([&](auto pc) { dma_piece(0, pc); });
-    static_for<RING>([&](auto rc) { load_b(decltype(rc)::value, rc); });
+    static_assert(RING <= KS, "weight look-ahead stays within two stages of a group");
+    static_for<C::ROUNDS>([&](auto pc) { dma_piece(grp, 0, pc); });
+    static_for<RING>([&](auto rc) { load_b(grp * KS + decltype(rc)::value, rc); });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int s = 0; s < nstages; ++s) {
-        compute(s);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int niter = (nstages + KSP - 1) / KSP;              // every wave passes the same number of barriers
+    for (int it = 0; it < niter; ++it) {
+        const int s = it * KSP + grp;
+        if (KSP == 1 || s < nstages) compute(s, it);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the drain inside compute, again for a skipped stage)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+
+    // ---- K split: groups 1 .. KSP-1 hand their tiles to group 0 through LDS; group 0 adds them in group order ----
+    if constexpr (KSP > 1) {
+        constexpr int NTILE = WMT * WNT, GRP_FLOATS = WGM * WGN * NTILE * 16 * 64;
+        static_assert((KSP - 1) * GRP_FLOATS * 4 <= KSP * C::TOTAL, "K-split exchange fits the stage buffers");
+        float *xch = (float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
+        if (grp != 0) {
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        xch[(size_t)(grp - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64] = v;
+                    }
+        }
+        __syncthreads();
+        if (grp != 0) return;
+#pragma unroll
+        for (int g = 1; g < KSP; ++g)
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[(size_t)(g - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64];
     }
 
     // dst[n][m] (Ggml.cs:6692-6697): D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]
@@ -199,19 +242,19 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
         }
 }
 
-template <int WMT, int WNT, int WGM, int WGN>
+template <int WMT, int WNT, int WGM, int WGN, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<WMT, WNT, WGM, WGN>;
-    auto kern = dense16_kernel<WMT, WNT, WGM, WGN>;
+    auto kern = dense16_kernel<WMT, WNT, WGM, WGN, KSP>;
     // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
     if (attr != hipSuccess) return attr;
     if (w->Mpad % C::TM != 0 || Npad % C::TN != 0) return hipErrorInvalidValue;
     const int64_t Kpad = dense16_kpad(w->K);
     const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
     const uint64_t w_bytes = (uint64_t)(Kpad / 8 + DENSE16_SPARE_PANELS) * w->Mpad * 16, a_bytes = (uint64_t)(Kpad / 8) * Npad * 16;
     if (w_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull || (uint64_t)C::TN * ldd * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
-    kern<<<dim3((unsigned)(tiles_m * tiles_n)), C::NT, C::TOTAL, st>>>(w->p16, apan, dst, (int)w->M, (int)N, (int)w->Mpad, (int)Npad,
+    kern<<<dim3((unsigned)(tiles_m * tiles_n)), C::NT * KSP, C::TOTAL * KSP, st>>>(w->p16, apan, dst, (int)w->M, (int)N, (int)w->Mpad, (int)Npad,
                                                                      (int)(Kpad / (16 * KS)), (int)ldd, tiles_m, tiles_n, (uint32_t)w_bytes,
                                                                      (uint32_t)a_bytes);
     return hipGetLastError();
@@ -231,9 +274,10 @@ bool dense16_serves(const ggml_hip_weight *w, int64_t N) {
     if (w->type != GGML_TYPE_F16 || !w->p16) return false;
     const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
     if ((Kpad / 8 + DENSE16_SPARE_PANELS) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (Kpad / 8) * Npad * 16 > 0xFFFFFFFFull) return false;
-    // the small-tile kernel of dense.hip reaches ~30 TFLOP/s: from 8 tiles of 128 x 128 on the matrix-core kernel is ahead even
-    // on a partly filled chip (4096 x 4096 x 512: 588 us there); batches of up to 8 rows go to the mat-vec form of dense.hip
-    return N > 8 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 8;
+    // Every F16 shape with more than 4 src1 rows (chosen from N alone, so that a row shard of any height runs the arithmetic of
+    // the unsplit matrix): the tile kernel of dense.hip took 588 us for 4096 x 4096 x 512.  Up to 4 rows: the mat-vec form of
+    // dense.hip (5 .. 8 rows: 22 us here against 25 us there at 4096 x 4096, 46 against 108 us at 32000 x 4096).
+    return N > 4;
 }
 
 hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st) {
@@ -246,5 +290,19 @@ hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1
 hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     const int64_t Npad = pad_act(N);
     if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    // batches up to 128 rows: K split four ways inside the workgroup (fixed by N and K: same summation tree for a row shard), on
+    // 32-row tiles, or on 128-row tiles of 16 waves where those cover the chip
+    static const int var = [] { const char *e = getenv("GGML_HIP_D16_TILE"); return e ? atoi(e) : 0; }();   // developer A/B switch
+    const int64_t nst = dense16_kpad(w->K) / (16 * KS);
+    if (N <= 128 && nst >= 8 && var != 9) {
+        if (var == 1 || (var != 2 && ((w->M + 127) / 128) * ((N + 63) / 64) >= 80)) return launch_cfg<1, 2, 4, 1, 4>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+        return launch_cfg<1, 2, 1, 1, 4>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    }
+    // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (as gemm_qmx.hip)
+    if (N <= 512 && nst >= 4 && var != 9 && var != 8) {
+        // the same two-way split on 128 x 128 tiles where those cover the chip
+        if (var == 7 || (var != 6 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 128)) return launch_cfg<2, 2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+        return launch_cfg<1, 2, 4, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    }
     return launch_cfg<2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
 }

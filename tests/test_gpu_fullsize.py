@@ -138,6 +138,28 @@ def test_small_batch_tile_forms_agree_bitwise(dev):
     W.free()
 
 
+@pytest.mark.parametrize("N", [100, 300])
+def test_dense_f16_tile_forms_agree_bitwise(dev, N):
+    """F16 weights: the K split of a batch (four ways up to 128 rows, two ways up to 512) is fixed by N and K, the tile shape by
+    the number of tiles -- a 2048-row shard and the 16384-row matrix run different tiles and must agree bit for bit."""
+    M, K = 16384, 2048
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3 + N)
+    w = torch.randn((M, K), generator=g, device="cuda").half()
+    x = torch.randn((N, K), generator=g, device="cuda")
+    rows = w.view(torch.uint8).view(M, -1)
+    W = dev.Weight.from_device(1, rows, K)
+    full = dev.mul_mat(W, x)
+    ref = x.half().double() @ w.double().T
+    err = (full.double() - ref).abs()
+    assert (err.max() / ref.pow(2).mean().sqrt()).item() < 1e-4
+    for (r0, r1) in ((0, 2048), (9000, 9700)):
+        Ws = dev.Weight.from_device(1, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1])
+        Ws.free()
+    W.free()
+
+
 def test_fullsize_byte_roundtrips(dev):
     M, K = 4096, 4096
     for t in (Q4_0, Q5_0, Q8_0):

@@ -322,7 +322,8 @@ def test_mul_mat_extreme_block_values(dev):
 def test_mul_mat_dense_matches_oracle(dev, t):
     for (M, K, N) in ((64, 128, 256), (1, 32, 1), (70, 100, 33), (256, 4096, 1),  # first = BASELINE config 1
                       (300, 4096, 3), (129, 1024, 8), (100, 520, 5), (77, 516, 2), (90, 1024, 19), (64, 512, 32),     # mat-vec form (K % 8 / K % 4, K >= 512), else the tile kernel
-                      (1024, 512, 200), (1000, 520, 130), (2050, 96, 64)):             # F16: the matrix-core kernel on partly filled grids, ragged M / N / K
+                      (1024, 512, 200), (1000, 520, 130), (2050, 96, 64),             # F16: the matrix-core kernel on partly filled grids, ragged M / N / K
+                      (1030, 1024, 64), (1500, 2080, 100), (11000, 1024, 33)):        # F16, N <= 128: four-way K split on 32-row / 128-row tiles
         w = _rand((M, K))
         x = _rand((N, K))
         wraw = w if t == O.F32 else w.astype(np.float16).view(np.uint16)
