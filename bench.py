@@ -129,6 +129,28 @@ def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
     return res
 
 
+def dense_config(device, wtype, M, K, N, iters):
+    """The dense mul_mat case (F16 / F32 weights): whole call (INIT + COMPUTE), matrix-pipe roofline."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    w = torch.randn((M, K), generator=g, device="cuda", dtype=torch.float32)
+    raw = (w.half() if wtype == 1 else w).contiguous().view(torch.uint8).view(M, -1)
+    W = device.Weight.from_device(wtype, raw, K)
+    x = torch.randn((N, K), generator=g, device="cuda", dtype=torch.float32)
+    out = torch.empty((N, M), device="cuda", dtype=torch.float32)
+    work = device.alloc_work(wtype, K, N)
+    stream = torch.cuda.current_stream()
+    for _ in range(3):
+        device.mul_mat(W, x, out=out, work=work)
+    t = event_time_ms(lambda: device.mul_mat(W, x, out=out, work=work), iters, stream)
+    tf = 2.0 * M * K * N / t / 1e9
+    peak = 2500.0 if wtype == 1 else 157.0      # MI355X_MICROARCH.md: dense f16 MFMA ~2.5 PF; f32 matrix 157 TF
+    W.free()
+    return {"workload": f"{'F16' if wtype == 1 else 'F32'} mul_mat M={M} K={K} N={N} (INIT + COMPUTE)", "ms_per_step": round(t, 5),
+            "gflops": round(tf * 1e3, 1),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +272,9 @@ def main():
                 "q8_0_ffn512": side_config(device, 4096, 11008, 512, copies=6, iters=30, qtype=Q8_0),
                 "q5_0_ffn512": side_config(device, 4096, 11008, 512, copies=8, iters=30, qtype=Q5_0),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=20),
+                # the dense case of the path (north_star: MFMA utilisation for the dense f16 / f32 mul_mat)
+                "dense_f16": dense_config(device, 1, 4096, 4096, 4096, iters=20),
+                "dense_f32": dense_config(device, 0, 4096, 4096, 4096, iters=5),
             }
             for k in ("batch1_M32000",):
                 out["other_configs"][k]["roofline"] = {"bound": "hbm", "achieved": out["other_configs"][k]["algorithmic_GBs"],
