@@ -1,5 +1,5 @@
 // dense16.hip -- K10b: dense f16 x f32 mul_mat (ggml_compute_forward_mul_mat_f16_f32, Ggml.cs:6180-6438) on the f16
-// matrix cores, for shapes that fill the chip.
+// matrix cores, for every shape with more than 4 src1 rows (fewer: the mat-vec form of dense.hip).
 //
 // The reference's INIT phase rounds src1 to Half (Ggml.cs:6362-6379) and ggml_vec_dot_f16 (Ggml.cs:2642-2651) sums
 // (float)h * (float)h in f64.  Here: convert_act_f16 does the same rounding (round-to-nearest-even, as (Half)x) into a
@@ -269,7 +269,7 @@ hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st) {
     return hipGetLastError();
 }
 
-// true when the f16 MFMA kernel serves this shape (a full grid of its smaller tile); else dense.hip does
+// true when the f16 MFMA kernel serves this shape; else dense.hip does
 bool dense16_serves(const ggml_hip_weight *w, int64_t N) {
     if (w->type != GGML_TYPE_F16 || !w->p16) return false;
     const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
