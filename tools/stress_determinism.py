@@ -11,7 +11,7 @@ from ggmlsharp_amd._lib import lib  # noqa: E402
 device.init(0)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
-SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29), (4096, 4096, 64), (777, 11008, 128)]
+SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29), (4096, 4096, 64), (777, 11008, 128), (16384, 1024, 100)]
 nbad = 0
 for (M, K, N) in SHAPES:
     for t in TYPES:
@@ -47,7 +47,7 @@ for (M, K, N) in SHAPES:
             del wd, xs, first
 lib().ggml_hip_debug_force_gemm(0)
 # dense weights: F16 (dense16.hip on full grids, dense.hip otherwise) and F32 (dense.hip)
-for (M, K, N) in ((4096, 4096, 4096), (2048, 1000, 300), (512, 4096, 7)):
+for (M, K, N) in ((4096, 4096, 4096), (2048, 1000, 300), (512, 4096, 7), (4096, 4096, 64), (16384, 2048, 100), (4096, 2048, 300), (3000, 4096, 3)):
     for t, dt in ((1, torch.float16), (0, torch.float32)):
         g = torch.Generator(device="cuda"); g.manual_seed(M + N + t)
         w = torch.randn((M, K), generator=g, device="cuda").to(dt)
