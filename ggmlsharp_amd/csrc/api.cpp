@@ -48,8 +48,8 @@ bool wq_ok(int t) {
 }
 bool weight_type_ok(int t) { return wq_ok(t) || t == GGML_TYPE_F32 || t == GGML_TYPE_F16; }
 // src1 rows up to which the mat-vec kernel serves a type (two-step form above GEMV_MAX_N): the types with small-batch MFMA
-// configurations leave it at 8, the two that only have the int8 kernel's 64 x 64 tiles behind them stay on it up to 16
-int64_t gemv_rows_max(int t) { return (t == GGML_TYPE_Q4_2 || t == GGML_TYPE_Q5_1) ? GEMV_WIDE_MAX_N : GEMV_MAX_N; }
+// configurations leave it at 8; Q4_2, which only has the int8 kernel's 64 x 64 tiles behind it, stays on it up to 16
+int64_t gemv_rows_max(int t) { return t == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N : GEMV_MAX_N; }
 bool has_min_plane(int t) { return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q4_2; }   // Q4_2: its second scale
 bool has_qh_plane(int t) { return t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
 size_t row_bytes_of(int t, int64_t k) { return TSIZE[t] * (size_t)(k / BLCK[t]); }
@@ -85,11 +85,12 @@ int gemm_force() {
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
     if (N <= GEMV_MAX_N || force == 1) return 0;
-    if (type == GGML_TYPE_Q4_2 || type == GGML_TYPE_Q5_1) return 0;   // served by the mat-vec and int8 kernels only (outside BASELINE's configs)
+    if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
     if ((nba + K_LOOKAHEAD) * (uint64_t)pad_rows(M) * 32 > 0xFFFFFFFFull || nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
     if (force == 2) return gemm_q16_image_kind(type);
+    if (type == GGML_TYPE_Q5_1 && force == 3) return 0;                 // no MX form: the forced choice falls back to the int8 kernel
     if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
     // Q5_0 / Q8_0: the f16 kernel's K-split form wins on prompt-sized batches (4096 x 11008 x 512: 104 / 113 us against 118 /
     // 127 us), the int8 kernel on everything larger.  Decided from N and K only, like the K split itself: never from M, so

@@ -157,7 +157,7 @@ hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int
 
 // N at or below this goes to the wave-reduction mat-vec kernel, above it to the MFMA kernel.
 #define GEMV_MAX_N 8
-// ... and up to this many src1 rows the mat-vec kernel serves the types that have no small-batch MFMA configuration (Q4_2,
-// Q5_1), in its two-step form (K1 planes, 16 columns per pass over the weights): 15 us at 4096 x 4096 x 16.  For the other
+// ... and up to this many src1 rows the mat-vec kernel serves the type that has no small-batch MFMA configuration (Q4_2),
+// in its two-step form (K1 planes, 16 columns per pass over the weights): 15 us at 4096 x 4096 x 16.  For the other
 // types the 32-row, four-way-K-split tiles of gemm_qmx.hip / gemm_q16.hip take over at 9 rows (13 us / 16.5 us there).
 #define GEMV_WIDE_MAX_N 16

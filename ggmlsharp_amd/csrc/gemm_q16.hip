@@ -84,7 +84,9 @@ __device__ __forceinline__ f16x8 unpack_nib8(uint32_t x) {
     return __builtin_bit_cast(f16x8, o);
 }
 
-// Q5_0 (Ggml.cs:1285-1289): t8 = the 8 high bits of elements e0..e7 (bit i of t8 = element e_i); value = (nib | hb << 4) - 16
+// Q5_0 (Ggml.cs:1285-1289): t8 = the 8 high bits of elements e0..e7 (bit i of t8 = element e_i); value = (nib | hb << 4) - OFF
+// (OFF = 16; Q5_1, Ggml.cs:1330-1334: the unsigned value, OFF = 0, its min term goes the way of Q4_1's)
+template <int OFF>
 __device__ __forceinline__ f16x8 unpack_q5(uint32_t x, uint32_t t8) {
     const uint32_t y = x >> 8;
     // spread: bit i of t8 -> bit 4 (+16 for i >= 4) in the plain slots, bit 8 (+16) in the x16 slots
@@ -93,10 +95,10 @@ __device__ __forceinline__ f16x8 unpack_q5(uint32_t x, uint32_t t8) {
     const uint32_t h2 = ((t8 & 0x04u) << 2) | ((t8 & 0x40u) << 14);
     const uint32_t h3 = ((t8 & 0x08u) << 5) | ((t8 & 0x80u) << 17);
     u32x4 o;
-    o[0] = magic_sub((x & 0x000F000Fu) | h0 | 0x64006400u, 1024.0f + 16.0f);
-    o[1] = magic_sub((x & 0x00F000F0u) | h1 | 0x64006400u, 1024.0f + 256.0f);
-    o[2] = magic_sub((y & 0x000F000Fu) | h2 | 0x64006400u, 1024.0f + 16.0f);
-    o[3] = magic_sub((y & 0x00F000F0u) | h3 | 0x64006400u, 1024.0f + 256.0f);
+    o[0] = magic_sub((x & 0x000F000Fu) | h0 | 0x64006400u, 1024.0f + OFF);
+    o[1] = magic_sub((x & 0x00F000F0u) | h1 | 0x64006400u, 1024.0f + 16.0f * OFF);
+    o[2] = magic_sub((y & 0x000F000Fu) | h2 | 0x64006400u, 1024.0f + OFF);
+    o[3] = magic_sub((y & 0x00F000F0u) | h3 | 0x64006400u, 1024.0f + 16.0f * OFF);
     return __builtin_bit_cast(f16x8, o);
 }
 
@@ -113,6 +115,8 @@ __device__ __forceinline__ f16x8 unpack_i8x8(uint32_t x0, uint32_t x1) {
 
 template <int TYPE> struct WT {
     static constexpr int QW = (TYPE == GGML_TYPE_Q8_0) ? 4 : 2;     // raw dwords per lane, m-tile and k-block
+    static constexpr bool MIN = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1;   // unsigned values + a min term
+    static constexpr bool QH = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;    // fifth bits
 };
 
 // WMT x WNT 32x32 tiles per wave, WGM x WGN waves per workgroup, KB k-blocks per LDS stage
@@ -120,7 +124,7 @@ template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
 struct Cfg {
     static constexpr int TM = WGM * WMT * 32, TN = WGN * WNT * 32, NT = WGM * WGN * 64;
     static constexpr int A_BYTES = KB * 4 * TN * 16;       // f16 activation image of one stage
-    static constexpr int NSC = (TYPE == GGML_TYPE_Q4_1) ? 2 : 1;
+    static constexpr int NSC = WT<TYPE>::MIN ? 2 : 1;
     static constexpr int SC_BYTES = KB * TN * 4;           // one f32 plane of row scales
     static constexpr int STAGE = A_BYTES + NSC * SC_BYTES;
     static constexpr int TOTAL = 2 * STAGE;
@@ -199,7 +203,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         } else if (wave < C::SC_CHUNKS / 64) {                           // uniform per wave
             const uint32_t sS0 = (uint32_t)s * KB * (uint32_t)(Npad * 4);
             blds16(rAd, sp + C::A_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
-            if (TYPE == GGML_TYPE_Q4_1) blds16(rAs, sp + C::A_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            if (WT<TYPE>::MIN) blds16(rAs, sp + C::A_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
         }
     };
 
@@ -218,8 +222,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
 
     // the planes carry two spare (zero) k-blocks past the padded end, so the look-ahead never needs a bounds check
     const rsrc_t rWq = make_rsrc(wqs, wq_bytes), rWd = make_rsrc(wd, wd_bytes);
-    const rsrc_t rWh = make_rsrc(TYPE == GGML_TYPE_Q5_0 ? (const void *)wqh : (const void *)wd, wd_bytes);
-    const rsrc_t rWm = make_rsrc(TYPE == GGML_TYPE_Q4_1 ? (const void *)wm : (const void *)wd, wd_bytes);
+    const rsrc_t rWh = make_rsrc(WT<TYPE>::QH ? (const void *)wqh : (const void *)wd, wd_bytes);
+    const rsrc_t rWm = make_rsrc(WT<TYPE>::MIN ? (const void *)wm : (const void *)wd, wd_bytes);
     auto load_raw_one = [&](int kb, Raw &r, auto ic) {
         constexpr int i = decltype(ic)::value;
         const uint32_t sq = (uint32_t)kb * w_blk, sd = (uint32_t)kb * d_blk;
@@ -231,8 +235,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
             r.q[i][0] = v[0]; r.q[i][1] = v[1];
         }
         r.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)offD[i], (int)sd, 0));
-        if constexpr (TYPE == GGML_TYPE_Q5_0) r.qh[i] = __builtin_amdgcn_raw_buffer_load_b32(rWh, (int)offD[i], (int)sd, 0);
-        if constexpr (TYPE == GGML_TYPE_Q4_1) r.mn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)offD[i], (int)sd, 0));
+        if constexpr (WT<TYPE>::QH) r.qh[i] = __builtin_amdgcn_raw_buffer_load_b32(rWh, (int)offD[i], (int)sd, 0);
+        if constexpr (WT<TYPE>::MIN) r.mn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)offD[i], (int)sd, 0));
     };
     auto unpack_one = [&](const Raw &r, Frag &f, auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -242,16 +246,17 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         } else if constexpr (TYPE == GGML_TYPE_Q4_1) {
             f.b[i][0] = unpack_nib8<0>(r.q[i][0]);
             f.b[i][1] = unpack_nib8<0>(r.q[i][1]);
-        } else if constexpr (TYPE == GGML_TYPE_Q5_0) {
+        } else if constexpr (WT<TYPE>::QH) {
+            constexpr int OFF = TYPE == GGML_TYPE_Q5_0 ? 16 : 0;
             const uint32_t t16 = r.qh[i] >> (16 * hh);
-            f.b[i][0] = unpack_q5(r.q[i][0], t16 & 0xFFu);
-            f.b[i][1] = unpack_q5(r.q[i][1], (t16 >> 8) & 0xFFu);
+            f.b[i][0] = unpack_q5<OFF>(r.q[i][0], t16 & 0xFFu);
+            f.b[i][1] = unpack_q5<OFF>(r.q[i][1], (t16 >> 8) & 0xFFu);
         } else {
             f.b[i][0] = unpack_i8x8(r.q[i][0], r.q[i][1]);
             f.b[i][1] = unpack_i8x8(r.q[i][QW - 2], r.q[i][QW - 1]);
         }
         f.d[i] = r.d[i];
-        if constexpr (TYPE == GGML_TYPE_Q4_1) f.mn[i] = r.mn[i];
+        if constexpr (WT<TYPE>::MIN) f.mn[i] = r.mn[i];
     };
 
     Raw raw;
@@ -288,7 +293,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         auto fetch_da = [&](auto nc, auto gc) {
             constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT, q = decltype(gc)::value;
             da[q] = *(const f32x4 *)(sDa + bb * C::TN + 32 * j + 8 * q);
-            if constexpr (TYPE == GGML_TYPE_Q4_1) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
+            if constexpr (WT<TYPE>::MIN) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
         };
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         // MFMAs of tile t in two halves (one wave cannot issue the second before the first has left the matrix pipe, so
@@ -351,7 +356,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
                                  : "v"(tacc[t & 1][4 * q + 0]), "v"(tacc[t & 1][4 * q + 1]), "v"(tacc[t & 1][4 * q + 2]),
                                    "v"(tacc[t & 1][4 * q + 3]), "v"(da[q][0]), "v"(da[q][1]), "v"(da[q][2]), "v"(da[q][3]), "v"(dw));
                 }
-                if constexpr (TYPE == GGML_TYPE_Q4_1) {                       // + m0 * (d1 * sum(a)) (Ggml.cs:1190-1196 factorised)
+                if constexpr (WT<TYPE>::MIN) {                                // + m0 * (d1 * sum(a)) (Ggml.cs:1190-1196 factorised)
                     const float mw = frag[bb & 1].mn[i];
                     asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
                                  : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3])
@@ -482,7 +487,7 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     if (N <= 128 && w->nbk >= 16 && !old128) {
         // same split on 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip); not for Q4_1 (registers)
         static const int tile = [] { const char *e = getenv("GGML_HIP_Q16_TILE"); return e ? atoi(e) : 0; }();   // A/B: 1 = 128-row, 2 = 32-row
-        if constexpr (TYPE != GGML_TYPE_Q4_1)
+        if constexpr (!WT<TYPE>::MIN)
             if (tile == 1 || (tile != 2 && ((w->M + 127) / 128) * ((N + 63) / 64) >= 80)) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st);
         return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
     }
@@ -501,6 +506,7 @@ hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, fl
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }
