@@ -485,10 +485,14 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // batches up to 128 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip)
     static const bool old128 = getenv("GGML_HIP_Q16_OLD128") != nullptr;   // developer A/B switch
     if (N <= 128 && w->nbk >= 16 && !old128) {
-        // same split on 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip); not for Q4_1 (registers)
-        static const int tile = [] { const char *e = getenv("GGML_HIP_Q16_TILE"); return e ? atoi(e) : 0; }();   // A/B: 1 = 128-row, 2 = 32-row
+        // same split on 64-row tiles of 8 waves / 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip; the
+        // 16-wave form not for the min-term types: registers)
+        static const int tile = [] { const char *e = getenv("GGML_HIP_Q16_TILE"); return e ? atoi(e) : 0; }();   // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
+        const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+        const int h = tile == 1 ? 128 : tile == 3 ? 64 : tile == 2 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || WT<TYPE>::MIN) ? 64 : 128);
         if constexpr (!WT<TYPE>::MIN)
-            if (tile == 1 || (tile != 2 && ((w->M + 127) / 128) * ((N + 63) / 64) >= 80)) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st);
+            if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st);
+        if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 4>(w, p, N, dst, ldd, st);
         return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
     }
     if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);

@@ -423,12 +423,15 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // Batches up to 128 rows: 32-row weight tiles with K split four ways inside the workgroup -- M / 32 x N / 64 workgroups of
     // 4 waves instead of M / 128 x N / 64 of 8 (4096 x 4096 x 64 covered 32 CUs).
     if (N <= 128 && w->nbk >= 16 && var != 3 && var != 9) {
-        // The same four-way split -- hence the same summation tree, bit for bit -- on 128-row tiles of 16 waves where those
-        // cover the chip (M = 32000, N = 64: 55 -> 35 us; M = 4096: 13 us on 32-row tiles, 23 us on these).  Q4_0 only: the
-        // 128 registers of a 1024-thread workgroup do not hold Q4_1's min-term operands.
-        const int64_t tn64 = (N + 63) / 64;
+        // The same four-way split -- hence the same summation tree, bit for bit -- on taller tiles where those cover the chip
+        // (one workgroup per CU either way).  Compute times in us, 32-row x 4 waves | 64-row x 8 | 128-row x 16, N = 64:
+        // M = 4096 13 | 14 | 23, M = 11008 29 | 17 | 27, M = 16384 30 | 18 | 27, M = 32000 57 | 34 | 32 (N = 128: 109 | 66 | 62).
+        // The 16-wave form only for Q4_0: the 128 registers of a 1024-thread workgroup do not hold Q4_1's min-term operands.
+        const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+        const int h = var == 12 ? 128 : var == 15 ? 64 : var == 13 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || TYPE != GGML_TYPE_Q4_0) ? 64 : 128);
         if constexpr (TYPE == GGML_TYPE_Q4_0)
-            if ((var == 12 || (var != 13 && tm128 * tn64 >= 80))) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+            if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+        if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
         return launch_cfg<TYPE, 1, 2, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
     }
     if (N <= 512 && w->nbk >= 8 && var != 3) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);

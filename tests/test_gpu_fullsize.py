@@ -124,18 +124,20 @@ def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
 
 def test_small_batch_tile_forms_agree_bitwise(dev):
     """Batches up to 128 rows: the K split (four wave groups) is fixed by N and K, the tile height by how many tiles there are --
-    32-row tiles for a 2048-row shard, 128-row tiles of 16 waves for the 16384-row matrix.  Same split, same order of the
-    partial sums: the shard is bit for bit the matching columns of the unsplit result."""
+    32-row tiles for a 2048-row shard, 64-row tiles of 8 waves for an 8192-row shard, 128-row tiles of 16 waves for the
+    16384-row matrix.  Same split, same order of the partial sums: a shard is bit for bit the matching columns of the unsplit
+    result.  (Q4_1 and Q8_0: the f16 / min-term variants of the same rule.)"""
     M, K, N = 16384, 1024, 100
-    rows, x = _make(dev, Q4_0, M, K, N, seed=5)
-    W = dev.Weight.from_device(Q4_0, rows, K)
-    full = dev.mul_mat(W, x)
-    _check_fp64(dev, Q4_0, rows, x, full, K)
-    for (r0, r1) in ((0, 2048), (8000, 9000)):
-        Ws = dev.Weight.from_device(Q4_0, rows, K, row_begin=r0, row_end=r1)
-        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1])
-        Ws.free()
-    W.free()
+    for t in (Q4_0, 3, Q8_0):
+        rows, x = _make(dev, t, M, K, N, seed=5 + t)
+        W = dev.Weight.from_device(t, rows, K)
+        full = dev.mul_mat(W, x)
+        _check_fp64(dev, t, rows, x, full, K)
+        for (r0, r1) in ((0, 2048), (8000, 9000), (0, 8192)):
+            Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+            assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, r0, r1)
+            Ws.free()
+        W.free()
 
 
 @pytest.mark.parametrize("N", [100, 300])
