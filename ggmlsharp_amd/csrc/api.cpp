@@ -64,8 +64,9 @@ int vec_dot_type(int t) {  // Ggml.cs:219-290
 
 // Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat (measured on MI355X):
 //   gemm_qmx.hip (MX matrix path, bf6 digits, one exact MFMA per tile and block) -- Q4_0 / Q4_1,
-//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q8_0 on prompt-sized batches (N <= 512, K split in the workgroup),
-//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q5_0 / Q8_0 otherwise.
+//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q5_1 / Q8_0 on prompt-sized batches (N <= 512, K split in the
+//                workgroup) and from 1024 rows up,
+//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q4_2, and Q5_0 / Q5_1 / Q8_0 in between.
 // GGML_HIP_GEMM=mx|f16|i8 forces one (developer A/B switch).  The MX kernel also has a two-digit form for Q5_0 / Q8_0
 // (two MFMAs per tile and block); it measured no faster than the kernels above, so its digit planes
 // (1.5 B / weight) are only built for weights uploaded while "mx" is forced.
@@ -92,11 +93,14 @@ int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     if (force == 2) return gemm_q16_image_kind(type);
     if (type == GGML_TYPE_Q5_1 && force == 3) return 0;                 // no MX form: the forced choice falls back to the int8 kernel
     if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
-    // Q5_0 / Q8_0: the f16 kernel's K-split form wins on prompt-sized batches (4096 x 11008 x 512: 104 / 113 us against 118 /
-    // 127 us), the int8 kernel on everything larger.  Decided from N and K only, like the K split itself: never from M, so
-    // a row shard runs the kernel form of the unsplit matrix.
+    // Q5_0 / Q5_1 / Q8_0: the f16 kernel's K-split form wins on prompt-sized batches (4096 x 11008 x 512: 92 / 110 us against 108 /
+    // 130 us for the int8 kernel) and its unsplit forms from 1024 rows up (Q8_0 4096^3 199 against 220 us, 32000 x 4096 x 1024 405
+    // against 450, 4096 x 11008 x 1024 172 against 194; Q5_1 4096 x 4096 x 1024 89 against 115 -- 4096 x 4096 x 2048 is the
+    // one shape measured the other way, 124 against 116); in between (4096 x 4096 x 640: 67 against 57 us) the int8 kernel's
+    // 64 x 64 tiles balance the chip better.  Decided from N and K only, like the K split itself: never from M, so a row shard
+    // runs the kernel form of the unsplit matrix.
     (void)M;
-    return (N <= 512 && K / QK >= 8) ? gemm_q16_image_kind(type) : 0;
+    return ((N <= 512 || N >= 1024) && K / QK >= 8) ? gemm_q16_image_kind(type) : 0;
 }
 
 int ensure_init() {

@@ -497,7 +497,9 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     }
     if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
     if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
-    return launch_cfg<TYPE, 2, 2, 2, 1, 4>(w, p, N, dst, ldd, st);
+    // otherwise 128 x 64 tiles of 4 waves (2 tiles per wave).  f16 compute us at N = 1024, this | 128 x 128 of 4 waves | 128 x 64 of 2 waves:
+    // Q8_0 4096 x 4096 69 | 84 | 104, 4096 x 11008 172 | 206 | 262, 11008 x 4096 175 | 181 | 213; Q5_1 4096 x 4096 89 | 114 | 144
+    return launch_cfg<TYPE, 1, 2, 4, 1, 4>(w, p, N, dst, ldd, st);
 }
 
 }  // namespace

@@ -59,6 +59,10 @@ CONFIGS = [  # BASELINE.json configs (M, K, N), Q5_0 standing in for the absent 
     ("q5_1 batch-1", 7, 11008, 4096, 1),
     ("q4_2 batch-8", 4, 4096, 4096, 8),
     ("decode batch of 16", Q4_0, 11008, 4096, 16),
+    # Q5_0 / Q5_1 / Q8_0 above 512 rows: int8 kernel below 1024 rows, the f16 kernel's unsplit forms from there (both tile shapes)
+    ("q5_0 700 rows", Q5_0, 4096, 4096, 700),
+    ("q5_1 1024 rows", 7, 4096, 4096, 1024),
+    ("q8_0 4096^3", Q8_0, 4096, 4096, 4096),
 ]
 
 
@@ -107,7 +111,7 @@ def test_row_shard_and_column_subset_are_bitwise_slices(dev):
     W.free()
 
 
-@pytest.mark.parametrize("t,N", [(Q5_0, 512), (Q8_0, 512), (Q8_0, 1024), (Q4_0, 2048), (Q4_0, 3)])
+@pytest.mark.parametrize("t,N", [(Q5_0, 512), (Q8_0, 512), (Q8_0, 640), (Q8_0, 1024), (Q8_0, 4096), (7, 1024), (Q4_0, 2048), (Q4_0, 3)])
 def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
     """The kernel form (MX / f16 with or without the K split / int8 / mat-vec) is chosen from the type, N and K -- never
     from M -- so a row shard computes bit for bit the matching columns of the unsplit result, whatever serves the shape."""
