@@ -169,7 +169,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     const int m0 = (t_lin % tiles_m) * C::TM;
     const int n0 = (t_lin / tiles_m) * C::TN;
 
-    float acc[WMT][WNT][16];
+    f32x16 acc[WMT][WNT];                                   // (register tuples: the min-term MFMA accumulates into them in place)
 #pragma unroll
     for (int i = 0; i < WMT; ++i)
 #pragma unroll
@@ -275,25 +275,31 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         const uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         const uint8_t *sA = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         const float *sDa = (const float *)(sp + C::A_BYTES) + wn * WNT * 32 + 4 * hh;
-        const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
+        // Min term: on the VALU (16 v_fmac per tile and block) for the 8-tile waves, whose registers are full; otherwise as a K = 2
+        // f32 MFMA per pair of k-blocks (issue_b) -- d1 * sum(a) is then read as its A operand, lane half hh = the odd block of the pair
+        constexpr bool MIN_MFMA = WT<TYPE>::MIN && NTILE < 8, MIN_VALU = WT<TYPE>::MIN && !MIN_MFMA;
+        const float *sSa = sDa + C::SC_BYTES / 4;                        // d1 * sum(a) (Q5_1: d1 * (s0 + s1))
+        const float *sSp = (const float *)(sp + C::A_BYTES + C::SC_BYTES) + hh * C::TN + wn * WNT * 32 + l31;
         const int kb0 = s * KB;
         constexpr int LAST = KB * NTILE - 1, DRAIN = (KB - 1) * NTILE + NTILE / 2;
         constexpr int PP = (NPIECE + DRAIN - 1) / DRAIN;                // DMA pieces per tile (1 unless a stage has few tiles)
         static_assert(PP <= 3 && NPIECE <= PP * DRAIN, "all DMA pieces are issued before the drain point");
 
         f16x8 af[2];
-        f32x4 da[4], sa[4];
+        f32x4 da[4], sa[MIN_VALU ? 4 : 1];
         f32x16 tacc[2];
+        float af_s = 0.0f;                                               // min term: A operand (row l31, k-block (bb - 1) + hh)
 
         auto fetch_af = [&](auto nc) {                                   // nc = n-tile index within the stage
             constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[kk] = *(const f16x8 *)(sA + ((bb * 4 + 2 * kk) * C::TN + 32 * j) * 16);
+            if constexpr (MIN_MFMA && (bb & 1)) af_s = sSp[(bb - 1) * C::TN + 32 * j];
         };
         auto fetch_da = [&](auto nc, auto gc) {
             constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT, q = decltype(gc)::value;
             da[q] = *(const f32x4 *)(sDa + bb * C::TN + 32 * j + 8 * q);
-            if constexpr (WT<TYPE>::MIN) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
+            if constexpr (MIN_VALU) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
         };
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         // MFMAs of tile t in two halves (one wave cannot issue the second before the first has left the matrix pipe, so
@@ -306,6 +312,13 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         auto issue_b = [&](auto tc) {
             constexpr int t = decltype(tc)::value, bb = t / NTILE, j = (t % NTILE) / WMT, i = t % WMT;
             tacc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], frag[bb & 1].b[i][1], thalf, 0, 0, 0);
+            // Min term, + m0 * (d1 * sum(a)) per block (Ggml.cs:1190-1196 factorised; Q5_1: m * (s0 + s1), :1344): an outer product per
+            // block, i.e. a K = 2 matrix product per pair of blocks -- one v_mfma_f32_32x32x2_f32 straight into the tile's
+            // accumulators, a whole tile step (32 VALU instructions) away from the scale-accumulates that touch them.
+            if constexpr (MIN_MFMA && (bb & 1)) {
+                const float mpair = hh ? frag[1].mn[i] : frag[0].mn[i];                   // k-blocks bb - 1 | bb in the two lane halves
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(af_s), "v"(mpair));
+            }
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             if constexpr (j == WNT - 1) {
                 unpack_one(raw, frag[(bb + 1) & 1], std::integral_constant<int, i>{});
@@ -332,7 +345,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
             if constexpr (t == DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (t < LAST) issue_a(std::integral_constant<int, t + 1>{});
             const float dw = frag[bb & 1].d[i];
-            float *ac = acc[i][j];
+            f32x16 &ac = acc[i][j];
             static_for<4>([&](auto gc) {
                 constexpr int q = decltype(gc)::value;
                 float t0, t1, t2, t3;
@@ -356,7 +369,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
                                  : "v"(tacc[t & 1][4 * q + 0]), "v"(tacc[t & 1][4 * q + 1]), "v"(tacc[t & 1][4 * q + 2]),
                                    "v"(tacc[t & 1][4 * q + 3]), "v"(da[q][0]), "v"(da[q][1]), "v"(da[q][2]), "v"(da[q][3]), "v"(dw));
                 }
-                if constexpr (WT<TYPE>::MIN) {                                // + m0 * (d1 * sum(a)) (Ggml.cs:1190-1196 factorised)
+                if constexpr (MIN_VALU) {
                     const float mw = frag[bb & 1].mn[i];
                     asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
                                  : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3])
@@ -431,7 +444,8 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nr = (wn * WNT + j) * 32 + (r & 3) + 8 * (r >> 2), mb = (wm_ * WMT + i) * 32;   // relative to (n0, m0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                    const float v = acc[i][j][r];           // (a named float: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rD, (int)lane_off,
                                                           (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
                 }
     } else {
@@ -445,8 +459,9 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nr = nb + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[i][j][r];
                     if (mok && n0 + nr + 4 * hh < N)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rD, (int)lane_off,
                                                               (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
                 }
             }

@@ -121,7 +121,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     const int m0 = (t_lin % tiles_m) * C::TM;
     const int n0 = (t_lin / tiles_m) * C::TN;
 
-    float acc[WMT][WNT][16];
+    f32x16 acc[WMT][WNT];                                   // (register tuples: the min-term MFMA of Q4_1 accumulates into them in place)
 #pragma unroll
     for (int i = 0; i < WMT; ++i)
 #pragma unroll
@@ -189,14 +189,16 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         const uint8_t *sA16 = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         const uint8_t *sA8 = sp + C::A16_BYTES + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 8;
         const float *sDa = (const float *)(sp + C::A16_BYTES + C::A8_BYTES) + wn * WNT * 32 + 4 * hh;
-        const float *sSa = sDa + C::SC_BYTES / 4;                        // Q4_1 only: d1 * sum(a)
+        // Q4_1 only: d1 * sum(a), read as the A operand of a 32x32x2 f32 MFMA -- lane half hh takes the odd k-block of a pair
+        const float *sSp = (const float *)(sp + C::A16_BYTES + C::A8_BYTES + C::SC_BYTES) + hh * C::TN + wn * WNT * 32 + l31;
         const int kb0 = s * KB;
         constexpr int LAST = KB * NTILE - 1, DRAIN = (KB - 1) * NTILE + NTILE / 2;
         static_assert(DRAIN == C::DRAIN_T && C::NPIECE <= C::PP * DRAIN, "all DMA pieces are issued before the drain point");
 
         u32x4 af_lo;
         u32x2 af_hi;
-        f32x4 da[4], sa[4];
+        float af_s = 0.0f;                                              // Q4_1: d1 * sum(a) of row l31, k-block (bb - 1) + hh
+        f32x4 da[4];
         f32x16 tacc[2];
         float dcur[WMT], mcur[WMT];
 
@@ -204,11 +206,11 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT;
             af_lo = *(const u32x4 *)(sA16 + (bb * 2 * C::TN + 32 * j) * 16);
             af_hi = *(const u32x2 *)(sA8 + (bb * 2 * C::TN + 32 * j) * 8);
+            if constexpr (TYPE == GGML_TYPE_Q4_1 && (bb & 1)) af_s = sSp[(bb - 1) * C::TN + 32 * j];
         };
         auto fetch_da = [&](auto nc, auto gc) {
             constexpr int g = decltype(nc)::value, bb = g / WNT, j = g % WNT, q = decltype(gc)::value;
             da[q] = *(const f32x4 *)(sDa + bb * C::TN + 32 * j + 8 * q);
-            if constexpr (TYPE == GGML_TYPE_Q4_1) sa[q] = *(const f32x4 *)(sSa + bb * C::TN + 32 * j + 8 * q);
         };
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         // the MFMA of tile t, then everything that becomes possible once it is issued
@@ -228,8 +230,17 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             }
             if constexpr (j == 0) {                                       // first use of this block's scales: keep them
                 dcur[i] = f.d[i];                                         // (the buffer is reloaded before the last use)
-                if constexpr (TYPE == GGML_TYPE_Q4_1) mcur[i] = fmaf(8.0f, f.d[i], f.mn[i]);   // nib = (nib - 8) + 8
+                if constexpr (TYPE == GGML_TYPE_Q4_1) {                   // nib = (nib - 8) + 8: the min term's weight factor is m0 + 8 d0
+                    const float m8 = fmaf(8.0f, f.d[i], f.mn[i]);
+                    // B operand of the pair's MFMA: k-blocks bb - 1 | bb in the two lane halves
+                    mcur[i] = (bb & 1) == 0 ? m8 : (hh ? m8 : mcur[i]);
+                }
             }
+            // Q4_1 min term, + (m0 + 8 d0) * (d1 * sum(a)) per block (Ggml.cs:1190-1196 factorised): an outer product per block, i.e.
+            // a K = 2 matrix product per pair of blocks -- one v_mfma_f32_32x32x2_f32 straight into the tile's accumulators,
+            // issued a whole tile step (32 VALU instructions) before and after the scale-accumulates that touch them.
+            if constexpr (TYPE == GGML_TYPE_Q4_1 && (bb & 1))
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(af_s), "v"(mcur[i]));
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 64))) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
             // (this group's k-blocks: the stage after s is s + KSP)
@@ -245,7 +256,6 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             constexpr int t = decltype(tc)::value, bb = t / NTILE, tl = t % NTILE, j = tl / WMT, i = tl % WMT;
             // this tile's weight scales, read before issue(t + 1) may replace them with the next block's (WMT == 1)
             const float dw = dcur[i];
-            const float mw = TYPE == GGML_TYPE_Q4_1 ? mcur[i] : 0.0f;
             if constexpr (!(GGML_MX_DBG & 1)) {
                 static_for<C::PP>([&](auto uc) {
                     constexpr int pc = C::PP * t + decltype(uc)::value;
@@ -258,7 +268,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             // flight across the barrier.
             if constexpr (t == DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (t < LAST) issue(std::integral_constant<int, t + 1>{});
-            float *ac = acc[i][j];
+            f32x16 &ac = acc[i][j];
             static_for<4>([&](auto gc) {
                 constexpr int q = decltype(gc)::value;
                 float t0, t1, t2, t3;
@@ -283,11 +293,6 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                                    "=&v"(t2), "=&v"(t3)
                                  : "v"(tacc[t & 1][4 * q + 0]), "v"(tacc[t & 1][4 * q + 1]), "v"(tacc[t & 1][4 * q + 2]),
                                    "v"(tacc[t & 1][4 * q + 3]), "v"(da[q][0]), "v"(da[q][1]), "v"(da[q][2]), "v"(da[q][3]), "v"(dw));
-                }
-                if constexpr (TYPE == GGML_TYPE_Q4_1) {                       // + (m0 + 8 d0) * (d1 * sum(a)) (Ggml.cs:1190-1196 factorised)
-                    asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
-                                 : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3])
-                                 : "v"(sa[q][0]), "v"(sa[q][1]), "v"(sa[q][2]), "v"(sa[q][3]), "v"(mw));
                 }
                 // this group's row scales are dead after the n-tile's last m-tile: fetch the next n-tile's into their place
                 if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 32)))
@@ -356,7 +361,8 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nr = (wn * WNT + j) * 32 + (r & 3) + 8 * (r >> 2), mb = (wm_ * WMT + i) * 32;   // relative to (n0, m0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                    const float v = acc[i][j][r];           // (a named float: __builtin_bit_cast of a vector ELEMENT reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rD, (int)lane_off,
                                                           (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
                 }
     } else {
@@ -370,8 +376,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nr = nb + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[i][j][r];
                     if (mok && n0 + nr + 4 * hh < N)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[i][j][r]), rD, (int)lane_off,
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rD, (int)lane_off,
                                                               (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
                 }
             }
@@ -426,7 +433,8 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         // The same four-way split -- hence the same summation tree, bit for bit -- on taller tiles where those cover the chip
         // (one workgroup per CU either way).  Compute times in us, 32-row x 4 waves | 64-row x 8 | 128-row x 16, N = 64:
         // M = 4096 13 | 14 | 23, M = 11008 29 | 17 | 27, M = 16384 30 | 18 | 27, M = 32000 57 | 34 | 32 (N = 128: 109 | 66 | 62).
-        // The 16-wave form only for Q4_0: the 128 registers of a 1024-thread workgroup do not hold Q4_1's min-term operands.
+        // The 16-wave form only for Q4_0: Q4_1 spills in the 128 registers of a 1024-thread workgroup and measures no faster
+        // (32000 x 4096 x 64: 43.5 against 42 us on 64-row tiles).
         const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
         const int h = var == 12 ? 128 : var == 15 ? 64 : var == 13 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || TYPE != GGML_TYPE_Q4_0) ? 64 : 128);
         if constexpr (TYPE == GGML_TYPE_Q4_0)
