@@ -89,11 +89,13 @@ __device__ __forceinline__ f16x8 unpack_nib8(uint32_t x) {
 template <int OFF>
 __device__ __forceinline__ f16x8 unpack_q5(uint32_t x, uint32_t t8) {
     const uint32_t y = x >> 8;
-    // spread: bit i of t8 -> bit 4 (+16 for i >= 4) in the plain slots, bit 8 (+16) in the x16 slots
-    const uint32_t h0 = ((t8 & 0x01u) << 4) | ((t8 & 0x10u) << 16);
-    const uint32_t h1 = ((t8 & 0x02u) << 7) | ((t8 & 0x20u) << 19);
-    const uint32_t h2 = ((t8 & 0x04u) << 2) | ((t8 & 0x40u) << 14);
-    const uint32_t h3 = ((t8 & 0x08u) << 5) | ((t8 & 0x80u) << 17);
+    // spread: bit i of t8 -> bit 4 (+16 for i >= 4) in the plain slots, bit 8 (+16) in the x16 slots.  One multiply puts a copy of
+    // t8 at bits 4..11 and 16..23 (t8 < 256: no overlap); each slot then takes its two bits with one shift and one mask.
+    const uint32_t p = t8 * 0x10010u;
+    const uint32_t h0 = p & 0x00100010u;
+    const uint32_t h1 = (p << 3) & 0x01000100u;
+    const uint32_t h2 = (p >> 2) & 0x00100010u;
+    const uint32_t h3 = (p << 1) & 0x01000100u;
     u32x4 o;
     o[0] = magic_sub((x & 0x000F000Fu) | h0 | 0x64006400u, 1024.0f + OFF);
     o[1] = magic_sub((x & 0x00F000F0u) | h1 | 0x64006400u, 1024.0f + 16.0f * OFF);
