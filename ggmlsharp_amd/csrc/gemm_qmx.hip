@@ -91,8 +91,11 @@ struct Cfg {
 // 1 = in place, for kb+1 (enough look-ahead when a wave has >= 4 m-tiles between two uses of a fragment)
 // KSP = 1 | 2 | 4: with 2 (4) the workgroup holds two (four) wave groups that take alternate LDS stages of K (each with its own stage
 // buffers) and add their accumulators through LDS at the end -- twice the waves for grids too small to fill the chip.
-template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP>
-__global__ __launch_bounds__(WGM * WGN * 64 * KSP, 2)
+// VS = 1 | 2 | 4 "virtual" groups per wave group: the wave group runs the stage sets of VS groups one after the other, keeping each
+// set's sum apart, and the sums are added in group order -- the summation tree of a KSP * VS-way split, bit for bit, without
+// the extra waves.  What fixes an element's bits is KSP * VS (chosen from N and K); how it is spread over waves may follow M.
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP, int VS>
+__global__ __launch_bounds__(WGM * WGN * 64 * KSP, (VS > 1 && WGM * WGN * KSP == 4 && WMT * WNT == 2 ? 3 : 2))   // (three 4-wave workgroups per CU: 168 registers)
 void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
                      const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
                      const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nstages,
@@ -102,6 +105,8 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     constexpr int NTILE = WMT * WNT, P = C::P;
     constexpr int NF = (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) ? 1 : 2;   // weight digits (fragments) per block
     static_assert(KB % 2 == 0, "fragment buffers alternate by k-block parity");
+    static_assert(VS == 1 || (KSP == 1 && (VS == 2 || VS == 4)) || (KSP == 2 && VS == 2), "virtual split forms");
+    constexpr int KV = KSP * VS;                            // width of the summation tree
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int lane = threadIdx.x & 63;
@@ -184,7 +189,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     Frag frag[FB];                                          // k-block kb uses frag[kb % FB]
     const int scale_a = hh ? 127 : 131;                     // E8M0: K group 0 (the ah digits) carries 2^4
 
-    auto compute = [&](int s, int buf) {                         // stage s of K, resident in stage buffer buf
+    auto compute = [&](int s, int sn, int buf) {                 // stage s of K, resident in stage buffer buf; sn = this wave group's next stage
         const uint8_t *sp = gsm + (buf & 1) * C::STAGE;
         const uint8_t *sA16 = sp + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         const uint8_t *sA8 = sp + C::A16_BYTES + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 8;
@@ -243,9 +248,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                 asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(af_s), "v"(mcur[i]));
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 64))) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
-            // (this group's k-blocks: the stage after s is s + KSP)
+            // (this group's k-blocks: the stage after s is sn)
             if constexpr (j == WNT - 1 && !(GGML_MX_DBG & 4))
-                load_frag_one(bb + FB < KB ? kb0 + bb + FB : kb0 + KSP * KB + (bb + FB - KB), f, std::integral_constant<int, i>{});
+                load_frag_one(bb + FB < KB ? kb0 + bb + FB : sn * KB + (bb + FB - KB), f, std::integral_constant<int, i>{});
         };
 
         fetch_af(std::integral_constant<int, 0>{});
@@ -259,7 +264,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             if constexpr (!(GGML_MX_DBG & 1)) {
                 static_for<C::PP>([&](auto uc) {
                     constexpr int pc = C::PP * t + decltype(uc)::value;
-                    if constexpr (pc < C::NPIECE) dma_piece(s + KSP, buf + 1, std::integral_constant<int, pc>{});
+                    if constexpr (pc < C::NPIECE) dma_piece(sn, buf + 1, std::integral_constant<int, pc>{});
                 });
             }
             // The DMA pieces of the next stage must have landed before this wave arrives at the stage's barrier.  Waiting
@@ -304,28 +309,47 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     // ---- main loop: double-buffered LDS, one barrier per stage (vmcnt(0): see gemm_q16.hip).  Group grp takes stages
     //      grp, grp + KSP, ...; every wave passes the same number of barriers. ----
     static_assert(FB <= KB, "fragment look-ahead stays within two stages");
-    static_for<C::NPIECE>([&](auto pc) { dma_piece(grp, 0, pc); });
+    const int s_first = grp * VS;                           // first stage of this wave group's first (virtual) group
+    static_for<C::NPIECE>([&](auto pc) { dma_piece(s_first, 0, pc); });
     static_for<WMT>([&](auto ic) {
-        load_frag_one(grp * KB, frag[0], ic);
-        if constexpr (FB == 2) load_frag_one(grp * KB + 1, frag[FB - 1], ic);
+        load_frag_one(s_first * KB, frag[0], ic);
+        if constexpr (FB == 2) load_frag_one(s_first * KB + 1, frag[FB - 1], ic);
     });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
-    const int niter = (nstages + KSP - 1) / KSP;
+    // Virtual group v = grp * VS + pass takes stages v, v + KV, v + 2 KV, ...; a wave group runs its passes back to back (the
+    // prefetch of a pass's last stage fetches the next pass's first), then idles through the barriers it has left.
+    f32x16 sav[VS > 1 ? WMT : 1][VS > 1 ? WNT : 1];         // sum of this wave group's finished passes
+    const int niter = VS * ((nstages + KV - 1) / KV);
+    int sc = s_first, pass = 0;
     for (int it = 0; it < niter; ++it) {
-        const int s = it * KSP + grp;
-        if (KSP == 1 || s < nstages) compute(s, it);
+        int sn = sc + KV, pn = pass;
+        if (VS > 1 && sn >= nstages) { pn = pass + 1; sn = pn < VS ? grp * VS + pn : nstages; }
+        if ((KSP == 1 && VS == 1) || sc < nstages) compute(sc, sn, it);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the drain inside compute, again for a skipped stage)
         if (!(GGML_MX_DBG & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (VS > 1) {
+            if (pn != pass && pn < VS) {                    // pass boundary (uniform): bank this pass's sum, start the next from zero
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j) {
+                        sav[i][j] = pass == 0 ? acc[i][j] : sav[i][j] + acc[i][j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                    }
+            }
+        }
+        sc = sn; pass = pn;
     }
 
     // ---- K split: groups 1 .. KSP-1 hand their accumulators to group 0 through LDS (the stage buffers are free now); group 0
     //      adds them in group order, so the summation tree is fixed ----
     if constexpr (KSP > 1) {
-        constexpr int GRP_FLOATS = WGM * WGN * NTILE * 16 * 64;           // one group's accumulators
-        static_assert((KSP - 1) * GRP_FLOATS * 4 <= KSP * C::TOTAL, "K-split exchange fits the stage buffers");
+        constexpr int GRP_FLOATS = WGM * WGN * NTILE * 16 * 64;           // one (virtual) group's accumulators
+        static_assert((KSP - 1) * VS * GRP_FLOATS * 4 <= KSP * C::TOTAL, "K-split exchange fits the stage buffers");
         float *xch = (float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
         if (grp != 0) {
 #pragma unroll
@@ -333,18 +357,31 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
 #pragma unroll
                 for (int j = 0; j < WNT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[(size_t)(grp - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (VS > 1) xch[(size_t)((grp - 1) * VS) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64] = sav[i][j][r];
+                        xch[(size_t)((grp - 1) * VS + VS - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64] = acc[i][j][r];
+                    }
         }
         __syncthreads();
         if (grp != 0) return;
+    }
+    if constexpr (VS > 1) {                                 // this wave group's own passes first, in order
 #pragma unroll
-        for (int g = 1; g < KSP; ++g)
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) acc[i][j] = sav[i][j] + acc[i][j];
+    }
+    if constexpr (KSP > 1) {
+        constexpr int GRP_FLOATS = WGM * WGN * NTILE * 16 * 64;
+        const float *xch = (const float *)smem + (size_t)wave * (NTILE * 16 * 64) + lane;
+#pragma unroll
+        for (int g = VS; g < KV; ++g)
 #pragma unroll
             for (int i = 0; i < WMT; ++i)
 #pragma unroll
                 for (int j = 0; j < WNT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[(size_t)(g - 1) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64];
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[(size_t)(g - VS) * GRP_FLOATS + ((i * WNT + j) * 16 + r) * 64];
     }
 
     // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31]; descriptor + per-lane offset + uniform row offset ----
@@ -385,10 +422,10 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     }
 }
 
-template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP = 1>
+template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP = 1, int VS = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
-    auto kern = gemm_qmx_kernel<TYPE, WMT, WNT, WGM, WGN, KB, FB, KSP>;
+    auto kern = gemm_qmx_kernel<TYPE, WMT, WNT, WGM, WGN, KB, FB, KSP, VS>;
     // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
     static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
     if (attr != hipSuccess) return attr;
@@ -442,10 +479,22 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
         return launch_cfg<TYPE, 1, 2, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
     }
+    // 129 .. 256 rows: the four-way tree as well.  Really split (8 waves per 64-row tile) while the tiles are few -- 4096 x 4096 x 256
+    // 28.5 -> 21 us, 4096 x 11008 x 256 62 -> 42 us -- and for larger M, where the split costs (11008 x 4096 x 256: 41.5 -> 52 us), two wave
+    // groups that each run two of the four stage sets one after the other: same tree, same bits, the geometry of the two-way form
+    // (11008 x 4096 x 256 44 us, 32000 x 4096 x 256 112 against 107 us: the banked sums cost registers).
+    // (Q4_0 only: Q4_1's second form spills at three workgroups per CU and runs 14 % behind its two-way form.)
+    if (TYPE == GGML_TYPE_Q4_0 && N <= 256 && w->nbk >= 16 && var != 3 && var != 9 && var != 20) {
+        const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+        if (var == 23 || (var != 24 && t64 <= 256)) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+        return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2, 2>(w, p, N, dst, ldd, st);
+    }
     // (64-row tiles of 4 waves, three per CU: grids that are not a multiple of 256 workgroups lose less in their last round --
     // 11008 x 4096 x 256: 53 -> 38 us, 32000 x 4096 x 256: 119 -> 107 us; 4096 x 4096 x 512 unchanged; var 17 = the 128-row form)
     // the largest grids keep the 128-row form (32000 x 4096 x 512: 171 us against 179 us)
     if (N <= 512 && w->nbk >= 8 && var != 3) {
+        // (the same two-way tree run by ONE wave group on unsplit 128 x 64 tiles measured level: 32000 x 4096 x 512 161 | 161 us,
+        // 11008 x 4096 x 512 74 | 79, 16384 x 4096 x 512 114 | 110)
         if (var == 17 || (var != 16 && tm128 * ((N + 63) / 64) >= 1536)) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
         return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
     }

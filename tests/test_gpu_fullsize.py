@@ -103,8 +103,8 @@ def test_row_shard_and_column_subset_are_bitwise_slices(dev):
         part = dev.mul_mat(Ws, x)
         assert torch.equal(part, full[:, r0:r1]), (r0, r1)
         Ws.free()
-    sub = dev.mul_mat(W, x[128:384].contiguous())
-    assert torch.equal(sub, full[128:384])
+    sub = dev.mul_mat(W, x[128:512].contiguous())                            # 384 rows: the same two-way K split as 512
+    assert torch.equal(sub, full[128:512])
     one = dev.mul_mat(W, x[7:8].contiguous())                                # N = 1 goes through the mat-vec kernel
     err = (one - full[7:8]).abs().max() / full[7:8].abs().max()
     assert err < 1e-5                                                        # different kernel, different summation tree
@@ -126,12 +126,15 @@ def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
     W.free()
 
 
-def test_small_batch_tile_forms_agree_bitwise(dev):
+@pytest.mark.parametrize("N", [100, 200])
+def test_small_batch_tile_forms_agree_bitwise(dev, N):
     """Batches up to 128 rows: the K split (four wave groups) is fixed by N and K, the tile height by how many tiles there are --
     32-row tiles for a 2048-row shard, 64-row tiles of 8 waves for an 8192-row shard, 128-row tiles of 16 waves for the
     16384-row matrix.  Same split, same order of the partial sums: a shard is bit for bit the matching columns of the unsplit
     result.  (Q4_1 and Q8_0: the f16 / min-term variants of the same rule.)"""
-    M, K, N = 16384, 1024, 100
+    M, K = 16384, 1024
+    # (N = 200, Q4_0 / Q4_1: the four-way tree again -- really split for the shards, two wave groups running two stage sets each
+    # for the whole matrix)
     for t in (Q4_0, 3, Q8_0):
         rows, x = _make(dev, t, M, K, N, seed=5 + t)
         W = dev.Weight.from_device(t, rows, K)
