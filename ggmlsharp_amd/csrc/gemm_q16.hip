@@ -499,9 +499,12 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // big tile (256 x 128, 8 tiles per wave) when it still fills the chip with >= 2 workgroups per CU; else 128 x 64
     const int64_t big = ((w->M + 255) / 256) * ((N + 127) / 128);
     // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (chosen from N and K only, see gemm_qmx.hip)
-    // batches up to 128 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip)
+    // batches up to 256 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip).  129 .. 256 rows, four-way |
+    // two-way us: Q8_0 4096 x 4096 x 256 27 | 37, 4096 x 11008 x 256 58 | 81, Q5_0 4096 x 4096 x 256 25 | 39; 11008 x 4096 x 256 63 | 58,
+    // 32000 x 4096 x 256 141 | 128
     static const bool old128 = getenv("GGML_HIP_Q16_OLD128") != nullptr;   // developer A/B switch
-    if (N <= 128 && w->nbk >= 16 && !old128) {
+    static const int n4 = [] { const char *e = getenv("GGML_HIP_Q16_N4"); return e ? atoi(e) : 256; }();   // developer A/B switch (128 = the former bound)
+    if (N <= n4 && w->nbk >= 16 && !old128) {
         // same split on 64-row tiles of 8 waves / 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip; the
         // 16-wave form not for the min-term types: registers)
         static const int tile = [] { const char *e = getenv("GGML_HIP_Q16_TILE"); return e ? atoi(e) : 0; }();   // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
