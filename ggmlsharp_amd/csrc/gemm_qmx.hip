@@ -466,7 +466,8 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // computes bit for bit what the unsplit matrix does (the summation tree of an element is a function of the kernel form).
     // Batches up to 128 rows: 32-row weight tiles with K split four ways inside the workgroup -- M / 32 x N / 64 workgroups of
     // 4 waves instead of M / 128 x N / 64 of 8 (4096 x 4096 x 64 covered 32 CUs).
-    if (N <= 128 && w->nbk >= 16 && var != 3 && var != 9) {
+    // (Q4_1: up to 256 rows this way -- 4096 x 4096 x 256 29 -> 23 us, 11008 x 4096 x 256 level at 58 us; Q4_0 has its own form for 129 .. 256 below)
+    if (N <= (TYPE == GGML_TYPE_Q4_0 || var == 20 ? 128 : 256) && w->nbk >= 16 && var != 3 && var != 9) {
         // The same four-way split -- hence the same summation tree, bit for bit -- on taller tiles where those cover the chip
         // (one workgroup per CU either way).  Compute times in us, 32-row x 4 waves | 64-row x 8 | 128-row x 16, N = 64:
         // M = 4096 13 | 14 | 23, M = 11008 29 | 17 | 27, M = 16384 30 | 18 | 27, M = 32000 57 | 34 | 32 (N = 128: 109 | 66 | 62).
