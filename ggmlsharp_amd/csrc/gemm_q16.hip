@@ -319,7 +319,9 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
             // accumulators, a whole tile step (32 VALU instructions) away from the scale-accumulates that touch them.
             if constexpr (MIN_MFMA && (bb & 1)) {
                 const float mpair = hh ? frag[1].mn[i] : frag[0].mn[i];                   // k-blocks bb - 1 | bb in the two lane halves
-                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(af_s), "v"(mpair));
+                // (a BUILTIN, so that hipcc pads its own reads of the result -- it splits the tuple with v_mov; the inline-asm readers
+                // are a tile step away: the dummy operand of this step's third scale-accumulate group keeps the MFMA above it)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_s, mpair, acc[i][j], 0, 0, 0);
             }
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             if constexpr (j == WNT - 1) {
@@ -357,6 +359,12 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
                 // reads it.  Tile t's MFMAs are pinned above tile t-1's 32 VALU instructions, so only the first tile of
                 // a stage can be short of them: it carries its own s_nop.
                 if constexpr (t == 0 && q == 0) asm volatile("s_nop 11" : "+v"(tacc[0]));
+                if constexpr (q == 2 && t < LAST && MIN_MFMA && (((t + 1) / NTILE) & 1)) {
+                    // the next tile's accumulators were just written by its min-term MFMA (issue_b above): this empty statement keeps
+                    // that MFMA above the two scale-accumulate groups that follow (volatile statements keep their order)
+                    constexpr int tn = t + 1, j1 = (tn % NTILE) / WMT, i1 = tn % WMT;
+                    asm volatile("" : "+v"(acc[i1][j1]));
+                }
                 if constexpr (q == 0 && t < LAST) {
                     asm volatile("v_mul_f32 %4, %8, %12\n\tv_mul_f32 %5, %9, %13\n\tv_mul_f32 %6, %10, %14\n\tv_mul_f32 %7, %11, %15\n\t"
                                  "v_fmac_f32 %0, %4, %16\n\tv_fmac_f32 %1, %5, %16\n\tv_fmac_f32 %2, %6, %16\n\tv_fmac_f32 %3, %7, %16"

@@ -243,9 +243,11 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             }
             // Q4_1 min term, + (m0 + 8 d0) * (d1 * sum(a)) per block (Ggml.cs:1190-1196 factorised): an outer product per block, i.e.
             // a K = 2 matrix product per pair of blocks -- one v_mfma_f32_32x32x2_f32 straight into the tile's accumulators,
-            // issued a whole tile step (32 VALU instructions) before and after the scale-accumulates that touch them.
+            // issued a whole tile step (32 VALU instructions) before and after the scale-accumulates that touch them.  A BUILTIN, so
+            // that hipcc pads its own reads of the result (it splits the tuple with v_mov); the inline-asm readers are kept a
+            // step away by an empty volatile statement on the tuple ahead of the previous tile's scale-accumulates (below).
             if constexpr (TYPE == GGML_TYPE_Q4_1 && (bb & 1))
-                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(af_s), "v"(mcur[i]));
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_s, mcur[i], acc[i][j], 0, 0, 0);
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 64))) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
             // (this group's k-blocks: the stage after s is sn)
@@ -281,6 +283,12 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                 // reads it.  Tile t's MFMA is pinned above tile t-1's 32 VALU instructions, so only the first tile of
                 // a stage can be short of them: it carries its own s_nop.
                 if constexpr (t == 0 && q == 0) asm volatile("s_nop 11" : "+v"(tacc[0]));
+                // Q4_1: the next tile's accumulators were just written by its min-term MFMA (issue(t + 1) above); this empty statement
+                // keeps that MFMA above this tile's 32 VALU instructions (volatile statements keep their order)
+                if constexpr (q == 0 && t < LAST && TYPE == GGML_TYPE_Q4_1 && (((t + 1) / NTILE) & 1)) {
+                    constexpr int tn = t + 1, j1 = (tn % NTILE) / WMT, i1 = tn % WMT;
+                    asm volatile("" : "+v"(acc[i1][j1]));
+                }
                 // acc += (sumi * d1) * d0, Ggml.cs:1158.  The other MFMA result rides along as a dummy operand of
                 // group 0 so that its MFMA stays above this tile's VALU work (which is what it overlaps with).
                 if constexpr ((GGML_MX_DBG & 16) != 0) {
