@@ -493,10 +493,12 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // groups that each run two of the four stage sets one after the other: same tree, same bits, the geometry of the two-way form
     // (11008 x 4096 x 256 44 us, 32000 x 4096 x 256 112 against 107 us: the banked sums cost registers).
     // (Q4_0 only: Q4_1's second form spills at three workgroups per CU and runs 14 % behind its two-way form.)
-    if (TYPE == GGML_TYPE_Q4_0 && N <= 256 && w->nbk >= 16 && var != 3 && var != 9 && var != 20) {
-        const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
-        if (var == 23 || (var != 24 && t64 <= 256)) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
-        return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2, 2>(w, p, N, dst, ldd, st);
+    if constexpr (TYPE == GGML_TYPE_Q4_0) {
+        if (N <= 256 && w->nbk >= 16 && var != 3 && var != 9 && var != 20) {
+            const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+            if (var == 23 || (var != 24 && t64 <= 256)) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+            return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2, 2>(w, p, N, dst, ldd, st);
+        }
     }
     // (64-row tiles of 4 waves, three per CU: grids that are not a multiple of 256 workgroups lose less in their last round --
     // 11008 x 4096 x 256: 53 -> 38 us, 32000 x 4096 x 256: 119 -> 107 us; 4096 x 4096 x 512 unchanged; var 17 = the 128-row form)
