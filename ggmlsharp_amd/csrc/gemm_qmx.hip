@@ -320,8 +320,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     const int s_first = grp * VS;                           // first stage of this wave group's first (virtual) group
     static_for<C::NPIECE>([&](auto pc) { dma_piece(s_first, 0, pc); });
     static_for<WMT>([&](auto ic) {
-        load_frag_one(s_first * KB, frag[0], ic);
-        if constexpr (FB == 2) load_frag_one(s_first * KB + 1, frag[FB - 1], ic);
+        static_for<FB>([&](auto gc) { load_frag_one(s_first * KB + decltype(gc)::value, frag[decltype(gc)::value], ic); });
     });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -506,6 +505,7 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     if (N <= 512 && w->nbk >= 8 && var != 3) {
         // (the same two-way tree run by ONE wave group on unsplit 128 x 64 tiles measured level: 32000 x 4096 x 512 161 | 161 us,
         // 11008 x 4096 x 512 74 | 79, 16384 x 4096 x 512 114 | 110)
+        // (weight fragments a whole stage ahead, FB = 4, with weights cold in HBM: 4096 x 4096 x 512 35.7 -> 34.9 us, the others level)
         if (var == 17 || (var != 16 && tm128 * ((N + 63) / 64) >= 1536)) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
         return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
     }
