@@ -126,6 +126,24 @@ def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
     W.free()
 
 
+@pytest.mark.parametrize("K", [512, 544, 1056, 2080])
+@pytest.mark.parametrize("N", [130, 256])
+def test_banked_four_way_tree_matches_the_real_split(dev, K, N):
+    """Q4_0, 129..256 rows: an 8192-row matrix runs the four-way summation tree as banked passes (two wave groups, two stage
+    sets each), a 1024-row shard runs it really split.  Stage counts that do not divide by four (K = 544: 5 stages, 1056: 9,
+    2080: 17) leave the stage sets unequal -- the bits must still agree, and match fp64."""
+    M = 8192
+    rows, x = _make(dev, Q4_0, M, K, N, seed=K + N)
+    W = dev.Weight.from_device(Q4_0, rows, K)
+    full = dev.mul_mat(W, x)
+    _check_fp64(dev, Q4_0, rows, x, full, K)
+    for (r0, r1) in ((0, 1024), (5000, 6024), (8000, 8192)):
+        Ws = dev.Weight.from_device(Q4_0, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (K, N, r0, r1)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("N", [100, 200])
 def test_small_batch_tile_forms_agree_bitwise(dev, N):
     """Batches up to 128 rows: the K split (four wave groups) is fixed by N and K, the tile height by how many tiles there are --
