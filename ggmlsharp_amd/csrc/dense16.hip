@@ -119,9 +119,20 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (t_lin % tiles_m) * C::TM;
-    const int n0 = (t_lin / tiles_m) * C::TN;
+    int tm_i, tn_i;
+    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {
+        // 2 x 4 blocks of the tile grid per XCD (gemm_qmx.hip): its resident workgroups share half of the weight panels and a
+        // quarter of the activation panels
+        const int hm = tiles_m >> 1, l = bid >> 3;
+        tm_i = (xcd & 1) * hm + l % hm;
+        tn_i = (xcd >> 1) * (tiles_n >> 2) + l / hm;
+    } else {
+        const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        tm_i = t_lin % tiles_m;
+        tn_i = t_lin / tiles_m;
+    }
+    const int m0 = tm_i * C::TM;
+    const int n0 = tn_i * C::TN;
 
     f32x16 acc[WMT][WNT];
 #pragma unroll
