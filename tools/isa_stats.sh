@@ -3,6 +3,7 @@
 set -e
 cd "$(dirname "$0")/../ggmlsharp_amd/csrc"
 F=$1; shift
+mkdir -p ../../tools/bin
 FL="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Wno-unused-variable -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FL "$@" --cuda-device-only -S $F -o ../../tools/bin/${F%.hip}.s
 python3 - ../../tools/bin/${F%.hip}.s <<'PY'
