@@ -7,6 +7,7 @@
 // gfx950), i.e. the reference's sum with f32 instead of f64 accumulation: ~1e-6 relative at these K, inside the
 // 1e-3 budget.  Same orientation as the quantized kernel: MFMA rows = src1 rows n, MFMA cols = weight rows m.
 #include "common.h"
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -93,6 +94,90 @@ __global__ __launch_bounds__(256) void dense_kernel(const void *__restrict__ wv,
         const int64_t n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (n < N && m < M) dst[n * ldd + m] = acc[r];
     }
+}
+
+// ---- F32 weights, large shapes: 128 x 128 tiles, 2 x 2 MFMA tiles per wave.  The 64 x 64 kernel above moves 16 KB from L2 per
+//      workgroup and 32-k stage for 16 MFMAs per wave -- ~48 B per clock and CU, the L1's limit; a 128 x 128 tile halves the
+//      bytes per flop and the LDS reads per MFMA.  Same arithmetic, same order (k ascending, two per v_mfma_f32_32x32x2_f32):
+//      bit for bit the result of the kernel above.  XCD-aware 1-D grid (2 x 4 blocks of the tile grid per XCD, gemm_qmx.hip).
+//      Needs K % 32 == 0, ld1 % 4 == 0, 16-byte aligned src1.
+__global__ __launch_bounds__(256) void dense_f32_big_kernel(const float *__restrict__ w, const float *__restrict__ x, float *__restrict__ dst,
+                                                           int64_t M, int64_t N, int64_t K, int64_t ld1, int64_t ldd, int tiles_m,
+                                                           int tiles_n) {
+    constexpr int BT = 128;
+    __shared__ float sX[BT * DLD];
+    __shared__ float sW[BT * DLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wm_ = wave & 1;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    int tm_i, tn_i;
+    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {
+        const int hm = tiles_m >> 1, l = bid >> 3;
+        tm_i = (xcd & 1) * hm + l % hm;
+        tn_i = (xcd >> 1) * (tiles_n >> 2) + l / hm;
+    } else {
+        const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        tm_i = t_lin % tiles_m;
+        tn_i = t_lin / tiles_m;
+    }
+    const int64_t m0 = (int64_t)tm_i * BT, n0 = (int64_t)tn_i * BT;
+
+    const int srow = tid >> 1, sk = (tid & 1) * 16;          // a thread stages 16 consecutive k of one row of each operand
+    const int64_t xr = (n0 + srow) < N ? (n0 + srow) : (N - 1);
+    const float *xp = x + xr * ld1 + sk;
+    const float *wp = w + (m0 + srow) * K + sk;              // < Mpad rows (padded rows are zero)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 xv[4], wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xv[e] = *(const float4 *)(xp + 4 * e); wv[e] = *(const float4 *)(wp + 4 * e); }
+    for (int64_t k0 = 0; k0 < K; k0 += DK) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float *px = &sX[srow * DLD + sk + 4 * e], *pw = &sW[srow * DLD + sk + 4 * e];
+            px[0] = xv[e].x; px[1] = xv[e].y; px[2] = xv[e].z; px[3] = xv[e].w;
+            pw[0] = wv[e].x; pw[1] = wv[e].y; pw[2] = wv[e].z; pw[3] = wv[e].w;
+        }
+        __syncthreads();
+        if (k0 + DK < K) {                                    // the next stage's loads fly during this stage's MFMAs
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[e] = *(const float4 *)(xp + k0 + DK + 4 * e); wv[e] = *(const float4 *)(wp + k0 + DK + 4 * e); }
+        }
+#pragma unroll
+        for (int s = 0; s < DK / 2; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a[j] = sX[(wn * 64 + 32 * j + l31) * DLD + 2 * s + hh];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = sW[(wm_ * 64 + 32 * i + l31) * DLD + 2 * s + hh];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t m = m0 + wm_ * 64 + 32 * i + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = n0 + wn * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = acc[i][j][r];
+                if (n < N && m < M) dst[n * ldd + m] = v;
+            }
+        }
 }
 
 // ---- N <= 8 (more rows in passes of 8): mat-vec, bandwidth-bound.  One wave per DGR weight rows: lanes stride K in 16-byte
@@ -191,6 +276,14 @@ hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int
     dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
     // K % 32 == 0 keeps every 8-element piece of a stage inside the row
     const bool vec = w->K % DK == 0 && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    {   // F32 weights, enough 128 x 128 tiles to fill the chip: the big-tile kernel (bitwise the same result)
+        static const bool old = getenv("GGML_HIP_DENSE_OLD") != nullptr;   // developer A/B switch
+        const int64_t tm = (w->M + 127) / 128, tn = (N + 127) / 128;
+        if (!f16 && vec && !old && tm * tn >= 256 && tm * tn < (1 << 30) && w->Mpad % 128 == 0) {
+            dense_f32_big_kernel<<<dim3((unsigned)(tm * tn)), 256, 0, st>>>((const float *)w->dense, x, dst, w->M, N, w->K, ld1, ldd, (int)tm, (int)tn);
+            return hipGetLastError();
+        }
+    }
     if (w->type == GGML_TYPE_F16) {
         if (vec) dense_kernel<true, true><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);
         else dense_kernel<true, false><<<grid, 256, 0, st>>>(w->dense, x, dst, w->M, N, w->K, ld1, ldd);

@@ -93,6 +93,27 @@ def test_dense_f16_fullsize_matches_fp64(dev, M, K, N):
     W.free()
 
 
+@pytest.mark.parametrize("M,K,N", [(2048, 1056, 2048 + 17), (4096, 512, 4096), (2000, 1024, 64)])
+def test_dense_f32_fullsize_matches_fp64(dev, M, K, N):
+    """ggml_compute_forward_mul_mat_f32 (Ggml.cs:5969-6178; dot 2631-2640: f32 products, f64 sum) at sizes served by the
+    128 x 128-tile kernel of dense.hip (the first two) and by its 64 x 64 one: f32 fma chain in k order, ~1e-6 relative."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + N)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    W = dev.Weight.from_device(0, w.contiguous().view(torch.uint8), K)
+    got = dev.mul_mat(W, x)
+    ref = x.double() @ w.double().T
+    err = (got.double() - ref).abs()
+    rms = ref.pow(2).mean().sqrt()
+    assert (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item() == 0, f"max err / rms = {(err.max() / rms).item():.3e}"
+    # a row shard goes through the other tile size (fewer tiles): same k order, same bits
+    Ws = dev.Weight.from_device(0, w.contiguous().view(torch.uint8), K, row_begin=128, row_end=640)
+    assert torch.equal(dev.mul_mat(Ws, x), got[:, 128:640])
+    Ws.free()
+    W.free()
+
+
 def test_row_shard_and_column_subset_are_bitwise_slices(dev):
     M, K, N = 4096, 4096, 512
     rows, x = _make(dev, Q4_0, M, K, N, seed=3)
