@@ -4,17 +4,23 @@
 Workload (BASELINE.json `metric`): Q4_0 mul_mat M=4096, K=4096, N=4096, f32 activations and weights already
 resident in HBM.  One step = one pass of ggml_compute_forward_mul_mat_q_f32 over that input:
 INIT phase (quantize the 4096 src1 rows to Q8_0) + COMPUTE phase (block-scaled exact-integer MFMA mat-mat on the MX
-matrix path, gemm_qmx.hip) [+ the all-gather of dst shards and the re-layout when --gpus > 1].
-  value  = effective GFLOP/s = 2*M*K*N*(ranks) / step time  (whole job)
+matrix path, gemm_qmx.hip) [+ the exchange of dst shards when --gpus > 1].
+  value  = effective GFLOP/s = 2*M*K*N / step time  (whole job)
   roofline = the dominant kernel (COMPUTE phase) alone, timed with HIP events on its stream
-  cpu_baseline = the oracle's scalar CPU path (reference algorithm) on the host cores, bounded sample
-Multi-GPU (--gpus G, launched by torch.distributed.run): the weight matrix is row-split, rank r owns rows
-[r*4096, (r+1)*4096) of a (4096*G) x 4096 matrix (weak scaling: per-GPU work fixed), every rank holds all of
-src1, dst shards are exchanged with one RCCL all-gather per step and re-laid-out to the reference's [N][M].
+  cpu_baseline = the oracle's scalar CPU path (reference algorithm) on the host cores, bounded sample, T = 1 and T = cores
+Multi-GPU (--gpus G): `python bench.py --gpus G` launches its own rank processes (python -m torch.distributed.run, one per
+GPU, before anything in this process touches a GPU) unless it already runs under one (WORLD_SIZE set).  The SAME 4096^3
+problem is row-split (strong scaling, BASELINE's 1 -> 8 metric): rank r owns rows [dr*r, dr*(r+1)) of W (Ggml.cs:6665-6672),
+every rank holds all of src1, and every rank ends with the whole reference-layout dst [N][M] (ggmlsharp_amd/dist.py: RCCL
+all-gather + re-layout, or direct peer stores, whichever the run verified and measured faster).  `other_configs` then
+carries the weak-scaling run (M = 4096 per rank) and BASELINE config 5 (Q4_0 32000 x 4096 x 512, row-split), each with
+compute-only / exchange-only / whole-step times.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +36,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x BF16 per clock, ~5 PF dense.  The MX kernel issues bf6 MFMAs
                             # (4x BF16 per clock, ~10 PF) over twice the algorithmic K (two digits per Q8 activation): the same
                             # 5 PF ceiling in algorithmic FLOPs.
+PROFILE_TRAFFIC = ("r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
 def algorithmic_bytes(M, K, N, blk=20):
@@ -48,6 +55,24 @@ def event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
+def per_call_ms(fn, iters, stream):
+    """One HIP event pair per call on the launch stream -> list of per-call durations."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record(stream)
+        fn()
+        b.record(stream)
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in ev]
+
+
+def stats(ts):
+    """median and p10 / p90 over >= 100 launches."""
+    a = np.sort(np.asarray(ts, dtype=np.float64))
+    return {"median_ms": round(float(np.median(a)), 5), "p10_ms": round(float(np.percentile(a, 10)), 5),
+            "p90_ms": round(float(np.percentile(a, 90)), 5), "launches": int(a.size)}
+
+
 Q5_0, Q8_0 = 6, 8
 BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36}          # Ggml.cs:76-82
 TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0"}
@@ -62,9 +87,27 @@ def make_weights_q4_0(M, K, seed, qtype=Q4_0):
     return device.quantize_rows(qtype, w)
 
 
-def cpu_baseline(M, K, n_cols, threads):
-    """The reference's CPU algorithm (oracle = C port, scalar block dots, INIT on one thread, rows split over
-    `threads`), timed on the host cores on a bounded sample of the same workload."""
+def physical_cores():
+    """Physical host cores this process may use: lscpu's sockets x cores-per-socket, capped by the CPU affinity mask."""
+    n = None
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {ln.split(":")[0].strip(): ln.split(":")[1].strip() for ln in out.splitlines() if ":" in ln}
+        n = int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+        model = kv.get("Model name", "?")
+    except Exception:
+        model = "?"
+    logical = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except Exception:
+        allowed = logical
+    if not n:
+        n = max(1, logical // 2)
+    return max(1, min(n, allowed)), logical, allowed, model
+
+
+def cpu_baseline_leg(M, K, n_cols, threads):
     import oracle_lib as O
     rng = np.random.default_rng(0)
     w = rng.standard_normal((M, K)).astype(np.float32)
@@ -74,9 +117,21 @@ def cpu_baseline(M, K, n_cols, threads):
     t0 = time.perf_counter()
     O.mul_mat(O.Q4_0, wq, x, M, K, n_cols, nth=threads)
     dt = time.perf_counter() - t0
-    return {"value": round(2.0 * M * K * n_cols / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"Q4_0 mul_mat M={M} K={K} N={n_cols} (first {n_cols} of 4096 src1 rows), {dt:.2f} s wall, "
-                      f"oracle/ggml_oracle.c scalar path, host has {os.cpu_count()} logical CPUs"}
+    return round(2.0 * M * K * n_cols / dt / 1e9, 2), dt
+
+
+def cpu_baseline(M, K):
+    """The reference's CPU algorithm (oracle = C port, scalar block dots, INIT on one thread, rows split over T threads,
+    Ggml.cs:6641-6698), timed on the host cores on bounded samples of the same workload: T = 1 and T = physical cores."""
+    cores, logical, allowed, model = physical_cores()
+    v1, dt1 = cpu_baseline_leg(M, K, 384, 1)
+    nT = 2048 if cores >= 8 else 384
+    vT, dtT = cpu_baseline_leg(M, K, nT, cores)
+    return {"value": vT, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"Q4_0 mul_mat M={M} K={K}, first {nT} of 4096 src1 rows on T={cores} threads ({dtT:.2f} s wall); "
+                      f"oracle/ggml_oracle.c scalar path; host: {model}, {logical} logical CPUs, {allowed} usable",
+            "single_thread": {"value": v1, "unit": "GFLOP/s", "cores": 1,
+                              "sample": f"first 384 of 4096 src1 rows, {dt1:.2f} s wall"}}
 
 
 def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
@@ -114,14 +169,18 @@ def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
     with torch.cuda.graph(graph):
         for _ in range(copies):
             step()
-    t_step = event_time_ms(graph.replay, max(3, iters // copies), stream) / copies
-    t_comp = event_time_ms(compute_only, iters, stream) if N > 8 else None
+    reps = max(20, iters // copies)
+    per = [t / copies for t in per_call_ms(graph.replay, reps, stream)]
+    t_step = float(np.median(per))
+    t_comp = float(np.median(per_call_ms(compute_only, iters, stream))) if N > 8 else None
     ab = algorithmic_bytes(M, K, N, BLOCK_BYTES[qtype])
     flops = 2.0 * M * K * N
+    st = stats(per)
     res = {"workload": f"{TYPE_NAME[qtype]} mul_mat M={M} K={K} N={N}", "ms_per_step": round(t_step, 5),
+           "p10_ms": st["p10_ms"], "p90_ms": st["p90_ms"],
            "gflops": round(flops / t_step / 1e6, 1), "algorithmic_GBs": round(ab / t_step / 1e6, 1),
            "hbm_frac": round(ab / t_step / 1e6 / HBM_PEAK_GBS, 4), "weight_copies_rotated": copies,
-           "timing": "hipGraph replay of one call per weight copy"}
+           "timing": f"median over {reps} hipGraph replays of one call per weight copy (dependent launches: includes the inter-kernel boundary)"}
     if t_comp is not None:
         res["compute_kernel_ms"] = round(t_comp, 5)
     for w in ws:
@@ -142,7 +201,7 @@ def dense_config(device, wtype, M, K, N, iters):
     stream = torch.cuda.current_stream()
     for _ in range(3):
         device.mul_mat(W, x, out=out, work=work)
-    t = event_time_ms(lambda: device.mul_mat(W, x, out=out, work=work), iters, stream)
+    t = float(np.median(per_call_ms(lambda: device.mul_mat(W, x, out=out, work=work), iters, stream)))
     tf = 2.0 * M * K * N / t / 1e9
     peak = 2500.0 if wtype == 1 else 157.0      # MI355X_MICROARCH.md: dense f16 MFMA ~2.5 PF; f32 matrix 157 TF
     W.free()
@@ -151,24 +210,191 @@ def dense_config(device, wtype, M, K, N, iters):
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)}}
 
 
+def seam1_host_config(M, K, N, iters):
+    """The DROP-IN path: ggml_graph_compute of one mul_mat node with HOST tensors (Seam 1, host pointers in and out), as
+    the C# host would run it -- the context pool registered for DMA (ggml_hip_register_host_pool, done by the mirror's
+    ggml_init), src1 / dst moved in chunks of src1 rows that overlap the kernels.  PCIe-inclusive: never the headline."""
+    from ggmlsharp_amd import ggml as G
+    rows = make_weights_q4_0(M, K, 77).cpu().numpy()
+    pool = (M * (K // 32) * 20) + 4 * K * N + 4 * M * N + (1 << 20)
+    ctx = G.ggml_init(pool)
+    try:
+        W = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        G.tensor_bytes(W)[:] = rows.reshape(-1)
+        G.tensor_f32(X)[:] = np.random.default_rng(3).standard_normal((1, 1, N, K)).astype(np.float32)
+        Y = G.ggml_mul_mat(ctx, W, X)
+        gf = G.ggml_build_forward(Y)
+        G.ggml_graph_compute(ctx, gf)          # uploads and caches the weights
+        G.ggml_graph_compute(ctx, gf)
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            G.ggml_graph_compute(ctx, gf)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        t = float(np.median(ts))
+        moved = 4.0 * K * N + 4.0 * M * N
+        return {"workload": f"Q4_0 mul_mat M={M} K={K} N={N}, host tensors through ggml_graph_compute (Seam 1)",
+                "ms_per_step": round(t, 4), "p10_ms": round(float(np.percentile(ts, 10)), 4), "p90_ms": round(float(np.percentile(ts, 90)), 4),
+                "pcie_GBs_both_directions": round(moved / t / 1e6, 1), "gflops": round(2.0 * M * K * N / t / 1e6, 1),
+                "host_bytes_in": 4 * K * N, "host_bytes_out": 4 * M * N}
+    finally:
+        G.ggml_free(ctx)
+
+
+def pcie_probe():
+    """Pinned host <-> device copy rates of this box (what bounds the drop-in path)."""
+    n = 64 << 20
+    h = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d = torch.empty(n, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    t_in = float(np.median(per_call_ms(lambda: d.copy_(h, non_blocking=True), 10, stream)))
+    t_out = float(np.median(per_call_ms(lambda: h.copy_(d, non_blocking=True), 10, stream)))
+    return {"h2d_GBs": round(n / t_in / 1e6, 1), "d2h_GBs": round(n / t_out / 1e6, 1)}
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: start N rank processes (one per GPU) and relay rank 0's JSON line.
+    Nothing in THIS process has touched a GPU (torch.cuda.device_count() does not initialise it on this image)."""
+    ndev = torch.cuda.device_count()
+    env = os.environ.copy()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = args.backend
+    if ndev < args.gpus:
+        # fewer devices than ranks (a one-GPU box): rehearse the whole N > 1 flow with ranks sharing devices; RCCL cannot put
+        # two ranks on one device, so gloo carries the collectives
+        env["GGML_BENCH_SHARE_DEVICES"] = str(max(ndev, 1))
+        backend = "gloo"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--backend", backend, "--exchange", args.exchange]
+    if args.no_side_configs:
+        cmd.append("--no-side-configs")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    return p.returncode if p.returncode else (0 if line else 1)
+
+
+def timed_steps(fn, warmup, steps, world):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt * 1e3 / steps
+
+
+def make_runner(device, gdist, M_total, K, N, world, rank, exchange, chunks, seed):
+    r0, r1 = gdist.shard_rows(M_total, world, rank)
+    # every rank draws ITS rows from a stream seeded by the row range, so any split of the same matrix holds the same weights
+    rows = make_weights_q4_0(max(r1 - r0, 1), K, seed=seed + r0)
+    W = device.Weight.from_device(Q4_0, rows, K, row_begin=0, row_end=r1 - r0)
+    del rows
+    return gdist.RowSplitMulMat(W, N, world, rank, M_total=M_total, chunks=chunks if world > 1 else 1, exchange=exchange), W
+
+
+def pick_exchange(device, gdist, world, rank, requested, K):
+    """Which exchange form runs: "rccl" always works; "push" (direct peer stores through IPC-shared dst buffers) is used
+    when every rank could set it up AND its result is bit for bit the RCCL form's on a small problem."""
+    import torch.distributed as dist
+    if world == 1:
+        return "none", "single GPU"
+    if requested == "rccl":
+        return "rccl", "requested"
+    ok = 1.0
+    why = "verified against the all-gather form"
+    try:
+        N, M = 96, 64 * world + 8
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        x = torch.randn((N, K), generator=g, device="cuda")
+        ra, wa = make_runner(device, gdist, M, K, N, world, rank, "rccl", 2, 4242)
+        rb, wb = make_runner(device, gdist, M, K, N, world, rank, "push", 2, 4242)
+        a = ra.step(x).clone()
+        b1 = rb.step(x).clone()
+        b2 = rb.step(x).clone()
+        torch.cuda.synchronize()
+        if not (torch.equal(a, b1) and torch.equal(a, b2)):
+            ok, why = 0.0, "push result differs from the all-gather result"
+        dist.barrier()
+        rb.close()
+    except Exception as e:  # noqa: BLE001 -- any failure of the IPC set-up selects the RCCL form
+        ok, why = 0.0, f"push set-up failed: {type(e).__name__}: {e}"[:200]
+    t = torch.tensor([ok], dtype=torch.float32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if float(t.item()) >= 1.0:
+        return "push", why
+    return "rccl", why if ok == 0.0 else "another rank could not use push"
+
+
+def multi_config(device, gdist, name, M_total, K, N, world, rank, exchange, chunks, steps, warmup):
+    """One row-split problem: whole step, compute only, exchange only (max over ranks each)."""
+    runner, W = make_runner(device, gdist, M_total, K, N, world, rank, exchange, chunks, seed=9000)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    x = torch.randn((N, K), generator=g, device="cuda", dtype=torch.float32)
+    t_step = timed_steps(lambda: runner.step(x), warmup, steps, world)
+    t_comp = timed_steps(lambda: runner.compute_only(x), max(2, warmup // 2), steps, world)
+    t_xchg = timed_steps(runner.exchange_only, max(2, warmup // 2), steps, world)
+    flops = 2.0 * M_total * K * N
+    S = 4 * N * gdist.shard_width(M_total, world)
+    res = {"workload": f"Q4_0 mul_mat M={M_total} K={K} N={N} row-split x{world} ({name})", "ms_per_step": round(t_step, 5),
+           "gflops": round(flops / t_step / 1e6, 1), "compute_only_ms": round(t_comp, 5), "exchange_only_ms": round(t_xchg, 5),
+           "overlap_gain_ms": round(t_comp + t_xchg - t_step, 5), "exchange": exchange, "chunks": chunks, "ranks": world,
+           "shard_bytes": S, "bytes_in_per_gpu": S * (world - 1),
+           "exchange_GBs_in_per_gpu": round(S * (world - 1) / t_xchg / 1e6, 1) if t_xchg > 0 else None}
+    runner.close() if hasattr(runner, "close") else None
+    W.free()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 flow on one GPU)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push"],
+                    help="dst shard exchange for --gpus > 1: RCCL all-gather + re-layout, or direct peer stores (auto: push when verified, else rccl)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if "GGML_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N > 1 flow with every rank on one GPU
+    if "GGML_BENCH_SHARE_DEVICES" in os.environ:      # rehearsal of the N > 1 flow with ranks sharing the box's device(s)
+        local_rank = local_rank % int(os.environ["GGML_BENCH_SHARE_DEVICES"])
+    if "GGML_BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["GGML_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -183,51 +409,62 @@ def main():
     device.init(local_rank)
 
     M, K, N = 4096, 4096, 4096
-    rows = make_weights_q4_0(M, K, seed=1000 + rank)       # this rank's row shard of the (M*world) x K matrix
-    W = device.Weight.from_device(Q4_0, rows, K)
-    del rows
+    exchange, exchange_why = pick_exchange(device, gdist, world, rank, args.exchange, K)
+    chunks = 4 if world > 1 else 1
+    runner, W = make_runner(device, gdist, M, K, N, world, rank, exchange, chunks, seed=1000)
     g = torch.Generator(device="cuda")
     g.manual_seed(1)
     x = torch.randn((N, K), generator=g, device="cuda", dtype=torch.float32)   # replicated src1
-    runner = gdist.RowSplitMulMat(W, N, world, rank, chunks=4 if world > 1 else 1)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        runner.step(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step(x)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt * 1e3 / args.steps
-    flops_step = 2.0 * M * K * N * world
+    ms_per_step = timed_steps(lambda: runner.step(x), args.warmup, args.steps, world)
+    flops_step = 2.0 * M * K * N
     value = flops_step / (ms_per_step * 1e-3) / 1e9
 
     out = {
         "metric": "effective GFLOP/s, Q4_0 mul_mat 4096x4096x4096 (2*M*K*N / step time)",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
         "dtype": "i8", "data": "synthetic",
-        "config": {"workload": f"Q4_0 mul_mat M={M * world} K={K} N={N} f32 src1, weights resident",
-                   "per_gpu": f"M={M} row shard, all of src1", "block_bytes": 20,
-                   "parallelism": f"row-split x{world} + all-gather" if world > 1 else "single GPU"},
+        "config": {"workload": f"Q4_0 mul_mat M={M} K={K} N={N} f32 src1, weights resident",
+                   "per_gpu": f"rows [{gdist.shard_rows(M, world, 0)[0]}, {gdist.shard_rows(M, world, 0)[1]}) of W on rank 0, all of src1, whole dst [N][M] on every rank",
+                   "block_bytes": 20,
+                   "parallelism": f"row-split x{world} (Ggml.cs:6665-6672) + exchange '{exchange}' ({exchange_why})" if world > 1 else "single GPU"},
     }
+    stream = torch.cuda.current_stream()
+    # per-step HIP events -> median / p10 / p90 (after the wall-clock region, same loop body)
+    n_ev = max(args.steps, 100) if world == 1 else args.steps
+    out["step_stats"] = stats(per_call_ms(lambda: runner.step(x), n_ev, stream))
 
-    if rank == 0:
+    if world > 1:
+        t_comp = timed_steps(lambda: runner.compute_only(x), 3, args.steps, world)
+        t_xchg = timed_steps(runner.exchange_only, 3, args.steps, world)
+        S = 4 * N * gdist.shard_width(M, world)
+        out["multi_gpu"] = {"compute_only_ms": round(t_comp, 5), "exchange_only_ms": round(t_xchg, 5),
+                            "overlap_gain_ms": round(t_comp + t_xchg - ms_per_step, 5), "exchange": exchange, "exchange_choice": exchange_why,
+                            "chunks": chunks, "ranks_observed": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                            "shard_bytes": S, "bytes_in_per_gpu": S * (world - 1),
+                            "exchange_GBs_in_per_gpu": round(S * (world - 1) / t_xchg / 1e6, 1) if t_xchg > 0 else None,
+                            "devices_shared_by_ranks": "GGML_BENCH_SHARE_DEVICES" in os.environ}
+        if hasattr(runner, "close"):
+            torch.distributed.barrier()
+            runner.close()
+        W.free()
+        if not args.no_side_configs:
+            small = max(5, args.steps // 4)
+            oc = {}
+            # the weak-scaling run of round 1 (per-GPU work fixed: rank r owns 4096 rows of a (4096 * G) x 4096 matrix)
+            oc["weak_4096_rows_per_gpu"] = multi_config(device, gdist, "weak scaling", 4096 * world, K, N, world, rank, exchange, chunks, small, 3)
+            # BASELINE.json configs[4]: Q4_0 32000 x 4096 x 512 row-split (Ms = 4000 at 8 GPUs)
+            oc["config5_vocab512"] = multi_config(device, gdist, "BASELINE config 5", 32000, K, 512, world, rank, exchange, 2, small, 3)
+            if exchange == "push":   # the RCCL form beside it, same problem
+                oc["headline_rccl_allgather"] = multi_config(device, gdist, "strong scaling, RCCL all-gather + re-layout", M, K, N, world, rank, "rccl", chunks, small, 3)
+            out["other_configs"] = oc
+
+    if world == 1 and rank == 0:
         # dominant kernel alone (COMPUTE phase), HIP events on the launch stream
-        stream = torch.cuda.current_stream()
         # timed inside the step sequence (INIT, COMPUTE, INIT, ...), as the kernels run in the measured loop: the same
         # kernel launched back to back on its own holds a higher clock and reads ~10 % faster
-        iters = 20
+        iters = 100
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
         for e0, e1, e2 in ev:
             e0.record(stream)
@@ -236,55 +473,67 @@ def main():
             device.mul_mat_compute(W, N, runner.shard, runner.work)
             e2.record(stream)
         torch.cuda.synchronize()
-        t_init = sum(e0.elapsed_time(e1) for e0, e1, _ in ev) / iters
-        t_comp = sum(e1.elapsed_time(e2) for _, e1, e2 in ev) / iters
+        init_ts = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+        comp_ts = [e1.elapsed_time(e2) for _, e1, e2 in ev]
+        t_init, t_comp = float(np.mean(init_ts)), float(np.mean(comp_ts))     # mean: what rocprofv3 --stats reports as average
         achieved = 2.0 * M * K * N / (t_comp * 1e-3) / 1e12
         ab = algorithmic_bytes(M, K, N)
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json)
+        traffic = None
         kernels = {0: ("gemm_q_kernel<Q4_0,2,2>", "v_mfma_i32_32x32x32_i8 + f32 block-scale epilogue on the VALU"),
                    1: ("gemm_q16_kernel<Q4_0,2,4,4,1>", "2 x v_mfma_f32_32x32x16_f16 per tile and block + f32 block-scale epilogue on the VALU"),
                    3: ("gemm_qmx_kernel<Q4_0,2,4,4,1>", "1 x v_mfma_scale_f32_32x32x64_f8f6f4 (bf6 digits, exact) per tile and block + f32 block-scale epilogue on the VALU")}
         from ggmlsharp_amd._lib import lib
         kname, kdesc = kernels.get(lib().ggml_hip_act_image_kind(Q4_0, M, K, N), kernels[0])
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f)[f"{kname} M=4096 K=4096 N=4096"]["traffic_bytes"]
-        except Exception:
-            pass
+        for fn in PROFILE_TRAFFIC:
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    traffic = json.load(f)[f"{kname} M=4096 K=4096 N=4096"]["traffic_bytes"]
+                break
+            except Exception:
+                pass
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
                            "kernel": f"{kname} ({kdesc})",
-                           "kernel_ms": round(t_comp, 5), "init_kernel_ms": round(t_init, 5),
+                           "kernel_ms": round(t_comp, 5), "kernel_ms_stats": stats(comp_ts), "init_kernel_ms": round(t_init, 5),
                            "algorithmic_bytes": ab,
                            "note": "the binding unit is the VALU, not the matrix pipe: the reference applies two f32 scales per 32-element "
                                    "block (Ggml.cs:1158) = 32 VALU instructions per 32x32 tile and block, floor ~55 us for this shape",
                            "hbm_view": {"achieved_GBs": round(ab / ((t_init + t_comp) * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                                         "frac": round(ab / ((t_init + t_comp) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                         "note": "algorithmic bytes / (INIT + COMPUTE kernel time); this shape is MFMA/VALU-bound, not HBM-bound"}}
-    if world == 1 and rank == 0:
         if not args.no_side_configs:
             out["other_configs"] = {
                 "batch1": side_config(device, 4096, 4096, 1, copies=32, iters=200),
-                "prompt512": side_config(device, 4096, 4096, 512, copies=32, iters=50),
+                "prompt512": side_config(device, 4096, 4096, 512, copies=32, iters=100),
                 "batch1_M32000": side_config(device, 32000, 4096, 1, copies=8, iters=100),   # the same mat-vec kernel on an 82 MB matrix
                 # BASELINE.json configs[3] (the reference has no k-quants: its 5-bit type Q5_0 stands in) and
-                # configs[4] on ONE GPU (the 8-GPU row split is `--gpus 8` of the headline shape)
-                "q8_0_ffn512": side_config(device, 4096, 11008, 512, copies=6, iters=30, qtype=Q8_0),
-                "q5_0_ffn512": side_config(device, 4096, 11008, 512, copies=8, iters=30, qtype=Q5_0),
-                "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=20),
+                # configs[4] on ONE GPU (the row split is `--gpus 8`: other_configs.config5_vocab512 of that line)
+                "q8_0_ffn512": side_config(device, 4096, 11008, 512, copies=6, iters=60, qtype=Q8_0),
+                "q5_0_ffn512": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_0),
+                "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
                 # the dense case of the path (north_star: MFMA utilisation for the dense f16 / f32 mul_mat)
                 "dense_f16": dense_config(device, 1, 4096, 4096, 4096, iters=20),
                 "dense_f32": dense_config(device, 0, 4096, 4096, 4096, iters=5),
             }
-            for k in ("batch1_M32000",):
+            for k in ("batch1", "batch1_M32000"):
                 out["other_configs"][k]["roofline"] = {"bound": "hbm", "achieved": out["other_configs"][k]["algorithmic_GBs"],
                                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["other_configs"][k]["hbm_frac"]}
-            out["other_configs"]["batch1"]["roofline"] = {"bound": "hbm", "achieved": out["other_configs"]["batch1"]["algorithmic_GBs"],
-                                                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                          "frac": out["other_configs"]["batch1"]["hbm_frac"]}
+            # the drop-in path with HOST tensors (PCIe-inclusive; never `value`)
+            try:
+                pc = pcie_probe()
+                s1 = {"pcie_probe": pc,
+                      "seam1_host_4096x4096x4096": seam1_host_config(4096, 4096, 4096, 10),
+                      "seam1_host_4096x4096x512": seam1_host_config(4096, 4096, 512, 30)}
+                for k in ("seam1_host_4096x4096x4096", "seam1_host_4096x4096x512"):
+                    c = s1[k]
+                    bound = max(c["host_bytes_in"] / pc["h2d_GBs"], c["host_bytes_out"] / pc["d2h_GBs"]) / 1e6   # ms, full duplex
+                    c["pcie_bound_ms"] = round(bound, 4)
+                    c["step_over_pcie_bound"] = round(c["ms_per_step"] / bound, 3)
+                out["other_configs"].update(s1)
+            except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
+                out["other_configs"]["seam1_host_error"] = f"{type(e).__name__}: {e}"[:300]
         if not args.no_cpu_baseline:
-            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(M, K, 2048 if threads >= 8 else 256, threads)
+            out["cpu_baseline"] = cpu_baseline(M, K)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,6 +1,7 @@
-"""ctypes binding of libggml_hip.so (the C-ABI declared in include/ggml_hip.h and include/ggml.h).
+"""ctypes binding of libggml_hip.so (the product: the C-ABI declared in include/ggml_hip.h) and of
+libggml_hostmirror.so (test support: the C++ stand-in for the reference's C# host, include/ggml.h).
 
-The library is built in-tree (ggmlsharp_amd/lib/libggml_hip.so) by `make -C ggmlsharp_amd/csrc`.
+Both are built in-tree (ggmlsharp_amd/lib/) by `make -C ggmlsharp_amd/csrc`.
 Nothing here falls back to a CPU implementation: if the library is missing, loading raises.
 """
 import ctypes as C
@@ -10,6 +11,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GGML_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libggml_hip.so")   # env: developer ablation builds
+MIRROR_PATH = os.path.join(PKG_DIR, "lib", "libggml_hostmirror.so")
 
 GGML_MAX_DIMS = 4
 GGML_MAX_OPT = 4
@@ -68,15 +70,39 @@ class ggml_cgraph(C.Structure):
 
 assert C.sizeof(ggml_cgraph) == 98360
 
-# every symbol include/ggml_hip.h and include/ggml.h declare: name -> (restype, argtypes)
+# every symbol include/ggml_hip.h declares (HIP_SYMBOLS, exported by libggml_hip.so) and include/ggml.h declares
+# (MIRROR_SYMBOLS, exported by libggml_hostmirror.so): name -> (restype, argtypes)
 _P = C.c_void_p
 _T = C.POINTER(ggml_tensor)
-SYMBOLS = {
-    # ggml_hip.h
+_PP = C.POINTER(C.c_void_p)
+HIP_SYMBOLS = {
     "ggml_hip_blck_size": (C.c_int, [C.c_int]),
     "ggml_hip_type_size": (C.c_size_t, [C.c_int]),
     "ggml_hip_device_count": (C.c_int, []),
     "ggml_hip_init": (C.c_int, [C.c_int]),
+    "ggml_hip_init_devices": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "ggml_hip_n_slots": (C.c_int, []),
+    "ggml_hip_slot_device": (C.c_int, [C.c_int]),
+    "ggml_hip_bind_thread": (C.c_int, [C.c_int]),
+    "ggml_hip_register_host_pool": (C.c_int, [_P, C.c_size_t]),
+    "ggml_hip_unregister_host_pool": (C.c_int, [_P]),
+    "ggml_hip_invalidate_range": (None, [_P, C.c_size_t]),
+    "ggml_hip_split_weight_upload": (C.c_int, [C.c_int, _P, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(_P)]),
+    "ggml_hip_split_weight_free": (None, [_P]),
+    "ggml_hip_split_weight_rows": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ggml_hip_mul_mat_split_dev": (C.c_int, [_P, _PP, C.c_int64, C.c_int64, _PP, C.c_int64]),
+    "ggml_hip_set_exchange": (C.c_int, [C.c_int]),
+    "ggml_hip_sync_slots": (C.c_int, []),
+    "ggml_hip_debug_rccl_selftest": (C.c_int, []),
+    "ggml_hip_ipc_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P), _P]),
+    "ggml_hip_ipc_open": (C.c_int, [_P, C.POINTER(_P)]),
+    "ggml_hip_ipc_close": (C.c_int, [_P]),
+    "ggml_hip_ipc_free": (C.c_int, [_P]),
+    "ggml_hip_push_columns_dev": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _PP, C.c_int, C.c_int64, C.c_int64, _P]),
+    "ggml_hip_slot_malloc": (_P, [C.c_int, C.c_size_t]),
+    "ggml_hip_slot_free": (None, [C.c_int, _P]),
+    "ggml_hip_slot_upload": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
+    "ggml_hip_slot_download": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
     "ggml_hip_shutdown": (None, []),
     "ggml_hip_last_error": (C.c_char_p, []),
     "ggml_hip_arch": (C.c_char_p, []),
@@ -116,7 +142,8 @@ SYMBOLS = {
     "ggml_hip_quantize_rows_src_dev": (C.c_int, [C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_add_q_f32_rows_dev": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
-    # ggml.h (host mirror)
+}
+MIRROR_SYMBOLS = {
     "ggml_init": (_P, [C.POINTER(ggml_init_params)]),
     "ggml_free": (None, [_P]),
     "ggml_used_mem": (C.c_size_t, [_P]),
@@ -152,6 +179,9 @@ SYMBOLS = {
 }
 
 
+SYMBOLS = dict(HIP_SYMBOLS, **MIRROR_SYMBOLS)
+
+
 def build(force=False):
     """Compile every HIP source for gfx950 into ggmlsharp_amd/lib/libggml_hip.so (hipcc cross-compiles without a GPU)."""
     if force:
@@ -160,13 +190,23 @@ def build(force=False):
     return LIB_PATH
 
 
+class _Libs:
+    """The product library and the host mirror behind one attribute namespace (ggml_hip_* / ggml_*)."""
+
+    def __init__(self, hip, mirror):
+        self.hip, self.mirror = hip, mirror
+
+    def __getattr__(self, name):
+        return getattr(self.hip if name.startswith("ggml_hip_") else self.mirror, name)
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not (os.path.exists(LIB_PATH) and os.path.exists(MIRROR_PATH)):
             if os.path.exists("/opt/rocm/bin/hipcc"):
                 build()
             else:
@@ -177,12 +217,14 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        hip = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)     # the mirror binds ggml_hip_* from it, as the C# host would
+        mirror = C.CDLL(MIRROR_PATH)
+        for L, table in ((hip, HIP_SYMBOLS), (mirror, MIRROR_SYMBOLS)):
+            for name, (res, args) in table.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+        _lib = _Libs(hip, mirror)
     return _lib
 
 

@@ -116,6 +116,38 @@ __device__ __forceinline__ int group8_sum(int v) {
 }
 #endif
 
+// ---- developer A/B switches: compiled in only with -DGGML_HIP_DEV (tools/build_variant.sh); the product library reads
+// no environment variable, so kernel selection in a host process never depends on its environment ----
+#include <stdlib.h>
+#ifdef GGML_HIP_DEV
+static inline int dev_env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool dev_env_set(const char *name) { return getenv(name) != nullptr; }
+static inline const char *dev_env_str(const char *name) { return getenv(name); }
+#else
+static inline int dev_env_int(const char *, int dflt) { return dflt; }
+static inline bool dev_env_set(const char *) { return false; }
+static inline const char *dev_env_str(const char *) { return nullptr; }
+#endif
+
+// ---- once per kernel AND device: hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel, and one
+// process may drive several devices (ggml_hip_init_devices).  One object per kernel instantiation (function-local static).
+#ifdef __cplusplus
+#include <atomic>
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    hipError_t max_dynamic_lds(const void *kern, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+        return e;
+    }
+};
+#endif
+
 // ---- kernel launchers (implemented in the .hip files) ----
 // layout.hip
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
@@ -124,6 +156,8 @@ hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStrea
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
                                     hipStream_t st);
+hipError_t launch_push_columns(const float *src, int64_t lds, int64_t N, int64_t Ms, float *const *peers, int G, int64_t ldd,
+                               int64_t col0, hipStream_t st);
 // quantize.hip
 hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st);
 int gemm_q16_image_kind(int type);   // which f16 image (1 nibble order, 2 byte-plane order) gemm_q16.hip wants for a weight type

@@ -277,7 +277,7 @@ hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int
     // K % 32 == 0 keeps every 8-element piece of a stage inside the row
     const bool vec = w->K % DK == 0 && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0;
     {   // F32 weights, enough 128 x 128 tiles to fill the chip: the big-tile kernel (bitwise the same result)
-        static const bool old = getenv("GGML_HIP_DENSE_OLD") != nullptr;   // developer A/B switch
+        static const bool old = dev_env_set("GGML_HIP_DENSE_OLD");   // developer A/B switch
         const int64_t tm = (w->M + 127) / 128, tn = (N + 127) / 128;
         if (!f16 && vec && !old && tm * tn >= 256 && tm * tn < (1 << 30) && w->Mpad % 128 == 0) {
             dense_f32_big_kernel<<<dim3((unsigned)(tm * tn)), 256, 0, st>>>((const float *)w->dense, x, dst, w->M, N, w->K, ld1, ldd, (int)tm, (int)tn);

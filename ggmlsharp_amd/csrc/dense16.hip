@@ -257,8 +257,8 @@ template <int WMT, int WNT, int WGM, int WGN, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<WMT, WNT, WGM, WGN>;
     auto kern = dense16_kernel<WMT, WNT, WGM, WGN, KSP>;
-    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
+        static PerDeviceOnce once;   // per kernel instantiation; the attribute is set once per device
+    const hipError_t attr = once.max_dynamic_lds((const void *)kern, C::TOTAL * KSP);
     if (attr != hipSuccess) return attr;
     if (w->Mpad % C::TM != 0 || Npad % C::TN != 0) return hipErrorInvalidValue;
     const int64_t Kpad = dense16_kpad(w->K);
@@ -303,7 +303,7 @@ hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N,
     if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     // batches up to 128 rows: K split four ways inside the workgroup (fixed by N and K: same summation tree for a row shard), on
     // 32-row tiles, or on 128-row tiles of 16 waves where those cover the chip
-    static const int var = [] { const char *e = getenv("GGML_HIP_D16_TILE"); return e ? atoi(e) : 0; }();   // developer A/B switch
+    static const int var = dev_env_int("GGML_HIP_D16_TILE", 0);   // developer A/B switch
     const int64_t nst = dense16_kpad(w->K) / (16 * KS);
     if (N <= 128 && nst >= 8 && var != 9) {
         if (var == 1 || (var != 2 && ((w->M + 127) / 128) * ((N + 63) / 64) >= 80)) return launch_cfg<1, 2, 4, 1, 4>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);

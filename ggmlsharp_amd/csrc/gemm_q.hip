@@ -435,8 +435,8 @@ template <int TYPE, int IT, int JT>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using T = Tile<TYPE, IT, JT>;
     auto kern = gemm_q_kernel<TYPE, IT, JT>;
-    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS);
+        static PerDeviceOnce once;   // per kernel instantiation; the attribute is set once per device
+    const hipError_t attr = once.max_dynamic_lds((const void *)kern, T::LDS);
     if (attr != hipSuccess) return attr;
     const int tiles_m = (int)((w->M + T::TM - 1) / T::TM), tiles_n = (int)((N + T::TN - 1) / T::TN);
     dim3 grid((unsigned)(tiles_m * tiles_n));
@@ -449,7 +449,7 @@ template <int TYPE>
 hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     // 128x128 tiles when they already give >= 2 workgroups per CU, else 64x64 to fill the chip
     const int64_t big = ((w->M + 127) / 128) * ((N + 127) / 128);
-    static const char *force = getenv("GGML_HIP_GEMM_TILE");  // developer override: "1" = 64x64, "2" = 128x128
+    static const char *force = dev_env_str("GGML_HIP_GEMM_TILE");  // developer override: "1" = 64x64, "2" = 128x128
     if (force && force[0] == '1') return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
     if (force && force[0] == '2') return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
     if (big >= 512) return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);

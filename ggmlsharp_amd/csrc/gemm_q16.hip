@@ -493,8 +493,8 @@ template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
     auto kern = gemm_q16_kernel<TYPE, WMT, WNT, WGM, WGN, KB, KSP>;
-    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
+        static PerDeviceOnce once;   // per kernel instantiation; the attribute is set once per device
+    const hipError_t attr = once.max_dynamic_lds((const void *)kern, C::TOTAL * KSP);
     if (attr != hipSuccess) return attr;
     if (w->Mpad % C::TM != 0 || p.Npad % C::TN != 0) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
@@ -521,12 +521,12 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // batches up to 256 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip).  129 .. 256 rows, four-way |
     // two-way us: Q8_0 4096 x 4096 x 256 27 | 37, 4096 x 11008 x 256 58 | 81, Q5_0 4096 x 4096 x 256 25 | 39; 11008 x 4096 x 256 63 | 58,
     // 32000 x 4096 x 256 141 | 128
-    static const bool old128 = getenv("GGML_HIP_Q16_OLD128") != nullptr;   // developer A/B switch
-    static const int n4 = [] { const char *e = getenv("GGML_HIP_Q16_N4"); return e ? atoi(e) : 256; }();   // developer A/B switch (128 = the former bound)
+    static const bool old128 = dev_env_set("GGML_HIP_Q16_OLD128");   // developer A/B switch
+    static const int n4 = dev_env_int("GGML_HIP_Q16_N4", 256);   // developer A/B switch (128 = the former bound)
     if (N <= n4 && w->nbk >= 16 && !old128) {
         // same split on 64-row tiles of 8 waves / 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip; the
         // 16-wave form not for the min-term types: registers)
-        static const int tile = [] { const char *e = getenv("GGML_HIP_Q16_TILE"); return e ? atoi(e) : 0; }();   // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
+        static const int tile = dev_env_int("GGML_HIP_Q16_TILE", 0);   // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
         const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
         const int h = tile == 1 ? 128 : tile == 3 ? 64 : tile == 2 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || WT<TYPE>::MIN) ? 64 : 128);
         if constexpr (!WT<TYPE>::MIN)

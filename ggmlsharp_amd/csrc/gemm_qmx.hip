@@ -32,6 +32,10 @@
 
 // Developer timing ablations (never in the product build): -DGGML_MX_DBG=<bits>  1 no barrier / DMA, 2 no LDS fragment
 // or scale reads after the first, 4 no weight reloads, 8 no MFMA after the first, 16 no scale-accumulate, 32 no row-scale reads, 64 no fragment reads.
+#if !defined(GGML_HIP_DEV)      // the product build has no ablation paths: the switches exist only under -DGGML_HIP_DEV
+#undef GGML_MX_DBG
+#undef GGML_MX_XCD1D
+#endif
 #ifndef GGML_MX_DBG
 #define GGML_MX_DBG 0
 #endif
@@ -447,8 +451,8 @@ template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP 
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
     auto kern = gemm_qmx_kernel<TYPE, WMT, WNT, WGM, WGN, KB, FB, KSP, VS>;
-    // once per process and kernel (a function-local static is initialised thread-safely; calls arrive on arbitrary threads)
-    static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::TOTAL * KSP);
+        static PerDeviceOnce once;   // per kernel instantiation; the attribute is set once per device
+    const hipError_t attr = once.max_dynamic_lds((const void *)kern, C::TOTAL * KSP);
     if (attr != hipSuccess) return attr;
     if (w->Mpad % C::TM != 0 || p.Npad % C::TN != 0 || !w->q6a || !w->q6b) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
@@ -471,7 +475,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
 template <int TYPE>
 hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     // the largest tile that still gives the chip ~2 workgroups per CU; small problems get more, smaller workgroups
-    static const int var = [] { const char *e = getenv("GGML_HIP_MX_TILE"); return e ? atoi(e) : 0; }();   // developer A/B switch
+    static const int var = dev_env_int("GGML_HIP_MX_TILE", 0);   // developer A/B switch
     const int64_t tm256 = (w->M + 255) / 256, tm128 = (w->M + 127) / 128, tn128 = (N + 127) / 128;
     // 8 tiles per wave only where the registers allow it: one weight digit and one scale plane (Q4_0)
     if constexpr (TYPE == GGML_TYPE_Q4_0) {

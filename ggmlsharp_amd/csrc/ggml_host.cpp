@@ -1,7 +1,11 @@
 // ggml_host.cpp -- host mirror of the GGMLSharp public API for the mul_mat path (include/ggml.h).
 // Same pool arithmetic, struct layouts and graph walk as the reference; MUL_MAT nodes are dispatched to the
 // HIP path (Seam 1).  There is deliberately no CPU compute here.
-#include "common.h"
+//
+// TEST SUPPORT, not product: this is the stand-in for the reference's C# host (no .NET toolchain in the image).  It is
+// built into its own library, libggml_hostmirror.so, which links libggml_hip.so exactly as the C# host would bind it --
+// through the exported ggml_hip_* C-ABI only.  The real host never loads it, and libggml_hip.so exports no ggml_* name
+// that could collide with a native ggml in the same process.
 #include "../../include/ggml.h"
 
 #include <cstdio>
@@ -126,6 +130,9 @@ ggml_context *ggml_init(const ggml_init_params *params) {
         for (int i = 0; i < GGML_MAX_CONTEXTS; i++) if (&g_contexts[i].context == ctx) g_contexts[i].used = false;
         return nullptr;
     }
+    // the pool is ONE allocation that every tensor's data lives in (Ggml.cs:1545): register it for DMA so that Seam 1 can
+    // overlap its copies with the kernels.  Best effort: without a device, or if pinning fails, the pool stays pageable.
+    if (mem_size >= (64u << 10) && ggml_hip_device_count() > 0) (void)ggml_hip_register_host_pool(ctx->mem_buffer, mem_size);
     return ctx;
 }
 
@@ -135,11 +142,10 @@ void ggml_free(ggml_context *ctx) {
     for (int i = 0; i < GGML_MAX_CONTEXTS; i++)
         if (&g_contexts[i].context == ctx) {
             g_contexts[i].used = false;
-            // the reference's ggml_free gives the device layer no callback; this mirror does, for every tensor in the pool
-            for (ggml_object *o = ctx->objects_begin; o != nullptr; o = o->next) {
-                const ggml_tensor *t = (const ggml_tensor *)((uint8_t *)ctx->mem_buffer + o->offs);
-                if (t->data) ggml_hip_invalidate(t->data);
-            }
+            // the reference's ggml_free gives the device layer no callback; this mirror does: in-flight copies are waited
+            // for, the pool is unpinned, and every cached / resident device copy made from it is dropped
+            (void)ggml_hip_unregister_host_pool(ctx->mem_buffer);
+            ggml_hip_invalidate_range(ctx->mem_buffer, ctx->mem_size);
             if (ctx->mem_buffer_owned) free(ctx->mem_buffer);
             break;
         }
@@ -187,10 +193,15 @@ ggml_tensor *ggml_set_f32(ggml_tensor *t, float value) {
         float *row = (float *)((uint8_t *)t->data + i * t->nb[1]);
         for (int64_t j = 0; j < nc; j++) row[j] = value;
     }
+    // a host write to tensor memory: a device copy cached from it (an F32 weight leaf) would be stale
+    if (n > 0 && nc > 0) ggml_hip_invalidate_range(t->data, (size_t)((n - 1) * (int64_t)t->nb[1] + nc * 4));
     return t;
 }
 float ggml_get_f32_1d(const ggml_tensor *t, int i) { return ((const float *)t->data)[i]; }
-void ggml_set_f32_1d(ggml_tensor *t, int i, float value) { ((float *)t->data)[i] = value; }
+void ggml_set_f32_1d(ggml_tensor *t, int i, float value) {
+    ((float *)t->data)[i] = value;
+    ggml_hip_invalidate_range((const float *)t->data + i, 4);
+}
 
 ggml_tensor *ggml_mul_mat(ggml_context *ctx, ggml_tensor *a, ggml_tensor *b) {
     if (!ctx || !a || !b) return nullptr;

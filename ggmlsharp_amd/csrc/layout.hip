@@ -162,20 +162,48 @@ __global__ void planar_to_aos_kernel(uint8_t *__restrict__ aos, uint64_t nb01, i
 // dense rows: plain strided copy (element size es bytes), rows fastest across blocks, 16 B per thread where possible
 __global__ void copy_rows_kernel(const uint8_t *__restrict__ src, uint64_t src_stride, uint8_t *__restrict__ dst,
                                  uint64_t dst_stride, int64_t rows, int64_t row_bytes) {
-    const int64_t r = blockIdx.y;
+    // rows walk a grid-stride loop in y (grid.y is clamped to 65535 by the launchers); a row of an odd number of
+    // halves ends in a 2-byte tail
     const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (r >= rows || c >= row_bytes) return;
-    *(uint32_t *)(dst + r * dst_stride + c) = *(const uint32_t *)(src + r * src_stride + c);
+    if (c >= row_bytes) return;
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        if (c + 4 <= row_bytes) *(uint32_t *)(dst + r * dst_stride + c) = *(const uint32_t *)(src + r * src_stride + c);
+        else *(uint16_t *)(dst + r * dst_stride + c) = *(const uint16_t *)(src + r * src_stride + c);
+    }
 }
 
 // [G][N][Ms] (rank-major all-gather result) -> [N][ldd] with column r*Ms + i
 __global__ void relayout_gathered_kernel(const float *__restrict__ g, int G, int64_t N, int64_t Ms, float *__restrict__ dst,
                                          int64_t M, int64_t ldd) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // global column in [0, G*Ms)
-    const int64_t n = blockIdx.y;
     if (col >= M || col >= (int64_t)G * Ms) return;
     const int64_t r = col / Ms, i = col - r * Ms;
-    dst[n * ldd + col] = g[(r * N + n) * Ms + i];
+    for (int64_t n = blockIdx.y; n < N; n += gridDim.y) dst[n * ldd + col] = g[(r * N + n) * Ms + i];
+}
+
+// Direct all-gather of dst shards by the compute units: the [N][Ms] shard (row stride lds) is stored as columns
+// [col0, col0 + Ms) of every peer's reference-layout [N][ldd] buffer -- peers reached over xGMI through peer-mapped /
+// IPC-opened pointers.  One hop, every link of the sender busy at once (blockIdx.y = peer), already in the final layout:
+// no [G][N][Ms] intermediate and no re-layout pass (SURVEY 8(e) "epilogue peer-writes").  16-byte accesses when aligned.
+struct PeerPtrs { float *p[16]; };
+template <bool VEC>
+__global__ __launch_bounds__(256) void push_columns_kernel(const float *__restrict__ src, int64_t lds, int64_t N, int64_t Ms, PeerPtrs peers,
+                                                           int64_t ldd, int64_t col0) {
+    float *__restrict__ dst = peers.p[blockIdx.y];
+    if (dst == nullptr) return;                     // (the sender's own slot when it computed in place)
+    if (VEC) {
+        const int64_t w4 = Ms / 4, total = N * w4;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = i / w4, c = (i - r * w4) * 4;
+            *(float4 *)(dst + r * ldd + col0 + c) = *(const float4 *)(src + r * lds + c);
+        }
+    } else {
+        const int64_t total = N * Ms;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = i / Ms, c = i - r * Ms;
+            dst[r * ldd + col0 + c] = src[r * lds + c];
+        }
+    }
 }
 
 // bf6 (e3m2) code of an integer |v| <= 8: 1 = 2^0, 2, 3 = 1.5 * 2, 4, 5 = 1.25 * 4, 6, 7, 8 (all exact)
@@ -254,7 +282,7 @@ hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, 
     if (rows <= 0) return hipSuccess;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
         const int64_t row_bytes = w->K * (type == GGML_TYPE_F32 ? 4 : 2);
-        dim3 grid((unsigned)((row_bytes / 4 + 255) / 256), (unsigned)rows);
+        dim3 grid((unsigned)(((row_bytes + 3) / 4 + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535));
         copy_rows_kernel<<<grid, 256, 0, st>>>(aos + (uint64_t)row_begin * nb01, nb01, (uint8_t *)w->dense,
                                                (uint64_t)row_bytes, rows, row_bytes);
         return hipGetLastError();
@@ -276,7 +304,7 @@ hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStrea
     if (w->M <= 0) return hipSuccess;
     if (w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_F16) {
         const int64_t row_bytes = w->K * (w->type == GGML_TYPE_F32 ? 4 : 2);
-        dim3 grid((unsigned)((row_bytes / 4 + 255) / 256), (unsigned)w->M);
+        dim3 grid((unsigned)(((row_bytes + 3) / 4 + 255) / 256), (unsigned)(w->M < 65535 ? w->M : 65535));
         copy_rows_kernel<<<grid, 256, 0, st>>>((const uint8_t *)w->dense, (uint64_t)row_bytes, aos, (uint64_t)row_bytes,
                                                w->M, row_bytes);
         return hipGetLastError();
@@ -299,7 +327,26 @@ hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStrea
 hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
                                     hipStream_t st) {
     if (N <= 0 || M <= 0) return hipSuccess;
-    dim3 grid((unsigned)((M + 255) / 256), (unsigned)N);
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)(N < 65535 ? N : 65535));
     relayout_gathered_kernel<<<grid, 256, 0, st>>>(g, G, N, Ms, dst, M, ldd);
+    return hipGetLastError();
+}
+
+hipError_t launch_push_columns(const float *src, int64_t lds, int64_t N, int64_t Ms, float *const *peers, int G, int64_t ldd,
+                               int64_t col0, hipStream_t st) {
+    if (N <= 0 || Ms <= 0 || G <= 0) return hipSuccess;
+    if (G > 16) return hipErrorInvalidValue;
+    PeerPtrs pp;
+    bool vec = Ms % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && col0 % 4 == 0 && ((uintptr_t)src & 15) == 0;
+    for (int g = 0; g < 16; ++g) {
+        pp.p[g] = g < G ? peers[g] : nullptr;
+        if (pp.p[g] && ((uintptr_t)pp.p[g] & 15) != 0) vec = false;
+    }
+    const int64_t work = vec ? N * (Ms / 4) : N * Ms;
+    int64_t bx = (work + 255) / 256;
+    if (bx > 2048) bx = 2048;                        // grid-stride: ~8 workgroups per CU and peer keep the links busy
+    dim3 grid((unsigned)bx, (unsigned)G);
+    if (vec) push_columns_kernel<true><<<grid, 256, 0, st>>>(src, lds, N, Ms, pp, ldd, col0);
+    else push_columns_kernel<false><<<grid, 256, 0, st>>>(src, lds, N, Ms, pp, ldd, col0);
     return hipGetLastError();
 }

@@ -643,7 +643,7 @@ hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1
     else if (image == 3) {
         // lane-per-block form when the 32-bit buffer offsets reach (they do for every shape whose image does); rows must
         // be 16-byte aligned for the DMA (ld1 % 4, checked by the callers for every device entry)
-        static const bool old_k1 = getenv("GGML_HIP_K1_OLD") != nullptr;   // developer A/B switch
+        static const bool old_k1 = dev_env_set("GGML_HIP_K1_OLD");   // developer A/B switch
         const uint64_t xb = ((uint64_t)(N - 1) * (uint64_t)ld1 + (uint64_t)K) * 4;
         if (!old_k1 && xb <= 0xFFFFFFFFull && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0) {
             dim3 g2((unsigned)(pad_kblocks(nbk) / 4), (unsigned)((N + 63) / 64));

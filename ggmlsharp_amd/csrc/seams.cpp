@@ -1,0 +1,621 @@
+// seams.cpp -- the C-ABI of include/ggml_hip.h, part 2: the host-pointer seams.
+//   Seam 1  ggml_compute_forward_mul_mat (Ggml.cs:6714-6744): pipelined host -> device / kernels / device -> host on
+//           three streams per device slot, row-split over the slots the caller is not bound away from, graph-scope
+//           residency, weight cache with invalidation on every write;
+//   its neighbours: cpy -> Q, add (q + f32, f32 + f32), mul, scale, rms_norm, silu;
+//   host pool registration (pinned DMA), graph scope, counters.
+#include "ctx.h"
+
+#include <memory>
+
+namespace ghip {
+
+// ---------------- host memory registered for DMA ----------------
+namespace {
+struct HostRange { const uint8_t *p; size_t n; };
+std::mutex g_pin_mu;
+std::vector<HostRange> g_pinned;
+}  // namespace
+
+bool host_range_pinned(const void *p, size_t n) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    const uint8_t *a = (const uint8_t *)p;
+    for (const HostRange &r : g_pinned)
+        if (a >= r.p && a + n <= r.p + r.n) return true;
+    return false;
+}
+
+namespace {
+
+// ---------------- which slots serve a call ----------------
+// A thread bound to a slot (ggml_hip_bind_thread) runs on that slot alone; an unbound caller gets every slot, i.e. the
+// reference's row partition (Ggml.cs:6665-6672) for mul_mat and replicated execution for the cheap element-wise nodes.
+struct Call {
+    std::vector<DeviceCtx *> ctxs;
+    std::vector<std::unique_lock<std::recursive_mutex>> locks;
+    int begin() {
+        int rc = ensure_init();
+        if (rc) return rc;
+        const int b = bound_slot();
+        if (b >= 0) ctxs.push_back(slot(b));
+        else for (int i = 0; i < n_slots(); ++i) ctxs.push_back(slot(i));
+        for (DeviceCtx *c : ctxs) {
+            if (!c) return fail(GGML_HIP_ERR_RUNTIME, "library was shut down during the call");
+            locks.emplace_back(c->mu);                 // slot order: no lock-order inversion between callers
+        }
+        return GGML_HIP_OK;
+    }
+    int G() const { return (int)ctxs.size(); }
+    bool in_graph() const { return ctxs[0]->graph_depth_ > 0; }
+};
+
+size_t tensor_host_bytes(const ggml_tensor *t) {   // bytes from data to the end of the last element (strided tensors included)
+    size_t end = 0;
+    const int blck = BLCK[t->type];
+    end = (size_t)((t->ne[0] + blck - 1) / blck) * TSIZE[t->type];
+    for (int i = 1; i < 4; ++i)
+        if (t->ne[i] > 1) end += (size_t)(t->ne[i] - 1) * t->nb[i];
+    return end;
+}
+
+// every writer of host tensor memory: weight-cache entries built from it and other resident copies overlapping it are stale
+void note_host_write(Call &call, const ggml_tensor *dst, bool keep_exact_resident) {
+    const size_t bytes = tensor_host_bytes(dst);
+    for (DeviceCtx *c : call.ctxs) {
+        c->invalidate(dst->data, bytes);
+        c->drop_overlapping(dst->data, bytes, keep_exact_resident);
+    }
+}
+
+// device pointer of a contiguous f32 operand on slot c: its resident copy if an earlier node of this graph produced it,
+// else an upload from host memory into `scratch` on the slot's compute stream
+int operand_f32(DeviceCtx *c, bool in_graph, const ggml_tensor *t, Scratch &scratch, const float **out) {
+    const size_t bytes = (size_t)nelem(t) * 4;
+    if (in_graph) {
+        const void *r = c->resident_lookup(t->data, bytes);
+        if (r) { *out = (const float *)r; ++c->resident_hits; return 0; }
+        if (c->sync_all()) return -1;   // host memory may still be receiving an earlier node's result
+    }
+    if (scratch.ensure(bytes)) return -1;
+    if (hipMemcpyAsync(scratch.p, t->data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+    c->h2d_bytes += bytes;
+    *out = (const float *)scratch.p;
+    return 0;
+}
+// device buffer for a contiguous f32 result: kept resident inside a graph scope (in place when dst shares src's data)
+float *result_f32(DeviceCtx *c, bool in_graph, const ggml_tensor *t, Scratch &scratch) {
+    const size_t bytes = (size_t)nelem(t) * 4;
+    if (in_graph) return (float *)c->resident_buffer(t->data, bytes);
+    return scratch.ensure(bytes) ? nullptr : (float *)scratch.p;
+}
+int finish_f32(DeviceCtx *c, bool in_graph, bool to_host, ggml_tensor *t, const float *dev) {
+    const size_t bytes = (size_t)nelem(t) * 4;
+    if (to_host) {
+        if (hipMemcpyAsync(t->data, dev, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+        c->d2h_bytes += bytes;
+    }
+    if (!in_graph && hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    return 0;
+}
+// the slots an element-wise node runs on: all of them inside a graph scope (every slot then holds every resident
+// tensor, so a later row-split mul_mat finds its src1 in its own HBM), the first one otherwise
+int eltwise_slots(const Call &call) { return call.in_graph() ? call.G() : 1; }
+
+// Seam-1 pipeline: src1 rows per chunk.  A function of N and K only (never of M or the slot count), so a row shard and the
+// unsplit matrix run the same kernel forms on the same chunks: bit-identical results for any split.
+int64_t seam_chunk_rows(int64_t N, int64_t K, bool pinned) {
+    if (!pinned) return N;                              // pageable memory: the runtime stages synchronously, nothing overlaps
+    const int64_t x_bytes = N * K * 4;
+    if (N < 64 || x_bytes < (2ll << 20)) return N;
+    int64_t nch = x_bytes / (4ll << 20);                // ~4 MiB of activations per chunk
+    if (nch < 2) nch = 2;
+    if (nch > PIPE_EVENTS / 2) nch = PIPE_EVENTS / 2;
+    int64_t rows = ((N + nch - 1) / nch + 31) / 32 * 32;
+    return rows < 32 ? 32 : rows;
+}
+
+}  // namespace
+}  // namespace ghip
+
+using namespace ghip;
+
+extern "C" {
+
+int ggml_hip_register_host_pool(void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(GGML_HIP_ERR_ARG, "null pool");
+    int rc = ensure_init();
+    if (rc) return rc;
+    rc = slot(0)->make_current();
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (const HostRange &r : g_pinned)
+            if (r.p == (const uint8_t *)ptr) return r.n == bytes ? GGML_HIP_OK : fail(GGML_HIP_ERR_ARG, "pool already registered with another size");
+    }
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pinned.push_back(HostRange{(const uint8_t *)ptr, bytes});
+    return GGML_HIP_OK;
+}
+
+int ggml_hip_unregister_host_pool(void *ptr) {
+    if (!ptr) return fail(GGML_HIP_ERR_ARG, "null pool");
+    bool found = false;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].p == (const uint8_t *)ptr) { bytes = g_pinned[i].n; g_pinned.erase(g_pinned.begin() + (long)i); found = true; break; }
+    }
+    if (!found) return GGML_HIP_OK;                      // never registered (no device at ggml_init time): nothing to undo
+    // no DMA may still target the pool, and nothing cached from it may outlive it
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        if (c->make_current() == GGML_HIP_OK) (void)c->sync_all();
+        c->invalidate(ptr, bytes);
+        c->drop_overlapping(ptr, bytes, false);
+    }
+    hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "hipHostUnregister: %s", hipGetErrorString(e)); }
+    return GGML_HIP_OK;
+}
+
+void ggml_hip_invalidate(const void *host_ptr) {
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        (void)c->make_current();
+        c->invalidate(host_ptr, 1);
+        c->drop_overlapping(host_ptr, 1, false);
+    }
+}
+
+void ggml_hip_invalidate_range(const void *host_ptr, size_t bytes) {
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        (void)c->make_current();
+        c->invalidate(host_ptr, bytes);
+        c->drop_overlapping(host_ptr, bytes, false);
+    }
+}
+
+void ggml_hip_invalidate_all(void) {
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        (void)c->make_current();
+        (void)c->sync_all();
+        c->free_cache();
+    }
+}
+
+/* Graph scope for ggml_graph_compute's node loop (Ggml.cs:3539-3704): see ctx.h "graph scope". */
+int ggml_hip_graph_begin(void) {
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    for (DeviceCtx *c : call.ctxs) ++c->graph_depth_;
+    return GGML_HIP_OK;
+}
+int ggml_hip_graph_end(void) {
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    if (call.ctxs[0]->graph_depth_ <= 0) return fail(GGML_HIP_ERR_ARG, "ggml_hip_graph_end without ggml_hip_graph_begin");
+    for (DeviceCtx *c : call.ctxs) {
+        int r = c->make_current();
+        if (!r) r = c->sync_all();                       // every node's dst is on the host from here on
+        if (r && !rc) rc = r;
+        if (--c->graph_depth_ == 0) c->drain(false);
+    }
+    return rc;
+}
+void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits) {
+    uint64_t a = 0, b = 0, h = 0;
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        a += c->h2d_bytes; b += c->d2h_bytes; h += c->resident_hits;
+    }
+    if (h2d_bytes) *h2d_bytes = a;
+    if (d2h_bytes) *d2h_bytes = b;
+    if (resident_hits) *resident_hits = h;
+}
+
+/* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
+ * ggml_mul_mat_impl (Ggml.cs:8228-8229); the reference silently drops them in Release, here they are errors. */
+int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                     const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    // offload convention of the reference's own dead GPU blocks (Ggml.cs:6510-6521)
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const int type = src0->type;
+    if (type < 0 || type >= GGML_TYPE_COUNT || !weight_type_ok(type))
+        return fail(GGML_HIP_ERR_TYPE, "src0 type %d unsupported (Q4_3/Q8_1 null slots; Q4_2/Q5_1 broken storage, SURVEY D7/D8)", type);
+    if (src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "src1 and dst must be F32");
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t ne10 = src1->ne[0], ne11 = src1->ne[1], ne12 = src1->ne[2], ne13 = src1->ne[3];
+    if (ne00 != ne10 || ne02 != ne12 || ne03 != ne13) return fail(GGML_HIP_ERR_SHAPE, "!ggml_can_mul_mat (Ggml.cs:8345-8353)");
+    if (dst->ne[0] != ne01 || dst->ne[1] != ne11 || dst->ne[2] != ne02 || dst->ne[3] != ne03)
+        return fail(GGML_HIP_ERR_SHAPE, "dst shape (Ggml.cs:6488-6491)");
+    if (src0->nb[0] != TSIZE[type]) return fail(GGML_HIP_ERR_SHAPE, "permuted src0 (Ggml.cs:6477)");
+    if (src0->nb[0] > src0->nb[1]) return fail(GGML_HIP_ERR_SHAPE, "transposed src0 (Ggml.cs:8229)");
+    if (src1->nb[0] != 4) return fail(GGML_HIP_ERR_SHAPE, "permuted src1 (Ggml.cs:6478)");
+    if (dst->nb[0] != 4 || dst->nb[0] > dst->nb[1] || dst->nb[1] > dst->nb[2] || dst->nb[2] > dst->nb[3])
+        return fail(GGML_HIP_ERR_SHAPE, "dst transposed or permuted (Ggml.cs:6481-6484)");
+    if (ne00 % BLCK[type] != 0) return fail(GGML_HIP_ERR_SHAPE, "ne00 %% 32 != 0 (Ggml.cs:6694)");
+    if (src1->nb[1] % 4 != 0 || dst->nb[1] % 4 != 0) return fail(GGML_HIP_ERR_SHAPE, "row strides must be multiples of 4");
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (ne01 == 0 || ne11 == 0 || ne02 * ne03 == 0) return GGML_HIP_OK;
+
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    const int G = call.G();
+    const bool in_graph = call.in_graph();
+    const int64_t nslice = ne02 * ne03;
+    const size_t x_bytes = (size_t)ne11 * ne10 * 4, d_full = (size_t)ne11 * ne01 * 4;
+    const size_t w_bytes = ggml_hip_mul_mat_work_size(type, ne00, ne11);
+    const bool src1_contig = src1->nb[1] == (uint64_t)ne10 * 4 && src1->nb[2] == src1->nb[1] * (uint64_t)ne11 &&
+                             src1->nb[3] == src1->nb[2] * (uint64_t)ne12;
+    const bool dst_contig = dst->nb[1] == (uint64_t)ne01 * 4 && dst->nb[2] == dst->nb[1] * (uint64_t)ne11 &&
+                            dst->nb[3] == dst->nb[2] * (uint64_t)ne02;
+    const bool pinned = host_range_pinned(src1->data, tensor_host_bytes(src1)) && host_range_pinned(dst->data, tensor_host_bytes(dst));
+    const int64_t chunk = seam_chunk_rows(ne11, ne10, pinned);
+    // a src0 that some node computes (or that is a leaf the host rewrites between computes without telling us) must not be
+    // served from the cache: only leaves are cached, and every seam that writes host memory invalidates what overlaps it
+    const bool cacheable = src0->op == GGML_OP_NONE;
+
+    // dst is about to be written: stale weight-cache entries / resident copies of anything overlapping it go first
+    note_host_write(call, dst, true);
+
+    std::vector<std::vector<ggml_hip_weight *>> W((size_t)G);       // [slot][slice]
+    std::vector<ggml_hip_weight *> to_free;                         // transient weights of a call outside a graph scope
+    std::vector<const uint8_t *> x_res((size_t)G, nullptr);
+    std::vector<uint8_t *> d_res((size_t)G, nullptr);
+    std::vector<int64_t> r0((size_t)G), r1((size_t)G);
+    for (int g = 0; g < G; ++g) {
+        DeviceCtx *c = call.ctxs[(size_t)g];
+        rc = c->make_current();
+        if (rc) return rc;
+        shard_rows(ne01, G, g, &r0[(size_t)g], &r1[(size_t)g]);
+        const CacheKey key{src0->data, type, ne00, ne01, ne02, ne03, src0->nb[1], src0->nb[2], src0->nb[3], r0[(size_t)g], r1[(size_t)g]};
+        auto it = cacheable ? c->cache.find(key) : c->cache.end();
+        if (it != c->cache.end()) {
+            W[(size_t)g] = it->second.slices;
+        } else {
+            // the source rows: a device copy left by the node that computed them (graph scope), else host memory -- which an
+            // earlier node's device -> host copy may still be filling, so wait for this slot's streams first
+            const uint8_t *dev_src = nullptr;
+            if (!cacheable && in_graph && ggml_hip_type_size(type) == src0->nb[0] && (type == GGML_TYPE_F32) && contiguous_f32(src0))
+                dev_src = (const uint8_t *)c->resident_lookup(src0->data, (size_t)nelem(src0) * 4);
+            if (!dev_src && in_graph) { rc = c->sync_all(); if (rc) return rc; }
+            std::vector<ggml_hip_weight *> slices;
+            for (int64_t i03 = 0; i03 < ne03 && !rc; ++i03)
+                for (int64_t i02 = 0; i02 < ne02 && !rc; ++i02) {
+                    ggml_hip_weight *w = nullptr;
+                    const size_t off = (size_t)(i02 * src0->nb[2] + i03 * src0->nb[3]);
+                    rc = make_weight(c, type, (dev_src ? dev_src : (const uint8_t *)src0->data) + off, dev_src == nullptr, ne00, ne01,
+                                     src0->nb[1], r0[(size_t)g], r1[(size_t)g], c->stream, &w);
+                    if (!rc) slices.push_back(w);
+                }
+            if (rc) {
+                for (ggml_hip_weight *x : slices) ggml_hip_weight_free(x);
+                for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x);
+                return rc;
+            }
+            W[(size_t)g] = slices;
+            if (cacheable) {
+                CachedWeight cw;
+                cw.host = src0->data; cw.host_bytes = tensor_host_bytes(src0); cw.slices = slices;
+                cw.row_begin = r0[(size_t)g]; cw.row_end = r1[(size_t)g];
+                c->cache.emplace(key, std::move(cw));
+            } else if (in_graph) {
+                for (ggml_hip_weight *x : slices) c->transient.push_back(x);     // alive until graph end (kernels in flight)
+            } else {
+                for (ggml_hip_weight *x : slices) to_free.push_back(x);
+            }
+        }
+        // graph scope: is src1 the (contiguous) dst of an earlier offloaded node?  will dst be kept?
+        if (in_graph && src1_contig) {
+            x_res[(size_t)g] = (const uint8_t *)c->resident_lookup(src1->data, x_bytes * (size_t)nslice);
+            if (x_res[(size_t)g]) ++c->resident_hits;
+        }
+        if (in_graph && dst_contig) {
+            d_res[(size_t)g] = (uint8_t *)c->resident_buffer(dst->data, d_full * (size_t)nslice);
+            if (!d_res[(size_t)g]) rc = fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for a resident dst");
+        }
+        const int64_t Ms = r1[(size_t)g] - r0[(size_t)g];
+        if (!rc && ((!x_res[(size_t)g] && c->src1.ensure(x_bytes)) || (!d_res[(size_t)g] && c->dst.ensure((size_t)ne11 * (size_t)(Ms > 0 ? Ms : 1) * 4)) ||
+                    c->work.ensure(w_bytes ? w_bytes : 16)))
+            rc = fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+        if (rc) { for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x); return rc; }
+    }
+
+    hipError_t e = hipSuccess;
+    for (int64_t i03 = 0; i03 < ne03 && !rc && e == hipSuccess; ++i03)
+        for (int64_t i02 = 0; i02 < ne02 && !rc && e == hipSuccess; ++i02) {  // slice offsets as in Ggml.cs:6566-6570
+            const int64_t sl = i03 * ne02 + i02;
+            const uint8_t *x_host = (const uint8_t *)src1->data + i02 * src1->nb[2] + i03 * src1->nb[3];
+            uint8_t *d_host = (uint8_t *)dst->data + i02 * dst->nb[2] + i03 * dst->nb[3];
+            for (int g = 0; g < G && !rc && e == hipSuccess; ++g) {
+                DeviceCtx *c = call.ctxs[(size_t)g];
+                const int64_t Ms = r1[(size_t)g] - r0[(size_t)g];
+                if (Ms <= 0) continue;
+                rc = c->make_current();
+                if (rc) break;
+                const ggml_hip_weight *w = W[(size_t)g][(size_t)sl];
+                const float *xd = x_res[(size_t)g] ? (const float *)(x_res[(size_t)g] + (size_t)sl * x_bytes) : (const float *)c->src1.p;
+                // device dst: this slot's columns of the resident [N][M] copy, or a [N][Ms] scratch shard
+                float *dd = d_res[(size_t)g] ? (float *)(d_res[(size_t)g] + (size_t)sl * d_full) + r0[(size_t)g] : (float *)c->dst.p;
+                const int64_t ldd = d_res[(size_t)g] ? ne01 : Ms;
+                // scratch reuse across calls and slices: uploads wait for the kernels issued so far (they may still read
+                // the src1 scratch), kernels wait for the device -> host copies issued so far (they read the dst scratch)
+                if (e == hipSuccess) e = hipEventRecord(c->ev_compute, c->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_d2h, c->s_d2h);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_d2h, 0);
+                if (!x_res[(size_t)g] && in_graph && e == hipSuccess) {
+                    // src1 comes from host memory: inside a graph scope an earlier node's device -> host copy into that
+                    // very memory may still be in flight
+                    rc = c->sync_all();
+                    if (rc) break;
+                }
+                int k = 0;
+                for (int64_t a = 0; a < ne11 && !rc && e == hipSuccess; a += chunk, ++k) {
+                    const int64_t n = ne11 - a < chunk ? ne11 - a : chunk;
+                    const int ke = k % PIPE_EVENTS;
+                    if (!x_res[(size_t)g]) {
+                        e = hipMemcpy2DAsync((uint8_t *)c->src1.p + (size_t)a * ne10 * 4, (size_t)ne10 * 4, x_host + (size_t)a * src1->nb[1],
+                                             src1->nb[1], (size_t)ne10 * 4, (size_t)n, hipMemcpyHostToDevice, c->s_h2d);
+                        c->h2d_bytes += (size_t)n * ne10 * 4;
+                        if (e == hipSuccess) e = hipEventRecord(c->ev_in[ke], c->s_h2d);
+                        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[ke], 0);
+                        if (e != hipSuccess) break;
+                    }
+                    rc = ggml_hip_mul_mat_dev(w, xd + (size_t)a * ne10, n, ne10, dd + (size_t)a * ldd, ldd, c->work.p, c->work.cap, c->stream);
+                    if (rc) break;
+                    e = hipEventRecord(c->ev_k[ke], c->stream);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_k[ke], 0);
+                    if (e == hipSuccess)
+                        e = hipMemcpy2DAsync(d_host + (size_t)a * dst->nb[1] + (size_t)r0[(size_t)g] * 4, dst->nb[1], dd + (size_t)a * ldd,
+                                             (size_t)ldd * 4, (size_t)Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
+                    c->d2h_bytes += (size_t)n * Ms * 4;
+                }
+            }
+            // row split inside a graph scope: every slot's resident copy of dst gets the other slots' columns, so the next
+            // node finds its operand whole in its own HBM (peer DMA over xGMI, or an in-process RCCL all-gather: multi.cpp)
+            if (!rc && e == hipSuccess && G > 1 && d_res[0]) {
+                std::vector<float *> bufs((size_t)G);
+                for (int g = 0; g < G; ++g) bufs[(size_t)g] = (float *)(d_res[(size_t)g] + (size_t)sl * d_full);
+                rc = exchange_columns(G, call.ctxs.data(), bufs.data(), ne11, ne01, r0.data(), r1.data());
+            }
+        }
+    if (e != hipSuccess && !rc) rc = fail(GGML_HIP_ERR_RUNTIME, "seam 1: %s", hipGetErrorString(e));
+    // outside a graph scope the call returns with dst on the host; inside, ggml_hip_graph_end waits once
+    if (!in_graph || rc || !to_free.empty())
+        for (DeviceCtx *c : call.ctxs) {
+            int r = c->make_current();
+            if (!r) r = c->sync_all();
+            if (r && !rc) rc = r;
+        }
+    for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x);
+    return rc;
+}
+
+/* ggml_compute_forward_cpy, quantizing branch of dup_f32 / dup_f16 (Ggml.cs:4339-4363, 3935-3966) */
+int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 struct ggml_tensor *dst) {
+    if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const int st = src0->type, dt = dst->type;
+    if (st != GGML_TYPE_F32 && st != GGML_TYPE_F16) return fail(GGML_HIP_ERR_TYPE, "cpy: src0 must be F32 or F16 (Ggml.cs:4602-4619)");
+    if (!wq_ok(dt))
+        return fail(GGML_HIP_ERR_TYPE, "cpy: only the quantizing branch is on this path (dst type %d)", dt);
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    const int64_t n_src = ne00 * ne01 * ne02 * ne03, n_dst = dst->ne[0] * dst->ne[1] * dst->ne[2] * dst->ne[3];
+    if (n_src != n_dst) return fail(GGML_HIP_ERR_SHAPE, "cpy: element counts differ (Ggml.cs:8281)");
+    const size_t es = st == GGML_TYPE_F32 ? 4 : 2;
+    if (src0->nb[0] != es) return fail(GGML_HIP_ERR_SHAPE, "cpy: src0 rows must be contiguous");
+    if (dst->nb[0] != TSIZE[dt] || dst->nb[1] != dst->nb[0] * (uint64_t)(dst->ne[0] / BLCK[dt]) || dst->nb[2] != dst->nb[1] * (uint64_t)dst->ne[1] ||
+        dst->nb[3] != dst->nb[2] * (uint64_t)dst->ne[2])
+        return fail(GGML_HIP_ERR_SHAPE, "cpy: dst must be contiguous (Ggml.cs:4290)");
+    if (ne00 % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "cpy: ne00 %% 32 != 0");
+    if (src0->nb[1] % 16 != 0 && ne01 * ne02 * ne03 > 1) return fail(GGML_HIP_ERR_SHAPE, "cpy: src0 row stride must be a multiple of 16 bytes");
+    if (!src0->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (n_src == 0) return GGML_HIP_OK;
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    DeviceCtx *c = call.ctxs[0];                      // the result goes to host memory only: one slot does it
+    rc = c->make_current();
+    if (rc) return rc;
+    if (call.in_graph()) { rc = c->sync_all(); if (rc) return rc; }   // operands may be dst of an earlier node still on its way to the host
+    note_host_write(call, dst, false);                // dst is usually a future src0: its cached device copy (if any) is now stale
+    const size_t row_in = (size_t)ne00 * es, rs = row_bytes_of(dt, ne00);   // rs as in Ggml.cs:4345
+    if (c->src1.ensure(row_in * ne01) || c->dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+    size_t id = 0;
+    for (int64_t i03 = 0; i03 < ne03; ++i03)
+        for (int64_t i02 = 0; i02 < ne02; ++i02) {
+            const uint8_t *src = (const uint8_t *)src0->data + i02 * src0->nb[2] + i03 * src0->nb[3];
+            HIP_TRY(hipMemcpy2DAsync(c->src1.p, row_in, src, src0->nb[1], row_in, (size_t)ne01, hipMemcpyHostToDevice, c->stream));
+            rc = ggml_hip_quantize_rows_src_dev(dt, st, c->src1.p, ne00, ne01, ne00, c->dst.p, c->stream);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync((uint8_t *)dst->data + id, c->dst.p, rs * ne01, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            id += rs * ne01;
+        }
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_add_f32 / _mul_f32 (Ggml.cs:4622-4682, 5007-5035): same-shape contiguous f32 operands */
+static int binary_f32_seam(int op, const struct ggml_tensor *src0, const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    const char *name = op == 0 ? "add_f32" : "mul_f32";
+    if (src0->type != GGML_TYPE_F32 || src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "%s: F32 operands only (Ggml.cs:5043-5056)", name);
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != src1->ne[i] || src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "%s: shapes differ (Ggml.cs:4628, 5014)", name);
+    if (!contiguous_f32(src0) || !contiguous_f32(src1) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "%s: contiguous operands only", name);
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    const bool in_graph = call.in_graph();
+    const int ns = eltwise_slots(call);
+    for (int g = 0; g < ns; ++g) {
+        DeviceCtx *c = call.ctxs[(size_t)g];
+        rc = c->make_current();
+        if (rc) return rc;
+        const float *a = nullptr, *b = nullptr;
+        if (operand_f32(c, in_graph, src0, c->src1, &a) || operand_f32(c, in_graph, src1, c->stage, &b)) return fail(GGML_HIP_ERR_RUNTIME, "%s: operand staging failed", name);
+        if (g == 0) note_host_write(call, dst, true);      // (after the operands were resolved: dst may alias one of them)
+        float *z = result_f32(c, in_graph, dst, c->dst);
+        if (!z) return fail(GGML_HIP_ERR_RUNTIME, "%s: hipMalloc failed", name);
+        HIP_TRY(launch_binary_f32(op, a, b, z, nelem(src0), c->stream));
+        if (finish_f32(c, in_graph, g == 0, dst, z)) return fail(GGML_HIP_ERR_RUNTIME, "%s: copy back failed", name);
+    }
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_add_q_f32 (Ggml.cs:4797-4906) */
+int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const int t = src0->type;
+    if (t == GGML_TYPE_F32) return binary_f32_seam(0, src0, src1, dst);      // ggml_compute_forward_add_f32 (Ggml.cs:4622-4682)
+    if (!wq_ok(t))
+        return fail(GGML_HIP_ERR_TYPE, "add: src0 must be F32 or quantized (add_q_f32), got type %d", t);
+    if (dst->type != t || src1->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "add_q_f32: dst must have src0's type, src1 F32 (Ggml.cs:4863-4865)");
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != src1->ne[i] || src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: shapes differ (Ggml.cs:4803)");
+    if (src0->nb[0] != TSIZE[t] || dst->nb[0] != TSIZE[t] || src1->nb[0] != 4) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: permuted operand (Ggml.cs:4853-4854)");
+    const int64_t ne00 = src0->ne[0], ne01 = src0->ne[1], ne02 = src0->ne[2], ne03 = src0->ne[3];
+    if (ne00 % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "ne00 %% 32 != 0 (Ggml.cs:4893)");
+    if (src1->nb[1] % 16 != 0 && ne01 > 1) return fail(GGML_HIP_ERR_SHAPE, "add_q_f32: src1 row stride must be a multiple of 16 bytes");
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (ne00 * ne01 * ne02 * ne03 == 0) return GGML_HIP_OK;
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    DeviceCtx *c = call.ctxs[0];
+    rc = c->make_current();
+    if (rc) return rc;
+    if (call.in_graph()) { rc = c->sync_all(); if (rc) return rc; }   // operands may be dst of an earlier node still on its way to the host
+    note_host_write(call, dst, false);
+    const size_t rs = row_bytes_of(t, ne00), rx = (size_t)ne00 * 4;
+    if (c->stage.ensure(rs * ne01) || c->src1.ensure(rx * ne01) || c->dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+    for (int64_t i03 = 0; i03 < ne03; ++i03)
+        for (int64_t i02 = 0; i02 < ne02; ++i02) {
+            const uint8_t *a = (const uint8_t *)src0->data + i02 * src0->nb[2] + i03 * src0->nb[3];
+            const uint8_t *b = (const uint8_t *)src1->data + i02 * src1->nb[2] + i03 * src1->nb[3];
+            // the reference offsets dst rows by i3*nb0 (Ggml.cs:4891), an upstream typo for nb3; intent is followed
+            uint8_t *d = (uint8_t *)dst->data + i02 * dst->nb[2] + i03 * dst->nb[3];
+            HIP_TRY(hipMemcpy2DAsync(c->stage.p, rs, a, src0->nb[1], rs, (size_t)ne01, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpy2DAsync(c->src1.p, rx, b, src1->nb[1], rx, (size_t)ne01, hipMemcpyHostToDevice, c->stream));
+            rc = ggml_hip_add_q_f32_rows_dev(t, c->stage.p, (const float *)c->src1.p, ne01, ne00, c->dst.p, c->stream);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy2DAsync(d, dst->nb[1], c->dst.p, rs, rs, (size_t)ne01, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_mul (Ggml.cs:5037-5056) */
+int ggml_hip_compute_forward_mul(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                 const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    return binary_f32_seam(1, src0, src1, dst);
+}
+
+/* ggml_compute_forward_scale_f32 (Ggml.cs:6746-6778): dst (a view of src0) *= *(float *)src1->data */
+int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                   const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (src0->type != GGML_TYPE_F32 || src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "scale: F32 only (Ggml.cs:6786-6799)");
+    if (nelem(src1) != 1) return fail(GGML_HIP_ERR_SHAPE, "scale: src1 must be a scalar (Ggml.cs:6755)");
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "scale: shapes differ (Ggml.cs:6754)");
+    if (!contiguous_f32(src0) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "scale: contiguous operands only (Ggml.cs:6752-6753)");
+    if (!src0->data || !src1->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    const bool in_graph = call.in_graph();
+    const int ns = eltwise_slots(call);
+    float v = 0.0f;
+    for (int g = 0; g < ns; ++g) {
+        DeviceCtx *c = call.ctxs[(size_t)g];
+        rc = c->make_current();
+        if (rc) return rc;
+        if (g == 0) {
+            if (in_graph) { rc = c->sync_all(); if (rc) return rc; }      // the scalar is read from host memory
+            v = *(const float *)src1->data;
+        }
+        // the reference scales dst's own memory: when dst is not a view of src0 that memory is whatever it held before, and
+        // so it is here (the device form of "dst" is then an upload of dst->data, not of src0->data)
+        const float *cur = nullptr;
+        if (operand_f32(c, in_graph, dst, c->src1, &cur)) return fail(GGML_HIP_ERR_RUNTIME, "scale: operand staging failed");
+        if (g == 0) note_host_write(call, dst, true);
+        float *z = result_f32(c, in_graph, dst, c->dst);
+        if (!z) return fail(GGML_HIP_ERR_RUNTIME, "scale: hipMalloc failed");
+        if (z != cur) HIP_TRY(hipMemcpyAsync(z, cur, (size_t)nelem(dst) * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(launch_scale_f32(z, nelem(dst), v, c->stream));
+        if (finish_f32(c, in_graph, g == 0, dst, z)) return fail(GGML_HIP_ERR_RUNTIME, "scale: copy back failed");
+    }
+    return GGML_HIP_OK;
+}
+
+// unary f32 seams share one body: which = 0 rms_norm (Ggml.cs:5858-5920), 1 silu (Ggml.cs:5705-5748)
+static int unary_f32_seam(int which, const struct ggml_tensor *src0, struct ggml_tensor *dst) {
+    const char *name = which == 0 ? "rms_norm" : "silu";
+    if (src0->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "%s: F32 only (Ggml.cs:5927-5940, 5755-5768)", name);
+    for (int i = 0; i < 4; ++i)
+        if (src0->ne[i] != dst->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "%s: shapes differ (Ggml.cs:5863, 5712)", name);
+    if (!contiguous_f32(src0) || !contiguous_f32(dst)) return fail(GGML_HIP_ERR_SHAPE, "%s: contiguous operands only (Ggml.cs:5710-5711)", name);
+    if (!src0->data || !dst->data) return fail(GGML_HIP_ERR_ARG, "null data");
+    if (nelem(src0) == 0) return GGML_HIP_OK;
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    const bool in_graph = call.in_graph();
+    const int ns = eltwise_slots(call);
+    for (int g = 0; g < ns; ++g) {
+        DeviceCtx *c = call.ctxs[(size_t)g];
+        rc = c->make_current();
+        if (rc) return rc;
+        const float *a = nullptr;
+        if (operand_f32(c, in_graph, src0, c->src1, &a)) return fail(GGML_HIP_ERR_RUNTIME, "%s: operand staging failed", name);
+        if (g == 0) note_host_write(call, dst, true);
+        float *z = result_f32(c, in_graph, dst, c->dst);
+        if (!z) return fail(GGML_HIP_ERR_RUNTIME, "%s: hipMalloc failed", name);
+        if (which == 0) HIP_TRY(launch_rms_norm_f32(a, z, nelem(src0) / src0->ne[0], src0->ne[0], c->stream));
+        else HIP_TRY(launch_silu_f32(a, z, nelem(src0), c->stream));
+        if (finish_f32(c, in_graph, g == 0, dst, z)) return fail(GGML_HIP_ERR_RUNTIME, "%s: copy back failed", name);
+    }
+    return GGML_HIP_OK;
+}
+
+/* ggml_compute_forward_rms_norm_f32 (Ggml.cs:5858-5920) */
+int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                      struct ggml_tensor *dst) {
+    if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    return unary_f32_seam(0, src0, dst);
+}
+
+/* ggml_compute_forward_silu_f32 (Ggml.cs:5705-5748) */
+int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                  struct ggml_tensor *dst) {
+    if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    return unary_f32_seam(1, src0, dst);
+}
+
+}  // extern "C"

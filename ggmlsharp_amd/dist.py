@@ -1,15 +1,21 @@
-"""Row-split of the weight matrix across the GPUs of one node + all-gather of the dst shards.
+"""Row-split of the weight matrix across the GPUs of one node + exchange of the dst shards (one process per GPU).
 
 The reference's only parallelism is a contiguous row partition of src0 over CPU threads
 (Ggml.cs:6665-6672: dr = ceil(nr / nth), thread ith owns rows [dr*ith, min(dr*(ith+1), nr))).  The same partition
-is used over ranks: one process per GPU, rank r keeps its row shard resident, every rank holds all of src1, and
-the dst shards ([N][Ms] each, m fastest) are exchanged with one all-gather (RCCL over xGMI under the "nccl"
-backend) and re-laid-out into the reference's dst layout [N][M] (Ggml.cs:6692-6697; SURVEY.md 8(e) layout catch).
-For N == 1 the gathered buffer already is that layout and the re-layout is skipped.
+is used over ranks: one process per GPU, rank r keeps its row shard resident, every rank holds all of src1 and quantizes
+it locally (deterministic, identical on every rank), and the dst shards are exchanged so that every rank ends with the
+reference's dst layout [N][M] (Ggml.cs:6692-6697).  Two exchange forms, identical bits (they only move data):
 
-With `chunks` > 1 src1 rows are processed in chunks and each chunk's gather is issued asynchronously, so the
-exchange of chunk i overlaps the kernels of chunk i+1.
+  "rccl"  dst shards [N][Ms] (m fastest) -> one all_gather_into_tensor per src1-row chunk (RCCL over xGMI under the
+          "nccl" backend), issued async so chunk i's gather overlaps chunk i+1's kernels -> the re-layout kernel
+          [G][N][Ms] -> [N][M] (SURVEY.md 8(e) layout catch; skipped for N == 1, where the gathered buffer IS the layout).
+  "push"  every rank's [N][M] result buffer is IPC-shared; a rank computes its rows straight into its own buffer's
+          columns and one kernel stores them into every peer's buffer (compute units over xGMI: one hop, all links of the
+          sender at once, final layout -- no [G][N][Ms] intermediate, no re-layout pass); one tiny all-reduce per step is
+          the barrier.  Two result buffers alternate, so a step's stores never race the previous step's consumers.
 """
+import ctypes as C
+
 import torch
 
 
@@ -25,6 +31,14 @@ def shard_width(M, world):
     return (M + world - 1) // world
 
 
+class _RawDeviceBuffer:
+    """A raw device allocation (ggml_hip_ipc_alloc / _open) seen by torch without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape):
+        self.ptr = ptr
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
 class RowSplitMulMat:
     """dst = mul_mat(W, x) with W row-split over `world` ranks.
 
@@ -33,7 +47,7 @@ class RowSplitMulMat:
     """
 
     def __init__(self, weight, N, world, rank, M_total=None, chunks=1, device=None, compute_shard=None, relayout=None,
-                 all_gather=None):
+                 all_gather=None, exchange="rccl", group_backend=None):
         self.W, self.N, self.world, self.rank = weight, N, world, rank
         self.Ms = weight.M if world == 1 else None
         if world > 1:
@@ -42,9 +56,11 @@ class RowSplitMulMat:
         else:
             self.M_total = weight.M
         self.chunks = max(1, min(chunks, N)) if world > 1 else 1
+        self.exchange = exchange if world > 1 else "none"
         dev = device if device is not None else "cuda"
-        self.shard = torch.zeros((N, self.Ms), dtype=torch.float32, device=dev)  # zero: pad columns of a short last shard
+        self.dev = dev
         self.work = None
+        self._push = None
         if compute_shard is None:
             from . import device as D
             self.work = D.alloc_work(weight.type, weight.K, N, dev)
@@ -57,20 +73,104 @@ class RowSplitMulMat:
             relayout = relayout or relayout_default
         self.compute_shard = compute_shard
         self.relayout = relayout
+        if self.exchange == "push":
+            self._setup_push(group_backend)
+            return
+        self.shard = torch.zeros((N, self.Ms), dtype=torch.float32, device=dev)  # zero: pad columns of a short last shard
         if world > 1:
             import torch.distributed as dist
             self.all_gather = all_gather or dist.all_gather_into_tensor
             self.gathered = torch.empty((world * N * self.Ms,), dtype=torch.float32, device=dev)
             self.out = torch.empty((N, self.M_total), dtype=torch.float32, device=dev)
 
+    # ---------------------------------------------------------------- "push": IPC-shared result buffers
+    def _setup_push(self, group_backend):
+        import torch.distributed as dist
+        from ._lib import check, lib
+        L = lib()
+        self._L = L
+        nbytes = self.N * self.M_total * 4
+        self._own, self._peers, self._views, self._opened = [], [], [], []
+        handles = torch.zeros((2, 64), dtype=torch.uint8)
+        for b in range(2):
+            p = C.c_void_p()
+            h = (C.c_uint8 * 64)()
+            check(L.ggml_hip_ipc_alloc(nbytes, C.byref(p), h), "ggml_hip_ipc_alloc")
+            self._own.append(p.value)
+            handles[b] = torch.tensor(list(h), dtype=torch.uint8)
+        on_gpu = (group_backend or dist.get_backend()) == "nccl"
+        mine = handles.cuda() if on_gpu else handles
+        allh = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allh, mine)
+        for b in range(2):
+            ptrs = []
+            for r in range(self.world):
+                if r == self.rank:
+                    ptrs.append(self._own[b])
+                    continue
+                hb = (C.c_uint8 * 64)(*allh[r][b].cpu().tolist())
+                p = C.c_void_p()
+                check(L.ggml_hip_ipc_open(hb, C.byref(p)), "ggml_hip_ipc_open")
+                self._opened.append(p.value)
+                ptrs.append(p.value)
+            self._peers.append(ptrs)
+            self._views.append(torch.as_tensor(_RawDeviceBuffer(self._own[b], (self.N, self.M_total)), device=self.dev))
+        self._flag = torch.zeros(1, dtype=torch.float32, device=self.dev if on_gpu else "cpu")
+        self._on_gpu = on_gpu
+        self._turn = 0
+        self.out = self._views[0]
+        self.shard = None
+        dist.barrier()
+
+    def close(self):
+        """Release the IPC mappings and the shared buffers of the "push" form (after a barrier of the caller's)."""
+        if self.exchange != "push" or self._own is None:
+            return
+        for p in self._opened:
+            self._L.ggml_hip_ipc_close(C.c_void_p(p))
+        self._views = []
+        self.out = None
+        for p in self._own:
+            self._L.ggml_hip_ipc_free(C.c_void_p(p))
+        self._own = None
+
     def _chunk_bounds(self):
         step = (self.N + self.chunks - 1) // self.chunks
         return [(a, min(a + step, self.N)) for a in range(0, self.N, step)]
+
+    def _step_push(self, x):
+        import torch.distributed as dist
+        from ._lib import check
+        b = self._turn
+        self._turn ^= 1
+        out = self._views[b]
+        r0, r1 = shard_rows(self.M_total, self.world, self.rank)
+        Mw = r1 - r0
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        peers = (C.c_void_p * self.world)(*[None if r == self.rank else p for r, p in enumerate(self._peers[b])])
+        for (a, e) in self._chunk_bounds():
+            if Mw > 0:
+                own = out[a:e, r0:r1]                                   # this rank's rows as columns of its own dst
+                self.compute_shard(x[a:e], own)
+                src = self._own[b] + (a * self.M_total + r0) * 4
+                shifted = (C.c_void_p * self.world)(*[None if p is None else p + a * self.M_total * 4 for p in peers])
+                check(self._L.ggml_hip_push_columns_dev(C.c_void_p(src), self.M_total, e - a, Mw, shifted, self.world,
+                                                        self.M_total, r0, stream), "ggml_hip_push_columns_dev")
+        # barrier: every rank's stores of this step have been issued and completed before anyone reads `out`
+        if self._on_gpu:
+            dist.all_reduce(self._flag)
+        else:
+            torch.cuda.synchronize()
+            dist.barrier()
+        self.out = out
+        return out
 
     def step(self, x):
         if self.world == 1:
             self.compute_shard(x, self.shard)
             return self.shard
+        if self.exchange == "push":
+            return self._step_push(x)
         Mw = self.W.M  # rows this rank really owns (the last rank may own fewer than Ms)
         pending = []
         off = 0
@@ -89,3 +189,41 @@ class RowSplitMulMat:
             else:
                 self.relayout(g, self.world, b - a, self.Ms, self.M_total, self.out[a:b])
         return self.out
+
+    # ---- timing probes for bench.py: the phases alone ----
+    def compute_only(self, x):
+        """INIT + COMPUTE of this rank's shard for every chunk, no exchange."""
+        if self.exchange == "push":
+            r0, r1 = shard_rows(self.M_total, self.world, self.rank)
+            for (a, e) in self._chunk_bounds():
+                if r1 > r0:
+                    self.compute_shard(x[a:e], self._views[0][a:e, r0:r1])
+            return
+        Mw = self.W.M
+        for (a, b) in self._chunk_bounds():
+            self.compute_shard(x[a:b], self.shard[a:b, :Mw])
+
+    def exchange_only(self):
+        """The exchange of already computed shards (+ re-layout / barrier), no kernels of the hot path."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        if self.exchange == "push":
+            from ._lib import check
+            r0, r1 = shard_rows(self.M_total, self.world, self.rank)
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            peers = (C.c_void_p * self.world)(*[None if r == self.rank else p for r, p in enumerate(self._peers[0])])
+            if r1 > r0:
+                check(self._L.ggml_hip_push_columns_dev(C.c_void_p(self._own[0] + r0 * 4), self.M_total, self.N, r1 - r0, peers,
+                                                        self.world, self.M_total, r0, stream), "ggml_hip_push_columns_dev")
+            if self._on_gpu:
+                dist.all_reduce(self._flag)
+            else:
+                torch.cuda.synchronize()
+                dist.barrier()
+            return
+        h = self.all_gather(self.gathered, self.shard.reshape(-1), async_op=True)
+        if h is not None:
+            h.wait()
+        if self.N > 1:
+            self.relayout(self.gathered.view(self.world, self.N, self.Ms), self.world, self.N, self.Ms, self.M_total, self.out)

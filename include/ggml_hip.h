@@ -25,6 +25,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: this header IS its export list */
+#endif
 
 /* ---------------- status codes ---------------- */
 enum ggml_hip_status {
@@ -112,25 +115,48 @@ struct ggml_compute_params {
 int    ggml_hip_blck_size(int type);
 size_t ggml_hip_type_size(int type);
 
-/* ---------------- lifecycle (replaces the dead ggml_init_cublas hook, Ggml.cs:1499-1504) ---------------- */
+/* ---------------- lifecycle (replaces the dead ggml_init_cublas hook, Ggml.cs:1499-1504) ----------------
+ * The library keeps one context per DEVICE SLOT (streams, scratch, weight cache, graph-scope residency): no process-wide
+ * device state.  ggml_hip_init(d) = one slot on device d.  ggml_hip_init_devices(n, ids) = n slots (ids NULL: devices
+ * 0..n-1): Seam 1 then row-splits every mul_mat over the slots with the reference's own partition (Ggml.cs:6665-6672) --
+ * the `n_devices` of SURVEY 8(b).  Two slots may name the same device (how the split is rehearsed on a one-GPU box).
+ * Re-initialising on a different device set is refused (GGML_HIP_ERR_ARG) until ggml_hip_shutdown.
+ * Threading: calls may arrive on any host thread.  A thread that called ggml_hip_bind_thread(s) runs every
+ * seam on slot s alone, concurrently with threads bound to other slots (one graph per device); an unbound thread
+ * (s = -1, the default) uses all slots. */
 int         ggml_hip_device_count(void);             /* 0 when no GPU is visible; never fails */
-int         ggml_hip_init(int device);               /* selects the device for the calling thread and later calls */
-void        ggml_hip_shutdown(void);                 /* frees the weight cache and internal buffers */
+int         ggml_hip_init(int device);
+int         ggml_hip_init_devices(int n_devices, const int *device_ids);
+int         ggml_hip_n_slots(void);
+int         ggml_hip_slot_device(int slot);          /* HIP device ordinal of a slot, -1 if out of range */
+int         ggml_hip_bind_thread(int slot);
+void        ggml_hip_shutdown(void);                 /* frees the weight caches and internal buffers of every slot */
 const char *ggml_hip_last_error(void);               /* thread-local, never NULL */
-const char *ggml_hip_arch(void);                     /* gcnArchName of the active device, "" before init */
+const char *ggml_hip_arch(void);                     /* gcnArchName of slot 0's device, "" before init */
+/* The reference's context pool is ONE host allocation (NativeMemory.AlignedAlloc, Ggml.cs:1545) that every tensor's data
+ * lives in.  Registering it (hipHostRegister) lets Seam 1 move src1 / dst by asynchronous DMA and overlap host -> device,
+ * kernels and device -> host in chunks of src1 rows on three streams; unregistered (pageable) memory still works, without
+ * the overlap.  Call unregister before freeing the pool (ggml_free, Ggml.cs:1584-1588): it waits for in-flight copies and
+ * drops every cached / resident device copy made from that memory. */
+int         ggml_hip_register_host_pool(void *ptr, size_t bytes);
+int         ggml_hip_unregister_host_pool(void *ptr);
 
 /* ---------------- Seam 1: ggml_compute_forward_mul_mat (Ggml.cs:6714-6744) ----------------
  * Host pointers in, host pointers out.  Follows the offload convention of the reference's own dead GPU
  * blocks (Ggml.cs:6510-6521): acts only for params->ith == 0 && params->type == GGML_TASK_COMPUTE and
  * returns GGML_HIP_OK immediately otherwise; loops the (i03, i02) slices (Ggml.cs:6566-6570).
- * src0 (the weights) is uploaded once, re-laid-out on the device and cached keyed by
- * (src0->data, type, ne, nb); call ggml_hip_invalidate() after rewriting or freeing that memory
+ * src0 (the weights) is uploaded once, re-laid-out on the device and cached keyed by (src0->data, type, ne, nb, row
+ * shard) -- only when src0 is a LEAF (op == GGML_OP_NONE): a src0 that a node computes is rebuilt every time, from the
+ * device copy its producer left in the graph scope when there is one.  Every seam of this library that writes host
+ * tensor memory drops the cache entries and resident copies overlapping what it wrote; a HOST that rewrites a leaf
+ * (ggml_set_f32, a direct store through tensor->data) or frees it must call ggml_hip_invalidate{,_range}
  * (ggml_free gives no callback, Ggml.cs:1566-1601).  params->wdata is not used. */
 int  ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params,
                                       const struct ggml_tensor *src0,
                                       const struct ggml_tensor *src1,
                                       struct ggml_tensor *dst);
-void ggml_hip_invalidate(const void *host_ptr);      /* drop the cached device copy keyed by this src0->data */
+void ggml_hip_invalidate(const void *host_ptr);      /* drop every cached / resident device copy whose host range holds this byte */
+void ggml_hip_invalidate_range(const void *host_ptr, size_t bytes);   /* ... that overlaps [host_ptr, host_ptr + bytes) */
 void ggml_hip_invalidate_all(void);
 /* Graph scope around the node loop of ggml_graph_compute (Ggml.cs:3539-3704), SURVEY 8(f) row 3.  Between begin and end
  * the device copy of every offloaded node's dst is kept (keyed by tensor->data): a later MUL_MAT whose src1 is that
@@ -173,7 +199,9 @@ int     ggml_hip_weight_type(const ggml_hip_weight *w);
  * For F32 / F16 weights it is ggml_compute_forward_mul_mat_f32 / _f16_f32 (Ggml.cs:5969-6178, 6180-6438).
  * d_src1: device f32 [N rows][K], row stride ld1 ELEMENTS; d_dst: device f32 [N][M], row stride ldd ELEMENTS
  * (the reference's dst layout: element (i01, ic) at ic*ne0 + i01, Ggml.cs:6692-6697).
- * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378). */
+ * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378).
+ * Alignment: for quantized weights d_src1 must be 16-byte aligned and ld1 a multiple of 4 (the INIT kernels read rows in
+ * 16-byte pieces); GGML_HIP_ERR_SHAPE otherwise.  The device the weight lives on is made current for the launch. */
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);
 /* Which layout step 1 writes into d_work for this weight type, M rows, K and N (introspection for tests and profiling tools):
  * 0 = int8 planes (mat-vec and int8-MFMA kernels), 1 / 2 = f16 images (gemm_q16.hip), 3 = bf6 digit image (gemm_qmx.hip). */
@@ -246,12 +274,51 @@ int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int6
 int ggml_hip_add_q_f32_rows_dev(int type, const void *d_blocks_in, const float *d_x, int64_t nrows, int64_t k,
                                 void *d_blocks_out, void *stream);
 
-/* ---------------- multi-GPU helper ----------------
- * After an all-gather of per-rank dst shards ([G][N][Ms], rank-major) produce the reference layout
- * [N][G*Ms -> M] (SURVEY.md 8(e) "layout catch").  rows of the last rank beyond M are dropped. */
+/* ---------------- several devices, one process (SURVEY 8(b) "n_devices", 8(e)) ----------------
+ * Row split of one weight matrix over the device slots with the reference's thread partition (Ggml.cs:6665-6672: dr =
+ * ceil(M / G), slot g owns rows [dr*g, min(dr*(g+1), M))).  ggml_hip_mul_mat_split_dev: d_src1[g] / d_dst[g] are slot g's
+ * device buffers (src1 [N][ld1] replicated, dst [N][ldd >= M]); every slot computes its rows on its own stream and writes
+ * them as columns [r0, r1) of ITS dst (the kernels take a row stride: no [G][N][Ms] intermediate, no re-layout pass); the
+ * exchange then completes every slot's dst.  Stream-ordered on the slots' streams: ggml_hip_sync_slots() waits.
+ * Exchange forms (ggml_hip_set_exchange): 0 = peer DMA over xGMI, one strided 2-D copy per (slot, peer) -- the default;
+ * 1 = RCCL ncclAllGather of contiguous shards + the re-layout kernel below (librccl is loaded at run time; needs distinct
+ * devices).  Both only move data: identical bits.  Every element equals the single-device result bit for bit (the kernel
+ * form is a function of N, K and the type, never of M). */
+typedef struct ggml_hip_split_weight ggml_hip_split_weight;
+int  ggml_hip_split_weight_upload(int type, const void *host_rows, int64_t ne00, int64_t ne01, uint64_t nb01,
+                                  ggml_hip_split_weight **out);
+void ggml_hip_split_weight_free(ggml_hip_split_weight *w);
+int  ggml_hip_split_weight_rows(const ggml_hip_split_weight *w, int slot, int64_t *row_begin, int64_t *row_end);
+int  ggml_hip_mul_mat_split_dev(const ggml_hip_split_weight *w, const float *const *d_src1, int64_t N, int64_t ld1,
+                                float *const *d_dst, int64_t ldd);
+int  ggml_hip_set_exchange(int mode);
+int  ggml_hip_sync_slots(void);
+int  ggml_hip_debug_rccl_selftest(void);             /* the RCCL exchange form on slot 0 alone (one rank), bytes checked */
+/* Device memory of a slot for hosts without their own HIP binding (the C# host): plain hipMalloc / hipMemcpy. */
+void *ggml_hip_slot_malloc(int slot, size_t bytes);
+void  ggml_hip_slot_free(int slot, void *p);
+int   ggml_hip_slot_upload(int slot, void *d_dst, const void *host_src, size_t bytes);
+int   ggml_hip_slot_download(int slot, void *host_dst, const void *d_src, size_t bytes);
+/* One process PER device, direct exchange (ggmlsharp_amd/dist.py, exchange "push"): every rank allocates its reference-
+ * layout dst [N][M] with ggml_hip_ipc_alloc, ships the 64-byte handle to its peers (any transport), opens theirs, and after
+ * computing its rows stores them as columns [col0, col0 + Ms) of EVERY rank's dst with one kernel (d_peers: HOST array of
+ * n_peers <= 16 device pointers, NULL entries skipped; compute units store over xGMI, one hop, all links at once, final
+ * layout -- SURVEY 8(e) "epilogue peer-writes").  The caller orders consumers behind a barrier of its own. */
+int ggml_hip_ipc_alloc(size_t bytes, void **d_ptr, uint8_t *handle64);
+int ggml_hip_ipc_open(const uint8_t *handle64, void **d_ptr);
+int ggml_hip_ipc_close(void *d_ptr);
+int ggml_hip_ipc_free(void *d_ptr);
+int ggml_hip_push_columns_dev(const float *d_shard, int64_t lds, int64_t N, int64_t Ms, float *const *d_peers, int n_peers,
+                              int64_t ldd, int64_t col0, void *stream);
+/* One process PER device (torch.distributed / RCCL ranks, ggmlsharp_amd/dist.py): after an all-gather of per-rank dst
+ * shards ([G][N][Ms], rank-major) produce the reference layout [N][G*Ms -> M] (SURVEY.md 8(e) "layout catch"); rows of
+ * the last rank beyond M are dropped. */
 int ggml_hip_relayout_gathered_dev(const float *d_gathered, int G, int64_t N, int64_t Ms, float *d_dst,
                                    int64_t M, int64_t ldd, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -25,13 +25,34 @@ def _declared(header):
     return sorted(set(names))
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.strip()})
+
+
 def test_library_exports_every_declared_symbol():
+    """libggml_hip.so (the product) exports exactly the ggml_hip_* names of include/ggml_hip.h -- no ggml_* name that
+    could collide with a native ggml in the host process, no C++ symbol; the host mirror (test support, its own
+    library) exports exactly what include/ggml.h declares."""
     L = _lib.lib()
-    declared = set(_declared("ggml_hip.h")) | set(_declared("ggml.h"))
-    assert len(declared) >= 45
-    for name in declared:
+    hip_decl = set(_declared("ggml_hip.h"))
+    mirror_decl = set(_declared("ggml.h")) - hip_decl
+    assert len(hip_decl) >= 59 and len(mirror_decl) >= 30
+    assert all(n.startswith("ggml_hip_") for n in hip_decl)
+    assert set(_exported(_lib.LIB_PATH)) == hip_decl, set(_exported(_lib.LIB_PATH)) ^ hip_decl
+    assert set(_exported(_lib.MIRROR_PATH)) == mirror_decl, set(_exported(_lib.MIRROR_PATH)) ^ mirror_decl
+    for name in hip_decl | mirror_decl:
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
-    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert hip_decl == set(_lib.HIP_SYMBOLS), hip_decl ^ set(_lib.HIP_SYMBOLS)
+    assert mirror_decl == set(_lib.MIRROR_SYMBOLS), mirror_decl ^ set(_lib.MIRROR_SYMBOLS)
+
+
+def test_product_library_reads_no_environment_variable():
+    """Developer A/B switches exist only in -DGGML_HIP_DEV builds: the product library does not import getenv."""
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
 
 
 def test_struct_sizes_match_reference_layout():
@@ -194,7 +215,7 @@ def test_reference_style_c_program_compiles_links_and_fails_loudly_without_gpu(t
     libdir = os.path.join(root, "ggmlsharp_amd", "lib")
     exe = str(tmp_path / "refprog")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "tests", "c", "reference_style_program.c"), "-L" + libdir, "-lggml_hip",
+                           os.path.join(root, "tests", "c", "reference_style_program.c"), "-L" + libdir, "-lggml_hostmirror", "-lggml_hip",
                            "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr

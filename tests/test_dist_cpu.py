@@ -105,7 +105,7 @@ def test_row_split_all_gather_world2(M, K, N, chunks):
 
 # ---------------------------------------------------------------- two ranks on ONE GPU: the real HIP shard kernels and the
 # real re-layout kernel, gloo standing in for RCCL (the driver runs the RCCL form on a whole node at round end)
-def _gpu_worker(rank, world, port, M, K, N, chunks, out_q):
+def _gpu_worker(rank, world, port, M, K, N, chunks, exchange, out_q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -122,10 +122,11 @@ def _gpu_worker(rank, world, port, M, K, N, chunks, out_q):
         r0, r1 = gdist.shard_rows(M, world, rank)
         rows_dev = torch.from_numpy(wq).cuda()
         shard = device.Weight.from_device(O.Q4_0, rows_dev, K, row_begin=r0, row_end=r1)
-        runner = gdist.RowSplitMulMat(shard, N, world, rank, M_total=M, chunks=chunks)   # HIP compute + HIP re-layout
+        runner = gdist.RowSplitMulMat(shard, N, world, rank, M_total=M, chunks=chunks, exchange=exchange)   # HIP compute + HIP re-layout / peer stores
         xd = torch.from_numpy(x).cuda()
         got = runner.step(xd).clone()
-        got2 = runner.step(xd)                  # second step reuses the buffers
+        got2 = runner.step(xd).clone()          # second step reuses the buffers (the push form alternates two)
+        got3 = runner.step(xd).clone()
         # the unsplit matrix on this GPU, over the same column chunks (the kernel form is a function of a call's N and K,
         # never of M: a row shard is bitwise a column slice of the unsplit result of the same call)
         Wfull = device.Weight.from_device(O.Q4_0, rows_dev, K)
@@ -133,19 +134,25 @@ def _gpu_worker(rank, world, port, M, K, N, chunks, out_q):
         ref = O.mul_mat(O.Q4_0, wq, x, M, K, N)[0, 0]
         rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
         close = bool(np.all(np.abs(got.cpu().numpy() - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms))
-        out_q.put((rank, bool(torch.equal(got, full)) and bool(torch.equal(got2, full)), close, tuple(got.shape)))
+        out_q.put((rank, bool(torch.equal(got, full)) and bool(torch.equal(got2, full)) and bool(torch.equal(got3, full)), close, tuple(got.shape)))
+        torch.cuda.synchronize()
+        dist.barrier()
+        runner.close()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["rccl", "push"])
 @pytest.mark.parametrize("M,K,N,chunks", [(300, 256, 70, 1), (515, 512, 130, 4), (1000, 128, 1, 1)])
-def test_row_split_world2_on_one_gpu_is_bitwise_the_unsplit_result(M, K, N, chunks):
+def test_row_split_world2_on_one_gpu_is_bitwise_the_unsplit_result(M, K, N, chunks, exchange):
+    """exchange "rccl": all-gather (gloo standing in for RCCL) + the re-layout kernel; "push": IPC-shared dst buffers across
+    the two PROCESSES and the peer-store kernel (ggml_hip_ipc_*, ggml_hip_push_columns_dev)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, M, K, N, chunks, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, M, K, N, chunks, exchange, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(world)]

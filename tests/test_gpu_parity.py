@@ -476,6 +476,6 @@ def test_reference_style_c_program_on_gpu(dev, tmp_path):
     libdir = os.path.join(root, "ggmlsharp_amd", "lib")
     exe = str(tmp_path / "refprog")
     subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "reference_style_program.c"),
-                           "-L" + libdir, "-lggml_hip", "-Wl,-rpath," + libdir, "-o", exe])
+                           "-L" + libdir, "-lggml_hostmirror", "-lggml_hip", "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
