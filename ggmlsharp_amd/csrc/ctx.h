@@ -65,7 +65,7 @@ struct CachedWeight {
 using CacheKey = std::tuple<const void *, int, int64_t, int64_t, int64_t, int64_t, uint64_t, uint64_t, uint64_t, int64_t, int64_t>;
 
 constexpr int MAX_SLOTS = 16;
-constexpr int PIPE_EVENTS = 16;                   // chunks in flight per Seam-1 call
+constexpr int PIPE_EVENTS = 32;                   // event pairs of the Seam-1 pipeline (chunks of one call reuse them round-robin)
 
 struct DeviceCtx {
     int slot = -1;

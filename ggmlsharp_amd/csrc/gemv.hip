@@ -256,11 +256,215 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K2f: the FUSED form (src1 is f32, N <= 8), restated around the latency chain instead of the barrier.
+//
+// What bounded the kernel above at small M was not bandwidth but its dependent chain: weight loads, THEN the activation
+// loads (vector-memory results return in issue order, so the x rows queued behind 40 KB of weights per workgroup), quantize,
+// __syncthreads, dots, reduce (PMC round 1: 64-77 % of wave-cycles in s_waitcnt / s_barrier).  Here
+//   * every WAVE quantizes exactly the k-blocks it consumes (its 4 k-lanes x 4 blocks of a 128-block chunk) into an LDS slice
+//     of its own: no workgroup barrier between the INIT arithmetic and the dots, waves drift apart freely;
+//   * the activation loads are issued FIRST, the weight stream right behind them: quantizing runs while the weights are in
+//     flight (the compiler's vmcnt for the x registers leaves the younger weight loads outstanding);
+//   * one barrier per row tile remains (the cross-wave reduction), on a double-buffered sRed.
+// Arithmetic, block -> lane assignment and summation tree are those of the kernel above, so the bits are too.
+template <int TYPE, int NC, int GV_ROWS>
+__global__ __launch_bounds__(GV_THREADS) void gemv_fused_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
+                                                                const float *__restrict__ wd, const float *__restrict__ wm,
+                                                                const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
+                                                                int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles) {
+    static_assert(GV_ROWS == 16 && GV_NKQ == 4, "lane = (row, k-lane) with 4 k-lanes per wave");
+    constexpr int CH = GV_CHUNK;                       // k-blocks per chunk, all waves together
+    constexpr int BPL = CH / GV_WORKERS;               // k-blocks per lane per chunk (4)
+    constexpr int WBLK = GV_NKQ * BPL;                 // k-blocks per WAVE per chunk (16): local id i = kq + 4 * j
+    // wave-private slice: per local block a slot of NC x {16 B even plane, 16 B odd plane} (+16 B so that the four k-lanes of
+    // a wave, NC * 32 B apart, never start on the same bank), then NC scales and NC block sums
+    constexpr int QSLOT = NC * 32 + 16;
+    constexpr int WSLICE = WBLK * QSLOT + WBLK * NC * 8;
+    __shared__ __attribute__((aligned(16))) uint8_t sAct[GV_WAVES * WSLICE];
+    __shared__ float sRed[2][GV_WAVES][NC][GV_ROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane % GV_ROWS, kq = lane / GV_ROWS, u = wave * GV_NKQ + kq;
+    uint8_t *const myq = sAct + wave * WSLICE;
+    float *const myd = (float *)(myq + WBLK * QSLOT);
+    int *const mys = (int *)(myd + WBLK * NC);
+    const bool single_chunk = nbk <= CH;
+    bool staged = false;
+    int parity = 0;
+    constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
+    constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
+
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x, parity ^= 1) {
+        const int nt = ntiles, xcd = vb & 7, q8 = nt >> 3, r8 = nt & 7;
+        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+        const int64_t row = (int64_t)tile * GV_ROWS + r;  // < Mpad by construction
+
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+
+        for (int64_t cb = 0; cb < nbk; cb += CH) {
+            const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
+            const bool stage_now = !(single_chunk && staged);
+
+            // 1. this wave's activation rows go out FIRST: item it = (column c, local block i), 8 lanes per item
+            constexpr int ITEMS = WBLK * NC / 8;           // passes of the wave (8 groups of 8 lanes per pass)
+            float4 v[ITEMS];
+            const int t = lane & 7, grp = lane >> 3;
+            if (stage_now) {
+#pragma unroll
+                for (int p = 0; p < ITEMS; ++p) {
+                    const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
+                    const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);        // block of the chunk
+                    const int cc = c < N ? c : N - 1, blc = bl < nbc ? bl : nbc - 1;
+                    v[p] = *(const float4 *)(x + (int64_t)cc * ld1 + (cb + blc) * QK + 4 * t);
+                }
+            }
+
+            // 2. the weight stream of the chunk right behind them (4 x 16 B + scales in flight per lane)
+            uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
+            float dw[BPL], mw[HAS_M ? BPL : 1];
+            uint32_t hb[HAS_H ? BPL : 1];
+#pragma unroll
+            for (int j = 0; j < BPL; ++j) {
+                const int bl = u + GV_WORKERS * j;
+                const bool ok = bl < nbc;
+                const int64_t b = cb + (ok ? bl : 0);
+                if (TYPE == GGML_TYPE_Q8_0) {
+                    q[j] = ld_w(qs + ((b * 2 + 0) * Mpad + row) * 16);
+                    q2[j] = ld_w(qs + ((b * 2 + 1) * Mpad + row) * 16);
+                } else {
+                    q[j] = ld_w(qs + (b * Mpad + row) * 16);
+                }
+                dw[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
+                if (HAS_M) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
+                if (HAS_H) hb[j] = qh[b * Mpad + row];
+            }
+
+            // 3. INIT phase for this wave's blocks (Ggml.cs:6641-6654 / quantize_row_q8_0 733-762, the arithmetic of K1)
+            if (stage_now) {
+                if (!single_chunk) __builtin_amdgcn_wave_barrier();   // (the previous chunk's reads of the slice are done: same wave, in order)
+#pragma unroll
+                for (int p = 0; p < ITEMS; ++p) {
+                    const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
+                    const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);
+                    const bool live = bl < nbc;                        // uniform over the 8 lanes of the group
+                    float amax = fmaxf(fmaxf(fabsf(v[p].x), fabsf(v[p].y)), fmaxf(fabsf(v[p].z), fabsf(v[p].w)));
+                    amax = group8_max(amax);
+                    const float d = amax / 127.0f;                  // Ggml.cs:751
+                    const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
+                    const int q0 = (int)rintf(v[p].x * id), q1 = (int)rintf(v[p].y * id);   // Ggml.cs:758-759 (D1, D2)
+                    const int q2_ = (int)rintf(v[p].z * id), q3 = (int)rintf(v[p].w * id);
+                    const int sum = group8_sum(q0 + q1 + q2_ + q3);
+                    const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2_ & 0xFFu) << 8);
+                    const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
+                    const bool even_lane = (t & 1) == 0;
+                    const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)(even_lane ? o16 : e16));
+                    const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));
+                    const int h = even_lane ? 0 : 1, off = even_lane ? 2 * t : 2 * t - 2;
+                    // a block past the end of K is written as zeros (its weights carry dw = 0; 0 * garbage could be NaN)
+                    *(uint32_t *)(myq + i * QSLOT + (c * 2 + h) * 16 + off) = live ? word : 0u;
+                    if (t == 0) { myd[i * NC + c] = live ? d : 0.0f; mys[i * NC + c] = live ? sum : 0; }
+                }
+                // same wave wrote and reads: LDS operations of one wave complete in order; only the compiler needs the fence
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                staged = true;
+            }
+
+            // 4. integer block dots + f32 scale-accumulate (Ggml.cs:1136-1159)
+#pragma unroll
+            for (int j = 0; j < BPL; ++j) {
+                const int i = kq + GV_NKQ * j;
+                const uint32_t qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+                uint32_t lo[4], hi[4];
+                if (TYPE == GGML_TYPE_Q8_0) {
+                    lo[0] = q[j].x; lo[1] = q[j].y; lo[2] = q[j].z; lo[3] = q[j].w;
+                    hi[0] = q2[j].x; hi[1] = q2[j].y; hi[2] = q2[j].z; hi[3] = q2[j].w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lo[k] = qq[k] & 0x0F0F0F0Fu;          // elements 8k+0,2,4,6  (Ggml.cs:1149)
+                        hi[k] = (qq[k] >> 4) & 0x0F0F0F0Fu;   // elements 8k+1,3,5,7  (Ggml.cs:1150)
+                        if (HAS_H) {                          // Ggml.cs:1285-1289 / 1330-1334
+                            lo[k] |= q5_high_bits(hb[j], k, 0);
+                            hi[k] |= q5_high_bits(hb[j], k, 1);
+                        }
+                        if (TYPE == GGML_TYPE_Q4_2) {         // (nib - 8) bytewise: the two half-block sums need their own offsets
+                            lo[k] = ((lo[k] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+                            hi[k] = ((hi[k] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint4 a0 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 0) * 16);
+                    const uint4 a1 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 1) * 16);
+                    const float da = myd[i * NC + c];
+                    const int sa = mys[i * NC + c];
+                    if (TYPE == GGML_TYPE_Q4_2) {
+                        int s0 = 0, s1 = 0;
+                        s0 = dot4(lo[0], a0.x, s0); s0 = dot4(lo[1], a0.y, s0); s0 = dot4(hi[0], a1.x, s0); s0 = dot4(hi[1], a1.y, s0);
+                        s1 = dot4(lo[2], a0.z, s1); s1 = dot4(lo[3], a0.w, s1); s1 = dot4(hi[2], a1.z, s1); s1 = dot4(hi[3], a1.w, s1);
+                        acc[c] = fmaf(dw[j] * da, (float)s0, acc[c]);
+                        acc[c] = fmaf(mw[j] * da, (float)s1, acc[c]);
+                        continue;
+                    }
+                    int sdot = 0;
+                    sdot = dot4(lo[0], a0.x, sdot); sdot = dot4(lo[1], a0.y, sdot); sdot = dot4(lo[2], a0.z, sdot); sdot = dot4(lo[3], a0.w, sdot);
+                    sdot = dot4(hi[0], a1.x, sdot); sdot = dot4(hi[1], a1.y, sdot); sdot = dot4(hi[2], a1.z, sdot); sdot = dot4(hi[3], a1.w, sdot);
+                    if (TYPE == GGML_TYPE_Q4_0) sdot -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
+                    if (TYPE == GGML_TYPE_Q5_0) sdot -= 16 * sa;
+                    acc[c] = fmaf(dw[j] * da, (float)sdot, acc[c]);
+                    if (TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);   // + m * (s0 + s1)
+                }
+            }
+        }
+
+        // 5. k-lanes by two xor-shuffles, waves through LDS: the fixed tree of the kernel above.  sRed alternates between two
+        //    buffers, so ONE barrier per tile orders everything (tile t+2's writes come after tile t+1's barrier, which every
+        //    wave reaches only after its tile-t reads)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float vsum = acc[c];
+#pragma unroll
+            for (int sft = GV_ROWS; sft < 64; sft <<= 1) vsum += __shfl_xor(vsum, sft);
+            if (kq == 0) sRed[parity][wave][c][r] = vsum;
+        }
+        __syncthreads();
+        for (int o = tid; o < GV_ROWS * NC; o += GV_THREADS) {
+            const int c = o / GV_ROWS, rr = o % GV_ROWS;
+            const int64_t m = (int64_t)tile * GV_ROWS + rr;
+            float quad[GV_WAVES / 4];                                                                   // fixed tree over the waves
+#pragma unroll
+            for (int qd = 0; qd < GV_WAVES / 4; ++qd)
+                quad[qd] = (sRed[parity][4 * qd][c][rr] + sRed[parity][4 * qd + 1][c][rr]) + (sRed[parity][4 * qd + 2][c][rr] + sRed[parity][4 * qd + 3][c][rr]);
+            const float tot = GV_WAVES == 4 ? quad[0] : GV_WAVES == 8 ? quad[0] + quad[1 % (GV_WAVES / 4)]
+                                            : (quad[0] + quad[1 % (GV_WAVES / 4)]) + (quad[2 % (GV_WAVES / 4)] + quad[3 % (GV_WAVES / 4)]);
+            if (m < M && c < N) dst[(int64_t)c * ldd + m] = tot;
+        }
+    }
+}
+
 template <int TYPE, bool FUSED, int ROWS>
 hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
                        int64_t ldd, hipStream_t st) {
     const int ntiles = (int)((w->M + ROWS - 1) / ROWS);
     dim3 grid((unsigned)(ntiles < GV_MAX_WGS ? ntiles : GV_MAX_WGS));
+#ifndef GV_OLD_FUSED
+#define GV_OLD_FUSED 0                 // A/B: the former fused kernel (block-wide staging behind a barrier)
+#endif
+    if constexpr (FUSED && !GV_OLD_FUSED) {
+#define GVF_LAUNCH(NC) gemv_fused_kernel<TYPE, NC, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles)
+        if (N <= 1) GVF_LAUNCH(1);
+        else if (N <= 2) GVF_LAUNCH(2);
+        else if (N <= 4) GVF_LAUNCH(4);
+        else GVF_LAUNCH(8);
+#undef GVF_LAUNCH
+        return hipGetLastError();
+    }
 #define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
