@@ -269,7 +269,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
 //   * one barrier per row tile remains (the cross-wave reduction), on a double-buffered sRed.
 // Arithmetic, block -> lane assignment and summation tree are those of the kernel above, so the bits are too.
 template <int TYPE, int NC, int GV_ROWS>
-__global__ __launch_bounds__(GV_THREADS) void gemv_fused_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
+__global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
+    const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
                                                                 const float *__restrict__ wd, const float *__restrict__ wm,
                                                                 const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
                                                                 int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles) {
@@ -295,67 +296,98 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_fused_kernel(const uint8_t *_
     constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
     constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
 
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x, parity ^= 1) {
+    // The work of a workgroup is a sequence of ITEMS (row tile, chunk of 128 k-blocks), tiles taken round-robin over the
+    // persistent grid.  The weight registers are double-buffered across items: item w+1's weights are requested BEFORE item
+    // w is consumed, so the memory pipe never drains between tiles (a tile's dots, reduction and barrier used to sit between
+    // two bursts of loads: ~10 % of a round at M = 32000).
+    const int nchunks = (int)((nbk + CH - 1) / CH);
+    const int my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nitems = my_tiles * nchunks;
+    auto tile_of = [&](int w) {
+        const int vb = (int)blockIdx.x + (w / nchunks) * (int)gridDim.x;
         const int nt = ntiles, xcd = vb & 7, q8 = nt >> 3, r8 = nt & 7;
-        const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
-        const int64_t row = (int64_t)tile * GV_ROWS + r;  // < Mpad by construction
-
-        float acc[NC];
+        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+    };
+    uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1], qn[BPL], q2n[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
+    float dw[BPL], mw[HAS_M ? BPL : 1], dwn[BPL], mwn[HAS_M ? BPL : 1];
+    uint32_t hb[HAS_H ? BPL : 1], hbn[HAS_H ? BPL : 1];
+    // the weight stream of one item (4 x 16 B + scales in flight per lane)
+    auto load_item = [&](int w, uint4 *Q, uint4 *Q2, float *DW, float *MW, uint32_t *HB) {
+        const int64_t row = (int64_t)tile_of(w) * GV_ROWS + r;  // < Mpad by construction
+        const int64_t cb = (int64_t)(w % nchunks) * CH;
+        const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
-
-        for (int64_t cb = 0; cb < nbk; cb += CH) {
-            const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
-            const bool stage_now = !(single_chunk && staged);
-
-            // 1. this wave's activation rows go out FIRST: item it = (column c, local block i), 8 lanes per item
-            constexpr int ITEMS = WBLK * NC / 8;           // passes of the wave (8 groups of 8 lanes per pass)
-            float4 v[ITEMS];
-            const int t = lane & 7, grp = lane >> 3;
-            if (stage_now) {
-#pragma unroll
-                for (int p = 0; p < ITEMS; ++p) {
-                    const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
-                    const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);        // block of the chunk
-                    const int cc = c < N ? c : N - 1, blc = bl < nbc ? bl : nbc - 1;
-                    v[p] = *(const float4 *)(x + (int64_t)cc * ld1 + (cb + blc) * QK + 4 * t);
-                }
+        for (int j = 0; j < BPL; ++j) {
+            const int bl = u + GV_WORKERS * j;
+            const bool ok = bl < nbc;
+            const int64_t b = cb + (ok ? bl : 0);
+            if (TYPE == GGML_TYPE_Q8_0) {
+                Q[j] = ld_w(qs + ((b * 2 + 0) * Mpad + row) * 16);
+                Q2[j] = ld_w(qs + ((b * 2 + 1) * Mpad + row) * 16);
+            } else {
+                Q[j] = ld_w(qs + (b * Mpad + row) * 16);
             }
+            DW[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
+            if (HAS_M) MW[j] = ok ? wm[b * Mpad + row] : 0.0f;
+            if (HAS_H) HB[j] = qh[b * Mpad + row];
+        }
+    };
 
-            // 2. the weight stream of the chunk right behind them (4 x 16 B + scales in flight per lane)
-            uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
-            float dw[BPL], mw[HAS_M ? BPL : 1];
-            uint32_t hb[HAS_H ? BPL : 1];
+    float acc[NC];
+    constexpr int ITEMS = WBLK * NC / 8;           // activation passes of the wave (8 groups of 8 lanes per pass)
+    const int t = lane & 7, grp = lane >> 3;
+    // prologue: the first item's activations go out FIRST, its weights right behind them
+    // (at most XB passes are held in registers at a time: all of them for N <= 2; wider batches fetch the later passes
+    // while they quantize the earlier ones)
+    constexpr int XB = ITEMS < 4 ? ITEMS : 4;
+    float4 v[XB];
+    auto load_x = [&](int w, int p0) {
+        const int64_t cb = (int64_t)(w % nchunks) * CH;
+        const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
 #pragma unroll
-            for (int j = 0; j < BPL; ++j) {
-                const int bl = u + GV_WORKERS * j;
-                const bool ok = bl < nbc;
-                const int64_t b = cb + (ok ? bl : 0);
-                if (TYPE == GGML_TYPE_Q8_0) {
-                    q[j] = ld_w(qs + ((b * 2 + 0) * Mpad + row) * 16);
-                    q2[j] = ld_w(qs + ((b * 2 + 1) * Mpad + row) * 16);
-                } else {
-                    q[j] = ld_w(qs + (b * Mpad + row) * 16);
-                }
-                dw[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
-                if (HAS_M) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
-                if (HAS_H) hb[j] = qh[b * Mpad + row];
-            }
+        for (int pp = 0; pp < XB; ++pp) {
+            const int p = p0 + pp;
+            const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
+            const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);        // block of the chunk
+            const int cc = c < N ? c : N - 1, blc = bl < nbc ? bl : nbc - 1;
+            v[pp] = *(const float4 *)(x + (int64_t)cc * ld1 + (cb + blc) * QK + 4 * t);
+        }
+    };
+    if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
+
+    for (int w = 0; w < nitems; ++w) {
+        const int cidx = w % nchunks;
+        const int64_t cb = (int64_t)cidx * CH;
+        const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
+        const int tile = tile_of(w);
+        if (cidx == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+        }
+        const bool stage_now = !(single_chunk && staged);
+        // (a K of several chunks: this item's activations were not requested by the previous iteration -- ask now, ahead of
+        // the next item's weights, so that their data returns first)
+        if (stage_now && w > 0) load_x(w, 0);
+        // 2. the NEXT item's weight stream goes out before this item is consumed
+        if (w + 1 < nitems) load_item(w + 1, qn, q2n, dwn, mwn, hbn);
+        {
 
             // 3. INIT phase for this wave's blocks (Ggml.cs:6641-6654 / quantize_row_q8_0 733-762, the arithmetic of K1)
             if (stage_now) {
                 if (!single_chunk) __builtin_amdgcn_wave_barrier();   // (the previous chunk's reads of the slice are done: same wave, in order)
 #pragma unroll
                 for (int p = 0; p < ITEMS; ++p) {
+                    if (p > 0 && p % XB == 0) load_x(w, p);
+                    const float4 vp = v[p % XB];
                     const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
                     const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);
                     const bool live = bl < nbc;                        // uniform over the 8 lanes of the group
-                    float amax = fmaxf(fmaxf(fabsf(v[p].x), fabsf(v[p].y)), fmaxf(fabsf(v[p].z), fabsf(v[p].w)));
+                    float amax = fmaxf(fmaxf(fabsf(vp.x), fabsf(vp.y)), fmaxf(fabsf(vp.z), fabsf(vp.w)));
                     amax = group8_max(amax);
                     const float d = amax / 127.0f;                  // Ggml.cs:751
                     const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
-                    const int q0 = (int)rintf(v[p].x * id), q1 = (int)rintf(v[p].y * id);   // Ggml.cs:758-759 (D1, D2)
-                    const int q2_ = (int)rintf(v[p].z * id), q3 = (int)rintf(v[p].w * id);
+                    const int q0 = (int)rintf(vp.x * id), q1 = (int)rintf(vp.y * id);   // Ggml.cs:758-759 (D1, D2)
+                    const int q2_ = (int)rintf(vp.z * id), q3 = (int)rintf(vp.w * id);
                     const int sum = group8_sum(q0 + q1 + q2_ + q3);
                     const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2_ & 0xFFu) << 8);
                     const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
@@ -422,6 +454,15 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_fused_kernel(const uint8_t *_
                 }
             }
         }
+        // the prefetched registers become the current ones
+#pragma unroll
+        for (int j = 0; j < BPL; ++j) {
+            q[j] = qn[j]; dw[j] = dwn[j];
+            if (TYPE == GGML_TYPE_Q8_0) q2[j] = q2n[j];
+            if (HAS_M) mw[j] = mwn[j];
+            if (HAS_H) hb[j] = hbn[j];
+        }
+        if (cidx != nchunks - 1) continue;              // the row tile's last chunk: reduce and store below
 
         // 5. k-lanes by two xor-shuffles, waves through LDS: the fixed tree of the kernel above.  sRed alternates between two
         //    buffers, so ONE barrier per tile orders everything (tile t+2's writes come after tile t+1's barrier, which every
@@ -445,6 +486,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_fused_kernel(const uint8_t *_
                                             : (quad[0] + quad[1 % (GV_WAVES / 4)]) + (quad[2 % (GV_WAVES / 4)] + quad[3 % (GV_WAVES / 4)]);
             if (m < M && c < N) dst[(int64_t)c * ldd + m] = tot;
         }
+        parity ^= 1;
     }
 }
 

@@ -370,8 +370,12 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
                     const int64_t n = ne11 - a < chunk ? ne11 - a : chunk;
                     const int ke = k % PIPE_EVENTS;
                     if (!x_res[(size_t)g]) {
-                        e = hipMemcpy2DAsync((uint8_t *)c->src1.p + (size_t)a * ne10 * 4, (size_t)ne10 * 4, x_host + (size_t)a * src1->nb[1],
-                                             src1->nb[1], (size_t)ne10 * 4, (size_t)n, hipMemcpyHostToDevice, c->s_h2d);
+                        if (src1->nb[1] == (uint64_t)ne10 * 4)     // contiguous rows: one linear DMA
+                            e = hipMemcpyAsync((uint8_t *)c->src1.p + (size_t)a * ne10 * 4, x_host + (size_t)a * src1->nb[1], (size_t)n * ne10 * 4,
+                                               hipMemcpyHostToDevice, c->s_h2d);
+                        else
+                            e = hipMemcpy2DAsync((uint8_t *)c->src1.p + (size_t)a * ne10 * 4, (size_t)ne10 * 4, x_host + (size_t)a * src1->nb[1],
+                                                 src1->nb[1], (size_t)ne10 * 4, (size_t)n, hipMemcpyHostToDevice, c->s_h2d);
                         c->h2d_bytes += (size_t)n * ne10 * 4;
                         if (e == hipSuccess) e = hipEventRecord(c->ev_in[ke], c->s_h2d);
                         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[ke], 0);
@@ -381,9 +385,13 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
                     if (rc) break;
                     e = hipEventRecord(c->ev_k[ke], c->stream);
                     if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_k[ke], 0);
-                    if (e == hipSuccess)
-                        e = hipMemcpy2DAsync(d_host + (size_t)a * dst->nb[1] + (size_t)r0[(size_t)g] * 4, dst->nb[1], dd + (size_t)a * ldd,
-                                             (size_t)ldd * 4, (size_t)Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
+                    if (e == hipSuccess) {
+                        if (dst->nb[1] == (uint64_t)Ms * 4 && ldd == Ms)    // whole contiguous rows (one slot): one linear DMA
+                            e = hipMemcpyAsync(d_host + (size_t)a * dst->nb[1], dd + (size_t)a * ldd, (size_t)n * Ms * 4, hipMemcpyDeviceToHost, c->s_d2h);
+                        else
+                            e = hipMemcpy2DAsync(d_host + (size_t)a * dst->nb[1] + (size_t)r0[(size_t)g] * 4, dst->nb[1], dd + (size_t)a * ldd,
+                                                 (size_t)ldd * 4, (size_t)Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
+                    }
                     c->d2h_bytes += (size_t)n * Ms * 4;
                 }
             }
