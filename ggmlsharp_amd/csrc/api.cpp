@@ -174,6 +174,15 @@ void DeviceCtx::invalidate(const void *host, size_t bytes) {
         }
     }
 }
+void DeviceCtx::drop_pipes() {
+    if (pipes.empty()) return;
+    (void)sync_all();
+    for (auto &kv : pipes) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    pipes.clear();
+}
 void DeviceCtx::free_cache() {
     for (auto &kv : cache)
         for (ggml_hip_weight *w : kv.second.slices) ggml_hip_weight_free(w);
@@ -216,6 +225,7 @@ int create_slot_locked(int i, int device) {
 void destroy_slot_locked(DeviceCtx *c) {
     (void)hipSetDevice(c->device);
     (void)c->sync_all();
+    c->drop_pipes();
     c->free_cache();
     c->src1.release(); c->dst.release(); c->work.release(); c->stage.release();
     c->drain(true);
@@ -286,7 +296,8 @@ static DeviceCtx *call_slot() {
 static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_weight **out) {
     ggml_hip_weight *w = new ggml_hip_weight();
     memset(w, 0, sizeof *w);
-    w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device;
+    static std::atomic<uint64_t> next_uid{1};
+    w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
     size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, total = 0;
     bool with6 = false;
     size_t off_p16 = 0;

@@ -65,6 +65,7 @@ struct ggml_hip_weight {
     uint8_t *p16;     // F16 only: k-panel-major copy [Kpad/8 + spare][Mpad][16 B] for dense16.hip
     size_t   bytes;
     int      device;
+    uint64_t uid;     // never reused: identifies the weight in cached launch graphs
 };
 
 // ---- activation scratch ("wdata"), planar like the weights; K1 writes one of two images into the `a8` region ----

@@ -308,9 +308,12 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
         const int nt = ntiles, xcd = vb & 7, q8 = nt >> 3, r8 = nt & 7;
         return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
     };
-    uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1], qn[BPL], q2n[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
-    float dw[BPL], mw[HAS_M ? BPL : 1], dwn[BPL], mwn[HAS_M ? BPL : 1];
-    uint32_t hb[HAS_H ? BPL : 1], hbn[HAS_H ? BPL : 1];
+    // (wider batches keep one register set: their activation registers already fill the budget, and the second set cost
+    // them a resident workgroup -- 32000 x 4096 x 8: 50.5 us with it against 41.9 without)
+    constexpr bool PF = NC == 1 && TYPE != GGML_TYPE_Q8_0;     // (Q8_0 carries two quant registers sets per block: spills with four)
+    uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1], qn[PF ? BPL : 1], q2n[PF && TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
+    float dw[BPL], mw[HAS_M ? BPL : 1], dwn[PF ? BPL : 1], mwn[PF && HAS_M ? BPL : 1];
+    uint32_t hb[HAS_H ? BPL : 1], hbn[PF && HAS_H ? BPL : 1];
     // the weight stream of one item (4 x 16 B + scales in flight per lane)
     auto load_item = [&](int w, uint4 *Q, uint4 *Q2, float *DW, float *MW, uint32_t *HB) {
         const int64_t row = (int64_t)tile_of(w) * GV_ROWS + r;  // < Mpad by construction
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     // prologue: the first item's activations go out FIRST, its weights right behind them
     // (at most XB passes are held in registers at a time: all of them for N <= 2; wider batches fetch the later passes
     // while they quantize the earlier ones)
-    constexpr int XB = ITEMS < 4 ? ITEMS : 4;
+    constexpr int XB = NC >= 8 ? 2 : (ITEMS < 4 ? ITEMS : 4);
     float4 v[XB];
     auto load_x = [&](int w, int p0) {
         const int64_t cb = (int64_t)(w % nchunks) * CH;
@@ -367,9 +370,13 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
         const bool stage_now = !(single_chunk && staged);
         // (a K of several chunks: this item's activations were not requested by the previous iteration -- ask now, ahead of
         // the next item's weights, so that their data returns first)
-        if (stage_now && w > 0) load_x(w, 0);
-        // 2. the NEXT item's weight stream goes out before this item is consumed
-        if (w + 1 < nitems) load_item(w + 1, qn, q2n, dwn, mwn, hbn);
+        if constexpr (PF) {
+            // 2. the NEXT item's weight stream goes out before this item is consumed
+            if (w + 1 < nitems) load_item(w + 1, qn, q2n, dwn, mwn, hbn);
+        } else if (w > 0) {
+            if (stage_now) load_x(w, 0);
+            load_item(w, q, q2, dw, mw, hb);
+        }
         {
 
             // 3. INIT phase for this wave's blocks (Ggml.cs:6641-6654 / quantize_row_q8_0 733-762, the arithmetic of K1)
@@ -454,13 +461,17 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
                 }
             }
         }
-        // the prefetched registers become the current ones
+        if constexpr (PF) {
+            // the prefetched registers become the current ones; a K of several chunks asks for the next item's activations
+            // now, behind its weights (already in flight) and ahead of the item after it
 #pragma unroll
-        for (int j = 0; j < BPL; ++j) {
-            q[j] = qn[j]; dw[j] = dwn[j];
-            if (TYPE == GGML_TYPE_Q8_0) q2[j] = q2n[j];
-            if (HAS_M) mw[j] = mwn[j];
-            if (HAS_H) hb[j] = hbn[j];
+            for (int j = 0; j < BPL; ++j) {
+                q[j] = qn[j]; dw[j] = dwn[j];
+                if (TYPE == GGML_TYPE_Q8_0) q2[j] = q2n[j];
+                if (HAS_M) mw[j] = mwn[j];
+                if (HAS_H) hb[j] = hbn[j];
+            }
+            if (!single_chunk && w + 1 < nitems) load_x(w + 1, 0);
         }
         if (cidx != nchunks - 1) continue;              // the row tile's last chunk: reduce and store below
 
@@ -499,13 +510,16 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
 #define GV_OLD_FUSED 0                 // A/B: the former fused kernel (block-wide staging behind a barrier)
 #endif
     if constexpr (FUSED && !GV_OLD_FUSED) {
+        // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
+        // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
+        if (N <= 4) {
 #define GVF_LAUNCH(NC) gemv_fused_kernel<TYPE, NC, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles)
-        if (N <= 1) GVF_LAUNCH(1);
-        else if (N <= 2) GVF_LAUNCH(2);
-        else if (N <= 4) GVF_LAUNCH(4);
-        else GVF_LAUNCH(8);
+            if (N <= 1) GVF_LAUNCH(1);
+            else if (N <= 2) GVF_LAUNCH(2);
+            else GVF_LAUNCH(4);
 #undef GVF_LAUNCH
-        return hipGetLastError();
+            return hipGetLastError();
+        }
     }
 #define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);

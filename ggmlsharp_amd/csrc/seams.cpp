@@ -115,6 +115,113 @@ int64_t seam_chunk_rows(int64_t N, int64_t K, bool pinned) {
     return rows;
 }
 
+// ---------------- the Seam-1 pipeline of one 2-D slice on one slot ----------------
+struct PipeArgs {
+    const ggml_hip_weight *w;
+    const uint8_t *x_host; uint64_t nb11;          // src1 rows on the host (ignored when x is resident)
+    uint8_t *d_host; uint64_t nb1;                 // dst rows on the host
+    const float *xd; bool upload;                  // src1 on the device (+ whether it has to be uploaded first)
+    float *dd; int64_t ldd;                        // dst on the device: base (already at this slot's column) and row stride
+    int64_t N, K, Ms, col0, chunk;
+    void *work; size_t work_cap;
+};
+
+// H2D of chunk k on s_h2d | INIT + COMPUTE of chunk k on stream | D2H of chunk k on s_d2h, chained by events.  With
+// `captured` the three streams are inside one stream capture that started on c->stream.
+int issue_chunks(DeviceCtx *c, const PipeArgs &a, bool captured) {
+    hipError_t e = hipSuccess;
+    // fork: uploads wait for everything issued so far on the compute stream (earlier kernels may still read the src1 scratch)
+    e = hipEventRecord(c->ev_compute, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
+    if (e == hipSuccess && captured) e = hipStreamWaitEvent(c->s_d2h, c->ev_compute, 0);
+    int k = 0;
+    for (int64_t r = 0; r < a.N && e == hipSuccess; r += a.chunk, ++k) {
+        const int64_t n = a.N - r < a.chunk ? a.N - r : a.chunk;
+        const int ke = k % PIPE_EVENTS;
+        if (a.upload) {
+            if (a.nb11 == (uint64_t)a.K * 4)      // contiguous rows: one linear DMA
+                e = hipMemcpyAsync((uint8_t *)a.xd + (size_t)r * a.K * 4, a.x_host + (size_t)r * a.nb11, (size_t)n * a.K * 4, hipMemcpyHostToDevice, c->s_h2d);
+            else
+                e = hipMemcpy2DAsync((uint8_t *)a.xd + (size_t)r * a.K * 4, (size_t)a.K * 4, a.x_host + (size_t)r * a.nb11, a.nb11, (size_t)a.K * 4,
+                                     (size_t)n, hipMemcpyHostToDevice, c->s_h2d);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_in[ke], c->s_h2d);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[ke], 0);
+            if (e != hipSuccess) break;
+        }
+        int rc = ggml_hip_mul_mat_dev(a.w, a.xd + (size_t)r * a.K, n, a.K, a.dd + (size_t)r * a.ldd, a.ldd, a.work, a.work_cap, c->stream);
+        if (rc) return rc;
+        e = hipEventRecord(c->ev_k[ke], c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_k[ke], 0);
+        if (e == hipSuccess) {
+            if (a.nb1 == (uint64_t)a.Ms * 4 && a.ldd == a.Ms)    // whole contiguous rows (one slot): one linear DMA
+                e = hipMemcpyAsync(a.d_host + (size_t)r * a.nb1, a.dd + (size_t)r * a.ldd, (size_t)n * a.Ms * 4, hipMemcpyDeviceToHost, c->s_d2h);
+            else
+                e = hipMemcpy2DAsync(a.d_host + (size_t)r * a.nb1 + (size_t)a.col0 * 4, a.nb1, a.dd + (size_t)r * a.ldd, (size_t)a.ldd * 4,
+                                     (size_t)a.Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
+        }
+    }
+    if (e == hipSuccess && captured) {          // join: a capture ends on its origin stream with every forked stream merged back
+        e = hipEventRecord(c->ev_d2h, c->s_d2h);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_d2h, 0);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_xchg, c->s_h2d);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xchg, 0);
+    }
+    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
+    return GGML_HIP_OK;
+}
+
+// The host side of a chunked pipeline is a dozen runtime calls per chunk (~40 us: as much as a chunk's PCIe time), so a
+// pipeline that recurs -- the same tensors computed again, the reference's ggml_graph_compute in a loop -- is captured into
+// a hipGraph the second time it is seen and replayed with ONE launch from then on (4096 x 4096 x 512: 0.39 -> see DESIGN.md).
+PipeKey pipe_key(const PipeArgs &a) {
+    return PipeKey{a.w->uid, (const void *)a.x_host, (const void *)a.d_host, (const void *)a.xd, (const void *)a.dd, a.work,
+                   a.N, a.K, a.Ms, a.col0, a.chunk, a.ldd, a.nb11, a.nb1, a.upload ? 1 : 0};
+}
+
+int run_pipeline(DeviceCtx *c, const PipeArgs &a, bool allow_graph) {
+    const int64_t nchunks = (a.N + a.chunk - 1) / a.chunk;
+    // order against work issued earlier on the copy streams (they read / write the scratch buffers this call reuses)
+    hipError_t e = hipEventRecord(c->ev_d2h, c->s_d2h);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_d2h, 0);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_xchg, c->s_h2d);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xchg, 0);
+    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
+    if (a.upload) c->h2d_bytes += (size_t)a.N * a.K * 4;
+    c->d2h_bytes += (size_t)a.N * a.Ms * 4;
+    if (!allow_graph || nchunks < 2) return issue_chunks(c, a, false);
+    const PipeKey key = pipe_key(a);
+    auto it = c->pipes.find(key);
+    if (it == c->pipes.end()) {                  // first sighting: run it directly and remember it
+        if (c->pipes.size() >= 64) c->drop_pipes();
+        c->pipes.emplace(key, PipeGraph{});
+        return issue_chunks(c, a, false);
+    }
+    PipeGraph &pg = it->second;
+    if (pg.failed) return issue_chunks(c, a, false);
+    if (!pg.exec) {                              // second sighting: capture
+        e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+        int rc = e == hipSuccess ? issue_chunks(c, a, true) : GGML_HIP_ERR_RUNTIME;
+        hipGraph_t g = nullptr;
+        hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(c->stream, &g) : e;
+        if (rc == GGML_HIP_OK && e2 == hipSuccess && g) e2 = hipGraphInstantiate(&pg.exec, g, nullptr, nullptr, 0);
+        if (rc != GGML_HIP_OK || e2 != hipSuccess || !pg.exec) {
+            (void)hipGetLastError();
+            if (g) (void)hipGraphDestroy(g);
+            pg.exec = nullptr; pg.failed = true;
+            return issue_chunks(c, a, false);    // (nothing of the failed capture was executed)
+        }
+        pg.graph = g;
+    }
+    e = hipGraphLaunch(pg.exec, c->stream);
+    // later direct work on the copy streams comes after the replay
+    if (e == hipSuccess) e = hipEventRecord(c->ev_compute, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_compute, 0);
+    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 graph replay: %s", hipGetErrorString(e));
+    ++c->graph_replays;
+    return GGML_HIP_OK;
+}
+
 }  // namespace
 }  // namespace ghip
 
@@ -155,6 +262,7 @@ int ggml_hip_unregister_host_pool(void *ptr) {
         DeviceCtx *c = slot(i);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         if (c->make_current() == GGML_HIP_OK) (void)c->sync_all();
+        c->drop_pipes();                                  // captured pipelines name addresses inside the pool
         c->invalidate(ptr, bytes);
         c->drop_overlapping(ptr, bytes, false);
     }
@@ -189,6 +297,7 @@ void ggml_hip_invalidate_all(void) {
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         (void)c->make_current();
         (void)c->sync_all();
+        c->drop_pipes();
         c->free_cache();
     }
 }
@@ -224,6 +333,16 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
     if (h2d_bytes) *h2d_bytes = a;
     if (d2h_bytes) *d2h_bytes = b;
     if (resident_hits) *resident_hits = h;
+}
+
+uint64_t ggml_hip_debug_graph_replays(void) {
+    uint64_t n = 0;
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        n += c->graph_replays;
+    }
+    return n;
 }
 
 /* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
@@ -353,47 +472,20 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
                 // device dst: this slot's columns of the resident [N][M] copy, or a [N][Ms] scratch shard
                 float *dd = d_res[(size_t)g] ? (float *)(d_res[(size_t)g] + (size_t)sl * d_full) + r0[(size_t)g] : (float *)c->dst.p;
                 const int64_t ldd = d_res[(size_t)g] ? ne01 : Ms;
-                // scratch reuse across calls and slices: uploads wait for the kernels issued so far (they may still read
-                // the src1 scratch), kernels wait for the device -> host copies issued so far (they read the dst scratch)
-                if (e == hipSuccess) e = hipEventRecord(c->ev_compute, c->stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
-                if (e == hipSuccess) e = hipEventRecord(c->ev_d2h, c->s_d2h);
-                if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_d2h, 0);
-                if (!x_res[(size_t)g] && in_graph && e == hipSuccess) {
+                if (!x_res[(size_t)g] && in_graph) {
                     // src1 comes from host memory: inside a graph scope an earlier node's device -> host copy into that
                     // very memory may still be in flight
                     rc = c->sync_all();
                     if (rc) break;
                 }
-                int k = 0;
-                for (int64_t a = 0; a < ne11 && !rc && e == hipSuccess; a += chunk, ++k) {
-                    const int64_t n = ne11 - a < chunk ? ne11 - a : chunk;
-                    const int ke = k % PIPE_EVENTS;
-                    if (!x_res[(size_t)g]) {
-                        if (src1->nb[1] == (uint64_t)ne10 * 4)     // contiguous rows: one linear DMA
-                            e = hipMemcpyAsync((uint8_t *)c->src1.p + (size_t)a * ne10 * 4, x_host + (size_t)a * src1->nb[1], (size_t)n * ne10 * 4,
-                                               hipMemcpyHostToDevice, c->s_h2d);
-                        else
-                            e = hipMemcpy2DAsync((uint8_t *)c->src1.p + (size_t)a * ne10 * 4, (size_t)ne10 * 4, x_host + (size_t)a * src1->nb[1],
-                                                 src1->nb[1], (size_t)ne10 * 4, (size_t)n, hipMemcpyHostToDevice, c->s_h2d);
-                        c->h2d_bytes += (size_t)n * ne10 * 4;
-                        if (e == hipSuccess) e = hipEventRecord(c->ev_in[ke], c->s_h2d);
-                        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[ke], 0);
-                        if (e != hipSuccess) break;
-                    }
-                    rc = ggml_hip_mul_mat_dev(w, xd + (size_t)a * ne10, n, ne10, dd + (size_t)a * ldd, ldd, c->work.p, c->work.cap, c->stream);
-                    if (rc) break;
-                    e = hipEventRecord(c->ev_k[ke], c->stream);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_k[ke], 0);
-                    if (e == hipSuccess) {
-                        if (dst->nb[1] == (uint64_t)Ms * 4 && ldd == Ms)    // whole contiguous rows (one slot): one linear DMA
-                            e = hipMemcpyAsync(d_host + (size_t)a * dst->nb[1], dd + (size_t)a * ldd, (size_t)n * Ms * 4, hipMemcpyDeviceToHost, c->s_d2h);
-                        else
-                            e = hipMemcpy2DAsync(d_host + (size_t)a * dst->nb[1] + (size_t)r0[(size_t)g] * 4, dst->nb[1], dd + (size_t)a * ldd,
-                                                 (size_t)ldd * 4, (size_t)Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
-                    }
-                    c->d2h_bytes += (size_t)n * Ms * 4;
-                }
+                PipeArgs pa;
+                pa.w = w; pa.x_host = x_host; pa.nb11 = src1->nb[1]; pa.d_host = d_host; pa.nb1 = dst->nb[1];
+                pa.xd = xd; pa.upload = !x_res[(size_t)g]; pa.dd = dd; pa.ldd = ldd;
+                pa.N = ne11; pa.K = ne10; pa.Ms = Ms; pa.col0 = r0[(size_t)g]; pa.chunk = chunk;
+                pa.work = c->work.p; pa.work_cap = c->work.cap;
+                // (graph capture only for pipelines that can recur unchanged: pinned host memory, cached leaf weights,
+                // outside a ggml graph scope -- inside one the resident buffers come from a recycling pool)
+                rc = run_pipeline(c, pa, pinned && cacheable && !in_graph);
             }
             // row split inside a graph scope: every slot's resident copy of dst gets the other slots' columns, so the next
             // node finds its operand whole in its own HBM (peer DMA over xGMI, or an in-process RCCL all-gather: multi.cpp)
