@@ -122,7 +122,6 @@ HIP_SYMBOLS = {
     "ggml_hip_graph_begin": (C.c_int, []),
     "ggml_hip_graph_end": (C.c_int, []),
     "ggml_hip_debug_transfer_counters": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "ggml_hip_debug_graph_replays": (C.c_uint64, []),
     "ggml_hip_act_image_kind": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64]),
     "ggml_hip_debug_force_gemm": (None, [C.c_int]),
     "ggml_hip_quantize_act_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),

@@ -174,15 +174,6 @@ void DeviceCtx::invalidate(const void *host, size_t bytes) {
         }
     }
 }
-void DeviceCtx::drop_pipes() {
-    if (pipes.empty()) return;
-    (void)sync_all();
-    for (auto &kv : pipes) {
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-    }
-    pipes.clear();
-}
 void DeviceCtx::free_cache() {
     for (auto &kv : cache)
         for (ggml_hip_weight *w : kv.second.slices) ggml_hip_weight_free(w);
@@ -225,7 +216,6 @@ int create_slot_locked(int i, int device) {
 void destroy_slot_locked(DeviceCtx *c) {
     (void)hipSetDevice(c->device);
     (void)c->sync_all();
-    c->drop_pipes();
     c->free_cache();
     c->src1.release(); c->dst.release(); c->work.release(); c->stage.release();
     c->drain(true);

@@ -64,11 +64,6 @@ struct CachedWeight {
 };
 using CacheKey = std::tuple<const void *, int, int64_t, int64_t, int64_t, int64_t, uint64_t, uint64_t, uint64_t, int64_t, int64_t>;
 
-// a recurring Seam-1 pipeline, captured into a hipGraph (seams.cpp run_pipeline)
-using PipeKey = std::tuple<uint64_t, const void *, const void *, const void *, const void *, const void *, int64_t, int64_t, int64_t, int64_t,
-                           int64_t, int64_t, uint64_t, uint64_t, int>;
-struct PipeGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool failed = false; };
-
 constexpr int MAX_SLOTS = 16;
 constexpr int PIPE_EVENTS = 32;                   // event pairs of the Seam-1 pipeline (chunks of one call reuse them round-robin)
 
@@ -87,8 +82,7 @@ struct DeviceCtx {
     std::vector<Resident> pool;                    // device buffers free for reuse
     std::vector<ggml_hip_weight *> transient;      // weights built for one node from a computed src0, freed at graph end
     std::map<CacheKey, CachedWeight> cache;        // Seam-1 weight cache
-    std::map<PipeKey, PipeGraph> pipes;            // captured Seam-1 pipelines
-    uint64_t h2d_bytes = 0, d2h_bytes = 0, resident_hits = 0, graph_replays = 0;
+    uint64_t h2d_bytes = 0, d2h_bytes = 0, resident_hits = 0;
     int graph_depth_ = 0;                          // ggml_hip_graph_begin / _end nesting on this slot
 
     int make_current() const;                      // hipSetDevice(device) as a status
@@ -101,7 +95,6 @@ struct DeviceCtx {
     void drain(bool free_all);
     void invalidate(const void *host, size_t bytes);          // weight-cache entries built from an overlapping host range
     void free_cache();
-    void drop_pipes();                             // destroy every captured pipeline (after a sync)
 };
 
 // ---- the slot table ----

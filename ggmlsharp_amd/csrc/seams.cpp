@@ -107,11 +107,12 @@ int64_t seam_chunk_rows(int64_t N, int64_t K, bool pinned) {
     if (!pinned) return N;                              // pageable memory: the runtime stages synchronously, nothing overlaps
     const int64_t x_bytes = N * K * 4;
     if (N < 128 || x_bytes < (2ll << 20)) return N;
-    // what the pipeline cannot hide is its fill and drain -- the first chunk's upload and the last chunk's download -- so
-    // chunks are small (N / 16 rows), but not below 64 rows (the kernels of a chunk must stay well under its PCIe time and
-    // every chunk costs the host a dozen enqueues); measured on MI355X / PCIe 5: 4096 x 4096 x 4096 1.71 ms with 8 chunks
-    int64_t rows = ((N + 15) / 16 + 31) / 32 * 32;
-    if (rows < 64) rows = 64;
+    // what the pipeline cannot hide is its fill and drain -- the first chunk's upload and the last chunk's download -- but
+    // every chunk costs the host ~10 runtime calls and each DMA its launch latency: N / 8 rows per chunk, at least 128
+    // (measured on MI355X / PCIe 5, 4096 x 4096 x {4096, 512}: 8 chunks 1.71 / 0.36 ms (two chunks at 512), 16 chunks 1.75 / 0.39 ms;
+    // the box moves 94 GB/s with both directions busy: 1.42 ms for the 134 MB of the first shape)
+    int64_t rows = ((N + 7) / 8 + 31) / 32 * 32;
+    if (rows < 128) rows = 128;
     return rows;
 }
 
@@ -126,14 +127,12 @@ struct PipeArgs {
     void *work; size_t work_cap;
 };
 
-// H2D of chunk k on s_h2d | INIT + COMPUTE of chunk k on stream | D2H of chunk k on s_d2h, chained by events.  With
-// `captured` the three streams are inside one stream capture that started on c->stream.
-int issue_chunks(DeviceCtx *c, const PipeArgs &a, bool captured) {
+// H2D of chunk k on s_h2d | INIT + COMPUTE of chunk k on stream | D2H of chunk k on s_d2h, chained by events.
+int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
     hipError_t e = hipSuccess;
     // fork: uploads wait for everything issued so far on the compute stream (earlier kernels may still read the src1 scratch)
     e = hipEventRecord(c->ev_compute, c->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
-    if (e == hipSuccess && captured) e = hipStreamWaitEvent(c->s_d2h, c->ev_compute, 0);
     int k = 0;
     for (int64_t r = 0; r < a.N && e == hipSuccess; r += a.chunk, ++k) {
         const int64_t n = a.N - r < a.chunk ? a.N - r : a.chunk;
@@ -160,26 +159,14 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a, bool captured) {
                                      (size_t)a.Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
         }
     }
-    if (e == hipSuccess && captured) {          // join: a capture ends on its origin stream with every forked stream merged back
-        e = hipEventRecord(c->ev_d2h, c->s_d2h);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_d2h, 0);
-        if (e == hipSuccess) e = hipEventRecord(c->ev_xchg, c->s_h2d);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xchg, 0);
-    }
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
     return GGML_HIP_OK;
 }
 
-// The host side of a chunked pipeline is a dozen runtime calls per chunk (~40 us: as much as a chunk's PCIe time), so a
-// pipeline that recurs -- the same tensors computed again, the reference's ggml_graph_compute in a loop -- is captured into
-// a hipGraph the second time it is seen and replayed with ONE launch from then on (4096 x 4096 x 512: 0.39 -> see DESIGN.md).
-PipeKey pipe_key(const PipeArgs &a) {
-    return PipeKey{a.w->uid, (const void *)a.x_host, (const void *)a.d_host, (const void *)a.xd, (const void *)a.dd, a.work,
-                   a.N, a.K, a.Ms, a.col0, a.chunk, a.ldd, a.nb11, a.nb1, a.upload ? 1 : 0};
-}
-
-int run_pipeline(DeviceCtx *c, const PipeArgs &a, bool allow_graph) {
-    const int64_t nchunks = (a.N + a.chunk - 1) / a.chunk;
+// (Capturing a recurring pipeline into a hipGraph and replaying it with one launch was built and measured: the replay runs
+// the copy and kernel branches one after the other -- 4096 x 4096 x 4096 3.10 ms against 1.75 ms for the three live
+// streams, x 512 0.66 against 0.39 -- so the pipeline is always issued directly.)
+int run_pipeline(DeviceCtx *c, const PipeArgs &a) {
     // order against work issued earlier on the copy streams (they read / write the scratch buffers this call reuses)
     hipError_t e = hipEventRecord(c->ev_d2h, c->s_d2h);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_d2h, 0);
@@ -188,38 +175,7 @@ int run_pipeline(DeviceCtx *c, const PipeArgs &a, bool allow_graph) {
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
     if (a.upload) c->h2d_bytes += (size_t)a.N * a.K * 4;
     c->d2h_bytes += (size_t)a.N * a.Ms * 4;
-    if (!allow_graph || nchunks < 2) return issue_chunks(c, a, false);
-    const PipeKey key = pipe_key(a);
-    auto it = c->pipes.find(key);
-    if (it == c->pipes.end()) {                  // first sighting: run it directly and remember it
-        if (c->pipes.size() >= 64) c->drop_pipes();
-        c->pipes.emplace(key, PipeGraph{});
-        return issue_chunks(c, a, false);
-    }
-    PipeGraph &pg = it->second;
-    if (pg.failed) return issue_chunks(c, a, false);
-    if (!pg.exec) {                              // second sighting: capture
-        e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
-        int rc = e == hipSuccess ? issue_chunks(c, a, true) : GGML_HIP_ERR_RUNTIME;
-        hipGraph_t g = nullptr;
-        hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(c->stream, &g) : e;
-        if (rc == GGML_HIP_OK && e2 == hipSuccess && g) e2 = hipGraphInstantiate(&pg.exec, g, nullptr, nullptr, 0);
-        if (rc != GGML_HIP_OK || e2 != hipSuccess || !pg.exec) {
-            (void)hipGetLastError();
-            if (g) (void)hipGraphDestroy(g);
-            pg.exec = nullptr; pg.failed = true;
-            return issue_chunks(c, a, false);    // (nothing of the failed capture was executed)
-        }
-        pg.graph = g;
-    }
-    e = hipGraphLaunch(pg.exec, c->stream);
-    // later direct work on the copy streams comes after the replay
-    if (e == hipSuccess) e = hipEventRecord(c->ev_compute, c->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_compute, 0);
-    if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 graph replay: %s", hipGetErrorString(e));
-    ++c->graph_replays;
-    return GGML_HIP_OK;
+    return issue_chunks(c, a);
 }
 
 }  // namespace
@@ -262,7 +218,6 @@ int ggml_hip_unregister_host_pool(void *ptr) {
         DeviceCtx *c = slot(i);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         if (c->make_current() == GGML_HIP_OK) (void)c->sync_all();
-        c->drop_pipes();                                  // captured pipelines name addresses inside the pool
         c->invalidate(ptr, bytes);
         c->drop_overlapping(ptr, bytes, false);
     }
@@ -297,7 +252,6 @@ void ggml_hip_invalidate_all(void) {
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         (void)c->make_current();
         (void)c->sync_all();
-        c->drop_pipes();
         c->free_cache();
     }
 }
@@ -333,16 +287,6 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
     if (h2d_bytes) *h2d_bytes = a;
     if (d2h_bytes) *d2h_bytes = b;
     if (resident_hits) *resident_hits = h;
-}
-
-uint64_t ggml_hip_debug_graph_replays(void) {
-    uint64_t n = 0;
-    for (int i = 0; i < n_slots(); ++i) {
-        DeviceCtx *c = slot(i);
-        std::lock_guard<std::recursive_mutex> lk(c->mu);
-        n += c->graph_replays;
-    }
-    return n;
 }
 
 /* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
@@ -483,9 +427,7 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
                 pa.xd = xd; pa.upload = !x_res[(size_t)g]; pa.dd = dd; pa.ldd = ldd;
                 pa.N = ne11; pa.K = ne10; pa.Ms = Ms; pa.col0 = r0[(size_t)g]; pa.chunk = chunk;
                 pa.work = c->work.p; pa.work_cap = c->work.cap;
-                // (graph capture only for pipelines that can recur unchanged: pinned host memory, cached leaf weights,
-                // outside a ggml graph scope -- inside one the resident buffers come from a recycling pool)
-                rc = run_pipeline(c, pa, pinned && cacheable && !in_graph);
+                rc = run_pipeline(c, pa);
             }
             // row split inside a graph scope: every slot's resident copy of dst gets the other slots' columns, so the next
             // node finds its operand whole in its own HBM (peer DMA over xGMI, or an in-process RCCL all-gather: multi.cpp)

@@ -167,10 +167,6 @@ int  ggml_hip_graph_begin(void);
 int  ggml_hip_graph_end(void);
 /* Bytes moved over PCIe by seam 1 so far and the number of src1 operands served from a resident dst (tests, tuning). */
 void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits);
-/* A Seam-1 call on registered (pinned) host memory runs as a pipeline of src1-row chunks: host -> device, INIT + COMPUTE,
- * device -> host on three streams.  A pipeline that recurs unchanged (same tensors, cached leaf weights) is captured into a
- * hipGraph the second time and replayed with one launch afterwards; this counts the replays. */
-uint64_t ggml_hip_debug_graph_replays(void);
 
 /* ---------------- resident weights (device level) ---------------- */
 typedef struct ggml_hip_weight ggml_hip_weight;      /* opaque: one 2-D weight matrix, re-laid-out on the device */

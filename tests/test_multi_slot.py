@@ -194,7 +194,7 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
     ref = O.mul_mat(O.Q4_0, wq, x, M, K, N, nth=8)[0, 0]
     assert_close(got, ref, "pinned pipeline")
     assert c1[0].value - c0[0].value == N * K * 4 and c1[1].value - c0[1].value == N * M * 4
-    # the same pipeline again and again: captured into a hipGraph on its second run, replayed afterwards -- same bits
+    # the same pipeline again and again on the same tensors -- same bits
     ctx = G.ggml_init(64 * 1024 * 1024)
     try:
         W = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
@@ -203,16 +203,14 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
         G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
         Y = G.ggml_mul_mat(ctx, W, X)
         gf = G.ggml_build_forward(Y)
-        r0 = lib().ggml_hip_debug_graph_replays()
         outs = []
         for i in range(5):
             G.tensor_f32(Y)[:] = -1.0
             G.ggml_graph_compute(ctx, gf)
             outs.append(G.tensor_f32(Y)[0, 0].copy())
-        assert lib().ggml_hip_debug_graph_replays() - r0 >= 3
         for o in outs:
             assert np.array_equal(o, got)
-        # new activations in the SAME tensor: the replay reads what is there now
+        # new activations in the SAME tensor
         x2 = _rand((N, K))
         G.tensor_f32(X)[:] = x2.reshape(1, 1, N, K)
         G.ggml_graph_compute(ctx, gf)
