@@ -74,8 +74,9 @@ def stats(ts):
 
 
 Q5_0, Q8_0 = 6, 8
-BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36}          # Ggml.cs:76-82
-TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0"}
+Q5_K = 113                                            # extension type (upstream k-quant format; absent from the reference)
+BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36, Q5_K: 22}   # Ggml.cs:76-82; Q5_K: 176 B per 256 weights
+TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0", Q5_K: "Q5_K"}
 
 
 def make_weights_q4_0(M, K, seed, qtype=Q4_0):
@@ -83,6 +84,13 @@ def make_weights_q4_0(M, K, seed, qtype=Q4_0):
     from ggmlsharp_amd import device
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
+    if qtype == Q5_K:
+        # no device quantizer for the extension type: raw super-blocks with every bit pattern of scales / quants and small
+        # finite half scales (d, dmin) -- valid Q5_K data with the toggle rate of real weights
+        rows = torch.randint(0, 256, (M, K // 256, 176), generator=g, device="cuda", dtype=torch.uint8)
+        hdr = torch.tensor([0.01, 0.02], dtype=torch.float16, device="cuda").view(torch.uint8)
+        rows[:, :, 0:4] = hdr
+        return rows.view(M, -1)
     w = torch.randn((M, K), generator=g, device="cuda", dtype=torch.float32)
     return device.quantize_rows(qtype, w)
 
@@ -510,6 +518,8 @@ def main():
                 # configs[4] on ONE GPU (the row split is `--gpus 8`: other_configs.config5_vocab512 of that line)
                 "q8_0_ffn512": side_config(device, 4096, 11008, 512, copies=6, iters=60, qtype=Q8_0),
                 "q5_0_ffn512": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_0),
+                # ... and Q5_K itself as an UNPINNED EXTRA (upstream format, no oracle in the reference; ggml_hip.h GGML_HIP_TYPE_Q5_K)
+                "q5_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_K),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
                 # the dense case of the path (north_star: MFMA utilisation for the dense f16 / f32 mul_mat)
                 "dense_f16": dense_config(device, 1, 4096, 4096, 4096, iters=20),

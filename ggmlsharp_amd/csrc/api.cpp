@@ -283,12 +283,13 @@ static DeviceCtx *call_slot() {
     return slot(b >= 0 ? b : 0);
 }
 
-static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_weight **out) {
+static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_weight **out, bool q5k = false) {
     ggml_hip_weight *w = new ggml_hip_weight();
     memset(w, 0, sizeof *w);
+    w->ext_type = q5k ? GGML_HIP_TYPE_Q5_K : 0;
     static std::atomic<uint64_t> next_uid{1};
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
-    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, total = 0;
+    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, total = 0;
     bool with6 = false;
     size_t off_p16 = 0;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
@@ -308,6 +309,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (has_qh_plane(type)) { off_qh = total; total += plane; }
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (gemm_force() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
+        if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
             off_6a = total; total += (size_t)nba * nf * w->Mpad * 16;
@@ -328,6 +330,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (has_min_plane(type)) w->m = (float *)((uint8_t *)base + off_m);
         if (has_qh_plane(type)) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
+        if (q5k) w->khdr = (uint8_t *)base + off_kh;
     }
     *out = w;
     return GGML_HIP_OK;
@@ -339,6 +342,38 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
                 int64_t row_begin, int64_t row_end, hipStream_t st, ggml_hip_weight **out) {
     if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
     *out = nullptr;
+    // Q5_K (unpinned extra, kquants.hip): super-blocks of 256 are re-laid-out as eight k-blocks of the planar Q5_1 form
+    const bool q5k = type == GGML_HIP_TYPE_Q5_K;
+    if (q5k) {
+        if (!rows || ne00 <= 0 || ne01 < 0 || row_begin < 0 || row_end < row_begin || row_end > ne01) return fail(GGML_HIP_ERR_ARG, "bad weight arguments");
+        if (ne00 % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K: ne00 %% 256 != 0 (QK_K)");
+        if (nb01 < (uint64_t)(ne00 / 256) * 176) return fail(GGML_HIP_ERR_SHAPE, "nb01 smaller than a row");
+        int rc = c ? GGML_HIP_OK : ensure_init();
+        if (rc) return rc;
+        if (!c) c = call_slot();
+        rc = c->make_current();
+        if (rc) return rc;
+        const int64_t rows_n = row_end - row_begin;
+        const uint64_t rb = (uint64_t)(ne00 / 256) * 176;
+        ggml_hip_weight *w = nullptr;
+        rc = alloc_weight(c, GGML_TYPE_Q5_1, ne00, rows_n, &w, true);
+        if (rc) return rc;
+        hipError_t e = hipMemsetAsync(w->qs, 0, w->bytes, st);
+        void *staging = nullptr;
+        if (e == hipSuccess && rows_on_host && rows_n > 0) {
+            e = hipMalloc(&staging, (size_t)rows_n * rb);
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(staging, rb, (const uint8_t *)rows + (uint64_t)row_begin * nb01, nb01, rb, (size_t)rows_n, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = launch_q5k_to_planar((const uint8_t *)staging, rb, 0, rows_n, w, st);
+        } else if (e == hipSuccess) {
+            e = launch_q5k_to_planar((const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (staging) (void)hipFree(staging);
+        if (e != hipSuccess) { (void)hipFree(w->qs); delete w; return fail(GGML_HIP_ERR_RUNTIME, "Q5_K weight upload: %s", hipGetErrorString(e)); }
+        *out = w;
+        return GGML_HIP_OK;
+    }
     if (type < 0 || type >= GGML_TYPE_COUNT || !weight_type_ok(type))
         return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type (Q4_3/Q8_1 have null slots, Ggml.cs:248,278-282)", type);
     if (!rows || ne00 <= 0 || ne01 < 0 || row_begin < 0 || row_end < row_begin || row_end > ne01)
@@ -397,8 +432,8 @@ using namespace ghip;
 
 extern "C" {
 
-int ggml_hip_blck_size(int type) { return (type >= 0 && type < GGML_TYPE_COUNT) ? BLCK[type] : 0; }
-size_t ggml_hip_type_size(int type) { return (type >= 0 && type < GGML_TYPE_COUNT) ? TSIZE[type] : 0; }
+int ggml_hip_blck_size(int type) { return type == GGML_HIP_TYPE_Q5_K ? 256 : (type >= 0 && type < GGML_TYPE_COUNT) ? BLCK[type] : 0; }
+size_t ggml_hip_type_size(int type) { return type == GGML_HIP_TYPE_Q5_K ? 176 : (type >= 0 && type < GGML_TYPE_COUNT) ? TSIZE[type] : 0; }
 
 int ggml_hip_device_count(void) {
     int n = 0;
@@ -463,12 +498,12 @@ int ggml_hip_weight_download(const ggml_hip_weight *w, void *host_rows, void *st
     rc = weight_device_current(w);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t row_bytes = TSIZE[w->type] * (size_t)(w->K / BLCK[w->type]);
+    const size_t row_bytes = w->ext_type == GGML_HIP_TYPE_Q5_K ? (size_t)(w->K / 256) * 176 : TSIZE[w->type] * (size_t)(w->K / BLCK[w->type]);
     const size_t total = row_bytes * (size_t)w->M;
     if (total == 0) return GGML_HIP_OK;
     void *staging = nullptr;
     HIP_TRY(hipMalloc(&staging, total));
-    hipError_t e = launch_planar_to_aos(w, (uint8_t *)staging, st);
+    hipError_t e = w->ext_type == GGML_HIP_TYPE_Q5_K ? launch_planar_to_q5k(w, (uint8_t *)staging, st) : launch_planar_to_aos(w, (uint8_t *)staging, st);
     if (e == hipSuccess) e = hipMemcpyAsync(host_rows, staging, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(staging);
@@ -487,10 +522,11 @@ void ggml_hip_weight_free(ggml_hip_weight *w) {
 }
 int64_t ggml_hip_weight_rows(const ggml_hip_weight *w) { return w ? w->M : 0; }
 int64_t ggml_hip_weight_cols(const ggml_hip_weight *w) { return w ? w->K : 0; }
-int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? w->type : -1; }
+int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? (w->ext_type ? w->ext_type : w->type) : -1; }
 
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
     if (K <= 0 || N <= 0) return 0;
+    if (type == GGML_HIP_TYPE_Q5_K) type = GGML_TYPE_Q5_1;      // same operand images
     if (type == GGML_TYPE_F16) return (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 2;   // src1 as Half (Ggml.cs:3356-3357), padded
     if (!is_q(type)) return 0;
     return act_bytes(K, pad_act(N));
@@ -516,11 +552,12 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     rc = weight_device_current(w);
     if (rc) return rc;
     act_planes p = act_carve(d_work, w->K, pad_act(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, w->M, w->K, N), (hipStream_t)stream));
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, w->M, w->K, N), (hipStream_t)stream,
+                                w->ext_type == GGML_HIP_TYPE_Q5_K));     // k-quant weights: the Q8_K rule (one scale per 256)
     return GGML_HIP_OK;
 }
 
-int ggml_hip_act_image_kind(int type, int64_t M, int64_t K, int64_t N) { return act_image_kind(type, M, K, N); }
+int ggml_hip_act_image_kind(int type, int64_t M, int64_t K, int64_t N) { return act_image_kind(type == GGML_HIP_TYPE_Q5_K ? GGML_TYPE_Q5_1 : type, M, K, N); }
 void ggml_hip_debug_force_gemm(int which) { g_force_gemm.store(which < 0 || which > 3 ? 0 : which); }
 
 int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
@@ -530,12 +567,14 @@ int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t
     if (K <= 0 || K % QK != 0 || ld1 < K) return fail(GGML_HIP_ERR_SHAPE, "K %% 32 != 0 or ld1 < K");
     int rc = check_src1_alignment(d_src1, ld1);
     if (rc) return rc;
-    if (image_kind < 0 || image_kind > 3) return fail(GGML_HIP_ERR_ARG, "image kind %d", image_kind);
+    const bool q8k = image_kind >= 16;                         // + 16: the Q8_K rule of the k-quants (K % 256 == 0; kinds 0..2)
+    if (q8k) image_kind -= 16;
+    if (image_kind < 0 || image_kind > 3 || (q8k && (image_kind == 3 || K % 256 != 0))) return fail(GGML_HIP_ERR_ARG, "image kind %d", image_kind);
     if (work_bytes < act_bytes(K, pad_act(N))) return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", act_bytes(K, pad_act(N)));
     // the MFMA images are written (and read) through 32-bit buffer offsets: 64 image bytes per row and k-block
     if (image_kind != 0 && (uint64_t)pad_kblocks(K / QK) * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull)
         return fail(GGML_HIP_ERR_SHAPE, "image kind %d needs K/32 * 64 * Npad < 4 GiB (ggml_hip_act_image_kind never selects it beyond that)", image_kind);
-    HIP_TRY(launch_quantize_act(d_src1, N, K, ld1, act_carve(d_work, K, pad_act(N)), image_kind, (hipStream_t)stream));
+    HIP_TRY(launch_quantize_act(d_src1, N, K, ld1, act_carve(d_work, K, pad_act(N)), image_kind, (hipStream_t)stream, q8k));
     return GGML_HIP_OK;
 }
 
@@ -578,7 +617,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
-    if (N <= GEMV_MAX_N) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
+    if (N <= GEMV_MAX_N && w->ext_type == 0) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
         rc = check_src1_alignment(d_src1, ld1);     // (float4 loads of the activation rows)
         if (rc) return rc;
         HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream));
@@ -602,6 +641,11 @@ int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_
 int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, int64_t k, float *d_y, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;
     if (!d_y || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (type == GGML_HIP_TYPE_Q5_K) {                           // unpinned extra (kquants.hip)
+        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K: k %% 256 != 0");
+        HIP_TRY(launch_dequantize_q5k(d_blocks, nrows, k, d_y, (hipStream_t)stream));
+        return GGML_HIP_OK;
+    }
     if (!wq_ok(type))
         return fail(GGML_HIP_ERR_TYPE, "dequantize: unsupported type %d (Q8_1 slot is null, Ggml.cs:278)", type);
     if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:839)");

@@ -63,6 +63,8 @@ struct ggml_hip_weight {
                       //   or 2 (Q5_0, Q8_0: w = 16 * wh + wl, fragment 0 = wl, fragment 1 = wh) -- gemm_qmx.hip
     void    *dense;
     uint8_t *p16;     // F16 only: k-panel-major copy [Kpad/8 + spare][Mpad][16 B] for dense16.hip
+    uint8_t *khdr;    // Q5_K only: the 16 header bytes (d, dmin, scales[12]) of every super-block, [K/256][Mpad][16 B]
+    int      ext_type; // 0, or GGML_HIP_TYPE_Q5_K: the weight was uploaded as k-quant super-blocks and lives in the planar Q5_1 form (type == Q5_1)
     size_t   bytes;
     int      device;
     uint64_t uid;     // never reused: identifies the weight in cached launch graphs
@@ -160,7 +162,11 @@ hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms
 hipError_t launch_push_columns(const float *src, int64_t lds, int64_t N, int64_t Ms, float *const *peers, int G, int64_t ldd,
                                int64_t col0, hipStream_t st);
 // quantize.hip
-hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st);
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st, bool q8k = false);
+// kquants.hip (Q5_K as an unpinned extra: the published upstream format, no oracle in the reference)
+hipError_t launch_q5k_to_planar(const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st);
+hipError_t launch_planar_to_q5k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
+hipError_t launch_dequantize_q5k(const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
 int gemm_q16_image_kind(int type);   // which f16 image (1 nibble order, 2 byte-plane order) gemm_q16.hip wants for a weight type
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
 hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,

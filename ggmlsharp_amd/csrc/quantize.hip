@@ -71,7 +71,10 @@ __device__ __forceinline__ uint32_t bf6_code_q(int v) {
 // IMG: 0 = int8 even/odd planes; 1 = f16 image in nibble order (Q4_0/Q4_1/Q5_0 weights); 2 = f16 image in byte-plane
 // order (Q8_0 weights) -- the k-slot orders of gemm_q16.hip; 3 = bf6 digit image of gemm_qmx.hip.  The f16 images carry `as` as the float d * sum(q)
 // (the Q8_1 s0 + s1 of Ggml.cs:820-821, intent D3) instead of the integer sum.
-template <int IMG>
+// K8 = true: the Q8_K rule of the published k-quants (kquants.hip; no counterpart in the reference): ONE scale per 256
+// elements -- a workgroup column of K1_BPB = 8 k-blocks is exactly one super-block of a row, held by the row's 8 lanes --
+// iscale = -128 / (first element of largest magnitude), q = min(127, round-half-even(iscale * x)), d = 1 / iscale.
+template <int IMG, bool K8 = false>
 __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restrict__ x, int64_t N, int64_t nbk, int64_t ld1,
                                                           int8_t *__restrict__ a8, float *__restrict__ ad,
                                                           int32_t *__restrict__ as, int64_t Npad) {
@@ -99,17 +102,45 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
         const int64_t b = b0 + j;
         v[j] = (b < nbk) ? *(const float4 *)(row + b * QK + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float k8_isc = 0.0f, k8_d = 0.0f;
+    if constexpr (K8) {
+        static_assert(K1_BPB * QK == 256 && IMG != 3, "one super-block per workgroup column; no bf6 image for k-quants");
+        float am = 0.0f, mx = 0.0f;
+        int ix = 0;                                         // this lane's first element of largest magnitude (element order)
+#pragma unroll
+        for (int j = 0; j < K1_BPB; ++j) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (fabsf(e[c]) > am) { am = fabsf(e[c]); mx = e[c]; ix = 32 * j + 4 * t + c; }
+        }
+        // over the row's 8 lanes: the larger magnitude wins, equal magnitudes the earlier element
+        auto join = [&](float oa, float om, int oi) {
+            const bool take = oa > am || (oa == am && oi < ix);
+            am = take ? oa : am; mx = take ? om : mx; ix = take ? oi : ix;
+        };
+        join(dpp_f<DPP_XOR1>(am), dpp_f<DPP_XOR1>(mx), dpp_i<DPP_XOR1>(ix));
+        join(dpp_f<DPP_XOR2>(am), dpp_f<DPP_XOR2>(mx), dpp_i<DPP_XOR2>(ix));
+        join(dpp_f<DPP_HALF_MIRROR>(am), dpp_f<DPP_HALF_MIRROR>(mx), dpp_i<DPP_HALF_MIRROR>(ix));
+        k8_isc = am != 0.0f ? -128.0f / mx : 0.0f;
+        k8_d = am != 0.0f ? 1.0f / k8_isc : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < K1_BPB; ++j) {
         const int64_t b = b0 + j;
         float amax = fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
         amax = group8_max(amax);
-        const float d = amax / 127.0f;                      // Ggml.cs:751
-        const float id = d != 0.0f ? 1.0f / d : 0.0f;       // Ggml.cs:752
-        const int q0 = (int)rintf(v[j].x * id);             // Ggml.cs:758-759 (all l, D2)
-        const int q1 = (int)rintf(v[j].y * id);
-        const int q2 = (int)rintf(v[j].z * id);
-        const int q3 = (int)rintf(v[j].w * id);
+        const float d = K8 ? k8_d : amax / 127.0f;                              // Ggml.cs:751
+        const float id = K8 ? k8_isc : (d != 0.0f ? 1.0f / d : 0.0f);           // Ggml.cs:752
+        if constexpr (K8) {                                 // min(127, nearest_int(iscale * x)): clamp before anything reads the values
+            v[j].x = fminf(127.0f, rintf(v[j].x * id)); v[j].y = fminf(127.0f, rintf(v[j].y * id));
+            v[j].z = fminf(127.0f, rintf(v[j].z * id)); v[j].w = fminf(127.0f, rintf(v[j].w * id));
+        }
+        const float qid = K8 ? 1.0f : id;                   // (K8: v already holds the quants; x * 1 and rintf of an integer are exact)
+        const int q0 = (int)rintf(v[j].x * qid);            // Ggml.cs:758-759 (all l, D2)
+        const int q1 = (int)rintf(v[j].y * qid);
+        const int q2 = (int)rintf(v[j].z * qid);
+        const int q3 = (int)rintf(v[j].w * qid);
         const int s = group8_sum(q0 + q1 + q2 + q3);
         if (IMG == 3) {
             // bf6 image of gemm_qmx.hip: a = 16*ah + al, ah = floor((a + 8) / 16) in [-8, 8], al in [-8, 7]; lane t owns
@@ -118,7 +149,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
             // its right neighbour's.
             // digits in float arithmetic (exact: |q| <= 127), codes from the f32 bit pattern: for an integer 1 <= |v| <= 8
             // the bf6 code (exponent bias 3, 2 mantissa bits) is (f32 bits >> 21) - ((127 - 3) << 2); 0 clamps to code 0
-            const float rv[4] = {rintf(v[j].x * id), rintf(v[j].y * id), rintf(v[j].z * id), rintf(v[j].w * id)};
+            const float rv[4] = {rintf(v[j].x * qid), rintf(v[j].y * qid), rintf(v[j].z * qid), rintf(v[j].w * qid)};
             uint32_t vh = 0, vl = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -150,7 +181,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
             continue;
         }
         if (IMG != 0) {
-            const float r0 = rintf(v[j].x * id), r1 = rintf(v[j].y * id), r2 = rintf(v[j].z * id), r3 = rintf(v[j].w * id);
+            const float r0 = rintf(v[j].x * qid), r1 = rintf(v[j].y * qid), r2 = rintf(v[j].z * qid), r3 = rintf(v[j].w * qid);
             const bool odd = (t & 1) != 0;
             uint32_t o0, o1;
             int panel, half8;
@@ -632,10 +663,17 @@ __global__ void q8_aos_to_planes_kernel(const uint8_t *__restrict__ in, int64_t 
 
 }  // namespace
 
-hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st) {
+hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st, bool q8k) {
     if (N <= 0) return hipSuccess;
     const int64_t nbk = K / QK;
     dim3 grid((unsigned)((nbk + K1_BPB - 1) / K1_BPB), (unsigned)((N + 31) / 32));
+    if (q8k) {                                              // Q8_K rule (kquants.hip): K is whole super-blocks, no bf6 image
+        if (K % 256 != 0 || image == 3) return hipErrorInvalidValue;
+        if (image == 1) quantize_act_kernel<1, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        else if (image == 2) quantize_act_kernel<2, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        else quantize_act_kernel<0, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        return hipGetLastError();
+    }
     if (image == 1)
         quantize_act_kernel<1><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
     else if (image == 2)

@@ -76,6 +76,14 @@ enum ggml_op {
 /* TypeDefs:292-297 */
 enum ggml_task_type { GGML_TASK_INIT = 0, GGML_TASK_COMPUTE = 1, GGML_TASK_FINALIZE = 2 };
 
+/* EXTENSION, not a reference type: the reference's enum stops at Q8_1 / I32 (TypeDefs:153-169) and holds no k-quants
+ * (SURVEY 8(a) row K), while BASELINE.json's north_star and config 4 name Q5_K.  Built to the PUBLISHED upstream format
+ * (ggml k_quants, 2023-06: 176-byte super-blocks of 256 weights; activations by the Q8_K rule) as an unpinned extra: no oracle
+ * exists in the reference, tests/np_kquants.py restates the published algorithm.  Accepted by ggml_hip_weight_upload /
+ * _from_device / _download, ggml_hip_mul_mat{,_init,_compute}_dev, ggml_hip_mul_mat_work_size and
+ * ggml_hip_dequantize_rows_dev only -- never inside a ggml_tensor (the reference cannot express the type). */
+#define GGML_HIP_TYPE_Q5_K 113
+
 #define GGML_MAX_DIMS 4
 #define GGML_MAX_OPT 4
 #define GGML_MAX_NODES 4096
@@ -212,7 +220,8 @@ int    ggml_hip_act_image_kind(int type, int64_t M, int64_t K, int64_t N);
  * the documented tolerance whichever runs; the environment variable GGML_HIP_GEMM=i8|f16|mx sets the initial value. */
 void   ggml_hip_debug_force_gemm(int which);
 /* Step 1 alone with an explicit layout: every src1 row -> Q8_0 (quantize_row_q8_0, Ggml.cs:733-762, the loop of
- * Ggml.cs:6641-6654) written as image `image_kind` (see above) into d_work. */
+ * Ggml.cs:6641-6654) written as image `image_kind` (see above) into d_work.  image_kind + 16 (kinds 0..2, K % 256 == 0):
+ * the Q8_K rule of the k-quant extension instead (one scale per 256 elements; see GGML_HIP_TYPE_Q5_K). */
 int    ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
                                  int image_kind, void *stream);
 int    ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1,

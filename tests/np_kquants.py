@@ -1,0 +1,155 @@
+"""numpy restatement of the PUBLISHED upstream k-quant algorithms that the Q5_K extension follows (ggml k_quants.c,
+2023-06: block_q5_K, block_q8_K, dequantize_row_q5_K, quantize_row_q8_K_reference, ggml_vec_dot_q5_K_q8_K scalar path).
+
+TEST INFRASTRUCTURE, and the only checker there is: the reference (kant2002/GGMLSharp) holds no k-quants at all
+(SURVEY 8(a) row K), the upstream source is not vendored anywhere in /root/reference, nothing here was run against it --
+PARITY UNPINNED.  `quantize_q5_K` below is NOT upstream's search-based quantizer (make_qkx1_quants): it is a simple valid
+encoder used to make test weights; the format's meaning is fixed by dequantize_q5_K alone."""
+import numpy as np
+
+QK_K = 256
+Q5K_BYTES = 176
+Q8K_BYTES = 292
+
+
+def unpack_scales(scales):
+    """get_scale_min_k4 for j = 0..7: scales [..., 12] uint8 -> (sc [..., 8], m [..., 8]) 6-bit values"""
+    q = scales.astype(np.uint32)
+    sc = np.empty(q.shape[:-1] + (8,), dtype=np.uint32)
+    m = np.empty_like(sc)
+    for j in range(4):
+        sc[..., j] = q[..., j] & 63
+        m[..., j] = q[..., j + 4] & 63
+    for j in range(4, 8):
+        sc[..., j] = (q[..., j + 4] & 0xF) | ((q[..., j - 4] >> 6) << 4)
+        m[..., j] = (q[..., j + 4] >> 4) | ((q[..., j] >> 6) << 4)
+    return sc, m
+
+
+def pack_scales(sc, m):
+    """inverse of unpack_scales (sc, m in 0..63) -> [..., 12] uint8"""
+    sc = sc.astype(np.uint32)
+    m = m.astype(np.uint32)
+    out = np.zeros(sc.shape[:-1] + (12,), dtype=np.uint32)
+    for j in range(4):
+        out[..., j] = (sc[..., j] & 63) | ((sc[..., j + 4] >> 4) << 6)
+        out[..., j + 4] = (m[..., j] & 63) | ((m[..., j + 4] >> 4) << 6)
+        out[..., j + 8] = (sc[..., j + 4] & 0xF) | ((m[..., j + 4] & 0xF) << 4)
+    return out.astype(np.uint8)
+
+
+def q5_values(blocks):
+    """blocks [nb, 176] uint8 -> the 5-bit values [nb, 256] in element order (dequantize_row_q5_K's unpacking)"""
+    qh = blocks[:, 16:48].astype(np.uint32)           # [nb, 32]
+    qs = blocks[:, 48:176].astype(np.uint32).reshape(-1, 4, 32)
+    out = np.empty((blocks.shape[0], 8, 32), dtype=np.uint32)
+    for g in range(4):
+        out[:, 2 * g] = (qs[:, g] & 0xF) + (((qh >> (2 * g)) & 1) << 4)
+        out[:, 2 * g + 1] = (qs[:, g] >> 4) + (((qh >> (2 * g + 1)) & 1) << 4)
+    return out.reshape(-1, 256)
+
+
+def dequantize_q5_K(blocks):
+    """[nb, 176] uint8 -> [nb, 256] float32: y = (d * sc) * q - (dmin * m), every operation a binary32 rounding"""
+    d = blocks[:, 0:2].copy().view(np.float16).astype(np.float32).reshape(-1, 1)
+    dmin = blocks[:, 2:4].copy().view(np.float16).astype(np.float32).reshape(-1, 1)
+    sc, m = unpack_scales(blocks[:, 4:16])
+    d1 = (d * sc.astype(np.float32)).astype(np.float32)          # [nb, 8]
+    m1 = (dmin * m.astype(np.float32)).astype(np.float32)
+    q = q5_values(blocks).reshape(-1, 8, 32).astype(np.float32)
+    y = ((d1[:, :, None] * q).astype(np.float32) - m1[:, :, None]).astype(np.float32)
+    return y.reshape(-1, 256)
+
+
+def quantize_q8_K(x):
+    """quantize_row_q8_K_reference: x [n, 256] float32 -> (d [n] f32, qs [n, 256] int8, bsums [n, 16] int16)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    ax = np.abs(x)
+    idx = np.argmax(ax, axis=1)                                   # first element of largest magnitude
+    mx = x[np.arange(x.shape[0]), idx]
+    amax = ax[np.arange(x.shape[0]), idx]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iscale = np.where(amax != 0, np.float32(-128.0) / mx, np.float32(0)).astype(np.float32)
+        d = np.where(amax != 0, np.float32(1.0) / iscale, np.float32(0)).astype(np.float32)
+    v = np.rint((x * iscale[:, None]).astype(np.float32))          # nearest_int: round half to even
+    q = np.minimum(v, 127).astype(np.int32)
+    bsums = q.reshape(-1, 16, 16).sum(axis=2).astype(np.int16)
+    return d, q.astype(np.int8), bsums
+
+
+def vec_dot_q5_K_q8_K(wblocks, d8, q8, bsums):
+    """one weight row [nb, 176] against one activation row (d8 [nb], q8 [nb, 256], bsums [nb, 16]) -> float32.
+    Per super-block, in order: sumf += (d * dy) * sum_j sc_j <q_j, a_j>  -  (dmin * dy) * sum_j m_j (bsum_2j + bsum_2j+1),
+    the integer sums exact (upstream's scalar path spreads the first term over 8 partial lanes; only the order of its
+    f32 additions differs)."""
+    F = np.float32
+    d = wblocks[:, 0:2].copy().view(np.float16).astype(F).reshape(-1)
+    dmin = wblocks[:, 2:4].copy().view(np.float16).astype(F).reshape(-1)
+    sc, m = unpack_scales(wblocks[:, 4:16])
+    q5 = q5_values(wblocks).astype(np.int64).reshape(-1, 8, 32)
+    a = q8.astype(np.int64).reshape(-1, 8, 32)
+    isum = (sc.astype(np.int64) * (q5 * a).sum(axis=2)).sum(axis=1)
+    bs = bsums.astype(np.int64).reshape(-1, 8, 2).sum(axis=2)
+    msum = (m.astype(np.int64) * bs).sum(axis=1)
+    sumf = F(0)
+    for i in range(wblocks.shape[0]):
+        sumf = F(sumf + F(F(d[i] * d8[i]) * F(isum[i])))
+        sumf = F(sumf - F(F(dmin[i] * d8[i]) * F(msum[i])))
+    return sumf
+
+
+def mul_mat_q5_K(wrows, x):
+    """wrows [M, K/256*176] uint8, x [N, K] f32 -> [N, M] f32 (the reference's dst layout), activations by the Q8_K rule"""
+    M = wrows.shape[0]
+    N, K = x.shape
+    nb = K // 256
+    d8, q8, bs = quantize_q8_K(x.reshape(-1, 256))
+    d8, q8, bs = d8.reshape(N, nb), q8.reshape(N, nb, 256), bs.reshape(N, nb, 16)
+    w = wrows.reshape(M, nb, 176)
+    # vectorised over (n, m): exact integer sums in int64, then the two float terms per super-block in f64 (a checker
+    # for 1e-3-relative parity, not a bit-level one)
+    dw = w[:, :, 0:2].copy().view(np.float16).astype(np.float64).reshape(M, nb)
+    dmin = w[:, :, 2:4].copy().view(np.float16).astype(np.float64).reshape(M, nb)
+    sc, mn = unpack_scales(w[:, :, 4:16])
+    q5 = q5_values(w.reshape(-1, 176)).astype(np.float64).reshape(M, nb, 8, 32)
+    a = q8.astype(np.float64).reshape(N, nb, 8, 32)
+    dots = np.einsum("mbjl,nbjl->nmbj", q5, a)                      # exact in f64 (|.| < 2^24)
+    isum = (dots * sc.astype(np.float64)[None]).sum(axis=3)          # [N, M, nb]
+    bsum = bs.astype(np.float64).reshape(N, nb, 8, 2).sum(axis=3)
+    msum = np.einsum("mbj,nbj->nmb", mn.astype(np.float64), bsum)
+    out = (dw[None] * d8.astype(np.float64)[:, None, :] * isum - dmin[None] * d8.astype(np.float64)[:, None, :] * msum).sum(axis=2)
+    return out.astype(np.float32)
+
+
+def quantize_q5_K(x):
+    """A simple VALID Q5_K encoder for test data (not upstream's): per 32-element sub-block an affine 5-bit code over
+    [min(0, min x), max x], its scale and offset re-quantized to 6 bits against the super-block's d / dmin."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 8, 32)
+    lo = np.minimum(x.min(axis=2), 0.0)                            # the format subtracts a non-negative offset
+    hi = np.maximum(x.max(axis=2), lo + 1e-30)
+    scale = (hi - lo) / 31.0
+    off = -lo
+    d = np.maximum(scale.max(axis=1), 1e-30) / 63.0
+    dmin = np.maximum(off.max(axis=1), 1e-30) / 63.0
+    d16 = d.astype(np.float16)
+    dmin16 = dmin.astype(np.float16)
+    df, dminf = d16.astype(np.float32), dmin16.astype(np.float32)
+    sc = np.clip(np.rint(scale / np.maximum(df[:, None], 1e-30)), 1, 63).astype(np.uint32)
+    m = np.clip(np.rint(off / np.maximum(dminf[:, None], 1e-30)), 0, 63).astype(np.uint32)
+    d1 = df[:, None] * sc
+    m1 = dminf[:, None] * m
+    q = np.clip(np.rint((x + m1[:, :, None]) / np.maximum(d1[:, :, None], 1e-30)), 0, 31).astype(np.uint32)
+    nb = x.shape[0]
+    blocks = np.zeros((nb, 176), dtype=np.uint8)
+    blocks[:, 0:2] = d16.reshape(-1, 1).view(np.uint8)
+    blocks[:, 2:4] = dmin16.reshape(-1, 1).view(np.uint8)
+    blocks[:, 4:16] = pack_scales(sc, m)
+    qh = np.zeros((nb, 32), dtype=np.uint32)
+    qs = np.zeros((nb, 4, 32), dtype=np.uint32)
+    for g in range(4):
+        qs[:, g] = (q[:, 2 * g] & 0xF) | ((q[:, 2 * g + 1] & 0xF) << 4)
+        qh |= ((q[:, 2 * g] >> 4) & 1) << (2 * g)
+        qh |= ((q[:, 2 * g + 1] >> 4) & 1) << (2 * g + 1)
+    blocks[:, 16:48] = qh.astype(np.uint8)
+    blocks[:, 48:176] = qs.reshape(nb, 128).astype(np.uint8)
+    return blocks

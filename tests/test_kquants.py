@@ -1,0 +1,181 @@
+"""Q5_K as an UNPINNED EXTRA (include/ggml_hip.h GGML_HIP_TYPE_Q5_K; ggmlsharp_amd/csrc/kquants.hip).  The reference has no
+k-quants and there is no oracle for them: the checker is tests/np_kquants.py, a numpy restatement of the published upstream
+format.  CPU tests: the restatement is self-consistent.  GPU tests: the device path against it -- dequantize, upload /
+download and the Q8_K activation image bit-exact, mul_mat within the path's tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import np_kquants as KQ
+
+RNG = np.random.default_rng(4242)
+Q5_K = 113
+
+
+def _rand(shape, scale=1.0):
+    return (RNG.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _random_blocks(nb):
+    """raw super-blocks: every bit pattern of scales / qh / qs, finite half scales"""
+    b = RNG.integers(0, 256, size=(nb, 176), dtype=np.uint8)
+    b[:, 0:2] = (RNG.random(nb).astype(np.float32) * 0.02 + 0.001).astype(np.float16).reshape(-1, 1).view(np.uint8)
+    b[:, 2:4] = (RNG.random(nb).astype(np.float32) * 0.05).astype(np.float16).reshape(-1, 1).view(np.uint8)
+    return b
+
+
+# ---------------------------------------------------------------- CPU: the restatement itself
+def test_scale_packing_roundtrip_and_value_unpacking():
+    sc = RNG.integers(0, 64, size=(50, 8))
+    m = RNG.integers(0, 64, size=(50, 8))
+    s2, m2 = KQ.unpack_scales(KQ.pack_scales(sc, m))
+    assert np.array_equal(s2, sc) and np.array_equal(m2, m)
+    # one block by hand: element 64 g + l = low nibble of qs[32 g + l] + bit 2g of qh[l]; 64 g + 32 + l = high nibble + bit 2g+1
+    b = np.zeros((1, 176), dtype=np.uint8)
+    b[0, 48 + 32 * 1 + 5] = 0xA7          # g = 1, l = 5: element 69 -> 7, element 101 -> 10
+    b[0, 16 + 5] = 0b00001100             # bits 2, 3 of qh[5]: fifth bit of elements 64 + 5 and 96 + 5
+    q = KQ.q5_values(b)[0]
+    assert q[69] == 7 + 16 and q[101] == 10 + 16 and q.sum() == 7 + 10 + 32
+
+
+def test_simple_quantizer_is_a_valid_encoding_close_to_its_input():
+    x = _rand((40, 256), 2.0)
+    x[3] = 0.0
+    x[4, :32] = 5.0                        # a constant sub-block above zero: offset 0, scale 5/31
+    blocks = KQ.quantize_q5_K(x)
+    y = KQ.dequantize_q5_K(blocks)
+    err = np.abs(y - x).reshape(40, 8, 32).max(axis=2)
+    rng = (np.maximum(x.reshape(40, 8, 32).max(axis=2), 0) - np.minimum(x.reshape(40, 8, 32).min(axis=2), 0))
+    assert np.all(err <= 0.08 * np.maximum(rng.max(axis=1, keepdims=True), 1e-6) + 1e-6)   # 5-bit code with 6-bit super-scales
+
+
+def test_q8_K_rule():
+    x = np.zeros((3, 256), dtype=np.float32)
+    x[0, 7] = -4.0
+    x[0, 9] = 4.0                          # equal magnitudes: the FIRST one (negative) sets the sign: iscale = 32, d = 1/32
+    x[0, 10] = 1.0 / 64                    # 0.5 -> tie -> 0
+    x[0, 11] = 3.0 / 64                    # 1.5 -> 2
+    x[1] = 0.0                             # all-zero super-block: d = 0
+    x[2, 0] = 2.0                          # iscale = -64: the max element maps to -128, its negation clamps to 127
+    x[2, 1] = -2.0
+    d, q, bs = KQ.quantize_q8_K(x)
+    assert d[0] == np.float32(1 / 32) and q[0, 7] == -128 and q[0, 9] == 127 and q[0, 10] == 0 and q[0, 11] == 2
+    assert d[1] == 0 and not q[1].any()
+    assert d[2] == np.float32(-1 / 64) and q[2, 0] == -128 and q[2, 1] == 127
+    assert bs[0, 0] == -128 + 127 + 2 and bs[2, 0] == -1
+
+
+def test_vec_dot_restatement_against_dequantized_product():
+    K = 1024
+    w = KQ.quantize_q5_K(_rand((K // 256, 256)))
+    x = _rand((1, K))
+    d8, q8, bs = KQ.quantize_q8_K(x.reshape(-1, 256))
+    got = KQ.vec_dot_q5_K_q8_K(w, d8, q8, bs)
+    exact = float(KQ.dequantize_q5_K(w).astype(np.float64).reshape(-1) @ (q8.astype(np.float64) * d8.astype(np.float64)[:, None]).reshape(-1))
+    assert abs(float(got) - exact) <= 1e-5 * max(1.0, abs(exact))
+    mm = KQ.mul_mat_q5_K(w.reshape(1, -1), x)
+    assert abs(float(mm[0, 0]) - exact) <= 1e-5 * max(1.0, abs(exact))
+
+
+# ---------------------------------------------------------------- GPU: the device path against the restatement
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    pytest.importorskip("torch")
+    from ggmlsharp_amd import device
+    device.init(0)
+    return device
+
+
+@gpu
+def test_dequantize_q5_K_bit_exact(dev):
+    import torch
+    for nb in (1, 7, 64):
+        b = np.concatenate([_random_blocks(nb), KQ.quantize_q5_K(_rand((nb, 256), 3.0))])
+        want = KQ.dequantize_q5_K(b)
+        got = dev.dequantize_rows(Q5_K, torch.from_numpy(b.reshape(1, -1)).cuda(), b.shape[0] * 256).cpu().numpy().reshape(-1, 256)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@gpu
+def test_upload_download_roundtrip_is_byte_exact_and_type_reported(dev):
+    from ggmlsharp_amd._lib import lib
+    M, K = 70, 768
+    rows = _random_blocks(M * K // 256).reshape(M, -1)
+    W = dev.Weight.from_host(Q5_K, rows, K)
+    assert lib().ggml_hip_weight_type(W.handle) == Q5_K and lib().ggml_hip_weight_rows(W.handle) == M
+    assert np.array_equal(W.download().reshape(M, -1), rows)
+    shard = dev.Weight.from_host(Q5_K, rows, K, row_begin=11, row_end=40)
+    assert np.array_equal(shard.download().reshape(29, -1), rows[11:40])
+    h = C.c_void_p()
+    assert lib().ggml_hip_weight_upload(Q5_K, rows.ctypes.data_as(C.c_void_p), 700, M, 528, 0, M, None, C.byref(h)) == -3   # K % 256
+
+
+@gpu
+@pytest.mark.parametrize("kind", [0, 1])
+def test_q8_K_activation_image_matches_the_rule_bitwise(dev, kind):
+    """INIT with the Q8_K rule (image kind + 16): decode the operand image back to quants and scales."""
+    import torch
+    from ggmlsharp_amd._lib import lib, check
+    N, K = 37, 1024
+    x = _rand((N, K), 2.0)
+    x[3, 256:512] = 0.0
+    x[5, 0] = 9.0
+    x[5, 200] = -9.0                                   # equal magnitudes: the first decides the sign
+    d8, q8, bs = KQ.quantize_q8_K(x.reshape(-1, 256))
+    d8, q8 = d8.reshape(N, K // 256), q8.reshape(N, K)
+    work = dev.alloc_work(Q5_K, K, N)
+    xd = torch.from_numpy(x).cuda()
+    check(lib().ggml_hip_quantize_act_dev(C.c_void_p(xd.data_ptr()), N, K, K, C.c_void_p(work.data_ptr()), work.numel(), 16 + kind, None), "quantize_act")
+    torch.cuda.synchronize()
+    nbk, Npad = K // 32, 256
+    raw = work.cpu().numpy()
+    img_bytes = nbk * 4 * Npad * 16
+    ad = raw[img_bytes: img_bytes + nbk * Npad * 4].view(np.float32).reshape(nbk, Npad)[:, :N].T          # [N, nbk]
+    asum = raw[img_bytes + nbk * Npad * 4: img_bytes + 2 * nbk * Npad * 4]
+    assert np.array_equal(ad, np.repeat(d8, 8, axis=1))                                                  # one scale per 256 elements
+    if kind == 0:
+        a8 = raw[: nbk * 2 * Npad * 16].view(np.int8).reshape(nbk, 2, Npad, 16)
+        q = np.empty((N, nbk, 32), dtype=np.int8)
+        q[:, :, 0::2] = a8[:, 0, :N, :].transpose(1, 0, 2)
+        q[:, :, 1::2] = a8[:, 1, :N, :].transpose(1, 0, 2)
+        assert np.array_equal(q.reshape(N, K), q8)
+        sums = asum.view(np.int32).reshape(nbk, Npad)[:, :N].T
+        assert np.array_equal(sums, q8.reshape(N, nbk, 32).astype(np.int32).sum(axis=2))
+    else:
+        sums = asum.view(np.float32).reshape(nbk, Npad)[:, :N].T
+        want = (np.repeat(d8, 8, axis=1) * q8.reshape(N, nbk, 32).astype(np.int32).sum(axis=2).astype(np.float32)).astype(np.float32)
+        assert np.array_equal(sums, want)
+
+
+def _close(got, ref, what):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    rms = np.sqrt(np.mean(ref * ref))
+    assert not (np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-5 * rms).any(), f"{what}: max err {np.abs(got - ref).max():.3e}, rms {rms:.3e}"
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-5 if ref.size >= 256 else True, what
+
+
+@gpu
+def test_mul_mat_q5_K_matches_the_restatement(dev):
+    """every kernel form behind the Q5_1 image of a Q5_K weight: mat-vec (N <= 8, two-step), f16 MFMA with 4- / 2-way K split
+    and unsplit, int8 MFMA; ragged M and N; raw random super-blocks as well as quantized normal data"""
+    import torch
+    for (M, K, N) in ((96, 256, 1), (300, 1024, 3), (128, 512, 8), (515, 768, 40), (256, 2048, 130), (640, 1024, 300),
+                      (130, 512, 600), (257, 768, 1100)):
+        for raw in (False, True):
+            rows = _random_blocks(M * K // 256).reshape(M, -1) if raw else KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
+            x = _rand((N, K))
+            ref = KQ.mul_mat_q5_K(rows, x)
+            W = dev.Weight.from_host(Q5_K, rows, K)
+            got = dev.mul_mat(W, torch.from_numpy(x).cuda()).cpu().numpy()
+            _close(got, ref, f"Q5_K {M}x{K}x{N} raw={raw}")
+    # a row shard is bitwise a column slice of the whole (the multi-GPU promise holds for the extension too)
+    M, K, N = 300, 1024, 70
+    rows = KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
+    xd = torch.from_numpy(_rand((N, K))).cuda()
+    whole = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K), xd)
+    part = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K, row_begin=100, row_end=260), xd)
+    assert torch.equal(part, whole[:, 100:260])
