@@ -140,6 +140,13 @@ HIP_SYMBOLS = {
     "ggml_hip_compute_forward_scale": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T]),
     "ggml_hip_compute_forward_rms_norm": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
     "ggml_hip_compute_forward_silu": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T]),
+    "ggml_hip_compute_forward_rms_norm_mul": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T]),
+    "ggml_hip_compute_forward_silu_mul": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T]),
+    "ggml_hip_compute_forward_mul_mat_add": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T, _T]),
+    "ggml_hip_compute_forward_mul_mat_scale": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T, _T]),
+    "ggml_hip_mul_mat_epilogue_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_size_t, C.c_int, _P, C.c_int64, _P,
+                                                 C.c_int64, C.c_float, _P]),
+    "ggml_hip_mul_mat_epilogue_fused": (C.c_int, [_P, C.c_int64]),
     "ggml_hip_quantize_rows_src_dev": (C.c_int, [C.c_int, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_add_q_f32_rows_dev": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),

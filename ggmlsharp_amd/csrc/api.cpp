@@ -217,7 +217,7 @@ void destroy_slot_locked(DeviceCtx *c) {
     (void)hipSetDevice(c->device);
     (void)c->sync_all();
     c->free_cache();
-    c->src1.release(); c->dst.release(); c->work.release(); c->stage.release();
+    c->src1.release(); c->dst.release(); c->dst2.release(); c->work.release(); c->stage.release();
     c->drain(true);
     for (int k = 0; k < PIPE_EVENTS; ++k) {
         if (c->ev_in[k]) (void)hipEventDestroy(c->ev_in[k]);
@@ -626,6 +626,54 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
     if (rc) return rc;
     return ggml_hip_mul_mat_compute_dev(w, N, d_dst, ldd, d_work, work_bytes, stream);
+}
+
+// does a kernel form with a fused store-phase epilogue serve this (weight, N)?  The fused mat-vec (N <= 4) and the MX mat-mat
+// (Q4_0 / Q4_1, N > 8); every other form runs the epilogue as its own launch behind the mat-mul.
+static bool epilogue_is_fused(const ggml_hip_weight *w, int64_t N) {
+    if (!is_q(w->type) || w->ext_type != 0) return false;
+    if (N <= GEMV_MAX_N) return gemv_fused_has_epilogue(N);
+    return act_image_kind(w->type, w->M, w->K, N) == 3;
+}
+
+int ggml_hip_mul_mat_epilogue_fused(const ggml_hip_weight *w, int64_t N) { return w && epilogue_is_fused(w, N) ? 1 : 0; }
+
+int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *d_dst, int64_t ldd,
+                                  void *d_work, size_t work_bytes, int mode, const float *d_addend, int64_t ld_add, float *d_dst2,
+                                  int64_t ldd2, float scale, void *stream) {
+    if (mode == 0) return ggml_hip_mul_mat_dev(w, d_src1, N, ld1, d_dst, ldd, d_work, work_bytes, stream);
+    if (!w) return fail(GGML_HIP_ERR_ARG, "null weight");
+    if (mode != 1 && mode != 2) return fail(GGML_HIP_ERR_ARG, "epilogue mode %d (1 = add, 2 = scale)", mode);
+    if (N <= 0 || w->M <= 0) return GGML_HIP_OK;
+    if (mode == 1 && (!d_addend || !d_dst2 || ld_add < w->M || ldd2 < w->M)) return fail(GGML_HIP_ERR_ARG, "add epilogue: addend / dst2 missing or too narrow");
+    const mm_epilogue ep = {mode, d_addend, ld_add, d_dst2, ldd2, scale};
+    if (epilogue_is_fused(w, N)) {
+        if (!d_src1 || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+        if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
+        int rc = weight_device_current(w);
+        if (rc) return rc;
+        if (N <= GEMV_MAX_N) {
+            rc = check_src1_alignment(d_src1, ld1);
+            if (rc) return rc;
+            HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream, &ep));
+            return GGML_HIP_OK;
+        }
+        rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
+        if (rc) return rc;
+        HIP_TRY(launch_gemm_qmx(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep));
+        return GGML_HIP_OK;
+    }
+    // no fused form for this kernel: the product, then the node's own kernel row by row (same values)
+    int rc = ggml_hip_mul_mat_dev(w, d_src1, N, ld1, d_dst, ldd, d_work, work_bytes, stream);
+    if (rc) return rc;
+    if (mode == 2) {
+        if (ldd == w->M) HIP_TRY(launch_scale_f32(d_dst, N * w->M, scale, (hipStream_t)stream));
+        else for (int64_t n = 0; n < N; ++n) HIP_TRY(launch_scale_f32(d_dst + n * ldd, w->M, scale, (hipStream_t)stream));
+        return GGML_HIP_OK;
+    }
+    if (ldd == w->M && ld_add == w->M && ldd2 == w->M) HIP_TRY(launch_binary_f32(0, d_dst, d_addend, d_dst2, N * w->M, (hipStream_t)stream));
+    else for (int64_t n = 0; n < N; ++n) HIP_TRY(launch_binary_f32(0, d_dst + n * ldd, d_addend + n * ld_add, d_dst2 + n * ldd2, w->M, (hipStream_t)stream));
+    return GGML_HIP_OK;
 }
 
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {

@@ -151,6 +151,17 @@ struct PerDeviceOnce {
 };
 #endif
 
+// ---- epilogue applied to the accumulators of a mat-mul kernel as they are stored (the add / scale node
+// that follows a mul_mat node, fused into its store phase).  mode 0: none.  mode 1 (add, Ggml.cs:4622-4682): dst keeps the
+// product, dst2[n][m] = product + addend[n][m] -- both nodes' data are materialised, one f32 add, bit for bit the separate
+// kernel.  mode 2 (scale, Ggml.cs:6746-6778, in place: the scale node is a view of the product): dst[n][m] = product * scale.
+struct mm_epilogue {
+    int mode;
+    const float *addend; int64_t ld_add;
+    float *dst2; int64_t ld2;
+    float scale;
+};
+
 // ---- kernel launchers (implemented in the .hip files) ----
 // layout.hip
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
@@ -186,13 +197,18 @@ hipError_t launch_binary_f32(int op, const float *x, const float *y, float *z, i
 hipError_t launch_scale_f32(float *z, int64_t n, float v, hipStream_t st);
 hipError_t launch_rms_norm_f32(const float *x, float *y, int64_t nr, int64_t nc, hipStream_t st);
 hipError_t launch_silu_f32(const float *x, float *y, int64_t n, hipStream_t st);
+// fused.hip: two nodes, one launch (both outputs written)
+hipError_t launch_rms_norm_mul_f32(const float *x, const float *g, float *n_out, float *y_out, int64_t nr, int64_t nc, hipStream_t st);
+hipError_t launch_silu_mul_f32(const float *a, const float *b, float *s_out, float *y_out, int64_t n, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,
-                               hipStream_t st);
+                               hipStream_t st, const mm_epilogue *ep = nullptr);
+bool gemv_fused_has_epilogue(int64_t N);       // the kernel form that serves N applies an mm_epilogue itself
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
-hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
+                           const mm_epilogue *ep = nullptr);
 hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st);
 

@@ -107,7 +107,7 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
                      const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
                      const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nstages,
                      int ldd, int tiles_m, int tiles_n, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes,
-                     uint32_t ad_bytes, uint32_t dst_bytes) {
+                     uint32_t ad_bytes, uint32_t dst_bytes, const mm_epilogue ep) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
     constexpr int NTILE = WMT * WNT, P = C::P;
     constexpr int NF = (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) ? 1 : 2;   // weight digits (fragments) per block
@@ -415,6 +415,38 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     const rsrc_t rD = make_rsrc(dst + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
     const bool full = n0 + C::TN <= N && m0 + C::TM <= M;                    // uniform
     const uint32_t lane_off = (uint32_t)((4 * hh * ldd + l31) * 4);
+    if (ep.mode != 0) {
+        // the add / scale node that follows this mul_mat, applied as the accumulators are stored (common.h mm_epilogue): uniform
+        // branch, taken only by the fused seams; one f32 operation per element, the separate kernel's result bit for bit
+        const int lda = (int)ep.ld_add, ld2 = (int)ep.ld2;
+        const rsrc_t rS = make_rsrc(ep.mode == 1 ? ep.addend + (size_t)n0 * lda + m0 : dst, 0xFFFFFFFFu);
+        const rsrc_t rD2 = make_rsrc(ep.mode == 1 ? ep.dst2 + (size_t)n0 * ld2 + m0 : dst, 0xFFFFFFFFu);
+        const uint32_t lane_s = (uint32_t)((4 * hh * lda + l31) * 4), lane_2 = (uint32_t)((4 * hh * ld2 + l31) * 4);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                const int mb = (wm_ * WMT + i) * 32, nb = (wn * WNT + j) * 32;        // relative to (n0, m0)
+                if (m0 + mb >= M || n0 + nb >= N) continue;                    // uniform
+                const bool mok = m0 + mb + l31 < M;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nr = nb + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[i][j][r];
+                    if (!(mok && n0 + nr + 4 * hh < N)) continue;
+                    if (ep.mode == 2) {
+                        const float o = v * ep.scale;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), rD, (int)lane_off, (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rD, (int)lane_off, (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
+                        const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, (int)lane_s, (int)((uint32_t)(nr * lda + mb) * 4u), 0));
+                        const float o = v + a;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, o), rD2, (int)lane_2, (int)((uint32_t)(nr * ld2 + mb) * 4u), 0);
+                    }
+                }
+            }
+        return;
+    }
     if (full) {
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
@@ -447,6 +479,10 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     }
 }
 
+// the epilogue of the call in flight on this host thread (set by launch_gemm_qmx around launch_typed: the tile-form selection
+// below has a dozen call sites, the epilogue concerns none of them)
+thread_local mm_epilogue t_epilogue = {0, nullptr, 0, nullptr, 0, 1.0f};
+
 template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB, int FB, int KSP = 1, int VS = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<TYPE, WMT, WNT, WGM, WGN, KB>;
@@ -468,7 +504,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     if (wq_bytes > LIM || a_bytes > LIM || (uint64_t)C::TN * (uint64_t)ldd * 4 > LIM) return hipErrorNotSupported;   // api.cpp routes such shapes to gemm_q.hip
     kern<<<grid, C::NT * KSP, C::TOTAL * KSP, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
                                         (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
-                                        (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes);
+                                        (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes, t_epilogue);
     return hipGetLastError();
 }
 
@@ -533,8 +569,15 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
 
 }  // namespace
 
-hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
+                           const mm_epilogue *ep) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
+    struct Scope {                                          // the epilogue lives for this launch only
+        explicit Scope(const mm_epilogue *e) { if (e) t_epilogue = *e; }
+        ~Scope() { t_epilogue = mm_epilogue{0, nullptr, 0, nullptr, 0, 1.0f}; }
+    } scope(ep);
+    if (ep && ep->mode == 1 && ((uint64_t)64 * (uint64_t)ep->ld_add * 4 > 0xFFFFFFFFull || (uint64_t)256 * (uint64_t)ep->ld2 * 4 > 0xFFFFFFFFull))
+        return hipErrorNotSupported;                        // (32-bit offsets inside a tile, as for dst)
     switch (w->type) {
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);

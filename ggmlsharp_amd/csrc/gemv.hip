@@ -35,6 +35,9 @@ template <int NC> struct GvChunk { static constexpr int value = NC <= 8 ? GV_CHU
 #ifndef GV_NT
 #define GV_NT 1       // non-temporal weight loads (A/B: -DGV_NT=0)
 #endif
+#ifndef GV_OLD_FUSED
+#define GV_OLD_FUSED 0                 // A/B: the former fused kernel (block-wide staging behind a barrier)
+#endif
 
 using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
 __device__ __forceinline__ uint4 ld_w(const uint8_t *p) {
@@ -273,7 +276,8 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
                                                                 const float *__restrict__ wd, const float *__restrict__ wm,
                                                                 const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
-                                                                int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles) {
+                                                                int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles,
+                                                                const mm_epilogue ep) {
     static_assert(GV_ROWS == 16 && GV_NKQ == 4, "lane = (row, k-lane) with 4 k-lanes per wave");
     constexpr int CH = GV_CHUNK;                       // k-blocks per chunk, all waves together
     constexpr int BPL = CH / GV_WORKERS;               // k-blocks per lane per chunk (4)
@@ -413,6 +417,12 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
                 staged = true;
             }
 
+            // (a K of several chunks: the next item's activations are requested as soon as this item's are quantized -- behind
+            // its weights, which are already in flight, and a whole dot phase ahead of their use)
+            if constexpr (PF) {
+                if (!single_chunk && w + 1 < nitems) load_x(w + 1, 0);
+            }
+
             // 4. integer block dots + f32 scale-accumulate (Ggml.cs:1136-1159)
 #pragma unroll
             for (int j = 0; j < BPL; ++j) {
@@ -462,8 +472,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
             }
         }
         if constexpr (PF) {
-            // the prefetched registers become the current ones; a K of several chunks asks for the next item's activations
-            // now, behind its weights (already in flight) and ahead of the item after it
+            // the prefetched registers become the current ones
 #pragma unroll
             for (int j = 0; j < BPL; ++j) {
                 q[j] = qn[j]; dw[j] = dwn[j];
@@ -471,7 +480,6 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
                 if (HAS_M) mw[j] = mwn[j];
                 if (HAS_H) hb[j] = hbn[j];
             }
-            if (!single_chunk && w + 1 < nitems) load_x(w + 1, 0);
         }
         if (cidx != nchunks - 1) continue;              // the row tile's last chunk: reduce and store below
 
@@ -495,7 +503,11 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
                 quad[qd] = (sRed[parity][4 * qd][c][rr] + sRed[parity][4 * qd + 1][c][rr]) + (sRed[parity][4 * qd + 2][c][rr] + sRed[parity][4 * qd + 3][c][rr]);
             const float tot = GV_WAVES == 4 ? quad[0] : GV_WAVES == 8 ? quad[0] + quad[1 % (GV_WAVES / 4)]
                                             : (quad[0] + quad[1 % (GV_WAVES / 4)]) + (quad[2 % (GV_WAVES / 4)] + quad[3 % (GV_WAVES / 4)]);
-            if (m < M && c < N) dst[(int64_t)c * ldd + m] = tot;
+            if (m < M && c < N) {
+                // the node that follows the mul_mat, applied as the product is stored (common.h mm_epilogue)
+                dst[(int64_t)c * ldd + m] = ep.mode == 2 ? tot * ep.scale : tot;
+                if (ep.mode == 1) ep.dst2[(int64_t)c * ep.ld2 + m] = tot + ep.addend[(int64_t)c * ep.ld_add + m];
+            }
         }
         parity ^= 1;
     }
@@ -503,17 +515,15 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
 
 template <int TYPE, bool FUSED, int ROWS>
 hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
-                       int64_t ldd, hipStream_t st) {
+                       int64_t ldd, hipStream_t st, const mm_epilogue *epp) {
+    const mm_epilogue ep = epp ? *epp : mm_epilogue{0, nullptr, 0, nullptr, 0, 1.0f};
     const int ntiles = (int)((w->M + ROWS - 1) / ROWS);
     dim3 grid((unsigned)(ntiles < GV_MAX_WGS ? ntiles : GV_MAX_WGS));
-#ifndef GV_OLD_FUSED
-#define GV_OLD_FUSED 0                 // A/B: the former fused kernel (block-wide staging behind a barrier)
-#endif
     if constexpr (FUSED && !GV_OLD_FUSED) {
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
-#define GVF_LAUNCH(NC) gemv_fused_kernel<TYPE, NC, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles)
+#define GVF_LAUNCH(NC) gemv_fused_kernel<TYPE, NC, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep)
             if (N <= 1) GVF_LAUNCH(1);
             else if (N <= 2) GVF_LAUNCH(2);
             else GVF_LAUNCH(4);
@@ -521,6 +531,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
             return hipGetLastError();
         }
     }
+    if (ep.mode != 0) return hipErrorNotSupported;          // (callers ask gemv_fused_has_epilogue first)
 #define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
@@ -533,25 +544,25 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
 
 template <int TYPE, bool FUSED>
 hipError_t launch_typed(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
-                        int64_t ldd, hipStream_t st) {
+                        int64_t ldd, hipStream_t st, const mm_epilogue *ep) {
     // 32 rows per workgroup measured 5 % faster at M = 32000 (4.46 vs 4.24 TB/s) and 13 % slower at M = 4096; a choice by
     // M would change the summation tree between a row shard and the unsplit matrix, and the multi-GPU path promises
     // bit-identical results for any split -- so one shape for every M.
-    return launch_rows<TYPE, FUSED, 16>(w, x, ld1, p, N, dst, ldd, st);
+    return launch_rows<TYPE, FUSED, 16>(w, x, ld1, p, N, dst, ldd, st, ep);
 }
 
 template <bool FUSED>
 hipError_t launch_any(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
-                      int64_t ldd, hipStream_t st) {
+                      int64_t ldd, hipStream_t st, const mm_epilogue *ep = nullptr) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
     if (N > (FUSED ? GEMV_MAX_N : GEMV_WIDE_MAX_N)) return hipErrorInvalidValue;
     switch (w->type) {
-    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1, FUSED>(w, x, ld1, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2, FUSED>(w, x, ld1, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1, FUSED>(w, x, ld1, p, N, dst, ldd, st);
-    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0, FUSED>(w, x, ld1, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
+    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
+    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
     default: return hipErrorInvalidValue;
     }
 }
@@ -563,7 +574,9 @@ hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, floa
 }
 
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,
-                               hipStream_t st) {
+                               hipStream_t st, const mm_epilogue *ep) {
     act_planes none = {nullptr, nullptr, nullptr, 0};
-    return launch_any<true>(w, x, ld1, none, N, dst, ldd, st);
+    return launch_any<true>(w, x, ld1, none, N, dst, ldd, st, ep);
 }
+
+bool gemv_fused_has_epilogue(int64_t N) { return N >= 1 && N <= 4 && !GV_OLD_FUSED; }

@@ -347,6 +347,35 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         if (node->op == GGML_OP_NONE) continue;
         ggml_compute_params params;
         params.ith = 0; params.nth = node->n_tasks; params.wsize = 0; params.wdata = nullptr;
+        // a node and the node right behind it that consumes it go to the device as ONE call when the
+        // library has the fused form (both nodes' data are still produced; the unfused seams are the fallback inside).
+        ggml_tensor *next = i + 1 < cgraph->n_nodes ? cgraph->nodes[i + 1] : nullptr;
+        int fused = 0;   // 1 rms_norm + mul, 2 silu + mul, 3 mul_mat + add, 4 mul_mat + scale
+        if (next && next->op == GGML_OP_MUL && (next->src0 == node || next->src1 == node) && next->src0 != next->src1 && next->data != node->data) {
+            if (node->op == GGML_OP_RMS_NORM) fused = 1;
+            else if (node->op == GGML_OP_SILU && node->data != node->src0->data) fused = 2;
+        } else if (next && node->op == GGML_OP_MUL_MAT && next->op == GGML_OP_ADD && next->src0 == node && next->src1 != node &&
+                   next->src1->type == GGML_TYPE_F32) {
+            fused = 3;
+        } else if (next && node->op == GGML_OP_MUL_MAT && next->op == GGML_OP_SCALE && next->src0 == node && next->data == node->data) {
+            fused = 4;
+        }
+        if (fused) {
+            ggml_tensor *other = next->src0 == node ? next->src1 : next->src0;
+            for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {
+                params.type = phase;
+                int rc;
+                if (fused == 1) rc = ggml_hip_compute_forward_rms_norm_mul(&params, node->src0, other, node, next);
+                else if (fused == 2) rc = ggml_hip_compute_forward_silu_mul(&params, node->src0, other, node, next);
+                else if (fused == 3) rc = ggml_hip_compute_forward_mul_mat_add(&params, node->src0, node->src1, node, next->src1, next);
+                else rc = ggml_hip_compute_forward_mul_mat_scale(&params, node->src0, node->src1, node, next->src1, next);
+                if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }
+            }
+            node->perf_runs++;
+            next->perf_runs++;
+            ++i;
+            continue;
+        }
         for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {  // Ggml.cs:3553-3670
             params.type = phase;
             int rc;

@@ -125,6 +125,11 @@ struct PipeArgs {
     float *dd; int64_t ldd;                        // dst on the device: base (already at this slot's column) and row stride
     int64_t N, K, Ms, col0, chunk;
     void *work; size_t work_cap;
+    // the node that follows the mul_mat, fused into its kernels (common.h mm_epilogue); mode 0 = none
+    int epi_mode = 0;
+    const float *addend = nullptr;                 // [N][Ms] on the device (mode 1)
+    float *dst2 = nullptr; uint8_t *d2_host = nullptr; uint64_t nb1_2 = 0;   // the add node's result, device and host
+    float scale = 1.0f;                            // mode 2
 };
 
 // H2D of chunk k on s_h2d | INIT + COMPUTE of chunk k on stream | D2H of chunk k on s_d2h, chained by events.
@@ -147,7 +152,9 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
             if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[ke], 0);
             if (e != hipSuccess) break;
         }
-        int rc = ggml_hip_mul_mat_dev(a.w, a.xd + (size_t)r * a.K, n, a.K, a.dd + (size_t)r * a.ldd, a.ldd, a.work, a.work_cap, c->stream);
+        int rc = ggml_hip_mul_mat_epilogue_dev(a.w, a.xd + (size_t)r * a.K, n, a.K, a.dd + (size_t)r * a.ldd, a.ldd, a.work, a.work_cap, a.epi_mode,
+                                               a.addend ? a.addend + (size_t)r * a.Ms : nullptr, a.Ms, a.dst2 ? a.dst2 + (size_t)r * a.Ms : nullptr, a.Ms,
+                                               a.scale, c->stream);
         if (rc) return rc;
         e = hipEventRecord(c->ev_k[ke], c->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_k[ke], 0);
@@ -157,6 +164,8 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
             else
                 e = hipMemcpy2DAsync(a.d_host + (size_t)r * a.nb1 + (size_t)a.col0 * 4, a.nb1, a.dd + (size_t)r * a.ldd, (size_t)a.ldd * 4,
                                      (size_t)a.Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
+            if (e == hipSuccess && a.epi_mode == 1)             // the add node's data goes to the host too (contiguous rows)
+                e = hipMemcpyAsync(a.d2_host + (size_t)r * a.nb1_2, a.dst2 + (size_t)r * a.Ms, (size_t)n * a.Ms * 4, hipMemcpyDeviceToHost, c->s_d2h);
         }
     }
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
@@ -174,7 +183,7 @@ int run_pipeline(DeviceCtx *c, const PipeArgs &a) {
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xchg, 0);
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
     if (a.upload) c->h2d_bytes += (size_t)a.N * a.K * 4;
-    c->d2h_bytes += (size_t)a.N * a.Ms * 4;
+    c->d2h_bytes += (size_t)a.N * a.Ms * 4 * (a.epi_mode == 1 ? 2 : 1);
     return issue_chunks(c, a);
 }
 
@@ -291,8 +300,16 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
 
 /* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
  * ggml_mul_mat_impl (Ggml.cs:8228-8229); the reference silently drops them in Release, here they are errors. */
-int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
-                                     const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+struct SeamEpi {                                    // the node after the mul_mat (fused seams below); mode as in mm_epilogue
+    int mode;
+    const struct ggml_tensor *addend;               // mode 1: the other operand of the add node
+    struct ggml_tensor *add_dst;                    //         and that node
+    float scale;                                    // mode 2
+};
+static const int SEAM_NOT_FUSABLE = 1;              // (internal) the caller runs the two seams one after the other
+
+static int seam1(const struct ggml_compute_params *params, const struct ggml_tensor *src0, const struct ggml_tensor *src1,
+                 struct ggml_tensor *dst, const SeamEpi *epi) {
     if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     // offload convention of the reference's own dead GPU blocks (Ggml.cs:6510-6521)
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
@@ -321,6 +338,16 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
     const int G = call.G();
     const bool in_graph = call.in_graph();
     const int64_t nslice = ne02 * ne03;
+    if (epi) {
+        // fused when one slot serves one 2-D slice with contiguous f32 tensors of dst's shape; anything else: two seams
+        bool ok = G == 1 && nslice == 1 && dst->nb[1] == (uint64_t)ne01 * 4;
+        if (ok && epi->mode == 1) {
+            const ggml_tensor *a = epi->addend, *d2 = epi->add_dst;
+            ok = a && d2 && a->data && d2->data && contiguous_f32(a) && contiguous_f32(d2) && a->ne[0] == ne01 && a->ne[1] == ne11 &&
+                 a->ne[2] == 1 && a->ne[3] == 1 && d2->ne[0] == ne01 && d2->ne[1] == ne11 && d2->ne[2] == 1 && d2->ne[3] == 1 && d2->data != dst->data;
+        }
+        if (!ok) return SEAM_NOT_FUSABLE;
+    }
     const size_t x_bytes = (size_t)ne11 * ne10 * 4, d_full = (size_t)ne11 * ne01 * 4;
     const size_t w_bytes = ggml_hip_mul_mat_work_size(type, ne00, ne11);
     const bool src1_contig = src1->nb[1] == (uint64_t)ne10 * 4 && src1->nb[2] == src1->nb[1] * (uint64_t)ne11 &&
@@ -399,6 +426,18 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
         if (rc) { for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x); return rc; }
     }
 
+    const float *epi_addend = nullptr;
+    float *epi_dst2 = nullptr;
+    if (epi && epi->mode == 1) {                   // (G == 1) the add node's other operand and its result buffer
+        DeviceCtx *c = call.ctxs[0];
+        if (operand_f32(c, in_graph, epi->addend, c->stage, &epi_addend)) rc = fail(GGML_HIP_ERR_RUNTIME, "mul_mat + add: operand staging failed");
+        if (!rc) {
+            note_host_write(call, epi->add_dst, true);
+            epi_dst2 = result_f32(c, in_graph, epi->add_dst, c->dst2);
+            if (!epi_dst2) rc = fail(GGML_HIP_ERR_RUNTIME, "mul_mat + add: hipMalloc failed");
+        }
+        if (rc) { for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x); return rc; }
+    }
     hipError_t e = hipSuccess;
     for (int64_t i03 = 0; i03 < ne03 && !rc && e == hipSuccess; ++i03)
         for (int64_t i02 = 0; i02 < ne02 && !rc && e == hipSuccess; ++i02) {  // slice offsets as in Ggml.cs:6566-6570
@@ -427,6 +466,10 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
                 pa.xd = xd; pa.upload = !x_res[(size_t)g]; pa.dd = dd; pa.ldd = ldd;
                 pa.N = ne11; pa.K = ne10; pa.Ms = Ms; pa.col0 = r0[(size_t)g]; pa.chunk = chunk;
                 pa.work = c->work.p; pa.work_cap = c->work.cap;
+                if (epi) {
+                    pa.epi_mode = epi->mode; pa.scale = epi->scale;
+                    if (epi->mode == 1) { pa.addend = epi_addend; pa.dst2 = epi_dst2; pa.d2_host = (uint8_t *)epi->add_dst->data; pa.nb1_2 = epi->add_dst->nb[1]; }
+                }
                 rc = run_pipeline(c, pa);
             }
             // row split inside a graph scope: every slot's resident copy of dst gets the other slots' columns, so the next
@@ -447,6 +490,48 @@ int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, c
         }
     for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x);
     return rc;
+}
+
+int ggml_hip_compute_forward_mul_mat(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                     const struct ggml_tensor *src1, struct ggml_tensor *dst) {
+    return seam1(params, src0, src1, dst, nullptr);
+}
+
+/* mul_mat node + the ADD node that consumes it (epilogue side): mm_dst = mul_mat(src0, src1),
+ * add_dst = mm_dst + addend, the add applied in the store phase of the mat-mul kernels where they have the form
+ * (ggml_hip_mul_mat_epilogue_fused), by the add kernel behind them otherwise; both nodes' data reach host memory. */
+int ggml_hip_compute_forward_mul_mat_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                         const struct ggml_tensor *src1, struct ggml_tensor *mm_dst,
+                                         const struct ggml_tensor *addend, struct ggml_tensor *add_dst) {
+    if (!params || !src0 || !src1 || !mm_dst || !addend || !add_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    const SeamEpi epi = {1, addend, add_dst, 1.0f};
+    int rc = seam1(params, src0, src1, mm_dst, &epi);
+    if (rc != SEAM_NOT_FUSABLE) return rc;
+    rc = seam1(params, src0, src1, mm_dst, nullptr);
+    if (rc) return rc;
+    return ggml_hip_compute_forward_add(params, mm_dst, addend, add_dst);
+}
+
+/* mul_mat node + the SCALE node on it (in place: the scale node is a view of the product, Ggml.cs:8265): the data both
+ * nodes share ends as product * scalar. */
+int ggml_hip_compute_forward_mul_mat_scale(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                           const struct ggml_tensor *src1, struct ggml_tensor *mm_dst,
+                                           const struct ggml_tensor *scalar, struct ggml_tensor *scale_dst) {
+    if (!params || !src0 || !src1 || !mm_dst || !scalar || !scale_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scalar->type != GGML_TYPE_F32 || nelem(scalar) != 1 || !scalar->data) return fail(GGML_HIP_ERR_SHAPE, "scale: src1 must be an F32 scalar (Ggml.cs:6755)");
+    bool fusable = scale_dst->data == mm_dst->data && scalar->op == GGML_OP_NONE;   // a view of the product; the scalar a leaf in host memory
+    for (int i = 0; i < 4; ++i) fusable = fusable && scale_dst->ne[i] == mm_dst->ne[i];
+    int rc = SEAM_NOT_FUSABLE;
+    if (fusable) {
+        const SeamEpi epi = {2, nullptr, nullptr, *(const float *)scalar->data};
+        rc = seam1(params, src0, src1, mm_dst, &epi);
+    }
+    if (rc != SEAM_NOT_FUSABLE) return rc;
+    rc = seam1(params, src0, src1, mm_dst, nullptr);
+    if (rc) return rc;
+    return ggml_hip_compute_forward_scale(params, mm_dst, scalar, scale_dst);
 }
 
 /* ggml_compute_forward_cpy, quantizing branch of dup_f32 / dup_f16 (Ggml.cs:4339-4363, 3935-3966) */
@@ -643,6 +728,65 @@ static int unary_f32_seam(int which, const struct ggml_tensor *src0, struct ggml
         if (finish_f32(c, in_graph, g == 0, dst, z)) return fail(GGML_HIP_ERR_RUNTIME, "%s: copy back failed", name);
     }
     return GGML_HIP_OK;
+}
+
+// two element-wise nodes, one launch (fused.hip): which = 0 rms_norm -> mul, 1 silu -> mul.  `first` is the operand of the
+// first node, `other` the second operand of the mul node; both nodes' results are written and reach host memory.
+static int fused_pair_seam(int which, const struct ggml_tensor *first, const struct ggml_tensor *other, struct ggml_tensor *mid_dst,
+                           struct ggml_tensor *mul_dst) {
+    const char *name = which == 0 ? "rms_norm + mul" : "silu + mul";
+    const ggml_tensor *all[4] = {first, other, mid_dst, mul_dst};
+    for (const ggml_tensor *t : all) {
+        if (t->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "%s: F32 only", name);
+        if (!contiguous_f32(t)) return fail(GGML_HIP_ERR_SHAPE, "%s: contiguous operands only", name);
+        if (!t->data) return fail(GGML_HIP_ERR_ARG, "null data");
+        for (int i = 0; i < 4; ++i)
+            if (t->ne[i] != first->ne[i]) return fail(GGML_HIP_ERR_SHAPE, "%s: shapes differ", name);
+    }
+    if (mid_dst->data == mul_dst->data) return fail(GGML_HIP_ERR_SHAPE, "%s: the two nodes share their data", name);
+    if (nelem(first) == 0) return GGML_HIP_OK;
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    const bool in_graph = call.in_graph();
+    const int ns = eltwise_slots(call);
+    for (int g = 0; g < ns; ++g) {
+        DeviceCtx *c = call.ctxs[(size_t)g];
+        rc = c->make_current();
+        if (rc) return rc;
+        const float *a = nullptr, *b = nullptr;
+        if (operand_f32(c, in_graph, first, c->src1, &a) || operand_f32(c, in_graph, other, c->stage, &b)) return fail(GGML_HIP_ERR_RUNTIME, "%s: operand staging failed", name);
+        if (g == 0) { note_host_write(call, mid_dst, true); note_host_write(call, mul_dst, true); }
+        float *z1 = result_f32(c, in_graph, mid_dst, c->dst), *z2 = result_f32(c, in_graph, mul_dst, c->dst2);
+        if (!z1 || !z2) return fail(GGML_HIP_ERR_RUNTIME, "%s: hipMalloc failed", name);
+        if (which == 0) HIP_TRY(launch_rms_norm_mul_f32(a, b, z1, z2, nelem(first) / first->ne[0], first->ne[0], c->stream));
+        else HIP_TRY(launch_silu_mul_f32(a, b, z1, z2, nelem(first), c->stream));
+        // (both copies on the compute stream; outside a graph scope the second finish waits for both)
+        if (g == 0) {
+            const size_t bytes = (size_t)nelem(first) * 4;
+            HIP_TRY(hipMemcpyAsync(mid_dst->data, z1, bytes, hipMemcpyDeviceToHost, c->stream));
+            c->d2h_bytes += bytes;
+        }
+        if (finish_f32(c, in_graph, g == 0, mul_dst, z2)) return fail(GGML_HIP_ERR_RUNTIME, "%s: copy back failed", name);
+    }
+    return GGML_HIP_OK;
+}
+
+/* rms_norm node + the MUL node that consumes it (prologue side of a mul_mat): norm_dst = rms_norm(x),
+ * mul_dst = norm_dst * g, one launch, the unfused kernels' bits */
+int ggml_hip_compute_forward_rms_norm_mul(const struct ggml_compute_params *params, const struct ggml_tensor *x,
+                                          const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst) {
+    if (!params || !x || !g || !norm_dst || !mul_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    return fused_pair_seam(0, x, g, norm_dst, mul_dst);
+}
+
+/* silu node + the MUL node that consumes it (the SwiGLU gate): silu_dst = silu(a), mul_dst = silu_dst * b */
+int ggml_hip_compute_forward_silu_mul(const struct ggml_compute_params *params, const struct ggml_tensor *a,
+                                      const struct ggml_tensor *b, struct ggml_tensor *silu_dst, struct ggml_tensor *mul_dst) {
+    if (!params || !a || !b || !silu_dst || !mul_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    return fused_pair_seam(1, a, b, silu_dst, mul_dst);
 }
 
 /* ggml_compute_forward_rms_norm_f32 (Ggml.cs:5858-5920) */

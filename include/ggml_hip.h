@@ -277,6 +277,34 @@ int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, 
  *                                                                  view of src0.                              (bit-exact) */
 int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                   struct ggml_tensor *dst);
+/* ---------------- fused neighbours (adjacent ops as prologues / epilogues of mul_mat) ----------------
+ * Two graph nodes served by one call; BOTH nodes' data are produced (the reference's contract: every node's data is in host
+ * memory after ggml_graph_compute), each value by the reference's own operation sequence -- bit for bit what the separate
+ * seams give.  The host's node loop (Ggml.cs:3539-3704) calls one of these for node i and skips node i + 1 when it sees the
+ * pair; every pair has the unfused seams as its fallback.
+ *   rms_norm_mul   norm_dst = rms_norm(x), mul_dst = norm_dst * g                 one launch (fused.hip)
+ *   silu_mul       silu_dst = silu(a),     mul_dst = silu_dst * b  (SwiGLU gate)  one launch (fused.hip)
+ *   mul_mat_add    mm_dst = mul_mat(src0, src1), add_dst = mm_dst + addend        the add is applied to the accumulators in
+ *   mul_mat_scale  mm_dst = scale_dst = mul_mat(src0, src1) * scalar (in place)   the store phase of the mat-mul kernels
+ * (epilogue forms exist in the fused mat-vec, N <= 4, and in the MX mat-mat of Q4_0 / Q4_1, N > 8:
+ * ggml_hip_mul_mat_epilogue_fused; elsewhere the node's own kernel runs behind the mat-mul inside the same call). */
+int ggml_hip_compute_forward_rms_norm_mul(const struct ggml_compute_params *params, const struct ggml_tensor *x,
+                                          const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst);
+int ggml_hip_compute_forward_silu_mul(const struct ggml_compute_params *params, const struct ggml_tensor *a,
+                                      const struct ggml_tensor *b, struct ggml_tensor *silu_dst, struct ggml_tensor *mul_dst);
+int ggml_hip_compute_forward_mul_mat_add(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                         const struct ggml_tensor *src1, struct ggml_tensor *mm_dst,
+                                         const struct ggml_tensor *addend, struct ggml_tensor *add_dst);
+int ggml_hip_compute_forward_mul_mat_scale(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
+                                           const struct ggml_tensor *src1, struct ggml_tensor *mm_dst,
+                                           const struct ggml_tensor *scalar, struct ggml_tensor *scale_dst);
+/* Device form of the epilogue: mode 1 add (d_dst keeps the product, d_dst2 = product + d_addend), mode 2 scale (d_dst =
+ * product * scale), mode 0 = ggml_hip_mul_mat_dev. */
+int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *d_dst, int64_t ldd,
+                                  void *d_work, size_t work_bytes, int mode, const float *d_addend, int64_t ld_add, float *d_dst2,
+                                  int64_t ldd2, float scale, void *stream);
+int ggml_hip_mul_mat_epilogue_fused(const ggml_hip_weight *w, int64_t N);   /* 1: the kernel form serving N applies it itself */
+
 /* Device forms.  src_type F32 or F16; source rows ld elements apart; blocks of all rows contiguous. */
 int ggml_hip_quantize_rows_src_dev(int type, int src_type, const void *d_x, int64_t ld, int64_t nrows, int64_t k,
                                    void *d_blocks, void *stream);

@@ -1,0 +1,167 @@
+"""GPU tests (-m gpu) of the fused neighbours of mul_mat (include/ggml_hip.h "fused neighbours"): every
+fused form must give, bit for bit, what the separate seams / kernels give, and both nodes' data must reach host memory."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ggmlsharp_amd import ggml as G
+from ggmlsharp_amd import _lib
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+RNG = np.random.default_rng(99)
+
+
+def _rand(shape, scale=1.0):
+    return (RNG.standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ggmlsharp_amd import device
+    device.init(0)
+    return device
+
+
+def _params(phase=_lib.GGML_TASK_COMPUTE):
+    return _lib.ggml_compute_params(phase, 0, 1, 0, None)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0])
+def test_epilogue_device_form_is_bitwise_product_then_node(dev, t):
+    from ggmlsharp_amd._lib import lib, check
+    L = lib()
+    for (M, K, N) in ((96, 256, 1), (130, 512, 3), (64, 256, 4), (200, 256, 6), (515, 512, 40), (260, 1024, 300), (128, 256, 1100)):
+        wq = O.quantize_row(t, _rand((M, K)))
+        W = dev.Weight.from_host(t, wq, K)
+        x = torch.from_numpy(_rand((N, K))).cuda()
+        r = torch.from_numpy(_rand((N, M))).cuda()
+        prod = dev.mul_mat(W, x)
+        work = dev.alloc_work(t, K, N)
+        fused = L.ggml_hip_mul_mat_epilogue_fused(W.handle, N)
+        assert fused == (1 if (N <= 4 or (N > 8 and t in (O.Q4_0, O.Q4_1))) else 0), (t, N)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d1 = torch.full((N, M + 8), -3.0, device="cuda")
+        d2 = torch.full((N, M + 4), -4.0, device="cuda")
+        check(L.ggml_hip_mul_mat_epilogue_dev(W.handle, C.c_void_p(x.data_ptr()), N, K, C.c_void_p(d1.data_ptr()), M + 8, C.c_void_p(work.data_ptr()),
+                                              work.numel(), 1, C.c_void_p(r.data_ptr()), M, C.c_void_p(d2.data_ptr()), M + 4, 1.0, st), "epilogue add")
+        assert torch.equal(d1[:, :M], prod) and torch.all(d1[:, M:] == -3.0), (t, M, K, N)
+        assert torch.equal(d2[:, :M], prod + r) and torch.all(d2[:, M:] == -4.0), (t, M, K, N)
+        d3 = torch.empty((N, M), device="cuda")
+        check(L.ggml_hip_mul_mat_epilogue_dev(W.handle, C.c_void_p(x.data_ptr()), N, K, C.c_void_p(d3.data_ptr()), M, C.c_void_p(work.data_ptr()),
+                                              work.numel(), 2, None, 0, None, 0, 0.3125, st), "epilogue scale")
+        assert torch.equal(d3, prod * np.float32(0.3125)), (t, M, K, N)
+
+
+def _block_graph(ctx, t, K, M1, N, w1q, x, g, r, s):
+    """out = add(mul_mat(W1, mul(rms_norm(X), Gn)), R);  sc = scale(mul_mat(W1, X), S);  gate = mul(silu(out), R)"""
+    X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+    Gn = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+    R = G.ggml_new_tensor_2d(ctx, G.F32, M1, N)
+    S = G.ggml_new_tensor_1d(ctx, G.F32, 1)
+    W1 = G.ggml_new_tensor_2d(ctx, t, K, M1)
+    G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
+    G.tensor_f32(Gn)[:] = g.reshape(1, 1, N, K)
+    G.tensor_f32(R)[:] = r.reshape(1, 1, N, M1)
+    G.tensor_f32(S)[:] = s
+    G.tensor_bytes(W1)[:] = w1q.reshape(-1)
+    t_norm = G.ggml_rms_norm(ctx, X)
+    t_mul = G.ggml_mul(ctx, t_norm, Gn)
+    t_mm = G.ggml_mul_mat(ctx, W1, t_mul)
+    t_add = G.ggml_add(ctx, t_mm, R)
+    t_mm2 = G.ggml_mul_mat(ctx, W1, X)
+    t_sc = G.ggml_scale(ctx, t_mm2, S)
+    t_silu = G.ggml_silu(ctx, t_add)
+    t_gate = G.ggml_mul(ctx, t_silu, R)
+    t_fin = G.ggml_add(ctx, t_gate, t_sc)
+    return [t_norm, t_mul, t_mm, t_add, t_mm2, t_sc, t_silu, t_gate, t_fin], t_fin
+
+
+@pytest.mark.parametrize("N", [1, 3, 6, 40, 300])
+def test_fused_graph_equals_the_node_by_node_seams_bitwise(dev, N):
+    """ggml_graph_compute takes the fused seams for (rms_norm, mul), (mul_mat, add), (mul_mat, scale), (silu, mul); the same
+    graph run node by node through the unfused seams gives identical bytes for EVERY node, and the values match the oracle
+    chain (element-wise nodes bit-exact given their inputs)."""
+    L = _lib.lib()
+    K, M1 = 256, 128
+    t = O.Q4_0
+    w1q = O.quantize_row(t, _rand((M1, K)))
+    x, g, r = _rand((N, K), 3.0), _rand((N, K)), _rand((N, M1))
+    res = {}
+    for mode in ("fused", "unfused"):
+        ctx = G.ggml_init(64 * 1024 * 1024)
+        try:
+            nodes, fin = _block_graph(ctx, t, K, M1, N, w1q, x, g, r, 0.125)
+            gf = G.ggml_build_forward(fin)
+            assert gf.n_nodes == 9
+            order = [gf.nodes[i] for i in range(gf.n_nodes)]
+            if mode == "fused":
+                G.ggml_graph_compute(ctx, gf)
+            else:
+                p = _params()
+                _lib.check(L.ggml_hip_graph_begin(), "begin")
+                for nd in order:
+                    c = nd.contents
+                    op = c.op
+                    if op == _lib.GGML_OP_MUL_MAT:
+                        rc = L.ggml_hip_compute_forward_mul_mat(C.byref(p), c.src0, c.src1, nd)
+                    elif op == _lib.GGML_OP_ADD:
+                        rc = L.ggml_hip_compute_forward_add(C.byref(p), c.src0, c.src1, nd)
+                    elif op == 4:
+                        rc = L.ggml_hip_compute_forward_mul(C.byref(p), c.src0, c.src1, nd)
+                    elif op == 21:
+                        rc = L.ggml_hip_compute_forward_scale(C.byref(p), c.src0, c.src1, nd)
+                    elif op == 19:
+                        rc = L.ggml_hip_compute_forward_rms_norm(C.byref(p), c.src0, nd)
+                    elif op == _lib.GGML_OP_SILU:
+                        rc = L.ggml_hip_compute_forward_silu(C.byref(p), c.src0, nd)
+                    else:
+                        raise AssertionError(op)
+                    _lib.check(rc, f"op {op}")
+                _lib.check(L.ggml_hip_graph_end(), "end")
+            res[mode] = [G.tensor_f32(nd)[0, 0].copy() for nd in nodes]
+        finally:
+            G.ggml_free(ctx)
+    for a, b, name in zip(res["fused"], res["unfused"], ["norm", "mul", "mm", "add", "mm2", "scale", "silu", "gate", "fin"]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"node {name} differs between the fused and the unfused path (N = {N})"
+    norm, mul, mm, add, mm2, sc, silu, gate, fin = res["fused"]
+    assert np.allclose(norm, O.eltwise("rms_norm", x), rtol=2e-7, atol=0)
+    assert np.array_equal(mul, O.eltwise("mul", norm, g))
+    ref_mm = O.mul_mat(t, w1q, np.ascontiguousarray(mul), M1, K, N)[0, 0]
+    rms = np.sqrt(np.mean(ref_mm.astype(np.float64) ** 2))
+    assert np.all(np.abs(mm - ref_mm) <= 1e-3 * np.abs(ref_mm) + 1e-5 * rms)
+    assert np.array_equal(add, O.eltwise("add", mm, r))
+    assert np.array_equal(mm2, sc)                                              # the scale node is a view: both hold product * s
+    ref_mm2 = O.mul_mat(t, w1q, x, M1, K, N)[0, 0]
+    rms2 = np.sqrt(np.mean(ref_mm2.astype(np.float64) ** 2))
+    assert np.all(np.abs(sc - 0.125 * ref_mm2) <= 1e-3 * np.abs(0.125 * ref_mm2) + 1e-5 * 0.125 * rms2)
+    assert np.array_equal(silu, O.eltwise("silu", add))
+    assert np.array_equal(gate, O.eltwise("mul", silu, r))
+    assert np.array_equal(fin, O.eltwise("add", gate, sc))
+
+
+def test_fused_seams_ignore_other_phases_and_threads(dev):
+    L = _lib.lib()
+    ctx = G.ggml_init(4 * 1024 * 1024)
+    try:
+        a = G.ggml_new_tensor_2d(ctx, G.F32, 64, 3)
+        b = G.ggml_new_tensor_2d(ctx, G.F32, 64, 3)
+        n = G.ggml_rms_norm(ctx, a)
+        y = G.ggml_mul(ctx, n, b)
+        G.ggml_set_f32(a, 1.0)
+        G.ggml_set_f32(b, 2.0)
+        G.tensor_f32(n)[:] = -9.0
+        G.tensor_f32(y)[:] = -9.0
+        for phase, ith in ((_lib.GGML_TASK_INIT, 0), (_lib.GGML_TASK_FINALIZE, 0), (_lib.GGML_TASK_COMPUTE, 1)):
+            p = _lib.ggml_compute_params(phase, ith, 2, 0, None)
+            assert L.ggml_hip_compute_forward_rms_norm_mul(C.byref(p), a, b, n, y) == 0
+            assert np.all(G.tensor_f32(y) == -9.0)
+        p = _params()
+        assert L.ggml_hip_compute_forward_rms_norm_mul(C.byref(p), a, b, n, y) == 0
+        assert np.allclose(G.tensor_f32(n), 1.0, rtol=1e-6) and np.allclose(G.tensor_f32(y), 2.0, rtol=1e-6)
+        bad = G.ggml_new_tensor_2d(ctx, G.F32, 32, 3)
+        assert L.ggml_hip_compute_forward_silu_mul(C.byref(p), a, bad, n, y) == _lib.ERR_SHAPE
+    finally:
+        G.ggml_free(ctx)
