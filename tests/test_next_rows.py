@@ -270,7 +270,9 @@ def test_transformer_style_chain_stays_on_device():
         assert np.array_equal(G.tensor_f32(t_out)[0, 0], O.eltwise("add", got_y2, r))   # bit-exact given its input
         # PCIe: only the four leaf activations go down (X, Gn, R; S is read on the host), every intermediate is a hit
         assert c1[0].value - c0[0].value == (2 * N * K + N * M2) * 4
-        assert c1[2].value - c0[2].value >= 5
+        # (the pairs (rms_norm, mul), (mul_mat, scale), (mul_mat, add) are fused calls: what is left to look up are the two
+        # src1 operands of the mul_mats, both found resident)
+        assert c1[2].value - c0[2].value >= 2
     finally:
         G.ggml_free(ctx)
 
