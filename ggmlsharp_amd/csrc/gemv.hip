@@ -271,7 +271,9 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
 //     flight (the compiler's vmcnt for the x registers leaves the younger weight loads outstanding);
 //   * one barrier per row tile remains (the cross-wave reduction), on a double-buffered sRed.
 // Arithmetic, block -> lane assignment and summation tree are those of the kernel above, so the bits are too.
-template <int TYPE, int NC, int GV_ROWS>
+// SC: all of K fits one chunk of 128 k-blocks (K <= 4096), a launch-time fact -- two instantiations instead of one kernel
+// that carries both schedules in its registers (the combined form spilled: 24 B of scratch at 128 registers)
+template <int TYPE, int NC, int GV_ROWS, bool SC>
 __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
     const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
                                                                 const float *__restrict__ wd, const float *__restrict__ wm,
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     uint8_t *const myq = sAct + wave * WSLICE;
     float *const myd = (float *)(myq + WBLK * QSLOT);
     int *const mys = (int *)(myd + WBLK * NC);
-    const bool single_chunk = nbk <= CH;
+    constexpr bool single_chunk = SC;
     bool staged = false;
     int parity = 0;
     constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     };
     // (wider batches keep one register set: their activation registers already fill the budget, and the second set cost
     // them a resident workgroup -- 32000 x 4096 x 8: 50.5 us with it against 41.9 without)
-    constexpr bool PF = NC == 1 && TYPE != GGML_TYPE_Q8_0;     // (Q8_0 carries two quant registers sets per block: spills with four)
+    constexpr bool PF = NC == 1 && SC;
     uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1], qn[PF ? BPL : 1], q2n[PF && TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
     float dw[BPL], mw[HAS_M ? BPL : 1], dwn[PF ? BPL : 1], mwn[PF && HAS_M ? BPL : 1];
     uint32_t hb[HAS_H ? BPL : 1], hbn[PF && HAS_H ? BPL : 1];
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
         // the look-ahead pays where a workgroup walks several row tiles of one chunk (4096 x 4096: 5.06 -> 4.66 us, M = 32000:
         // 19.3 -> 18.7); with K in several chunks the activations of every item have to be fetched and quantized as well, and
         // asking for them first, weights behind, in the item's own iteration measured better (4096 x 11008: 9.0 against 10.0 us)
-        const bool pf = PF && single_chunk;
+        constexpr bool pf = PF;
         if (pf) {
             // 2. the NEXT item's weight stream goes out before this item is consumed
             if constexpr (PF) { if (w + 1 < nitems) load_item(w + 1, qn, q2n, dwn, mwn, hbn); }
@@ -523,7 +525,8 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
-#define GVF_LAUNCH(NC) gemv_fused_kernel<TYPE, NC, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep)
+#define GVF_LAUNCH(NC) do { if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep); \
+                             else gemv_fused_kernel<TYPE, NC, ROWS, false><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep); } while (0)
             if (N <= 1) GVF_LAUNCH(1);
             else if (N <= 2) GVF_LAUNCH(2);
             else GVF_LAUNCH(4);

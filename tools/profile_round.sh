@@ -9,8 +9,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$T -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-side-configs > $R/gpurun_out/prof_$T.log 2>&1 || exit 2
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$T_$tag -- python3 $R/tools/kbench.py --cfg q4_0:4096:4096:4096 q4_0:4096:4096:1:32 --iters 3 --no-check > $R/gpurun_out/pmc_$T_$tag.log 2>&1 || exit 3
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmc_${T}_$tag -- python3 $R/tools/kbench.py --cfg q4_0:4096:4096:4096 q4_0:4096:4096:1:32 --iters 3 --no-check > $R/gpurun_out/pmc_${T}_$tag.log 2>&1 || exit 3
 done
 # dense f16 path: MFMA utilisation of dense16_kernel (SQ_VALU_MFMA_BUSY_CYCLES / 4 SIMD-cycles vs SQ_BUSY...)
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmc_$T_dense16 -- python3 $R/tools/kbench.py --cfg f16:4096:4096:4096 --iters 5 > $R/gpurun_out/pmc_$T_dense16.log 2>&1 || exit 4
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmc_${T}_dense16 -- python3 $R/tools/kbench.py --cfg f16:4096:4096:4096 --iters 5 > $R/gpurun_out/pmc_${T}_dense16.log 2>&1 || exit 4
 echo ok
