@@ -260,7 +260,28 @@ def pcie_probe():
     torch.cuda.synchronize()
     t_in = float(np.median(per_call_ms(lambda: d.copy_(h, non_blocking=True), 10, stream)))
     t_out = float(np.median(per_call_ms(lambda: h.copy_(d, non_blocking=True), 10, stream)))
-    return {"h2d_GBs": round(n / t_in / 1e6, 1), "d2h_GBs": round(n / t_out / 1e6, 1)}
+    # both directions at once (what a pipelined Seam-1 call asks of the link): two streams, one copy each way
+    h2 = torch.empty(n, dtype=torch.uint8).pin_memory()
+    d2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        s1.wait_event(a)
+        s2.wait_event(a)
+        with torch.cuda.stream(s1):
+            d.copy_(h, non_blocking=True)
+        with torch.cuda.stream(s2):
+            h2.copy_(d2, non_blocking=True)
+        stream.wait_stream(s1)
+        stream.wait_stream(s2)
+        b.record(stream)
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    return {"h2d_GBs": round(n / t_in / 1e6, 1), "d2h_GBs": round(n / t_out / 1e6, 1),
+            "both_ways_total_GBs": round(2 * n / float(np.median(ts)) / 1e6, 1)}
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU
@@ -536,7 +557,9 @@ def main():
                       "seam1_host_4096x4096x512": seam1_host_config(4096, 4096, 512, 30)}
                 for k in ("seam1_host_4096x4096x4096", "seam1_host_4096x4096x512"):
                     c = s1[k]
-                    bound = max(c["host_bytes_in"] / pc["h2d_GBs"], c["host_bytes_out"] / pc["d2h_GBs"]) / 1e6   # ms, full duplex
+                    # ms: each direction at its one-way rate, and both together at the rate the link holds with both busy
+                    bound = max(c["host_bytes_in"] / pc["h2d_GBs"], c["host_bytes_out"] / pc["d2h_GBs"],
+                                (c["host_bytes_in"] + c["host_bytes_out"]) / pc["both_ways_total_GBs"]) / 1e6
                     c["pcie_bound_ms"] = round(bound, 4)
                     c["step_over_pcie_bound"] = round(c["ms_per_step"] / bound, 3)
                 out["other_configs"].update(s1)

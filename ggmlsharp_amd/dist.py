@@ -117,6 +117,7 @@ class RowSplitMulMat:
             self._views.append(torch.as_tensor(_RawDeviceBuffer(self._own[b], (self.N, self.M_total)), device=self.dev))
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.dev if on_gpu else "cpu")
         self._on_gpu = on_gpu
+        self._side = torch.cuda.Stream()
         self._turn = 0
         self.out = self._views[0]
         self.shard = None
@@ -146,16 +147,19 @@ class RowSplitMulMat:
         out = self._views[b]
         r0, r1 = shard_rows(self.M_total, self.world, self.rank)
         Mw = r1 - r0
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        main = torch.cuda.current_stream()
+        side = self._side                                               # the stores of chunk i overlap the kernels of chunk i + 1
         peers = (C.c_void_p * self.world)(*[None if r == self.rank else p for r, p in enumerate(self._peers[b])])
         for (a, e) in self._chunk_bounds():
             if Mw > 0:
                 own = out[a:e, r0:r1]                                   # this rank's rows as columns of its own dst
                 self.compute_shard(x[a:e], own)
+                side.wait_stream(main)
                 src = self._own[b] + (a * self.M_total + r0) * 4
                 shifted = (C.c_void_p * self.world)(*[None if p is None else p + a * self.M_total * 4 for p in peers])
                 check(self._L.ggml_hip_push_columns_dev(C.c_void_p(src), self.M_total, e - a, Mw, shifted, self.world,
-                                                        self.M_total, r0, stream), "ggml_hip_push_columns_dev")
+                                                        self.M_total, r0, C.c_void_p(side.cuda_stream)), "ggml_hip_push_columns_dev")
+        main.wait_stream(side)
         # barrier: every rank's stores of this step have been issued and completed before anyone reads `out`
         if self._on_gpu:
             dist.all_reduce(self._flag)
