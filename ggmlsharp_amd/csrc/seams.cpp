@@ -101,32 +101,19 @@ int finish_f32(DeviceCtx *c, bool in_graph, bool to_host, ggml_tensor *t, const 
 // tensor, so a later row-split mul_mat finds its src1 in its own HBM), the first one otherwise
 int eltwise_slots(const Call &call) { return call.in_graph() ? call.G() : 1; }
 
-// Seam-1 pipeline: the src1-row chunks of a call.  A function of N and K only (never of M or the slot count), so a row shard
-// and the unsplit matrix run the same kernel forms on the same chunks: bit-identical results for any split.
-// What a pipeline cannot hide is its fill and drain -- the first chunk's upload and the last chunk's download -- while every
-// chunk costs the host ~10 runtime calls and each DMA its launch latency.  So: a body of N / 8 rows per chunk (at least 128)
-// with a quarter- and a half-size chunk at either end.  Measured on MI355X / PCIe 5 (94 GB/s with both directions busy),
-// 4096 x 4096 x {4096, 512}: uniform 8 chunks 1.71-1.75 / 0.36 ms, uniform 16 chunks 1.75 / 0.39 ms.
-std::vector<int64_t> seam_chunks(int64_t N, int64_t K, bool pinned) {
-    std::vector<int64_t> out;
+// Seam-1 pipeline: src1 rows per chunk.  A function of N and K only (never of M or the slot count), so a row shard and the
+// unsplit matrix run the same kernel forms on the same chunks: bit-identical results for any split.
+int64_t seam_chunk_rows(int64_t N, int64_t K, bool pinned) {
+    if (!pinned) return N;                              // pageable memory: the runtime stages synchronously, nothing overlaps
     const int64_t x_bytes = N * K * 4;
-    if (!pinned || N < 256 || x_bytes < (4ll << 20)) {   // pageable memory: the runtime stages synchronously, nothing overlaps
-        out.push_back(N);
-        return out;
-    }
-    int64_t body = ((N + 7) / 8 + 31) / 32 * 32;
-    if (body < 128) body = 128;
-    std::vector<int64_t> head;
-    if (body >= 512) { head.push_back(body / 4); head.push_back(body / 2); }
-    else if (body >= 256) head.push_back(body / 2);
-    int64_t used = 0;
-    for (int64_t h : head) used += 2 * h;
-    if (used >= N) { head.clear(); used = 0; }
-    for (int64_t h : head) out.push_back(h);
-    int64_t rest = N - used;
-    while (rest > 0) { const int64_t c = rest < body + body / 2 ? rest : body; out.push_back(c); rest -= c; }
-    for (size_t i = head.size(); i-- > 0;) out.push_back(head[i]);
-    return out;
+    if (N < 128 || x_bytes < (2ll << 20)) return N;
+    // what the pipeline cannot hide is its fill and drain -- the first chunk's upload and the last chunk's download -- but
+    // every chunk costs the host ~10 runtime calls and each DMA its launch latency: N / 8 rows per chunk, at least 128
+    // (measured on MI355X / PCIe 5, 4096 x 4096 x {4096, 512}: 8 chunks 1.71 / 0.36 ms (two chunks at 512), 16 chunks 1.75 / 0.39 ms;
+    // the box moves 94 GB/s with both directions busy: 1.42 ms for the 134 MB of the first shape)
+    int64_t rows = ((N + 7) / 8 + 31) / 32 * 32;
+    if (rows < 128) rows = 128;
+    return rows;
 }
 
 // ---------------- the Seam-1 pipeline of one 2-D slice on one slot ----------------
@@ -136,8 +123,7 @@ struct PipeArgs {
     uint8_t *d_host; uint64_t nb1;                 // dst rows on the host
     const float *xd; bool upload;                  // src1 on the device (+ whether it has to be uploaded first)
     float *dd; int64_t ldd;                        // dst on the device: base (already at this slot's column) and row stride
-    int64_t N, K, Ms, col0;
-    const std::vector<int64_t> *chunks;            // rows per chunk, in order (seam_chunks)
+    int64_t N, K, Ms, col0, chunk;
     void *work; size_t work_cap;
     // the node that follows the mul_mat, fused into its kernels (common.h mm_epilogue); mode 0 = none
     int epi_mode = 0;
@@ -153,9 +139,8 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
     e = hipEventRecord(c->ev_compute, c->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->s_h2d, c->ev_compute, 0);
     int k = 0;
-    int64_t r = 0;
-    for (size_t ci = 0; ci < a.chunks->size() && e == hipSuccess; r += (*a.chunks)[ci], ++ci, ++k) {
-        const int64_t n = (*a.chunks)[ci];
+    for (int64_t r = 0; r < a.N && e == hipSuccess; r += a.chunk, ++k) {
+        const int64_t n = a.N - r < a.chunk ? a.N - r : a.chunk;
         const int ke = k % PIPE_EVENTS;
         if (a.upload) {
             if (a.nb11 == (uint64_t)a.K * 4)      // contiguous rows: one linear DMA
@@ -370,7 +355,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
     const bool dst_contig = dst->nb[1] == (uint64_t)ne01 * 4 && dst->nb[2] == dst->nb[1] * (uint64_t)ne11 &&
                             dst->nb[3] == dst->nb[2] * (uint64_t)ne02;
     const bool pinned = host_range_pinned(src1->data, tensor_host_bytes(src1)) && host_range_pinned(dst->data, tensor_host_bytes(dst));
-    const std::vector<int64_t> chunks = seam_chunks(ne11, ne10, pinned);
+    const int64_t chunk = seam_chunk_rows(ne11, ne10, pinned);
     // a src0 that some node computes (or that is a leaf the host rewrites between computes without telling us) must not be
     // served from the cache: only leaves are cached, and every seam that writes host memory invalidates what overlaps it
     const bool cacheable = src0->op == GGML_OP_NONE;
@@ -479,7 +464,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 PipeArgs pa;
                 pa.w = w; pa.x_host = x_host; pa.nb11 = src1->nb[1]; pa.d_host = d_host; pa.nb1 = dst->nb[1];
                 pa.xd = xd; pa.upload = !x_res[(size_t)g]; pa.dd = dd; pa.ldd = ldd;
-                pa.N = ne11; pa.K = ne10; pa.Ms = Ms; pa.col0 = r0[(size_t)g]; pa.chunks = &chunks;
+                pa.N = ne11; pa.K = ne10; pa.Ms = Ms; pa.col0 = r0[(size_t)g]; pa.chunk = chunk;
                 pa.work = c->work.p; pa.work_cap = c->work.cap;
                 if (epi) {
                     pa.epi_mode = epi->mode; pa.scale = epi->scale;
