@@ -439,7 +439,11 @@ def main():
 
     M, K, N = 4096, 4096, 4096
     exchange, exchange_why = pick_exchange(device, gdist, world, rank, args.exchange, K)
-    chunks = 4 if world > 1 else 1
+    # src1-row chunks (chunk i's exchange overlaps chunk i + 1's kernels): only where a chunk's kernels still fill the chip.
+    # One launch of the MX mat-mat runs the whole K loop per workgroup (>= 40 us at K = 4096 whatever the grid): measured on
+    # one GPU, 512 x 4096 x 4096 45 us in one launch against 4 x 38 us in chunks of 1024 rows; 4096 x 4096 x 4096 160 against
+    # 4 x 54 us.  So a row shard of the strong-scaling problem (Ms = 4096 / G) is not chunked; the weak-scaling problem is.
+    chunks = 1 if (world == 1 or gdist.shard_width(M, world) < 4096) else 4
     runner, W = make_runner(device, gdist, M, K, N, world, rank, exchange, chunks, seed=1000)
     g = torch.Generator(device="cuda")
     g.manual_seed(1)
@@ -482,7 +486,7 @@ def main():
             small = max(5, args.steps // 4)
             oc = {}
             # the weak-scaling run of round 1 (per-GPU work fixed: rank r owns 4096 rows of a (4096 * G) x 4096 matrix)
-            oc["weak_4096_rows_per_gpu"] = multi_config(device, gdist, "weak scaling", 4096 * world, K, N, world, rank, exchange, chunks, small, 3)
+            oc["weak_4096_rows_per_gpu"] = multi_config(device, gdist, "weak scaling", 4096 * world, K, N, world, rank, exchange, 4, small, 3)
             # BASELINE.json configs[4]: Q4_0 32000 x 4096 x 512 row-split (Ms = 4000 at 8 GPUs)
             oc["config5_vocab512"] = multi_config(device, gdist, "BASELINE config 5", 32000, K, 512, world, rank, exchange, 2, small, 3)
             if exchange == "push":   # the RCCL form beside it, same problem
