@@ -218,6 +218,7 @@ void destroy_slot_locked(DeviceCtx *c) {
     (void)c->sync_all();
     c->free_cache();
     c->src1.release(); c->dst.release(); c->dst2.release(); c->work.release(); c->stage.release();
+    for (Scratch &a : c->aux) a.release();
     c->drain(true);
     for (int k = 0; k < PIPE_EVENTS; ++k) {
         if (c->ev_in[k]) (void)hipEventDestroy(c->ev_in[k]);
@@ -674,6 +675,40 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
     if (ldd == w->M && ld_add == w->M && ldd2 == w->M) HIP_TRY(launch_binary_f32(0, d_dst, d_addend, d_dst2, N * w->M, (hipStream_t)stream));
     else for (int64_t n = 0; n < N; ++n) HIP_TRY(launch_binary_f32(0, d_dst + n * ldd, d_addend + n * ld_add, d_dst2 + n * ldd2, w->M, (hipStream_t)stream));
     return GGML_HIP_OK;
+}
+
+// rms_norm -> mul -> mul_mat [-> add | scale] on device-resident rows.  One launch where the fused mat-vec serves N (the
+// prologue computes and quantizes y = (x * rms_scale) * g in-kernel and writes both nodes' results), else the pair kernel of
+// fused.hip followed by the mat-mul with its epilogue.  d_x, d_g: [N] rows, ld_x / ld_g elements apart; d_norm, d_y: [N][K].
+static bool prologue_is_fused(const ggml_hip_weight *w, int64_t N, const float *d_x, int64_t ld_x, const float *d_g, int64_t ld_g,
+                              const float *d_norm, const float *d_y) {
+    return is_q(w->type) && w->ext_type == 0 && gemv_fused_has_epilogue(N) && ld_x % 4 == 0 && ld_g % 4 == 0 &&
+           (((uintptr_t)d_x | (uintptr_t)d_g | (uintptr_t)d_norm | (uintptr_t)d_y) & 15) == 0;
+}
+
+int ggml_hip_norm_mul_mat_fused(const ggml_hip_weight *w, int64_t N) {
+    return w && is_q(w->type) && w->ext_type == 0 && gemv_fused_has_epilogue(N) ? 1 : 0;
+}
+
+int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_t ld_x, const float *d_g, int64_t ld_g, int64_t N,
+                              float *d_norm, float *d_y, float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, int mode,
+                              const float *d_addend, int64_t ld_add, float *d_dst2, int64_t ldd2, float scale, void *stream) {
+    if (!w || !d_x || !d_g || !d_norm || !d_y || !d_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (N <= 0 || w->M <= 0) return GGML_HIP_OK;
+    if (ld_x < w->K || ld_g < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "row stride smaller than a row");
+    if (mode < 0 || mode > 2) return fail(GGML_HIP_ERR_ARG, "epilogue mode %d", mode);
+    if (mode == 1 && (!d_addend || !d_dst2 || ld_add < w->M || ldd2 < w->M)) return fail(GGML_HIP_ERR_ARG, "add epilogue: addend / dst2 missing or too narrow");
+    int rc = weight_device_current(w);
+    if (rc) return rc;
+    if (prologue_is_fused(w, N, d_x, ld_x, d_g, ld_g, d_norm, d_y)) {
+        const mm_prologue pro = {d_g, ld_g, d_norm, d_y};
+        const mm_epilogue ep = {mode, d_addend, ld_add, d_dst2, ldd2, scale};
+        HIP_TRY(launch_gemv_q_fused_pro(w, d_x, ld_x, pro, N, d_dst, ldd, (hipStream_t)stream, mode ? &ep : nullptr));
+        return GGML_HIP_OK;
+    }
+    if (ld_x == w->K && ld_g == w->K) HIP_TRY(launch_rms_norm_mul_f32(d_x, d_g, d_norm, d_y, N, w->K, (hipStream_t)stream));
+    else for (int64_t n = 0; n < N; ++n) HIP_TRY(launch_rms_norm_mul_f32(d_x + n * ld_x, d_g + n * ld_g, d_norm + n * w->K, d_y + n * w->K, 1, w->K, (hipStream_t)stream));
+    return ggml_hip_mul_mat_epilogue_dev(w, d_y, N, w->K, d_dst, ldd, d_work, work_bytes, mode, d_addend, ld_add, d_dst2, ldd2, scale, stream);
 }
 
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {

@@ -162,6 +162,15 @@ struct mm_epilogue {
     float scale;
 };
 
+// ---- prologue of the fused mat-vec (prologue side): the activation row the kernel quantizes is not read
+// but COMPUTED, y = (x * rms_scale(x)) * g -- the rms_norm -> mul pair in front of a mul_mat (Ggml.cs:5858-5920, 5007-5035) --
+// with the reference's own operation sequence (f32 squares summed in f64 in the unfused kernel's order, one f32 multiply per
+// node); workgroup 0 also writes both nodes' results (n_out = the norm, y_out = the product), [N][K] contiguous.
+struct mm_prologue {
+    const float *g; int64_t ld_g;
+    float *n_out; float *y_out;
+};
+
 // ---- kernel launchers (implemented in the .hip files) ----
 // layout.hip
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,
@@ -205,6 +214,9 @@ hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, floa
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,
                                hipStream_t st, const mm_epilogue *ep = nullptr);
 bool gemv_fused_has_epilogue(int64_t N);       // the kernel form that serves N applies an mm_epilogue itself
+// the same launch with the rms_norm -> mul prologue (N <= 4 only: gemv_fused_has_epilogue)
+hipError_t launch_gemv_q_fused_pro(const ggml_hip_weight *w, const float *x, int64_t ld1, const mm_prologue &pro, int64_t N, float *dst,
+                                   int64_t ldd, hipStream_t st, const mm_epilogue *ep = nullptr);
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,

@@ -76,7 +76,7 @@ struct DeviceCtx {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;  // Seam-1 pipeline: host -> device, device -> host
     hipEvent_t ev_in[PIPE_EVENTS] = {}, ev_k[PIPE_EVENTS] = {};
     hipEvent_t ev_compute = nullptr, ev_d2h = nullptr, ev_xchg = nullptr, ev_ready = nullptr;
-    Scratch src1, dst, dst2, work, stage;
+    Scratch src1, dst, dst2, work, stage, aux[4];
     // graph scope: host data pointer -> device copy kept while the graph runs
     std::map<const void *, Resident> resident;
     std::vector<Resident> pool;                    // device buffers free for reuse

@@ -273,13 +273,14 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
 // Arithmetic, block -> lane assignment and summation tree are those of the kernel above, so the bits are too.
 // SC: all of K fits one chunk of 128 k-blocks (K <= 4096), a launch-time fact -- two instantiations instead of one kernel
 // that carries both schedules in its registers (the combined form spilled: 24 B of scratch at 128 registers)
-template <int TYPE, int NC, int GV_ROWS, bool SC>
-__global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
+// PRO: the rms_norm -> mul prologue (common.h mm_prologue): the quantized row is (x * rms_scale) * g, computed here.
+template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO = false>
+__global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
     const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
                                                                 const float *__restrict__ wd, const float *__restrict__ wm,
                                                                 const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
                                                                 int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles,
-                                                                const mm_epilogue ep) {
+                                                                const mm_epilogue ep, const mm_prologue pro) {
     static_assert(GV_ROWS == 16 && GV_NKQ == 4, "lane = (row, k-lane) with 4 k-lanes per wave");
     constexpr int CH = GV_CHUNK;                       // k-blocks per chunk, all waves together
     constexpr int BPL = CH / GV_WORKERS;               // k-blocks per lane per chunk (4)
@@ -299,6 +300,25 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     constexpr bool single_chunk = SC;
     bool staged = false;
     int parity = 0;
+    __shared__ float sScale[NC];
+    if constexpr (PRO) {
+        // rms_norm's row scale (Ggml.cs:5889-5915), one wave per src1 row, in the element order and f64 tree of the unfused
+        // kernel (eltwise.hip rms_norm_f32_kernel): the same bits
+        if (wave < N) {
+            const float *xr = x + (int64_t)wave * ld1;
+            const int64_t nc = nbk * QK;
+            double sum = 0.0;
+            for (int64_t i = lane; i < nc; i += 64) {
+                const float sq = xr[i] * xr[i];
+                sum += (double)sq;
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_xor(sum, sft);
+            const float mean = (float)(sum / (double)nc);
+            if (lane == 0) sScale[wave] = 1.0f / sqrtf(mean + 1e-6f);
+        }
+        __syncthreads();
+    }
     constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
     constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
 
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     // (at most XB passes are held in registers at a time: all of them for N <= 2; wider batches fetch the later passes
     // while they quantize the earlier ones)
     constexpr int XB = NC >= 8 ? 2 : (ITEMS < 4 ? ITEMS : 4);
-    float4 v[XB];
+    float4 v[XB], vg[PRO ? XB : 1];
     auto load_x = [&](int w, int p0) {
         const int64_t cb = (int64_t)(w % nchunks) * CH;
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
@@ -360,6 +380,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
             const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);        // block of the chunk
             const int cc = c < N ? c : N - 1, blc = bl < nbc ? bl : nbc - 1;
             v[pp] = *(const float4 *)(x + (int64_t)cc * ld1 + (cb + blc) * QK + 4 * t);
+            if constexpr (PRO) vg[pp] = *(const float4 *)(pro.g + (int64_t)cc * pro.ld_g + (cb + blc) * QK + 4 * t);
         }
     };
     if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
@@ -395,10 +416,22 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
 #pragma unroll
                 for (int p = 0; p < ITEMS; ++p) {
                     if (p > 0 && p % XB == 0) load_x(w, p);
-                    const float4 vp = v[p % XB];
+                    float4 vp = v[p % XB];
                     const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
                     const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);
                     const bool live = bl < nbc;                        // uniform over the 8 lanes of the group
+                    if constexpr (PRO) {
+                        const int cc = c < N ? c : N - 1;
+                        const float sc = sScale[cc];
+                        const float4 gg = vg[p % XB];
+                        const float4 nn = make_float4(vp.x * sc, vp.y * sc, vp.z * sc, vp.w * sc);          // the rms_norm node
+                        vp = make_float4(nn.x * gg.x, nn.y * gg.y, nn.z * gg.z, nn.w * gg.w);              // the mul node
+                        if (blockIdx.x == 0 && live && c < N) {       // both nodes' data, written once (every workgroup computes the same)
+                            const int64_t e = (int64_t)c * (nbk * QK) + (cb + bl) * QK + 4 * t;
+                            *(float4 *)(pro.n_out + e) = nn;
+                            *(float4 *)(pro.y_out + e) = vp;
+                        }
+                    }
                     float amax = fmaxf(fmaxf(fabsf(vp.x), fabsf(vp.y)), fmaxf(fabsf(vp.z), fabsf(vp.w)));
                     amax = group8_max(amax);
                     const float d = amax / 127.0f;                  // Ggml.cs:751
@@ -515,6 +548,9 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 ? 4 : 2)) void gemv_fused_kern
     }
 }
 
+// the prologue of the call in flight on this host thread (launch_gemv_q_fused_pro sets it around the type dispatch)
+thread_local const mm_prologue *t_prologue = nullptr;
+
 template <int TYPE, bool FUSED, int ROWS>
 hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, act_planes p, int64_t N, float *dst,
                        int64_t ldd, hipStream_t st, const mm_epilogue *epp) {
@@ -525,16 +561,22 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
-#define GVF_LAUNCH(NC) do { if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep); \
-                             else gemv_fused_kernel<TYPE, NC, ROWS, false><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep); } while (0)
+#define GVF_ARGS w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep
+#define GVF_LAUNCH(NC) do { \
+        if (t_prologue) { \
+            if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
+            else gemv_fused_kernel<TYPE, NC, ROWS, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
+        } else if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
+        else gemv_fused_kernel<TYPE, NC, ROWS, false><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); } while (0)
             if (N <= 1) GVF_LAUNCH(1);
             else if (N <= 2) GVF_LAUNCH(2);
             else GVF_LAUNCH(4);
 #undef GVF_LAUNCH
+#undef GVF_ARGS
             return hipGetLastError();
         }
     }
-    if (ep.mode != 0) return hipErrorNotSupported;          // (callers ask gemv_fused_has_epilogue first)
+    if (ep.mode != 0 || t_prologue) return hipErrorNotSupported;          // (callers ask gemv_fused_has_epilogue first)
 #define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
@@ -583,3 +625,14 @@ hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t
 }
 
 bool gemv_fused_has_epilogue(int64_t N) { return N >= 1 && N <= 4 && !GV_OLD_FUSED; }
+
+hipError_t launch_gemv_q_fused_pro(const ggml_hip_weight *w, const float *x, int64_t ld1, const mm_prologue &pro, int64_t N, float *dst,
+                                   int64_t ldd, hipStream_t st, const mm_epilogue *ep) {
+    if (!gemv_fused_has_epilogue(N)) return hipErrorNotSupported;
+    struct Scope {
+        explicit Scope(const mm_prologue *p) { t_prologue = p; }
+        ~Scope() { t_prologue = nullptr; }
+    } scope(&pro);
+    act_planes none = {nullptr, nullptr, nullptr, 0};
+    return launch_any<true>(w, x, ld1, none, N, dst, ldd, st, ep);
+}

@@ -350,6 +350,28 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         // a node and the node right behind it that consumes it go to the device as ONE call when the
         // library has the fused form (both nodes' data are still produced; the unfused seams are the fallback inside).
         ggml_tensor *next = i + 1 < cgraph->n_nodes ? cgraph->nodes[i + 1] : nullptr;
+        // the longest form first: rms_norm, mul, mul_mat [, add] -- the pre-projection chain of a transformer block -- goes down
+        // as one call (one LAUNCH for decode-sized batches; the library splits it into pair + mul_mat otherwise)
+        if (node->op == GGML_OP_RMS_NORM && i + 2 < cgraph->n_nodes) {
+            ggml_tensor *mul = cgraph->nodes[i + 1], *mm = cgraph->nodes[i + 2];
+            ggml_tensor *add = i + 3 < cgraph->n_nodes ? cgraph->nodes[i + 3] : nullptr;
+            const bool pair = mul->op == GGML_OP_MUL && (mul->src0 == node || mul->src1 == node) && mul->src0 != mul->src1 && mul->data != node->data;
+            if (pair && mm->op == GGML_OP_MUL_MAT && mm->src1 == mul && mm->src0 != mul && mm->src0 != node) {
+                const bool with_add = add && add->op == GGML_OP_ADD && add->src0 == mm && add->src1 != mm && add->src1 != mul && add->src1 != node &&
+                                      add->src1->type == GGML_TYPE_F32;
+                ggml_tensor *g = mul->src0 == node ? mul->src1 : mul->src0;
+                for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {
+                    params.type = phase;
+                    int rc = ggml_hip_compute_forward_norm_mul_mat(&params, node->src0, g, node, mul, mm->src0, mm, with_add ? add->src1 : nullptr,
+                                                                   with_add ? add : nullptr);
+                    if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }
+                }
+                node->perf_runs++; mul->perf_runs++; mm->perf_runs++;
+                if (with_add) add->perf_runs++;
+                i += with_add ? 3 : 2;
+                continue;
+            }
+        }
         int fused = 0;   // 1 rms_norm + mul, 2 silu + mul, 3 mul_mat + add, 4 mul_mat + scale
         if (next && next->op == GGML_OP_MUL && (next->src0 == node || next->src1 == node) && next->src0 != next->src1 && next->data != node->data) {
             if (node->op == GGML_OP_RMS_NORM) fused = 1;

@@ -130,6 +130,11 @@ struct PipeArgs {
     const float *addend = nullptr;                 // [N][Ms] on the device (mode 1)
     float *dst2 = nullptr; uint8_t *d2_host = nullptr; uint64_t nb1_2 = 0;   // the add node's result, device and host
     float scale = 1.0f;                            // mode 2
+    // the rms_norm -> mul pair in front of the mul_mat, computed by the mat-vec's prologue (common.h mm_prologue): src1 IS the
+    // mul node; x / g are its inputs on the device, pro_n / pro_y receive both nodes' results ([N][K]), n_host / y_host their tensors
+    const float *pro_x = nullptr, *pro_g = nullptr;
+    float *pro_n = nullptr, *pro_y = nullptr;
+    uint8_t *n_host = nullptr, *y_host = nullptr;
 };
 
 // H2D of chunk k on s_h2d | INIT + COMPUTE of chunk k on stream | D2H of chunk k on s_d2h, chained by events.
@@ -152,7 +157,12 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
             if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[ke], 0);
             if (e != hipSuccess) break;
         }
-        int rc = ggml_hip_mul_mat_epilogue_dev(a.w, a.xd + (size_t)r * a.K, n, a.K, a.dd + (size_t)r * a.ldd, a.ldd, a.work, a.work_cap, a.epi_mode,
+        int rc;
+        if (a.pro_x)        // (a prologue call is a single chunk: N <= 4)
+            rc = ggml_hip_norm_mul_mat_dev(a.w, a.pro_x, a.K, a.pro_g, a.K, n, a.pro_n, a.pro_y, a.dd, a.ldd, a.work, a.work_cap, a.epi_mode, a.addend, a.Ms,
+                                           a.dst2, a.Ms, a.scale, c->stream);
+        else
+            rc = ggml_hip_mul_mat_epilogue_dev(a.w, a.xd + (size_t)r * a.K, n, a.K, a.dd + (size_t)r * a.ldd, a.ldd, a.work, a.work_cap, a.epi_mode,
                                                a.addend ? a.addend + (size_t)r * a.Ms : nullptr, a.Ms, a.dst2 ? a.dst2 + (size_t)r * a.Ms : nullptr, a.Ms,
                                                a.scale, c->stream);
         if (rc) return rc;
@@ -166,6 +176,10 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
                                      (size_t)a.Ms * 4, (size_t)n, hipMemcpyDeviceToHost, c->s_d2h);
             if (e == hipSuccess && a.epi_mode == 1)             // the add node's data goes to the host too (contiguous rows)
                 e = hipMemcpyAsync(a.d2_host + (size_t)r * a.nb1_2, a.dst2 + (size_t)r * a.Ms, (size_t)n * a.Ms * 4, hipMemcpyDeviceToHost, c->s_d2h);
+            if (e == hipSuccess && a.pro_x) {                    // ... and so do the norm and the mul node's
+                e = hipMemcpyAsync(a.n_host, a.pro_n, (size_t)n * a.K * 4, hipMemcpyDeviceToHost, c->s_d2h);
+                if (e == hipSuccess) e = hipMemcpyAsync(a.y_host, a.pro_y, (size_t)n * a.K * 4, hipMemcpyDeviceToHost, c->s_d2h);
+            }
         }
     }
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
@@ -183,7 +197,7 @@ int run_pipeline(DeviceCtx *c, const PipeArgs &a) {
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xchg, 0);
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
     if (a.upload) c->h2d_bytes += (size_t)a.N * a.K * 4;
-    c->d2h_bytes += (size_t)a.N * a.Ms * 4 * (a.epi_mode == 1 ? 2 : 1);
+    c->d2h_bytes += (size_t)a.N * a.Ms * 4 * (a.epi_mode == 1 ? 2 : 1) + (a.pro_x ? (size_t)a.N * a.K * 8 : 0);
     return issue_chunks(c, a);
 }
 
@@ -300,11 +314,16 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
 
 /* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
  * ggml_mul_mat_impl (Ggml.cs:8228-8229); the reference silently drops them in Release, here they are errors. */
+static bool src1_contig_early(const ggml_tensor *t) { return t->nb[0] == 4 && t->nb[1] == (uint64_t)t->ne[0] * 4; }
+
 struct SeamEpi {                                    // the node after the mul_mat (fused seams below); mode as in mm_epilogue
     int mode;
     const struct ggml_tensor *addend;               // mode 1: the other operand of the add node
     struct ggml_tensor *add_dst;                    //         and that node
     float scale;                                    // mode 2
+    // prologue (rms_norm -> mul in front): src1 of the call is the mul node; these are the pair's operands and the norm node
+    const struct ggml_tensor *pro_x = nullptr, *pro_g = nullptr;
+    struct ggml_tensor *pro_norm = nullptr;
 };
 static const int SEAM_NOT_FUSABLE = 1;              // (internal) the caller runs the two seams one after the other
 
@@ -345,6 +364,13 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
             const ggml_tensor *a = epi->addend, *d2 = epi->add_dst;
             ok = a && d2 && a->data && d2->data && contiguous_f32(a) && contiguous_f32(d2) && a->ne[0] == ne01 && a->ne[1] == ne11 &&
                  a->ne[2] == 1 && a->ne[3] == 1 && d2->ne[0] == ne01 && d2->ne[1] == ne11 && d2->ne[2] == 1 && d2->ne[3] == 1 && d2->data != dst->data;
+        }
+        if (ok && epi->pro_x) {    // the prologue form: the fused mat-vec only (N <= 4), contiguous [K, N] operands
+            const ggml_tensor *ts[3] = {epi->pro_x, epi->pro_g, epi->pro_norm};
+            ok = ne11 <= 4 && is_q(type) && src1_contig_early(src1) && contiguous_f32(src1);
+            for (const ggml_tensor *t : ts)
+                ok = ok && t && t->data && contiguous_f32(t) && t->ne[0] == ne10 && t->ne[1] == ne11 && t->ne[2] == 1 && t->ne[3] == 1;
+            ok = ok && epi->pro_norm->data != src1->data && epi->pro_norm->data != dst->data;
         }
         if (!ok) return SEAM_NOT_FUSABLE;
     }
@@ -438,6 +464,22 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
         }
         if (rc) { for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x); return rc; }
     }
+    const float *pro_x = nullptr, *pro_g = nullptr;
+    float *pro_n = nullptr, *pro_y = nullptr;
+    if (epi && epi->pro_x) {                        // (G == 1) the pair's operands and both nodes' result buffers
+        DeviceCtx *c = call.ctxs[0];
+        if (operand_f32(c, in_graph, epi->pro_x, c->aux[0], &pro_x) || operand_f32(c, in_graph, epi->pro_g, c->aux[1], &pro_g))
+            rc = fail(GGML_HIP_ERR_RUNTIME, "norm + mul + mul_mat: operand staging failed");
+        if (!rc) {
+            note_host_write(call, epi->pro_norm, true);
+            note_host_write(call, src1, true);
+            pro_n = result_f32(c, in_graph, epi->pro_norm, c->aux[2]);
+            pro_y = result_f32(c, in_graph, src1, c->aux[3]);
+            if (!pro_n || !pro_y) rc = fail(GGML_HIP_ERR_RUNTIME, "norm + mul + mul_mat: hipMalloc failed");
+        }
+        if (rc) { for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x); return rc; }
+        x_res[0] = nullptr;                         // src1 is produced by this call, not looked up
+    }
     hipError_t e = hipSuccess;
     for (int64_t i03 = 0; i03 < ne03 && !rc && e == hipSuccess; ++i03)
         for (int64_t i02 = 0; i02 < ne02 && !rc && e == hipSuccess; ++i02) {  // slice offsets as in Ggml.cs:6566-6570
@@ -455,7 +497,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 // device dst: this slot's columns of the resident [N][M] copy, or a [N][Ms] scratch shard
                 float *dd = d_res[(size_t)g] ? (float *)(d_res[(size_t)g] + (size_t)sl * d_full) + r0[(size_t)g] : (float *)c->dst.p;
                 const int64_t ldd = d_res[(size_t)g] ? ne01 : Ms;
-                if (!x_res[(size_t)g] && in_graph) {
+                if (!x_res[(size_t)g] && in_graph && !(epi && epi->pro_x)) {
                     // src1 comes from host memory: inside a graph scope an earlier node's device -> host copy into that
                     // very memory may still be in flight
                     rc = c->sync_all();
@@ -466,6 +508,11 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 pa.xd = xd; pa.upload = !x_res[(size_t)g]; pa.dd = dd; pa.ldd = ldd;
                 pa.N = ne11; pa.K = ne10; pa.Ms = Ms; pa.col0 = r0[(size_t)g]; pa.chunk = chunk;
                 pa.work = c->work.p; pa.work_cap = c->work.cap;
+                if (epi && epi->pro_x) {
+                    pa.upload = false;
+                    pa.pro_x = pro_x; pa.pro_g = pro_g; pa.pro_n = pro_n; pa.pro_y = pro_y;
+                    pa.n_host = (uint8_t *)epi->pro_norm->data; pa.y_host = (uint8_t *)src1->data;
+                }
                 if (epi) {
                     pa.epi_mode = epi->mode; pa.scale = epi->scale;
                     if (epi->mode == 1) { pa.addend = epi_addend; pa.dst2 = epi_dst2; pa.d2_host = (uint8_t *)epi->add_dst->data; pa.nb1_2 = epi->add_dst->nb[1]; }
@@ -532,6 +579,25 @@ int ggml_hip_compute_forward_mul_mat_scale(const struct ggml_compute_params *par
     rc = seam1(params, src0, src1, mm_dst, nullptr);
     if (rc) return rc;
     return ggml_hip_compute_forward_scale(params, mm_dst, scalar, scale_dst);
+}
+
+/* rms_norm node, the MUL node that consumes it, the MUL_MAT node whose src1 that is [, the ADD node on the product]: the
+ * whole pre-projection chain of a transformer block as ONE launch for decode-sized batches (N <= 4: the fused mat-vec computes
+ * y = (x * rms_scale) * g in its prologue, quantizes it in-kernel and applies the add in its store phase); larger batches, several
+ * slots or strided tensors run the pair seam and the mul_mat(+add) seam one after the other.  Every node's data is produced. */
+int ggml_hip_compute_forward_norm_mul_mat(const struct ggml_compute_params *params, const struct ggml_tensor *x, const struct ggml_tensor *g,
+                                          struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst, const struct ggml_tensor *src0,
+                                          struct ggml_tensor *mm_dst, const struct ggml_tensor *addend, struct ggml_tensor *add_dst) {
+    if (!params || !x || !g || !norm_dst || !mul_dst || !src0 || !mm_dst || ((addend == nullptr) != (add_dst == nullptr))) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    SeamEpi epi = {addend ? 1 : 0, addend, add_dst, 1.0f};
+    epi.pro_x = x; epi.pro_g = g; epi.pro_norm = norm_dst;
+    int rc = seam1(params, src0, mul_dst, mm_dst, &epi);
+    if (rc != SEAM_NOT_FUSABLE) return rc;
+    rc = ggml_hip_compute_forward_rms_norm_mul(params, x, g, norm_dst, mul_dst);
+    if (rc) return rc;
+    if (addend) return ggml_hip_compute_forward_mul_mat_add(params, src0, mul_dst, mm_dst, addend, add_dst);
+    return seam1(params, src0, mul_dst, mm_dst, nullptr);
 }
 
 /* ggml_compute_forward_cpy, quantizing branch of dup_f32 / dup_f16 (Ggml.cs:4339-4363, 3935-3966) */

@@ -284,6 +284,7 @@ int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, cons
  * pair; every pair has the unfused seams as its fallback.
  *   rms_norm_mul   norm_dst = rms_norm(x), mul_dst = norm_dst * g                 one launch (fused.hip)
  *   silu_mul       silu_dst = silu(a),     mul_dst = silu_dst * b  (SwiGLU gate)  one launch (fused.hip)
+ *   norm_mul_mat   the three (or, with an add node, four) nodes rms_norm, mul, mul_mat [, add] as ONE launch for N <= 4
  *   mul_mat_add    mm_dst = mul_mat(src0, src1), add_dst = mm_dst + addend        the add is applied to the accumulators in
  *   mul_mat_scale  mm_dst = scale_dst = mul_mat(src0, src1) * scalar (in place)   the store phase of the mat-mul kernels
  * (epilogue forms exist in the fused mat-vec, N <= 4, and in the MX mat-mat of Q4_0 / Q4_1, N > 8:
@@ -298,6 +299,18 @@ int ggml_hip_compute_forward_mul_mat_add(const struct ggml_compute_params *param
 int ggml_hip_compute_forward_mul_mat_scale(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                            const struct ggml_tensor *src1, struct ggml_tensor *mm_dst,
                                            const struct ggml_tensor *scalar, struct ggml_tensor *scale_dst);
+/* rms_norm -> mul -> mul_mat [-> add]: the norm in front of a projection and the residual behind it, for decode-sized
+ * batches ONE launch (x: the norm's operand, g: the mul's other operand; addend / add_dst NULL when no add node follows) */
+int ggml_hip_compute_forward_norm_mul_mat(const struct ggml_compute_params *params, const struct ggml_tensor *x,
+                                          const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst,
+                                          const struct ggml_tensor *src0, struct ggml_tensor *mm_dst,
+                                          const struct ggml_tensor *addend, struct ggml_tensor *add_dst);
+/* Device form of the prologue + epilogue: d_norm = rms_norm(d_x), d_y = d_norm * d_g (both [N][K] contiguous), then the
+ * product of w and d_y with the epilogue `mode` (0 none).  ggml_hip_norm_mul_mat_fused: 1 when it is one launch. */
+int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_t ld_x, const float *d_g, int64_t ld_g, int64_t N,
+                              float *d_norm, float *d_y, float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, int mode,
+                              const float *d_addend, int64_t ld_add, float *d_dst2, int64_t ldd2, float scale, void *stream);
+int ggml_hip_norm_mul_mat_fused(const ggml_hip_weight *w, int64_t N);
 /* Device form of the epilogue: mode 1 add (d_dst keeps the product, d_dst2 = product + d_addend), mode 2 scale (d_dst =
  * product * scale), mode 0 = ggml_hip_mul_mat_dev. */
 int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *d_dst, int64_t ldd,

@@ -165,3 +165,34 @@ def test_fused_seams_ignore_other_phases_and_threads(dev):
         assert L.ggml_hip_compute_forward_silu_mul(C.byref(p), a, bad, n, y) == _lib.ERR_SHAPE
     finally:
         G.ggml_free(ctx)
+
+
+def test_chain_device_form_one_launch_for_decode_batches(dev):
+    """ggml_hip_norm_mul_mat_dev: rms_norm -> mul -> mul_mat -> add on device rows; N <= 4 is one launch (prologue + epilogue of
+    the fused mat-vec), larger N the pair kernel + the mat-mul: the same bits either way, equal to the separate steps."""
+    from ggmlsharp_amd._lib import lib, check
+    L = lib()
+    M, K = 200, 512
+    for t in (O.Q4_0, O.Q5_1, O.Q8_0):
+        wq = O.quantize_row(t, _rand((M, K)))
+        W = dev.Weight.from_host(t, wq, K)
+        for N in (1, 2, 3, 4, 6, 40):
+            assert L.ggml_hip_norm_mul_mat_fused(W.handle, N) == (1 if N <= 4 else 0)
+            x = torch.from_numpy(_rand((N, K), 2.0)).cuda()
+            g = torch.from_numpy(_rand((N, K))).cuda()
+            r = torch.from_numpy(_rand((N, M))).cuda()
+            nrm = torch.empty((N, K), device="cuda")
+            y = torch.empty((N, K), device="cuda")
+            d1 = torch.empty((N, M), device="cuda")
+            d2 = torch.empty((N, M), device="cuda")
+            work = dev.alloc_work(t, K, N)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            check(L.ggml_hip_norm_mul_mat_dev(W.handle, C.c_void_p(x.data_ptr()), K, C.c_void_p(g.data_ptr()), K, N, C.c_void_p(nrm.data_ptr()),
+                                              C.c_void_p(y.data_ptr()), C.c_void_p(d1.data_ptr()), M, C.c_void_p(work.data_ptr()), work.numel(), 1,
+                                              C.c_void_p(r.data_ptr()), M, C.c_void_p(d2.data_ptr()), M, 1.0, st), "norm_mul_mat")
+            want_n = O.eltwise("rms_norm", x.cpu().numpy())
+            assert np.allclose(nrm.cpu().numpy(), want_n, rtol=2e-7, atol=0)
+            assert np.array_equal(y.cpu().numpy(), O.eltwise("mul", nrm.cpu().numpy(), g.cpu().numpy()))
+            prod = dev.mul_mat(W, y)                       # the separate mul_mat on the same y
+            assert torch.equal(d1, prod), (t, N)
+            assert torch.equal(d2, prod + r), (t, N)
