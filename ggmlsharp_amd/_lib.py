@@ -148,6 +148,7 @@ HIP_SYMBOLS = {
     "ggml_hip_norm_mul_mat_dev": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, _P, C.c_size_t, C.c_int, _P,
                                              C.c_int64, _P, C.c_int64, C.c_float, _P]),
     "ggml_hip_norm_mul_mat_fused": (C.c_int, [_P, C.c_int64]),
+    "ggml_hip_rms_norm_mul_rows_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "ggml_hip_mul_mat_epilogue_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_size_t, C.c_int, _P, C.c_int64, _P,
                                                  C.c_int64, C.c_float, _P]),
     "ggml_hip_mul_mat_epilogue_fused": (C.c_int, [_P, C.c_int64]),

@@ -711,6 +711,13 @@ int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_
     return ggml_hip_mul_mat_epilogue_dev(w, d_y, N, w->K, d_dst, ldd, d_work, work_bytes, mode, d_addend, ld_add, d_dst2, ldd2, scale, stream);
 }
 
+int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_norm, float *d_y, int64_t nrows, int64_t k, void *stream) {
+    if (nrows <= 0 || k <= 0) return GGML_HIP_OK;
+    if (!d_x || !d_g || !d_norm || !d_y) return fail(GGML_HIP_ERR_ARG, "null argument");
+    HIP_TRY(launch_rms_norm_mul_f32(d_x, d_g, d_norm, d_y, nrows, k, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;  // empty input: nothing to do (buffers may be null)
     if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");

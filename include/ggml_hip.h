@@ -311,6 +311,8 @@ int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_
                               float *d_norm, float *d_y, float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, int mode,
                               const float *d_addend, int64_t ld_add, float *d_dst2, int64_t ldd2, float scale, void *stream);
 int ggml_hip_norm_mul_mat_fused(const ggml_hip_weight *w, int64_t N);
+/* The pair kernel alone on contiguous device rows: d_norm = rms_norm(d_x) (Ggml.cs:5858-5920), d_y = d_norm * d_g. */
+int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_norm, float *d_y, int64_t nrows, int64_t k, void *stream);
 /* Device form of the epilogue: mode 1 add (d_dst keeps the product, d_dst2 = product + d_addend), mode 2 scale (d_dst =
  * product * scale), mode 0 = ggml_hip_mul_mat_dev. */
 int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *d_dst, int64_t ldd,
