@@ -171,6 +171,38 @@ struct mm_prologue {
     float *n_out; float *y_out;
 };
 
+#ifdef __HIPCC__
+// rms_norm's row scale 1 / sqrt(mean(x^2) + 1e-6) (Ggml.cs:5889-5915: f32 squares summed in f64), computed by ONE wave: lane L
+// sums elements L, L + 64, ... in order, then the xor tree over lanes -- the summation order every kernel that needs the
+// scale shares (eltwise.hip, fused.hip, the mat-vec's prologue), so they agree bit for bit.  The loads of 32 iterations are
+// issued together: written as a plain loop the row cost one L2 round trip per iteration (64 x ~100 ns for K = 4096 -- the
+// whole time of a decode-sized norm).
+__device__ __forceinline__ float rms_row_scale(const float *__restrict__ xr, int64_t nc, int lane) {
+    constexpr int UN = 32;
+    double sum = 0.0;
+    for (int64_t i0 = 0; i0 < nc; i0 += 64 * UN) {
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t i = i0 + lane + 64 * u;
+            v[u] = i < nc ? xr[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t i = i0 + lane + 64 * u;
+            if (i < nc) {
+                const float sq = v[u] * v[u];           // float product, then widened (Ggml.cs:5903)
+                sum += (double)sq;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+    const float mean = (float)(sum / (double)nc);       // Ggml.cs:5906
+    return 1.0f / sqrtf(mean + 1e-6f);                  // Ggml.cs:5889, 5915
+}
+#endif
+
 // ---- kernel launchers (implemented in the .hip files) ----
 // layout.hip
 hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows,

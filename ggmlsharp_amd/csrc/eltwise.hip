@@ -48,16 +48,9 @@ __global__ __launch_bounds__(256) void rms_norm_f32_kernel(const float *__restri
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nr) return;
     const float *xr = x + row * nc;
-    double sum = 0.0;
-    for (int64_t i = lane; i < nc; i += 64) {
-        const float sq = xr[i] * xr[i];                 // float product, then widened (Ggml.cs:5903)
-        sum += (double)sq;
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
-    const float mean = (float)(sum / (double)nc);       // Ggml.cs:5906
-    const float scale = 1.0f / sqrtf(mean + 1e-6f);     // Ggml.cs:5889, 5915
+    const float scale = rms_row_scale(xr, nc, lane);
     float *yr = y + row * nc;
+#pragma unroll 8
     for (int64_t i = lane; i < nc; i += 64) yr[i] = xr[i] * scale;
 }
 

@@ -21,15 +21,8 @@ __global__ __launch_bounds__(256) void rms_norm_mul_kernel(const float *__restri
     if (row >= nr) return;
     const float *xr = x + row * nc, *gr = g + row * nc;
     float *nrw = n_out + row * nc, *yr = y_out + row * nc;
-    double sum = 0.0;
-    for (int64_t i = lane; i < nc; i += 64) {
-        const float sq = xr[i] * xr[i];                     // float product, then widened (Ggml.cs:5903)
-        sum += (double)sq;
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
-    const float mean = (float)(sum / (double)nc);           // Ggml.cs:5906
-    const float scale = 1.0f / sqrtf(mean + 1e-6f);         // Ggml.cs:5889, 5915
+    const float scale = rms_row_scale(xr, nc, lane);
+#pragma unroll 8
     for (int64_t i = lane; i < nc; i += 64) {
         const float nn = xr[i] * scale;                     // ggml_vec_scale_f32 (Ggml.cs:5917)
         nrw[i] = nn;

@@ -305,17 +305,8 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
         // rms_norm's row scale (Ggml.cs:5889-5915), one wave per src1 row, in the element order and f64 tree of the unfused
         // kernel (eltwise.hip rms_norm_f32_kernel): the same bits
         if (wave < N) {
-            const float *xr = x + (int64_t)wave * ld1;
-            const int64_t nc = nbk * QK;
-            double sum = 0.0;
-            for (int64_t i = lane; i < nc; i += 64) {
-                const float sq = xr[i] * xr[i];
-                sum += (double)sq;
-            }
-#pragma unroll
-            for (int sft = 32; sft > 0; sft >>= 1) sum += __shfl_xor(sum, sft);
-            const float mean = (float)(sum / (double)nc);
-            if (lane == 0) sScale[wave] = 1.0f / sqrtf(mean + 1e-6f);
+            const float sc = rms_row_scale(x + (int64_t)wave * ld1, nbk * QK, lane);
+            if (lane == 0) sScale[wave] = sc;
         }
         __syncthreads();
     }
