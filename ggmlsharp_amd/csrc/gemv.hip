@@ -301,15 +301,6 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     bool staged = false;
     int parity = 0;
     __shared__ float sScale[NC];
-    if constexpr (PRO) {
-        // rms_norm's row scale (Ggml.cs:5889-5915), one wave per src1 row, in the element order and f64 tree of the unfused
-        // kernel (eltwise.hip rms_norm_f32_kernel): the same bits
-        if (wave < N) {
-            const float sc = rms_row_scale(x + (int64_t)wave * ld1, nbk * QK, lane);
-            if (lane == 0) sScale[wave] = sc;
-        }
-        __syncthreads();
-    }
     constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
     constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
 
@@ -374,7 +365,19 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
             if constexpr (PRO) vg[pp] = *(const float4 *)(pro.g + (int64_t)cc * pro.ld_g + (cb + blc) * QK + 4 * t);
         }
     };
-    if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
+    if constexpr (PRO) {
+        // rms_norm's row scale (Ggml.cs:5889-5915): wave c computes row c's, in the element order and f64 tree every kernel
+        // shares (common.h rms_row_scale).  The other waves put their first item's loads in flight BEFORE they wait for it,
+        // the computing waves right after: the weight stream starts at launch, not behind the norm.
+        if (wave < N) {
+            const float sc = rms_row_scale(x + (int64_t)wave * ld1, nbk * QK, lane);
+            if (lane == 0) sScale[wave] = sc;
+        }
+        if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
+        __syncthreads();
+    } else {
+        if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
+    }
 
     for (int w = 0; w < nitems; ++w) {
         const int cidx = w % nchunks;
