@@ -174,11 +174,11 @@ struct mm_prologue {
 #ifdef __HIPCC__
 // rms_norm's row scale 1 / sqrt(mean(x^2) + 1e-6) (Ggml.cs:5889-5915: f32 squares summed in f64), computed by ONE wave: lane L
 // sums elements L, L + 64, ... in order, then the xor tree over lanes -- the summation order every kernel that needs the
-// scale shares (eltwise.hip, fused.hip, the mat-vec's prologue), so they agree bit for bit.  The loads of 32 iterations are
+// scale shares (eltwise.hip, fused.hip, the mat-vec's prologue), so they agree bit for bit.  The loads of 64 iterations are
 // issued together: written as a plain loop the row cost one L2 round trip per iteration (64 x ~100 ns for K = 4096 -- the
 // whole time of a decode-sized norm).
 __device__ __forceinline__ float rms_row_scale(const float *__restrict__ xr, int64_t nc, int lane) {
-    constexpr int UN = 32;
+    constexpr int UN = 64;                             // one round trip for a row of up to 4096 elements
     double sum = 0.0;
     for (int64_t i0 = 0; i0 < nc; i0 += 64 * UN) {
         float v[UN];
