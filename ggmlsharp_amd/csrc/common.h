@@ -172,14 +172,25 @@ struct mm_prologue {
 };
 
 #ifdef __HIPCC__
-// rms_norm's row scale 1 / sqrt(mean(x^2) + 1e-6) (Ggml.cs:5889-5915: f32 squares summed in f64), computed by ONE wave: lane L
-// sums elements L, L + 64, ... in order, then the xor tree over lanes -- the summation order every kernel that needs the
-// scale shares (eltwise.hip, fused.hip, the mat-vec's prologue), so they agree bit for bit.  The loads of 64 iterations are
-// issued together: written as a plain loop the row cost one L2 round trip per iteration (64 x ~100 ns for K = 4096 -- the
-// whole time of a decode-sized norm).
+// rms_norm's row scale 1 / sqrt(mean(x^2) + 1e-6) (Ggml.cs:5889-5915: f32 squares summed in f64), computed by ONE wave.  The
+// reference adds the squares one after the other; any order of the f64 additions is within ~1e-16 of that, and ONE order is
+// shared by every kernel that needs the scale (eltwise.hip, fused.hip, the mat-vec's prologue), so they agree bit for bit:
+//   lane L holds four partial sums, partial q taking elements L + 64 (4 j + q), j = 0, 1, ... in order; lane total =
+//   (p0 + p1) + (p2 + p3); lanes are joined inside rows of 16 by DPP (xor 1, xor 2, half mirror, row mirror -- after two
+//   xor steps a quad is uniform, so a mirror is a swap of uniform groups), then rows by xor 16 and xor 32.
+// Written for latency: a decode-sized norm is one wave working alone -- the loads of 32 iterations are in flight together (a
+// plain loop cost one L2 round trip per iteration: 64 x ~100 ns at K = 4096), the f64 chain is 16 deep instead of 64, and
+// only the last two lane steps go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)dpp_i<CTRL>((int)(uint32_t)u), hi = (uint32_t)dpp_i<CTRL>((int)(uint32_t)(u >> 32));
+    return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+#define DPP_ROW_MIRROR 0x140  /* lane i <-> 15 - i inside each row of 16 */
 __device__ __forceinline__ float rms_row_scale(const float *__restrict__ xr, int64_t nc, int lane) {
-    constexpr int UN = 64;                             // one round trip for a row of up to 4096 elements
-    double sum = 0.0;
+    constexpr int UN = 32;
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t i0 = 0; i0 < nc; i0 += 64 * UN) {
         float v[UN];
 #pragma unroll
@@ -192,12 +203,17 @@ __device__ __forceinline__ float rms_row_scale(const float *__restrict__ xr, int
             const int64_t i = i0 + lane + 64 * u;
             if (i < nc) {
                 const float sq = v[u] * v[u];           // float product, then widened (Ggml.cs:5903)
-                sum += (double)sq;
+                p[u & 3] += (double)sq;
             }
         }
     }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+    double sum = (p[0] + p[1]) + (p[2] + p[3]);
+    sum += dpp_d<DPP_XOR1>(sum);
+    sum += dpp_d<DPP_XOR2>(sum);
+    sum += dpp_d<DPP_HALF_MIRROR>(sum);
+    sum += dpp_d<DPP_ROW_MIRROR>(sum);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
     const float mean = (float)(sum / (double)nc);       // Ggml.cs:5906
     return 1.0f / sqrtf(mean + 1e-6f);                  // Ggml.cs:5889, 5915
 }
