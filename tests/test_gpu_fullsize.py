@@ -219,3 +219,16 @@ def test_fullsize_byte_roundtrips(dev):
     y = dev.dequantize_rows(Q8_0, rows, K)
     again = dev.dequantize_rows(Q8_0, dev.quantize_rows(Q8_0, y), K)
     assert torch.allclose(again, y, rtol=0, atol=float(y.abs().max()) * 2 ** -20)
+
+
+def test_short_wide_shard_runs_the_one_tile_form_with_the_unsplit_bits(dev):
+    """A 512-row shard against thousands of src1 rows (the multi-GPU strong-scaling piece) takes 64 x 64 tiles of 1-tile waves
+    (two waves per SIMD instead of one); K loop and per-element order are the unsplit matrix's: bitwise its columns."""
+    M, K, N = 4096, 512, 3100
+    for t in (Q4_0, 3):                                 # Q4_0, Q4_1
+        rows, x = _make(dev, t, M, K, N, seed=11)
+        W = dev.Weight.from_device(t, rows, K)
+        full = dev.mul_mat(W, x)
+        for (r0, r1) in ((0, 512), (1536, 2048), (3600, 4096)):
+            Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+            assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, r0, r1)
