@@ -568,9 +568,14 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // and a lone wave issues its scale-accumulates at half the rate of two (45 us where the work is 20).  64 x 64 tiles of four
     // 1-tile waves put two waves on every SIMD with the same unsplit K loop per element: the same bits, only the geometry
     // follows M (var 31 / 32 force either form).
-    const int64_t wg64 = ((w->M + 63) / 64) * ((N + 63) / 64);
-    if (var == 32 || (var != 31 && tm128 * ((N + 63) / 64) <= 256 && wg64 >= 384))
-        return launch_cfg<TYPE, 1, 1, 2, 2, 4, 2>(w, p, N, dst, ldd, st);                          // 64 x 64, 1 tile per wave
+    // Q4_0 only: with one tile per wave Q4_1's min-term MFMA would land between other scale-accumulates of its own tile than
+    // in the multi-tile forms -- a different f32 addition order (measured: last-bit differences against the unsplit matrix).
+    // 512 x 4096 x 4096: 45.1 -> 40.6 us (the form is stage-latency bound: four tile-blocks of work per wave and barrier).
+    if constexpr (TYPE == GGML_TYPE_Q4_0) {
+        const int64_t wg64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+        if (var == 32 || (var != 31 && tm128 * ((N + 63) / 64) <= 256 && wg64 >= 384))
+            return launch_cfg<TYPE, 1, 1, 2, 2, 4, 2>(w, p, N, dst, ldd, st);                      // 64 x 64, 1 tile per wave
+    }
     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
 }
 

@@ -225,7 +225,7 @@ def test_short_wide_shard_runs_the_one_tile_form_with_the_unsplit_bits(dev):
     """A 512-row shard against thousands of src1 rows (the multi-GPU strong-scaling piece) takes 64 x 64 tiles of 1-tile waves
     (two waves per SIMD instead of one); K loop and per-element order are the unsplit matrix's: bitwise its columns."""
     M, K, N = 4096, 512, 3100
-    for t in (Q4_0, 3):                                 # Q4_0, Q4_1
+    for t in (Q4_0, 3):                                 # Q4_0 (the one-tile form), Q4_1 (stays on the 128 x 64 form)
         rows, x = _make(dev, t, M, K, N, seed=11)
         W = dev.Weight.from_device(t, rows, K)
         full = dev.mul_mat(W, x)
