@@ -358,23 +358,24 @@ def pick_exchange(device, gdist, world, rank, requested, K):
         return "rccl", "requested"
     ok = 1.0
     why = "verified against the all-gather form"
+    N, M = 96, 64 * world + 8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x = torch.randn((N, K), generator=g, device="cuda")
+    ra, wa = make_runner(device, gdist, M, K, N, world, rank, "rccl", 2, 4242)
+    a = ra.step(x).clone()
     try:
-        N, M = 96, 64 * world + 8
-        g = torch.Generator(device="cuda")
-        g.manual_seed(5)
-        x = torch.randn((N, K), generator=g, device="cuda")
-        ra, wa = make_runner(device, gdist, M, K, N, world, rank, "rccl", 2, 4242)
+        # (the set-up keeps every rank in step with its peers whatever fails locally and raises on ALL ranks or on none)
         rb, wb = make_runner(device, gdist, M, K, N, world, rank, "push", 2, 4242)
-        a = ra.step(x).clone()
-        b1 = rb.step(x).clone()
-        b2 = rb.step(x).clone()
-        torch.cuda.synchronize()
-        if not (torch.equal(a, b1) and torch.equal(a, b2)):
-            ok, why = 0.0, "push result differs from the all-gather result"
-        dist.barrier()
-        rb.close()
-    except Exception as e:  # noqa: BLE001 -- any failure of the IPC set-up selects the RCCL form
-        ok, why = 0.0, f"push set-up failed: {type(e).__name__}: {e}"[:200]
+    except Exception as e:  # noqa: BLE001 -- the IPC set-up is unavailable: the RCCL form runs
+        return "rccl", f"push set-up failed: {type(e).__name__}: {e}"[:200]
+    b1 = rb.step(x).clone()
+    b2 = rb.step(x).clone()
+    torch.cuda.synchronize()
+    if not (torch.equal(a, b1) and torch.equal(a, b2)):
+        ok, why = 0.0, "push result differs from the all-gather result"
+    dist.barrier()
+    rb.close()
     t = torch.tensor([ok], dtype=torch.float32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if float(t.item()) >= 1.0:

@@ -85,6 +85,9 @@ class RowSplitMulMat:
 
     # ---------------------------------------------------------------- "push": IPC-shared result buffers
     def _setup_push(self, group_backend):
+        """Every rank runs the SAME sequence of collectives whatever fails locally (a rank that raised early while its peers
+        sat in a collective would leave the job out of step): handles are exchanged, every rank tries to open its peers',
+        one all-reduce tells everybody whether EVERY rank succeeded, and only then does anyone raise."""
         import torch.distributed as dist
         from ._lib import check, lib
         L = lib()
@@ -92,29 +95,49 @@ class RowSplitMulMat:
         nbytes = self.N * self.M_total * 4
         self._own, self._peers, self._views, self._opened = [], [], [], []
         handles = torch.zeros((2, 64), dtype=torch.uint8)
-        for b in range(2):
-            p = C.c_void_p()
-            h = (C.c_uint8 * 64)()
-            check(L.ggml_hip_ipc_alloc(nbytes, C.byref(p), h), "ggml_hip_ipc_alloc")
-            self._own.append(p.value)
-            handles[b] = torch.tensor(list(h), dtype=torch.uint8)
+        err = None
+        try:
+            for b in range(2):
+                p = C.c_void_p()
+                h = (C.c_uint8 * 64)()
+                check(L.ggml_hip_ipc_alloc(nbytes, C.byref(p), h), "ggml_hip_ipc_alloc")
+                self._own.append(p.value)
+                handles[b] = torch.tensor(list(h), dtype=torch.uint8)
+        except Exception as e:  # noqa: BLE001 -- reported after the collectives below
+            err = e
         on_gpu = (group_backend or dist.get_backend()) == "nccl"
         mine = handles.cuda() if on_gpu else handles
         allh = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allh, mine)
-        for b in range(2):
-            ptrs = []
-            for r in range(self.world):
-                if r == self.rank:
-                    ptrs.append(self._own[b])
-                    continue
-                hb = (C.c_uint8 * 64)(*allh[r][b].cpu().tolist())
-                p = C.c_void_p()
-                check(L.ggml_hip_ipc_open(hb, C.byref(p)), "ggml_hip_ipc_open")
-                self._opened.append(p.value)
-                ptrs.append(p.value)
-            self._peers.append(ptrs)
-            self._views.append(torch.as_tensor(_RawDeviceBuffer(self._own[b], (self.N, self.M_total)), device=self.dev))
+        if err is None:
+            try:
+                for b in range(2):
+                    ptrs = []
+                    for r in range(self.world):
+                        if r == self.rank:
+                            ptrs.append(self._own[b])
+                            continue
+                        hb = (C.c_uint8 * 64)(*allh[r][b].cpu().tolist())
+                        p = C.c_void_p()
+                        check(L.ggml_hip_ipc_open(hb, C.byref(p)), "ggml_hip_ipc_open")
+                        self._opened.append(p.value)
+                        ptrs.append(p.value)
+                    self._peers.append(ptrs)
+                    self._views.append(torch.as_tensor(_RawDeviceBuffer(self._own[b], (self.N, self.M_total)), device=self.dev))
+            except Exception as e:  # noqa: BLE001
+                err = e
+        ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float32, device=self.dev if on_gpu else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            self._views = []
+            for p in self._opened:
+                L.ggml_hip_ipc_close(C.c_void_p(p))
+            self._opened = []
+            dist.barrier()                                 # nobody frees a buffer a peer still has mapped
+            for p in self._own:
+                L.ggml_hip_ipc_free(C.c_void_p(p))
+            self._own = None
+            raise RuntimeError(f"push exchange unavailable on at least one rank (this rank: {err!r})")
         self._flag = torch.zeros(1, dtype=torch.float32, device=self.dev if on_gpu else "cpu")
         self._on_gpu = on_gpu
         self._side = torch.cuda.Stream()
