@@ -173,12 +173,15 @@ def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
     torch.cuda.synchronize()
     # Launch-bound from Python below ~10 us per call: replay a captured hipGraph of `copies` whole mul_mat calls
     # (one per distinct weight matrix) so the GPU-side rate is what is timed.
+    # (at least 32 calls per graph: a replay has a fixed cost of several microseconds of its own, which two or four calls of
+    # a large shape do not amortise -- M = 32000 read 1.5-2 us per call high with one call per copy)
+    nodes = copies * max(1, -(-32 // copies))
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        for _ in range(copies):
+        for _ in range(nodes):
             step()
-    reps = max(20, iters // copies)
-    per = [t / copies for t in per_call_ms(graph.replay, reps, stream)]
+    reps = max(20, iters // nodes)
+    per = [t / nodes for t in per_call_ms(graph.replay, reps, stream)]
     t_step = float(np.median(per))
     t_comp = float(np.median(per_call_ms(compute_only, iters, stream))) if N > 8 else None
     ab = algorithmic_bytes(M, K, N, BLOCK_BYTES[qtype])
@@ -188,7 +191,7 @@ def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
            "p10_ms": st["p10_ms"], "p90_ms": st["p90_ms"],
            "gflops": round(flops / t_step / 1e6, 1), "algorithmic_GBs": round(ab / t_step / 1e6, 1),
            "hbm_frac": round(ab / t_step / 1e6 / HBM_PEAK_GBS, 4), "weight_copies_rotated": copies,
-           "timing": f"median over {reps} hipGraph replays of one call per weight copy (dependent launches: includes the inter-kernel boundary)"}
+           "timing": f"median over {reps} hipGraph replays of {nodes} calls rotating over the weight copies (dependent launches: includes the inter-kernel boundary)"}
     if t_comp is not None:
         res["compute_kernel_ms"] = round(t_comp, 5)
     for w in ws:

@@ -290,7 +290,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
     w->ext_type = q5k ? GGML_HIP_TYPE_Q5_K : 0;
     static std::atomic<uint64_t> next_uid{1};
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
-    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, total = 0;
+    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, off_gs = 0, total = 0;
     bool with6 = false;
     size_t off_p16 = 0;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
@@ -308,6 +308,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         off_d = total; total += plane;
         if (has_min_plane(type)) { off_m = total; total += plane; }
         if (has_qh_plane(type)) { off_qh = total; total += plane; }
+        off_gs = total; total += (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (gemm_force() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
         if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
@@ -330,6 +331,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         w->d = (float *)((uint8_t *)base + off_d);
         if (has_min_plane(type)) w->m = (float *)((uint8_t *)base + off_m);
         if (has_qh_plane(type)) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
+        w->gs = (uint32_t *)((uint8_t *)base + off_gs);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
         if (q5k) w->khdr = (uint8_t *)base + off_kh;
     }
@@ -369,6 +371,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
         } else if (e == hipSuccess) {
             e = launch_q5k_to_planar((const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
         }
+        if (e == hipSuccess) e = launch_gemv_side_image(w, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (staging) (void)hipFree(staging);
         if (e != hipSuccess) { (void)hipFree(w->qs); delete w; return fail(GGML_HIP_ERR_RUNTIME, "Q5_K weight upload: %s", hipGetErrorString(e)); }
@@ -407,6 +410,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
         e = launch_repack_to_planar(type, dev_rows, nb01, row_begin, rows_n, w, st);
     }
     if (e == hipSuccess) e = launch_nibbles_to_bf6(w, st);
+    if (e == hipSuccess) e = launch_gemv_side_image(w, st);
     if (e == hipSuccess) e = launch_f16_rows_to_panels(w, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (staging) (void)hipFree(staging);

@@ -63,6 +63,10 @@ struct ggml_hip_weight {
                       //   or 2 (Q5_0, Q8_0: w = 16 * wh + wl, fragment 0 = wl, fragment 1 = wh) -- gemm_qmx.hip
     void    *dense;
     uint8_t *p16;     // F16 only: k-panel-major copy [Kpad/8 + spare][Mpad][16 B] for dense16.hip
+    uint32_t *gs;     // mat-vec side image (gemv.hip): the per-block words a 16-row tile needs beside its nibbles, tile-major
+                      //   [Mpad/16][nbk][NP][16 rows] 4-byte words, planes in the order d, m, qh (NP = 1..3 by type).  A copy of
+                      //   d / m / qh: in their [k-block][row] planes a tile's share of a k-block is one 64-byte piece per plane
+                      //   (a fifth of the bytes cost a third of the mat-vec's time, tools/stream_floor.hip)
     uint8_t *khdr;    // Q5_K only: the 16 header bytes (d, dmin, scales[12]) of every super-block, [K/256][Mpad][16 B]
     int      ext_type; // 0, or GGML_HIP_TYPE_Q5_K: the weight was uploaded as k-quant super-blocks and lives in the planar Q5_1 form (type == Q5_1)
     size_t   bytes;
@@ -225,6 +229,10 @@ hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, 
                                    ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st);
+hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st);   // d / m / qh planes -> w->gs (after every write of the planes)
+static inline int gemv_side_planes(int type) {
+    return 1 + ((type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) ? 1 : 0) + ((type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1) ? 1 : 0);
+}
 hipError_t launch_relayout_gathered(const float *g, int G, int64_t N, int64_t Ms, float *dst, int64_t M, int64_t ldd,
                                     hipStream_t st);
 hipError_t launch_push_columns(const float *src, int64_t lds, int64_t N, int64_t Ms, float *const *peers, int G, int64_t ldd,

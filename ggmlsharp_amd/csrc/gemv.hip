@@ -49,6 +49,14 @@ __device__ __forceinline__ uint4 ld_w(const uint8_t *p) {
 #endif
 }
 
+// A result store the compiler's wait-count bookkeeping does not see.  On gfx9 loads and stores share `vmcnt` but only
+// operations of one kind return in order, so with a store possibly in flight hipcc turns every later "wait for this load"
+// into "wait for everything" -- which drained the look-ahead weight stream once per row tile.  Hidden in asm, the store
+// still occupies a counter slot, which only makes the counted waits of the loads conservative (never short).
+__device__ __forceinline__ void st_result(float *p, float v) {
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
 }
@@ -65,13 +73,13 @@ __device__ __forceinline__ uint32_t q5_high_bits(uint32_t qh, int i, int sel) {
 // FUSED = false: src1 was quantized earlier (K1 planes, or reference Q8 blocks through ggml_hip_vec_dot).
 // The weight loads of a chunk are issued before the activations are staged, so both latencies overlap.
 template <int TYPE, int NC, bool FUSED, int GV_ROWS>
-__global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
-                                                    const float *__restrict__ wd, const float *__restrict__ wm,
+__global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ gs,
                                                     const float *__restrict__ x, int64_t ld1,
                                                     const int8_t *__restrict__ a8, const float *__restrict__ ad,
                                                     const int32_t *__restrict__ as, float *__restrict__ dst, int64_t M,
                                                     int64_t Mpad, int64_t Npad, int64_t nbk, int64_t ldd, int N, int ntiles) {
     constexpr int CH = GvChunk<NC>::value;
+    static_assert(GV_ROWS == 16, "the side image (ggml_hip_weight::gs) is laid out in 16-row tiles");
     static_assert(!FUSED || NC <= 8, "the fused form quantizes N columns per workgroup: N <= 8 only");
     __shared__ uint4 sA[CH * 2 * NC];
     __shared__ float sD[CH * NC];
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
         uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
         constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
         constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
+        constexpr int NP = 1 + (HAS_M ? 1 : 0) + (HAS_H ? 1 : 0);
         float dw[BPL], mw[HAS_M ? BPL : 1];
         uint32_t hb[HAS_H ? BPL : 1];
 #pragma unroll
@@ -119,9 +128,11 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
             } else {
                 q[j] = ld_w(qs + (b * Mpad + row) * 16);
             }
-            dw[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
-            if (HAS_M) mw[j] = ok ? wm[b * Mpad + row] : 0.0f;
-            if (HAS_H) hb[j] = qh[b * Mpad + row];
+            // scales / mins / fifth bits from the tile-major side image (common.h ggml_hip_weight::gs)
+            const uint32_t *g = gs + (((int64_t)tile * nbk + b) * NP) * 16 + r;
+            dw[j] = ok ? __uint_as_float(g[0]) : 0.0f;   // dw = 0 kills the contribution of a block past the end
+            if (HAS_M) mw[j] = ok ? __uint_as_float(g[16]) : 0.0f;
+            if (HAS_H) hb[j] = g[16 * (NP - 1)];
         }
 
         // 2. activations of the chunk -> LDS (int8 even/odd planes + scale + block sum); once per workgroup if K fits
@@ -276,8 +287,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
 // PRO: the rms_norm -> mul prologue (common.h mm_prologue): the quantized row is (x * rms_scale) * g, computed here.
 template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO = false>
 __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
-    const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh,
-                                                                const float *__restrict__ wd, const float *__restrict__ wm,
+    const uint8_t *__restrict__ qs, const uint32_t *__restrict__ gs,
                                                                 const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
                                                                 int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles,
                                                                 const mm_epilogue ep, const mm_prologue pro) {
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     __shared__ float sScale[NC];
     constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
     constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
+    constexpr int NP = 1 + (HAS_M ? 1 : 0) + (HAS_H ? 1 : 0);
 
     // The work of a workgroup is a sequence of ITEMS (row tile, chunk of 128 k-blocks), tiles taken round-robin over the
     // persistent grid.  The weight registers are double-buffered across items: item w+1's weights are requested BEFORE item
@@ -324,7 +335,8 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     uint32_t hb[HAS_H ? BPL : 1], hbn[PF && HAS_H ? BPL : 1];
     // the weight stream of one item (4 x 16 B + scales in flight per lane)
     auto load_item = [&](int w, uint4 *Q, uint4 *Q2, float *DW, float *MW, uint32_t *HB) {
-        const int64_t row = (int64_t)tile_of(w) * GV_ROWS + r;  // < Mpad by construction
+        const int tl = tile_of(w);
+        const int64_t row = (int64_t)tl * GV_ROWS + r;  // < Mpad by construction
         const int64_t cb = (int64_t)(w % nchunks) * CH;
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
 #pragma unroll
@@ -338,9 +350,14 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
             } else {
                 Q[j] = ld_w(qs + (b * Mpad + row) * 16);
             }
-            DW[j] = ok ? wd[b * Mpad + row] : 0.0f;   // dw = 0 kills the contribution of a block past the end
-            if (HAS_M) MW[j] = ok ? wm[b * Mpad + row] : 0.0f;
-            if (HAS_H) HB[j] = qh[b * Mpad + row];
+            // (unconditional loads from a clamped block: no branch and no use of a result inside the load sequence -- the item's
+            // consumer zeroes the scales of a block past the end of K)
+            // scales / mins / fifth bits from the tile-major side image (common.h ggml_hip_weight::gs): the four k-lanes of a
+            // wave read four adjacent 64-byte pieces
+            const uint32_t *g = gs + (((int64_t)tl * nbk + b) * NP) * 16 + r;
+            DW[j] = __uint_as_float(g[0]);
+            if (HAS_M) MW[j] = __uint_as_float(g[16]);
+            if (HAS_H) HB[j] = g[16 * (NP - 1)];
         }
     };
 
@@ -379,7 +396,9 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
         if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
     }
 
-    for (int w = 0; w < nitems; ++w) {
+    // one item: INIT arithmetic for this wave's blocks (first item of a single-chunk K, every item otherwise), block dots on
+    // the weight registers handed in, and -- on a row tile's last chunk -- the reduction and the store
+    auto do_item = [&](int w, const uint4 *Q, const uint4 *Q2, const float *DW, const float *MW, const uint32_t *HB) {
         const int cidx = w % nchunks;
         const int64_t cb = (int64_t)cidx * CH;
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
@@ -389,128 +408,103 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
             for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
         }
         const bool stage_now = !(single_chunk && staged);
-        // (a K of several chunks: this item's activations were not requested by the previous iteration -- ask now, ahead of
-        // the next item's weights, so that their data returns first)
-        // the look-ahead pays where a workgroup walks several row tiles of one chunk (4096 x 4096: 5.06 -> 4.66 us, M = 32000:
-        // 19.3 -> 18.7); with K in several chunks the activations of every item have to be fetched and quantized as well, and
-        // asking for them first, weights behind, in the item's own iteration measured better (4096 x 11008: 9.0 against 10.0 us)
-        constexpr bool pf = PF;
-        if (pf) {
-            // 2. the NEXT item's weight stream goes out before this item is consumed
-            if constexpr (PF) { if (w + 1 < nitems) load_item(w + 1, qn, q2n, dwn, mwn, hbn); }
-        } else if (w > 0) {
-            if (stage_now) load_x(w, 0);
-            load_item(w, q, q2, dw, mw, hb);
-        }
-        {
-
-            // 3. INIT phase for this wave's blocks (Ggml.cs:6641-6654 / quantize_row_q8_0 733-762, the arithmetic of K1)
-            if (stage_now) {
-                if (!single_chunk) __builtin_amdgcn_wave_barrier();   // (the previous chunk's reads of the slice are done: same wave, in order)
+        // 3. INIT phase for this wave's blocks (Ggml.cs:6641-6654 / quantize_row_q8_0 733-762, the arithmetic of K1)
+        if (stage_now) {
+            if (!single_chunk) __builtin_amdgcn_wave_barrier();   // (the previous chunk's reads of the slice are done: same wave, in order)
 #pragma unroll
-                for (int p = 0; p < ITEMS; ++p) {
-                    if (p > 0 && p % XB == 0) load_x(w, p);
-                    float4 vp = v[p % XB];
-                    const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
-                    const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);
-                    const bool live = bl < nbc;                        // uniform over the 8 lanes of the group
-                    if constexpr (PRO) {
-                        const int cc = c < N ? c : N - 1;
-                        const float sc = sScale[cc];
-                        const float4 gg = vg[p % XB];
-                        const float4 nn = make_float4(vp.x * sc, vp.y * sc, vp.z * sc, vp.w * sc);          // the rms_norm node
-                        vp = make_float4(nn.x * gg.x, nn.y * gg.y, nn.z * gg.z, nn.w * gg.w);              // the mul node
-                        if (blockIdx.x == 0 && live && c < N) {       // both nodes' data, written once (every workgroup computes the same)
-                            const int64_t e = (int64_t)c * (nbk * QK) + (cb + bl) * QK + 4 * t;
-                            *(float4 *)(pro.n_out + e) = nn;
-                            *(float4 *)(pro.y_out + e) = vp;
-                        }
-                    }
-                    float amax = fmaxf(fmaxf(fabsf(vp.x), fabsf(vp.y)), fmaxf(fabsf(vp.z), fabsf(vp.w)));
-                    amax = group8_max(amax);
-                    const float d = amax / 127.0f;                  // Ggml.cs:751
-                    const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
-                    const int q0 = (int)rintf(vp.x * id), q1 = (int)rintf(vp.y * id);   // Ggml.cs:758-759 (D1, D2)
-                    const int q2_ = (int)rintf(vp.z * id), q3 = (int)rintf(vp.w * id);
-                    const int sum = group8_sum(q0 + q1 + q2_ + q3);
-                    const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2_ & 0xFFu) << 8);
-                    const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
-                    const bool even_lane = (t & 1) == 0;
-                    const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)(even_lane ? o16 : e16));
-                    const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));
-                    const int h = even_lane ? 0 : 1, off = even_lane ? 2 * t : 2 * t - 2;
-                    // a block past the end of K is written as zeros (its weights carry dw = 0; 0 * garbage could be NaN)
-                    *(uint32_t *)(myq + i * QSLOT + (c * 2 + h) * 16 + off) = live ? word : 0u;
-                    if (t == 0) { myd[i * NC + c] = live ? d : 0.0f; mys[i * NC + c] = live ? sum : 0; }
-                }
-                // same wave wrote and reads: LDS operations of one wave complete in order; only the compiler needs the fence
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                staged = true;
-            }
-
-
-            // 4. integer block dots + f32 scale-accumulate (Ggml.cs:1136-1159)
-#pragma unroll
-            for (int j = 0; j < BPL; ++j) {
-                const int i = kq + GV_NKQ * j;
-                const uint32_t qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-                uint32_t lo[4], hi[4];
-                if (TYPE == GGML_TYPE_Q8_0) {
-                    lo[0] = q[j].x; lo[1] = q[j].y; lo[2] = q[j].z; lo[3] = q[j].w;
-                    hi[0] = q2[j].x; hi[1] = q2[j].y; hi[2] = q2[j].z; hi[3] = q2[j].w;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        lo[k] = qq[k] & 0x0F0F0F0Fu;          // elements 8k+0,2,4,6  (Ggml.cs:1149)
-                        hi[k] = (qq[k] >> 4) & 0x0F0F0F0Fu;   // elements 8k+1,3,5,7  (Ggml.cs:1150)
-                        if (HAS_H) {                          // Ggml.cs:1285-1289 / 1330-1334
-                            lo[k] |= q5_high_bits(hb[j], k, 0);
-                            hi[k] |= q5_high_bits(hb[j], k, 1);
-                        }
-                        if (TYPE == GGML_TYPE_Q4_2) {         // (nib - 8) bytewise: the two half-block sums need their own offsets
-                            lo[k] = ((lo[k] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
-                            hi[k] = ((hi[k] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
-                        }
+            for (int p = 0; p < ITEMS; ++p) {
+                if (p > 0 && p % XB == 0) load_x(w, p);
+                float4 vp = v[p % XB];
+                const int it = grp + 8 * p, c = it / WBLK, i = it % WBLK;
+                const int bl = wave * GV_NKQ + (i & 3) + GV_WORKERS * (i >> 2);
+                const bool live = bl < nbc;                        // uniform over the 8 lanes of the group
+                if constexpr (PRO) {
+                    const int cc = c < N ? c : N - 1;
+                    const float sc = sScale[cc];
+                    const float4 gg = vg[p % XB];
+                    const float4 nn = make_float4(vp.x * sc, vp.y * sc, vp.z * sc, vp.w * sc);          // the rms_norm node
+                    vp = make_float4(nn.x * gg.x, nn.y * gg.y, nn.z * gg.z, nn.w * gg.w);              // the mul node
+                    if (blockIdx.x == 0 && live && c < N) {       // both nodes' data, written once (every workgroup computes the same)
+                        const int64_t e = (int64_t)c * (nbk * QK) + (cb + bl) * QK + 4 * t;
+                        *(float4 *)(pro.n_out + e) = nn;
+                        *(float4 *)(pro.y_out + e) = vp;
                     }
                 }
+                float amax = fmaxf(fmaxf(fabsf(vp.x), fabsf(vp.y)), fmaxf(fabsf(vp.z), fabsf(vp.w)));
+                amax = group8_max(amax);
+                const float d = amax / 127.0f;                  // Ggml.cs:751
+                const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
+                const int q0 = (int)rintf(vp.x * id), q1 = (int)rintf(vp.y * id);   // Ggml.cs:758-759 (D1, D2)
+                const int q2_ = (int)rintf(vp.z * id), q3 = (int)rintf(vp.w * id);
+                const int sum = group8_sum(q0 + q1 + q2_ + q3);
+                const uint32_t e16 = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q2_ & 0xFFu) << 8);
+                const uint32_t o16 = ((uint32_t)q1 & 0xFFu) | (((uint32_t)q3 & 0xFFu) << 8);
+                const bool even_lane = (t & 1) == 0;
+                const uint32_t recv = (uint32_t)dpp_i<DPP_XOR1>((int)(even_lane ? o16 : e16));
+                const uint32_t word = even_lane ? (e16 | (recv << 16)) : (recv | (o16 << 16));
+                const int h = even_lane ? 0 : 1, off = even_lane ? 2 * t : 2 * t - 2;
+                // a block past the end of K is written as zeros (its weights carry dw = 0; 0 * garbage could be NaN)
+                *(uint32_t *)(myq + i * QSLOT + (c * 2 + h) * 16 + off) = live ? word : 0u;
+                if (t == 0) { myd[i * NC + c] = live ? d : 0.0f; mys[i * NC + c] = live ? sum : 0; }
+            }
+            // same wave wrote and reads: LDS operations of one wave complete in order; only the compiler needs the fence
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            staged = true;
+        }
+
+        // 4. integer block dots + f32 scale-accumulate (Ggml.cs:1136-1159)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const uint4 a0 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 0) * 16);
-                    const uint4 a1 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 1) * 16);
-                    const float da = myd[i * NC + c];
-                    const int sa = mys[i * NC + c];
-                    if (TYPE == GGML_TYPE_Q4_2) {
-                        int s0 = 0, s1 = 0;
-                        s0 = dot4(lo[0], a0.x, s0); s0 = dot4(lo[1], a0.y, s0); s0 = dot4(hi[0], a1.x, s0); s0 = dot4(hi[1], a1.y, s0);
-                        s1 = dot4(lo[2], a0.z, s1); s1 = dot4(lo[3], a0.w, s1); s1 = dot4(hi[2], a1.z, s1); s1 = dot4(hi[3], a1.w, s1);
-                        acc[c] = fmaf(dw[j] * da, (float)s0, acc[c]);
-                        acc[c] = fmaf(mw[j] * da, (float)s1, acc[c]);
-                        continue;
+        for (int j = 0; j < BPL; ++j) {
+            const int i = kq + GV_NKQ * j;
+            const bool ok = u + GV_WORKERS * j < nbc;
+            const float dwj = ok ? DW[j] : 0.0f;          // dw = 0 kills the contribution of a block past the end
+            const float mwj = HAS_M && ok ? MW[HAS_M ? j : 0] : 0.0f;
+            const uint32_t qq[4] = {Q[j].x, Q[j].y, Q[j].z, Q[j].w};
+            uint32_t lo[4], hi[4];
+            if (TYPE == GGML_TYPE_Q8_0) {
+                lo[0] = Q[j].x; lo[1] = Q[j].y; lo[2] = Q[j].z; lo[3] = Q[j].w;
+                hi[0] = Q2[j].x; hi[1] = Q2[j].y; hi[2] = Q2[j].z; hi[3] = Q2[j].w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lo[k] = qq[k] & 0x0F0F0F0Fu;          // elements 8k+0,2,4,6  (Ggml.cs:1149)
+                    hi[k] = (qq[k] >> 4) & 0x0F0F0F0Fu;   // elements 8k+1,3,5,7  (Ggml.cs:1150)
+                    if (HAS_H) {                          // Ggml.cs:1285-1289 / 1330-1334
+                        lo[k] |= q5_high_bits(HB[j], k, 0);
+                        hi[k] |= q5_high_bits(HB[j], k, 1);
                     }
-                    int sdot = 0;
-                    sdot = dot4(lo[0], a0.x, sdot); sdot = dot4(lo[1], a0.y, sdot); sdot = dot4(lo[2], a0.z, sdot); sdot = dot4(lo[3], a0.w, sdot);
-                    sdot = dot4(hi[0], a1.x, sdot); sdot = dot4(hi[1], a1.y, sdot); sdot = dot4(hi[2], a1.z, sdot); sdot = dot4(hi[3], a1.w, sdot);
-                    if (TYPE == GGML_TYPE_Q4_0) sdot -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
-                    if (TYPE == GGML_TYPE_Q5_0) sdot -= 16 * sa;
-                    acc[c] = fmaf(dw[j] * da, (float)sdot, acc[c]);
-                    if (TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1) acc[c] = fmaf(mw[j], da * (float)sa, acc[c]);   // + m * (s0 + s1)
+                    if (TYPE == GGML_TYPE_Q4_2) {         // (nib - 8) bytewise: the two half-block sums need their own offsets
+                        lo[k] = ((lo[k] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+                        hi[k] = ((hi[k] | 0x80808080u) - 0x08080808u) ^ 0x80808080u;
+                    }
                 }
             }
-        }
-        if constexpr (PF) {
-            // the prefetched registers become the current ones (pf is uniform; without it nothing was prefetched)
-            if (pf)
 #pragma unroll
-            for (int j = 0; j < BPL; ++j) {
-                q[j] = qn[j]; dw[j] = dwn[j];
-                if (TYPE == GGML_TYPE_Q8_0) q2[j] = q2n[j];
-                if (HAS_M) mw[j] = mwn[j];
-                if (HAS_H) hb[j] = hbn[j];
+            for (int c = 0; c < NC; ++c) {
+                const uint4 a0 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 0) * 16);
+                const uint4 a1 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 1) * 16);
+                const float da = myd[i * NC + c];
+                const int sa = mys[i * NC + c];
+                if (TYPE == GGML_TYPE_Q4_2) {
+                    int s0 = 0, s1 = 0;
+                    s0 = dot4(lo[0], a0.x, s0); s0 = dot4(lo[1], a0.y, s0); s0 = dot4(hi[0], a1.x, s0); s0 = dot4(hi[1], a1.y, s0);
+                    s1 = dot4(lo[2], a0.z, s1); s1 = dot4(lo[3], a0.w, s1); s1 = dot4(hi[2], a1.z, s1); s1 = dot4(hi[3], a1.w, s1);
+                    acc[c] = fmaf(dwj * da, (float)s0, acc[c]);
+                    acc[c] = fmaf(mwj * da, (float)s1, acc[c]);
+                    continue;
+                }
+                int sdot = 0;
+                sdot = dot4(lo[0], a0.x, sdot); sdot = dot4(lo[1], a0.y, sdot); sdot = dot4(lo[2], a0.z, sdot); sdot = dot4(lo[3], a0.w, sdot);
+                sdot = dot4(hi[0], a1.x, sdot); sdot = dot4(hi[1], a1.y, sdot); sdot = dot4(hi[2], a1.z, sdot); sdot = dot4(hi[3], a1.w, sdot);
+                if (TYPE == GGML_TYPE_Q4_0) sdot -= 8 * sa;   // (nib - 8) * a summed = nib*a summed - 8 * sum(a)
+                if (TYPE == GGML_TYPE_Q5_0) sdot -= 16 * sa;
+                acc[c] = fmaf(dwj * da, (float)sdot, acc[c]);
+                if (TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1) acc[c] = fmaf(mwj, da * (float)sa, acc[c]);   // + m * (s0 + s1)
             }
         }
-        if (cidx != nchunks - 1) continue;              // the row tile's last chunk: reduce and store below
+        if (cidx != nchunks - 1) return;                // the row tile's last chunk: reduce and store below
 
         // 5. k-lanes by two xor-shuffles, waves through LDS: the fixed tree of the kernel above.  sRed alternates between two
         //    buffers, so ONE barrier per tile orders everything (tile t+2's writes come after tile t+1's barrier, which every
@@ -534,11 +528,44 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
                                             : (quad[0] + quad[1 % (GV_WAVES / 4)]) + (quad[2 % (GV_WAVES / 4)] + quad[3 % (GV_WAVES / 4)]);
             if (m < M && c < N) {
                 // the node that follows the mul_mat, applied as the product is stored (common.h mm_epilogue)
-                dst[(int64_t)c * ldd + m] = ep.mode == 2 ? tot * ep.scale : tot;
-                if (ep.mode == 1) ep.dst2[(int64_t)c * ep.ld2 + m] = tot + ep.addend[(int64_t)c * ep.ld_add + m];
+                st_result(dst + (int64_t)c * ldd + m, ep.mode == 2 ? tot * ep.scale : tot);
+                if (ep.mode == 1) st_result(ep.dst2 + (int64_t)c * ep.ld2 + m, tot + ep.addend[(int64_t)c * ep.ld_add + m]);
             }
         }
         parity ^= 1;
+    };
+
+    if constexpr (PF) {
+        // The look-ahead pays where a workgroup walks several row tiles of one chunk (4096 x 4096: 5.06 -> 4.66 us, M = 32000:
+        // 19.3 -> 18.7).  Two register sets take turns (the loop is unrolled by two items): a copy "current = next" at the end
+        // of an item would make the wave wait for the look-ahead data THERE, i.e. drain the memory pipe once per row tile.
+        // The steady-state loop issues its look-ahead loads UNCONDITIONALLY (a load sequence behind a branch makes hipcc's
+        // wait counts assume the worst of both paths: every wait for the current set then also waited for half of the set
+        // just requested); the last one or two items run below it.
+        int w = 0;
+        for (; w + 2 < nitems; w += 2) {
+            load_item(w + 1, qn, q2n, dwn, mwn, hbn);                          // the NEXT item's weight stream goes out first
+            do_item(w, q, q2, dw, mw, hb);
+            load_item(w + 2, q, q2, dw, mw, hb);
+            do_item(w + 1, qn, q2n, dwn, mwn, hbn);
+        }
+        if (w + 1 < nitems) {
+            load_item(w + 1, qn, q2n, dwn, mwn, hbn);
+            do_item(w, q, q2, dw, mw, hb);
+            do_item(w + 1, qn, q2n, dwn, mwn, hbn);
+        } else if (w < nitems) {
+            do_item(w, q, q2, dw, mw, hb);
+        }
+    } else {
+        // with K in several chunks the activations of every item have to be fetched and quantized as well, and asking for them
+        // first, weights behind, in the item's own iteration measured better (4096 x 11008: 9.0 against 10.0 us)
+        for (int w = 0; w < nitems; ++w) {
+            if (w > 0) {
+                if (!(single_chunk && staged)) load_x(w, 0);
+                load_item(w, q, q2, dw, mw, hb);
+            }
+            do_item(w, q, q2, dw, mw, hb);
+        }
     }
 }
 
@@ -555,7 +582,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
-#define GVF_ARGS w->qs, w->qh, w->d, w->m, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep
+#define GVF_ARGS w->qs, w->gs, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep
 #define GVF_LAUNCH(NC) do { \
         if (t_prologue) { \
             if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
@@ -571,7 +598,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         }
     }
     if (ep.mode != 0 || t_prologue) return hipErrorNotSupported;          // (callers ask gemv_fused_has_epilogue first)
-#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->qh, w->d, w->m, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
+#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->gs, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
     else if (N <= 4) GV_LAUNCH(4);

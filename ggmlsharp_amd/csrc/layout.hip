@@ -262,7 +262,28 @@ __global__ void quants_to_bf6_kernel(const uint8_t *__restrict__ qs, const uint3
     }
 }
 
+// d / m / qh planes -> the mat-vec's tile-major side image (common.h ggml_hip_weight::gs); one thread per (row, k-block)
+__global__ void gemv_side_image_kernel(const float *__restrict__ d, const float *__restrict__ mm, const uint32_t *__restrict__ qh, int64_t Mpad,
+                                       int64_t nbk, int np, uint32_t *__restrict__ gs) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mpad) return;
+    for (int64_t b = blockIdx.y; b < nbk; b += gridDim.y) {
+        uint32_t *o = gs + (((m >> 4) * nbk + b) * np) * 16 + (m & 15);
+        int pl = 0;
+        o[16 * pl++] = __float_as_uint(d[b * Mpad + m]);
+        if (mm) o[16 * pl++] = __float_as_uint(mm[b * Mpad + m]);
+        if (qh) o[16 * pl++] = qh[b * Mpad + m];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st) {
+    if (!w->gs || w->nbk <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->Mpad + 255) / 256), (unsigned)(w->nbk < 65535 ? w->nbk : 65535));
+    gemv_side_image_kernel<<<grid, 256, 0, st>>>(w->d, w->m, w->qh, w->Mpad, w->nbk, gemv_side_planes(w->type), w->gs);
+    return hipGetLastError();
+}
 
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st) {
     if (!w->q6a || w->M <= 0) return hipSuccess;
