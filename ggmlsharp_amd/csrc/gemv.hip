@@ -35,6 +35,11 @@ template <int NC> struct GvChunk { static constexpr int value = NC <= 8 ? GV_CHU
 #ifndef GV_NT
 #define GV_NT 1       // non-temporal weight loads (A/B: -DGV_NT=0)
 #endif
+#ifndef GV_PF_WGS
+#define GV_PF_WGS 256                  // the look-ahead form (N = 1, K <= 4096) keeps two row tiles per wave in flight: ONE workgroup per CU
+                                       // (A/B 512 -> 256: M = 11008 8.0 -> 7.6 us, M = 32000 16.1 -> 15.7, M = 65536 28.9 -> 28.5; the forms
+                                       // without look-ahead need the second workgroup: 32000 x 4096 x 8 37.1 -> 41.8 us with 256)
+#endif
 #ifndef GV_OLD_FUSED
 #define GV_OLD_FUSED 0                 // A/B: the former fused kernel (block-wide staging behind a barrier)
 #endif
@@ -96,10 +101,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
     const bool single_chunk = nbk <= GvChunk<NC>::value;
     bool staged = false;
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-    // XCD-aware tile order: virtual blocks b and b+8 share an XCD (and its L2) in the first round, so give each XCD a
-    // contiguous range of row tiles -- neighbouring tiles share the 128-byte lines of the scale plane.  Bijective.
-    const int nt = ntiles, xcd = vb & 7, q8 = nt >> 3, r8 = nt & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+    const int tile = vb;   // launch order (see the fused kernel below)
     const int64_t row = (int64_t)tile * GV_ROWS + r;  // < Mpad by construction
 
     float acc[NC];
@@ -323,9 +325,10 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     const int my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nitems = my_tiles * nchunks;
     auto tile_of = [&](int w) {
-        const int vb = (int)blockIdx.x + (w / nchunks) * (int)gridDim.x;
-        const int nt = ntiles, xcd = vb & 7, q8 = nt >> 3, r8 = nt & 7;
-        return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+        // row tiles in launch order (neighbouring workgroups stream neighbouring 256-byte pieces of every k-block row; the
+        // per-XCD ranges this used to hand out existed for the [k-block][row] scale plane, whose 128-byte lines two tiles
+        // shared -- with the tile-major side image they cost 3-6 % at M >= 11008)
+        return (int)blockIdx.x + (w / nchunks) * (int)gridDim.x;
     };
     // (wider batches keep one register set: their activation registers already fill the budget, and the second set cost
     // them a resident workgroup -- 32000 x 4096 x 8: 50.5 us with it against 41.9 without)
@@ -579,6 +582,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
     const int ntiles = (int)((w->M + ROWS - 1) / ROWS);
     dim3 grid((unsigned)(ntiles < GV_MAX_WGS ? ntiles : GV_MAX_WGS));
     if constexpr (FUSED && !GV_OLD_FUSED) {
+        if (N <= 1 && w->nbk <= GV_CHUNK && ntiles > GV_PF_WGS) grid = dim3((unsigned)GV_PF_WGS);
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
