@@ -562,7 +562,9 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     } else {
         // with K in several chunks the activations of every item have to be fetched and quantized as well, and asking for them
         // first, weights behind, in the item's own iteration measured better -- again with the two-set look-ahead of the
-        // single-chunk form extended to the activations (4096 x 11008: 8.1 against 8.7 us, 11008 x 11008: 16.5 against 18.1)
+        // single-chunk form extended to the activations (4096 x 11008: 8.1 against 8.7 us, 11008 x 11008: 16.5 against 18.1),
+        // and against ONE chunk of 384 k-blocks (all 11 block loads of a lane at once, same bits: any chunk size that is a
+        // multiple of 32 leaves a lane's block sequence alone): 4096 x 11008 9.4 us, 4096 x 8192 8.8 against 6.6
         for (int w = 0; w < nitems; ++w) {
             if (w > 0) {
                 if (!(single_chunk && staged)) load_x(w, 0);
