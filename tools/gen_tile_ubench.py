@@ -6,6 +6,7 @@ import sys
 RAND = "--rand" in sys.argv    # per-lane pseudo-random operand data and unit block scales: realistic toggling (power), not constants
 ACC, T0, T1, DA, TMP, A0, A1, B0, B1, DW, LD = 0, 16, 32, 48, 64, 68, 72, 76, 80, 84, 88   # VGPR bases
 P0, P1, PA, PB, NV = 48, 104, 64, 72, 120
+PQ, ACC2 = 120, 152   # mxq kinds: 32 outer-product registers, second accumulator tile
 SCL = LD + 15 if RAND else LD + 12          # E8M0 block-scale byte(s): 2^0 with --rand, 2^-127 (results ~0) otherwise   # outer-product variant: d0 (x) d1 by a bf16 MFMA, then 16 v_fmac
 
 
@@ -77,19 +78,35 @@ def tile(kind, cur, nxt):
         ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b128 v[{LD + 4}:{LD + 7}], v{LD + 12} offset:1024",
               f"ds_read_b64 v[{LD + 8}:{LD + 9}], v{LD + 12} offset:2048"]
         return [mm] + ld + f[:8] + [pp] + f[8:12] + ["s_waitcnt lgkmcnt(0)"] + f[12:]
+    if kind in ("mxq", "mxq_real"):
+        # per PAIR of tiles (the wave's two m-tiles of one n-tile and k-block): 2 MX MFMAs -> S0, S1; ONE v_mfma_f32_32x32x1_2b_f32
+        # = two exact f32 outer products (activation scales) (x) (weight scales of m-tile 0 | 1) -> P (32 registers); acc += S * P:
+        # 16 VALU per tile.  Single-buffered (the kernel's register budget): the partner wave fills the MFMA latency.
+        s0, s1 = T0, T1
+        mm = [f"v_mfma_scale_f32_32x32x64_f8f6f4 v[{t}:{t + 15}], v[{A0}:{A0 + 5}], v[{B0}:{B0 + 5}], 0, v{SCL}, v{SCL} op_sel_hi:[0,0,0] cbsz:3 blgp:3" for t in (s0, s1)]
+        pq = f"v_mfma_f32_32x32x1_2b_f32 v[{PQ}:{PQ + 31}], v{DW}, v{DW + 1}, 0"
+        f0 = [f"v_fmac_f32 v{ACC + r}, v{s0 + r}, v{PQ + r}" for r in range(16)]
+        f1 = [f"v_fmac_f32 v{ACC2 + r}, v{s1 + r}, v{PQ + 16 + r}" for r in range(16)]
+        ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b64 v[{LD + 4}:{LD + 5}], v{LD + 12} offset:1024",
+              f"ds_read_b32 v{LD + 8}, v{LD + 12} offset:2048"] if kind == "mxq_real" else []
+        wt = ["s_waitcnt lgkmcnt(0)"] if kind == "mxq_real" else []
+        # order: P first (64 cycles), the MX pair behind it; the fmacs of S0 need S0 (issued 2 MFMAs ago) and P
+        return [pq] + mm + ld + ["s_nop 7", "s_nop 7"] + f0 + wt + f1
     raise ValueError(kind)
 
 
-KINDS = ["valu", "mfma", "mx_only", "mx", "mx_real", "mxp_only", "mxp", "mxp_real"]
+KINDS = ["valu", "mfma", "mx_only", "mx", "mx_real", "mxp_only", "mxp", "mxp_real", "mxq", "mxq_real"]
 src = ['// generated by tools/gen_tile_ubench.py -- do not edit', '#include <hip/hip_runtime.h>', '#include <cstdio>', '']
 for k in KINDS:
-    body = tile(k, T0, T1) + tile(k, T1, T0)
+    body = tile(k, T0, T1) if k.startswith("mxq") else tile(k, T0, T1) + tile(k, T1, T0)
     init = [f"v_cvt_f32_u32 v{r}, v{LD + 13}" for r in range(ACC, ACC + 16)]
     init += [f"v_mov_b32 v{r}, 0x3c004000" for r in range(A0, B1 + 4)]          # f16 pairs (2.0, 1.0)
     init += [f"v_mov_b32 v{r}, 0x3f7fe000" for r in range(DA, DA + 16)]          # ~0.9998
     init += [f"v_mov_b32 v{DW}, 0x3f801000", f"v_mov_b32 v{DW + 1}, 0x3f801000", f"v_mov_b32 v{LD + 12}, 0"]  # LD+12: LDS address 0 and (as an E8M0 byte 0) a tiny block scale
     init += [f"v_mov_b32 v{r}, 0x40400000" for r in range(T0, T1 + 16)] + [f"v_mov_b32 v{r}, 0x12345" for r in range(LD, LD + 12)]
     init += [f"v_mov_b32 v{r}, 0x3f801000" for r in list(range(P0, P0 + 16)) + list(range(P1, P1 + 16))]
+    if k.startswith("mxq"):
+        init += [f"v_cvt_f32_u32 v{r}, v{LD + 13}" for r in range(ACC2, ACC2 + 16)] + [f"v_mov_b32 v{r}, 0x3f801000" for r in range(PQ, PQ + 32)]
     # bf16 scale fragments as the kernel would hold them: k slots 0..5 in lanes 0..31, everything else zero
     init += [f"v_and_b32 v{LD + 14}, 63, v{LD + 13}", f"v_cmp_gt_u32 vcc, 32, v{LD + 14}", f"v_mov_b32 v{LD + 15}, 0x3c123f81"]
     init += [f"v_cndmask_b32 v{r}, 0, v{LD + 15}, vcc" for r in (PA, PA + 1, PA + 2, PB, PB + 1, PB + 2)] + [f"v_mov_b32 v{PA + 3}, 0", f"v_mov_b32 v{PB + 3}, 0"]
@@ -109,11 +126,12 @@ for k in KINDS:
             for r in (PA, PA + 1, PA + 2, PB, PB + 1, PB + 2):
                 init += rnd(r, 0x007F007F, 0x3F803F80, 0x61c88647 + 2 * r) + [f"v_cndmask_b32 v{r}, 0, v{r}, vcc"]
         init += [f"v_mov_b32 v{SCL}, 0x7f7f7f7f"]
-    clob = ", ".join(f'"v{i}"' for i in range(0, NV)) + ', "vcc"'
+    clob = ", ".join(f'"v{i}"' for i in range(0, 184 if k.startswith("mxq") else NV)) + ', "vcc"'
     asm = "\\n\\t".join(init + ["s_mov_b32 s20, %1", "s_memtime s[22:23]", "s_waitcnt lgkmcnt(0)", "1:"] + body +
                         ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 1b", "s_nop 15", "s_nop 15", "s_memtime s[24:25]",
                          "s_waitcnt lgkmcnt(0)", "s_sub_u32 %0, s24, s22", f"v_mov_b32 %2, v{ACC}"])
-    src += [f'__global__ void k_{k}(float *out, unsigned *cyc, int n) {{', '    __shared__ float lds[1024];', '    lds[threadIdx.x & 1023] = 1.0f;',
+    lb = "__launch_bounds__(512) " if k.startswith("mxq") else ""
+    src += [f'__global__ void {lb}k_{k}(float *out, unsigned *cyc, int n) {{', '    __shared__ float lds[1024];', '    lds[threadIdx.x & 1023] = 1.0f;',
             '    __syncthreads();', '    unsigned dt; float r;',
             f'    asm volatile("v_mov_b32 v{LD + 13}, %3\\n\\t{asm}" : "=s"(dt), "+s"(n), "=v"(r) : "v"(threadIdx.x) : {clob}, "s20", "s22", "s23", "s24", "s25", "scc", "memory");',
             '    out[blockIdx.x * blockDim.x + threadIdx.x] = r + lds[(threadIdx.x * 7) & 1023];', '    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = dt;', '}', '']
@@ -145,7 +163,7 @@ src += ['template <typename K> void run(const char *name, K kern, int w, float *
         '    printf("%-8s waves/SIMD %d: %8.1f us  %7.1f cyc/tile/wave  %7.1f cyc/tile/SIMD  %6.2f ns/tile/SIMD  clock %.2f GHz\\n", name, w, ms * 1e3,',
         '           cyc / (2.0 * iters), cyc / (2.0 * iters) / w, ms * 1e6 / (2.0 * iters) / w, cyc / (ms * 1e6));', '}', '',
         'int main() {', '    float *o; unsigned *c; hipMalloc(&o, 256 * 1024 * 4); hipMalloc(&c, 4);', '    for (int w = 1; w <= 4; ++w) {']
-src += [f'        run("{k}", k_{k}, w, o, c);' for k in KINDS]
+src += [(f'        if (w <= 2) run("{k}", k_{k}, w, o, c);' if k.startswith("mxq") else f'        run("{k}", k_{k}, w, o, c);') for k in KINDS]
 src += ['    }',
         '    { const int iters = 4000; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;',
         '      auto t = [&](const char *nm, auto kern) { kern<<<256, 512>>>(o, c, 100); hipDeviceSynchronize(); hipEventRecord(e0); kern<<<256, 512>>>(o, c, iters); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);',
