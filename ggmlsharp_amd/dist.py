@@ -109,6 +109,20 @@ class RowSplitMulMat:
         mine = handles.cuda() if on_gpu else handles
         allh = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(allh, mine)
+        # which device every rank computes on: a store into a peer's buffer needs peer access between the two devices, and a
+        # store without it is a GPU fault, not an error code -- ask before any kernel touches a peer pointer
+        di = torch.device(self.dev).index
+        my_dev = di if di is not None else torch.cuda.current_device()
+        devs = torch.tensor([my_dev], dtype=torch.int64)
+        devs = devs.cuda() if on_gpu else devs
+        alld = [torch.empty_like(devs) for _ in range(self.world)]
+        dist.all_gather(alld, devs)
+        if err is None:
+            for r in range(self.world):
+                pd = int(alld[r].item())
+                if r != self.rank and pd != my_dev and not torch.cuda.can_device_access_peer(my_dev, pd):
+                    err = RuntimeError(f"device {my_dev} has no peer access to device {pd} (rank {r})")
+                    break
         if err is None:
             try:
                 for b in range(2):
