@@ -100,6 +100,7 @@ int DeviceCtx::make_current() const {
     return GGML_HIP_OK;
 }
 int DeviceCtx::sync_all() {
+    d2h_busy = false;
     hipError_t e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s_h2d);
     if (e == hipSuccess) e = hipStreamSynchronize(s_d2h);
@@ -123,12 +124,55 @@ const void *DeviceCtx::resident_lookup(const void *host, size_t bytes) {
 }
 // a write to host range [host, host + bytes) makes every OTHER resident copy that overlaps it stale (a view with an
 // offset gets its own entry; the parent's device copy must not be served afterwards)
+void DeviceCtx::owe(void *host, const void *dev, size_t bytes) {
+    for (Owed &o : owed)
+        if (o.host == host) { o.dev = dev; o.bytes = bytes; return; }
+    owed.push_back(Owed{host, dev, bytes});
+}
+int DeviceCtx::pay(const void *only_dev) {
+    if (owed.empty()) return GGML_HIP_OK;
+    std::vector<Owed> now, keep;
+    for (const Owed &o : owed) (only_dev == nullptr || o.dev == only_dev ? now : keep).push_back(o);
+    owed.swap(keep);
+    if (now.empty()) return GGML_HIP_OK;
+    d2h_busy = true;
+    // through the device mapping of the registered pool: one kernel for up to 32 copies; anything else: a DMA each
+    std::vector<const void *> src; std::vector<void *> dst; std::vector<size_t> nb;
+    hipError_t e = hipSuccess;
+    for (const Owed &o : now) {
+        d2h_bytes += o.bytes;
+        void *m = ((uintptr_t)o.host % 4 == 0 && (uintptr_t)o.dev % 4 == 0 && o.bytes % 4 == 0) ? host_range_device_ptr(o.host, o.bytes) : nullptr;
+        if (m) { src.push_back(o.dev); dst.push_back(m); nb.push_back(o.bytes); }
+        else if (e == hipSuccess) e = hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream);
+    }
+    for (size_t i = 0; i < src.size() && e == hipSuccess; i += 32) {
+        const int n = (int)(src.size() - i < 32 ? src.size() - i : 32);
+        e = launch_scatter_copy(src.data() + i, dst.data() + i, nb.data() + i, n, stream);
+    }
+    return e == hipSuccess ? GGML_HIP_OK : fail(GGML_HIP_ERR_RUNTIME, "device -> host copy of graph results: %s", hipGetErrorString(e));
+}
+// Only what may still be on its way matters: a range that is owed a result is paid first; copies already issued are waited
+// for; otherwise (the common case in a graph scope: leaves and nothing in flight) the upload can go out at once.
+int DeviceCtx::before_host_read(const void *host, size_t bytes) {
+    const uint8_t *a = (const uint8_t *)host, *b = a + bytes;
+    for (const Owed &o : owed) {
+        const uint8_t *x = (const uint8_t *)o.host, *y = x + o.bytes;
+        if (x < b && a < y) return pay_and_sync();
+    }
+    return d2h_busy ? sync_all() : GGML_HIP_OK;
+}
+int DeviceCtx::pay_and_sync() {
+    int rc = pay();
+    const int r2 = sync_all();
+    return rc ? rc : r2;
+}
 void DeviceCtx::drop_overlapping(const void *host, size_t bytes, bool keep_exact) {
     const uint8_t *a = (const uint8_t *)host, *b = a + bytes;
     for (auto it = resident.begin(); it != resident.end();) {
         const uint8_t *x = (const uint8_t *)it->first, *y = x + it->second.bytes;
         const bool overlap = x < b && a < y;
         if (overlap && !(keep_exact && it->first == host)) {
+            (void)pay(it->second.p);               // its host copy goes out (stream-ordered) before the buffer is reused
             pool.push_back(it->second);
             it = resident.erase(it);
         } else {
@@ -141,6 +185,7 @@ void *DeviceCtx::resident_buffer(const void *host, size_t bytes) {
     auto old = resident.find(host);
     if (old != resident.end()) {
         if (old->second.bytes >= bytes) return old->second.p;      // the same tensor computed again: reuse its buffer
+        (void)pay(old->second.p);
         pool.push_back(old->second);
         resident.erase(old);
     }
@@ -151,6 +196,7 @@ void *DeviceCtx::resident_buffer(const void *host, size_t bytes) {
     return p;
 }
 void DeviceCtx::drain(bool free_all) {
+    if (!owed.empty()) (void)pay_and_sync();       // (graph end has paid already; a shutdown inside a scope has not)
     for (auto &kv : resident) pool.push_back(kv.second);
     resident.clear();
     for (ggml_hip_weight *w : transient) ggml_hip_weight_free(w);

@@ -229,6 +229,8 @@ hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, 
                                    ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st);
+// up to 32 device buffers -> device-visible (mapped host) destinations in one launch; sizes and addresses multiples of 4
+hipError_t launch_scatter_copy(const void *const *src, void *const *dst, const size_t *bytes, int n, hipStream_t st);
 hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st);   // d / m / qh planes -> w->gs (after every write of the planes)
 static inline int gemv_side_planes(int type) {
     return 1 + ((type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) ? 1 : 0) + ((type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1) ? 1 : 0);

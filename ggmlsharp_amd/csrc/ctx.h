@@ -84,6 +84,17 @@ struct DeviceCtx {
     std::map<CacheKey, CachedWeight> cache;        // Seam-1 weight cache
     uint64_t h2d_bytes = 0, d2h_bytes = 0, resident_hits = 0;
     int graph_depth_ = 0;                          // ggml_hip_graph_begin / _end nesting on this slot
+    // graph scope: results whose host copy is still owed.  A node of a graph scope costs the host ONE kernel launch; the
+    // device -> host copies every node's data needs (the reference leaves every node's data in host memory) are issued
+    // together -- one scatter kernel writing through the device mapping of the registered pool -- when the scope ends, when a
+    // buffer is about to be recycled, or before anything reads host memory that may be owed.
+    struct Owed { void *host; const void *dev; size_t bytes; };
+    std::vector<Owed> owed;
+    void owe(void *host, const void *dev, size_t bytes);      // (replaces an entry for the same host pointer)
+    int pay(const void *only_dev = nullptr);                  // issue the copies on `stream` (all, or the one reading `only_dev`)
+    int pay_and_sync();                                       // ... and wait: host memory is current afterwards
+    bool d2h_busy = false;                                    // a device -> host copy was issued since the last sync_all
+    int before_host_read(const void *host, size_t bytes);     // host memory [host, host + bytes) is about to be read (uploaded)
 
     int make_current() const;                      // hipSetDevice(device) as a status
     int sync_all();                                // every stream of this slot
@@ -106,6 +117,8 @@ extern std::mutex g_table_mu;
 
 // host memory registered for DMA (ggml_hip_register_host_pool): true when [p, p + n) lies inside a registered range
 bool host_range_pinned(const void *p, size_t n);
+// device-visible address of registered host memory [p, p + n) (hipHostRegisterMapped), nullptr when it is not registered
+void *host_range_device_ptr(const void *p, size_t n);
 
 // ---- weights ----
 int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int64_t ne00, int64_t ne01, uint64_t nb01,

@@ -276,7 +276,40 @@ __global__ void gemv_side_image_kernel(const float *__restrict__ d, const float 
     }
 }
 
+// up to 32 device buffers -> (device-mapped) host tensors in one launch: blockIdx.y = copy, 16-byte pieces where both ends allow
+struct scatter_table { const void *src[32]; void *dst[32]; unsigned long long bytes[32]; };
+__global__ void scatter_copy_kernel(const scatter_table t) {
+    const int e = blockIdx.y;
+    const uint8_t *s = (const uint8_t *)t.src[e];
+    uint8_t *d = (uint8_t *)t.dst[e];
+    const size_t n = (size_t)t.bytes[e];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const size_t n16 = n / 16;
+        for (size_t i = i0; i < n16; i += stride) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+        for (size_t i = n16 * 4 + i0; i < n / 4; i += stride) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
+    } else {
+        for (size_t i = i0; i < n / 4; i += stride) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_scatter_copy(const void *const *src, void *const *dst, const size_t *bytes, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > 32) return hipErrorInvalidValue;
+    scatter_table t;
+    size_t mx = 0;
+    for (int i = 0; i < 32; ++i) {
+        t.src[i] = i < n ? src[i] : nullptr; t.dst[i] = i < n ? dst[i] : nullptr; t.bytes[i] = i < n ? bytes[i] : 0;
+        if (i < n && bytes[i] > mx) mx = bytes[i];
+    }
+    size_t bx = (mx / 16 + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;                               // a copy of any size is a grid-stride loop; PCIe, not CUs, bounds it
+    scatter_copy_kernel<<<dim3((unsigned)bx, (unsigned)n), 256, 0, st>>>(t);
+    return hipGetLastError();
+}
 
 hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st) {
     if (!w->gs || w->nbk <= 0) return hipSuccess;

@@ -12,7 +12,7 @@ namespace ghip {
 
 // ---------------- host memory registered for DMA ----------------
 namespace {
-struct HostRange { const uint8_t *p; size_t n; };
+struct HostRange { const uint8_t *p; size_t n; uint8_t *dev; };   // dev: the range's device-visible address (nullptr: not mapped)
 std::mutex g_pin_mu;
 std::vector<HostRange> g_pinned;
 }  // namespace
@@ -23,6 +23,14 @@ bool host_range_pinned(const void *p, size_t n) {
     for (const HostRange &r : g_pinned)
         if (a >= r.p && a + n <= r.p + r.n) return true;
     return false;
+}
+
+void *host_range_device_ptr(const void *p, size_t n) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    const uint8_t *a = (const uint8_t *)p;
+    for (const HostRange &r : g_pinned)
+        if (r.dev && a >= r.p && a + n <= r.p + r.n) return r.dev + (a - r.p);
+    return nullptr;
 }
 
 namespace {
@@ -74,7 +82,14 @@ int operand_f32(DeviceCtx *c, bool in_graph, const ggml_tensor *t, Scratch &scra
     if (in_graph) {
         const void *r = c->resident_lookup(t->data, bytes);
         if (r) { *out = (const float *)r; ++c->resident_hits; return 0; }
-        if (c->sync_all()) return -1;   // host memory may still be receiving an earlier node's result
+        if (c->before_host_read(t->data, bytes)) return -1;   // host memory may be owed an earlier node's result, or still receiving it
+        // the upload stays resident for the rest of the scope: a leaf used by several nodes (the residual stream) moves once
+        void *keep = c->resident_buffer(t->data, bytes);
+        if (!keep) return -1;
+        if (hipMemcpyAsync(keep, t->data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+        c->h2d_bytes += bytes;
+        *out = (const float *)keep;
+        return 0;
     }
     if (scratch.ensure(bytes)) return -1;
     if (hipMemcpyAsync(scratch.p, t->data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
@@ -90,7 +105,9 @@ float *result_f32(DeviceCtx *c, bool in_graph, const ggml_tensor *t, Scratch &sc
 }
 int finish_f32(DeviceCtx *c, bool in_graph, bool to_host, ggml_tensor *t, const float *dev) {
     const size_t bytes = (size_t)nelem(t) * 4;
-    if (to_host) {
+    if (to_host && in_graph) {
+        c->owe(t->data, dev, bytes);        // (dev is the tensor's resident buffer: result_f32)
+    } else if (to_host) {
         if (hipMemcpyAsync(t->data, dev, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
         c->d2h_bytes += bytes;
     }
@@ -197,6 +214,7 @@ int run_pipeline(DeviceCtx *c, const PipeArgs &a) {
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xchg, 0);
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "seam 1 pipeline: %s", hipGetErrorString(e));
     if (a.upload) c->h2d_bytes += (size_t)a.N * a.K * 4;
+    c->d2h_busy = true;
     c->d2h_bytes += (size_t)a.N * a.Ms * 4 * (a.epi_mode == 1 ? 2 : 1) + (a.pro_x ? (size_t)a.N * a.K * 8 : 0);
     return issue_chunks(c, a);
 }
@@ -219,10 +237,14 @@ int ggml_hip_register_host_pool(void *ptr, size_t bytes) {
         for (const HostRange &r : g_pinned)
             if (r.p == (const uint8_t *)ptr) return r.n == bytes ? GGML_HIP_OK : fail(GGML_HIP_ERR_ARG, "pool already registered with another size");
     }
-    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    // the device-visible address of the pool: graph scopes write their results through it (DeviceCtx::pay).  One slot only:
+    // with several devices every one would need its own mapping, and their element-wise results come from slot 0 anyway.
+    void *dev = nullptr;
+    if (n_slots() != 1 || hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }
     std::lock_guard<std::mutex> lk(g_pin_mu);
-    g_pinned.push_back(HostRange{(const uint8_t *)ptr, bytes});
+    g_pinned.push_back(HostRange{(const uint8_t *)ptr, bytes, (uint8_t *)dev});
     return GGML_HIP_OK;
 }
 
@@ -240,7 +262,7 @@ int ggml_hip_unregister_host_pool(void *ptr) {
     for (int i = 0; i < n_slots(); ++i) {
         DeviceCtx *c = slot(i);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
-        if (c->make_current() == GGML_HIP_OK) (void)c->sync_all();
+        if (c->make_current() == GGML_HIP_OK) (void)c->pay_and_sync();
         c->invalidate(ptr, bytes);
         c->drop_overlapping(ptr, bytes, false);
     }
@@ -294,7 +316,7 @@ int ggml_hip_graph_end(void) {
     if (call.ctxs[0]->graph_depth_ <= 0) return fail(GGML_HIP_ERR_ARG, "ggml_hip_graph_end without ggml_hip_graph_begin");
     for (DeviceCtx *c : call.ctxs) {
         int r = c->make_current();
-        if (!r) r = c->sync_all();                       // every node's dst is on the host from here on
+        if (!r) r = c->pay_and_sync();                   // every node's dst is on the host from here on
         if (r && !rc) rc = r;
         if (--c->graph_depth_ == 0) c->drain(false);
     }
@@ -409,7 +431,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
             const uint8_t *dev_src = nullptr;
             if (!cacheable && in_graph && ggml_hip_type_size(type) == src0->nb[0] && (type == GGML_TYPE_F32) && contiguous_f32(src0))
                 dev_src = (const uint8_t *)c->resident_lookup(src0->data, (size_t)nelem(src0) * 4);
-            if (!dev_src && in_graph) { rc = c->sync_all(); if (rc) return rc; }
+            if (!dev_src && in_graph) { rc = c->pay_and_sync(); if (rc) return rc; }
             std::vector<ggml_hip_weight *> slices;
             for (int64_t i03 = 0; i03 < ne03 && !rc; ++i03)
                 for (int64_t i02 = 0; i02 < ne02 && !rc; ++i02) {
@@ -500,8 +522,35 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 if (!x_res[(size_t)g] && in_graph && !(epi && epi->pro_x)) {
                     // src1 comes from host memory: inside a graph scope an earlier node's device -> host copy into that
                     // very memory may still be in flight
-                    rc = c->sync_all();
+                    rc = c->before_host_read(x_host, (size_t)(ne11 - 1) * src1->nb[1] + (size_t)ne10 * 4);
                     if (rc) break;
+                }
+                // Graph scope, one slot, one chunk, dst kept resident: the node is its kernels on the compute stream and
+                // nothing else -- no fork / join over the copy streams, no device -> host copy of its own (DeviceCtx::owe:
+                // the host copies of a scope's results go out together).  17 nodes of a 7B decoder layer at batch 1:
+                // 439 -> see DESIGN 8 us per graph compute.
+                if (in_graph && G == 1 && d_res[0] && ne11 <= chunk && (x_res[0] || (epi && epi->pro_x) || src1->nb[1] == (uint64_t)ne10 * 4)) {
+                    const bool pro = epi && epi->pro_x;
+                    if (!x_res[0] && !pro) {
+                        e = hipMemcpyAsync(c->src1.p, x_host, (size_t)ne11 * ne10 * 4, hipMemcpyHostToDevice, c->stream);
+                        if (e != hipSuccess) break;
+                        c->h2d_bytes += (size_t)ne11 * ne10 * 4;
+                    }
+                    const int mode = epi ? epi->mode : 0;
+                    if (pro)
+                        rc = ggml_hip_norm_mul_mat_dev(w, pro_x, ne10, pro_g, ne10, ne11, pro_n, pro_y, dd, ldd, c->work.p, c->work.cap, mode, epi_addend, Ms,
+                                                       epi_dst2, Ms, epi->scale, c->stream);
+                    else
+                        rc = ggml_hip_mul_mat_epilogue_dev(w, xd, ne11, ne10, dd, ldd, c->work.p, c->work.cap, mode, epi_addend, Ms, epi_dst2, Ms,
+                                                           epi ? epi->scale : 1.0f, c->stream);
+                    if (rc) break;
+                    c->owe(d_host, dd, (size_t)ne11 * ne01 * 4);
+                    if (mode == 1) c->owe(epi->add_dst->data, epi_dst2, (size_t)ne11 * ne01 * 4);
+                    if (pro) {
+                        c->owe(epi->pro_norm->data, pro_n, (size_t)ne11 * ne10 * 4);
+                        c->owe(src1->data, pro_y, (size_t)ne11 * ne10 * 4);
+                    }
+                    continue;
                 }
                 PipeArgs pa;
                 pa.w = w; pa.x_host = x_host; pa.nb11 = src1->nb[1]; pa.d_host = d_host; pa.nb1 = dst->nb[1];
@@ -627,7 +676,7 @@ int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const
     DeviceCtx *c = call.ctxs[0];                      // the result goes to host memory only: one slot does it
     rc = c->make_current();
     if (rc) return rc;
-    if (call.in_graph()) { rc = c->sync_all(); if (rc) return rc; }   // operands may be dst of an earlier node still on its way to the host
+    if (call.in_graph()) { rc = c->pay_and_sync(); if (rc) return rc; }   // operands may be dst of an earlier node owed to / on its way to the host
     note_host_write(call, dst, false);                // dst is usually a future src0: its cached device copy (if any) is now stale
     const size_t row_in = (size_t)ne00 * es, rs = row_bytes_of(dt, ne00);   // rs as in Ggml.cs:4345
     if (c->src1.ensure(row_in * ne01) || c->dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
@@ -698,7 +747,7 @@ int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const
     DeviceCtx *c = call.ctxs[0];
     rc = c->make_current();
     if (rc) return rc;
-    if (call.in_graph()) { rc = c->sync_all(); if (rc) return rc; }   // operands may be dst of an earlier node still on its way to the host
+    if (call.in_graph()) { rc = c->pay_and_sync(); if (rc) return rc; }   // operands may be dst of an earlier node owed to / on its way to the host
     note_host_write(call, dst, false);
     const size_t rs = row_bytes_of(t, ne00), rx = (size_t)ne00 * 4;
     if (c->stage.ensure(rs * ne01) || c->src1.ensure(rx * ne01) || c->dst.ensure(rs * ne01)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
@@ -749,7 +798,7 @@ int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, con
         rc = c->make_current();
         if (rc) return rc;
         if (g == 0) {
-            if (in_graph) { rc = c->sync_all(); if (rc) return rc; }      // the scalar is read from host memory
+            if (in_graph) { rc = c->pay_and_sync(); if (rc) return rc; }      // the scalar is read from host memory
             v = *(const float *)src1->data;
         }
         // the reference scales dst's own memory: when dst is not a view of src0 that memory is whatever it held before, and
@@ -830,8 +879,12 @@ static int fused_pair_seam(int which, const struct ggml_tensor *first, const str
         // (both copies on the compute stream; outside a graph scope the second finish waits for both)
         if (g == 0) {
             const size_t bytes = (size_t)nelem(first) * 4;
-            HIP_TRY(hipMemcpyAsync(mid_dst->data, z1, bytes, hipMemcpyDeviceToHost, c->stream));
-            c->d2h_bytes += bytes;
+            if (in_graph) {
+                c->owe(mid_dst->data, z1, bytes);
+            } else {
+                HIP_TRY(hipMemcpyAsync(mid_dst->data, z1, bytes, hipMemcpyDeviceToHost, c->stream));
+                c->d2h_bytes += bytes;
+            }
         }
         if (finish_f32(c, in_graph, g == 0, mul_dst, z2)) return fail(GGML_HIP_ERR_RUNTIME, "%s: copy back failed", name);
     }
