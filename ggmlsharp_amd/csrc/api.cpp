@@ -99,7 +99,45 @@ int DeviceCtx::make_current() const {
     if (e != hipSuccess) return fail(GGML_HIP_ERR_RUNTIME, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     return GGML_HIP_OK;
 }
+uint64_t DeviceCtx::scratch_sig() const {
+    uint64_t h = 1469598103934665603ull;
+    const void *ps[] = {src1.p, dst.p, dst2.p, work.p, stage.p, aux[0].p, aux[1].p, aux[2].p, aux[3].p};
+    for (const void *q : ps) { h ^= (uint64_t)(uintptr_t)q; h *= 1099511628211ull; }
+    return h;
+}
+void DeviceCtx::scope_dirty() {
+    if (scope_mode == 1) { scope_clean = false; return; }
+    if (scope_mode != 2) return;
+    // capturing, and the next thing cannot be captured: end the capture, run what it holds, go on live
+    scope_mode = 0;
+    {   // (a weight re-upload after an invalidation lands here once; a scope that keeps doing it is left alone)
+        Captured &e = captured[scope_key];
+        e.seen = 0;
+        if (++e.strikes >= 3) { e.refused = true; ++n_refused; }
+    }
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(stream, &g) == hipSuccess && g) {
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+            (void)hipGraphLaunch(ex, stream);
+            (void)hipStreamSynchronize(stream);
+            (void)hipGraphExecDestroy(ex);
+        }
+        (void)hipGraphDestroy(g);
+    } else {
+        (void)hipGetLastError();
+    }
+}
+void DeviceCtx::drop_captured() {
+    for (auto &kv : captured) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+        for (Resident &r : kv.second.buffers) pool.push_back(r);
+    }
+    captured.clear();
+}
 int DeviceCtx::sync_all() {
+    scope_dirty();
     d2h_busy = false;
     hipError_t e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s_h2d);
@@ -113,6 +151,7 @@ void *DeviceCtx::take(size_t n) {
             pool.erase(pool.begin() + (long)i);
             return p;
         }
+    scope_dirty();                                 // (an allocation is not something a capture may contain)
     void *p = nullptr;
     if (hipMalloc(&p, n) != hipSuccess) return nullptr;
     return p;
@@ -202,6 +241,7 @@ void DeviceCtx::drain(bool free_all) {
     for (ggml_hip_weight *w : transient) ggml_hip_weight_free(w);
     transient.clear();
     if (free_all) {
+        drop_captured();
         for (Resident &r : pool) (void)hipFree(r.p);
         pool.clear();
     }
@@ -212,7 +252,7 @@ void DeviceCtx::invalidate(const void *host, size_t bytes) {
     for (auto it = cache.begin(); it != cache.end();) {
         const uint8_t *x = (const uint8_t *)it->second.host, *y = x + (it->second.host_bytes ? it->second.host_bytes : 1);
         if (x < b && a < y) {
-            if (!synced) { (void)sync_all(); synced = true; }     // kernels of an open graph scope may still read the entry
+            if (!synced) { (void)sync_all(); drop_captured(); synced = true; }     // kernels of an open graph scope may still read the entry
             for (ggml_hip_weight *w : it->second.slices) ggml_hip_weight_free(w);
             it = cache.erase(it);
         } else {
@@ -221,6 +261,7 @@ void DeviceCtx::invalidate(const void *host, size_t bytes) {
     }
 }
 void DeviceCtx::free_cache() {
+    drop_captured();
     for (auto &kv : cache)
         for (ggml_hip_weight *w : kv.second.slices) ggml_hip_weight_free(w);
     cache.clear();

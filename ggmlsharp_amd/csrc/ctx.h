@@ -93,6 +93,23 @@ struct DeviceCtx {
     void owe(void *host, const void *dev, size_t bytes);      // (replaces an entry for the same host pointer)
     int pay(const void *only_dev = nullptr);                  // issue the copies on `stream` (all, or the one reading `only_dev`)
     int pay_and_sync();                                       // ... and wait: host memory is current afterwards
+    // Keyed graph scopes (ggml_hip_graph_begin_keyed): the caller names the graph it is about to run.  A scope that needed
+    // nothing but launches on the compute stream (observed once) is captured into a hipGraph the second time and REPLAYED with one
+    // launch from the third time on: the seams return at once, leaf data is re-read from host memory by the captured copies.
+    struct Captured {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        std::vector<Resident> buffers;             // the scope's resident buffers, owned by the entry while it can be replayed
+        uint64_t scratch_sig = 0;                  // the scratch pointers baked into the captured launches
+        int seen = 0, strikes = 0; bool refused = false;   // refused: a capture failed outright, or was cut short three times
+    };
+    std::map<uint64_t, Captured> captured;
+    uint64_t scope_key = 0;
+    int scope_mode = 0;                            // 0 plain, 1 observing, 2 capturing, 3 replaying
+    bool scope_clean = true;
+    uint64_t n_observed = 0, n_captured = 0, n_replayed = 0, n_refused = 0;   // keyed scopes by what became of them (tests, tuning)
+    uint64_t scratch_sig() const;
+    void scope_dirty();                            // something other than a compute-stream launch is about to happen
+    void drop_captured();                          // device pointers the captured graphs hold are about to go away
     bool d2h_busy = false;                                    // a device -> host copy was issued since the last sync_all
     int before_host_read(const void *host, size_t bytes);     // host memory [host, host + bytes) is about to be read (uploaded)
 

@@ -339,8 +339,25 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         node->n_tasks = 1;
     }
     cgraph->work_size = 0;
-    // graph scope: results of offloaded nodes stay in HBM for the nodes that consume them
-    int grc = ggml_hip_graph_begin();
+    // graph scope: results of offloaded nodes stay in HBM for the nodes that consume them.  The scope is
+    // named by a hash over everything that decides the calls made below (include/ggml_hip.h ggml_hip_graph_begin_keyed): a
+    // graph that is computed again and again -- a decoder's token loop -- is replayed as one captured launch.
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](uint64_t v) { key ^= v; key *= 1099511628211ull; };
+    auto mix_tensor = [&mix](const ggml_tensor *t) {
+        if (!t) { mix(0x9e3779b97f4a7c15ull); return; }
+        mix((uint64_t)(uintptr_t)t); mix((uint64_t)(uintptr_t)t->data); mix((uint64_t)t->type); mix((uint64_t)t->op);
+        for (int d = 0; d < 4; ++d) { mix((uint64_t)t->ne[d]); mix((uint64_t)t->nb[d]); }
+    };
+    mix((uint64_t)cgraph->n_nodes);
+    for (int i = 0; i < cgraph->n_nodes; i++) {
+        const ggml_tensor *node = cgraph->nodes[i];
+        mix_tensor(node); mix_tensor(node->src0); mix_tensor(node->src1);
+        if (node->op == GGML_OP_SCALE && node->src1 && node->src1->data && node->src1->type == GGML_TYPE_F32) {   // read on the host at issue time
+            uint32_t bits; memcpy(&bits, node->src1->data, 4); mix(bits);
+        }
+    }
+    int grc = ggml_hip_graph_begin_keyed(key ? key : 1);
     if (grc != GGML_HIP_OK) return grc;
     for (int i = 0; i < cgraph->n_nodes; i++) {
         ggml_tensor *node = cgraph->nodes[i];

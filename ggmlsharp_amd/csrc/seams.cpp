@@ -302,13 +302,38 @@ void ggml_hip_invalidate_all(void) {
 }
 
 /* Graph scope for ggml_graph_compute's node loop (Ggml.cs:3539-3704): see ctx.h "graph scope". */
-int ggml_hip_graph_begin(void) {
+static int graph_begin(uint64_t key) {
     Call call;
     int rc = call.begin();
     if (rc) return rc;
     for (DeviceCtx *c : call.ctxs) ++c->graph_depth_;
+    DeviceCtx *c = call.ctxs[0];
+    if (key == 0 || call.G() != 1 || c->graph_depth_ != 1) return GGML_HIP_OK;
+    rc = c->make_current();
+    if (rc) return rc;
+    c->scope_key = key;
+    c->scope_clean = true;
+    c->scope_mode = 1;
+    auto it = c->captured.find(key);
+    if (it == c->captured.end()) return GGML_HIP_OK;                 // first sight: observe
+    DeviceCtx::Captured &e = it->second;
+    if (e.refused) { c->scope_mode = 0; return GGML_HIP_OK; }
+    if (!e.exec && e.seen == 0) return GGML_HIP_OK;                  // not observed clean yet: keep observing
+    if (e.exec) {
+        if (e.scratch_sig == c->scratch_sig()) { c->scope_mode = 3; return GGML_HIP_OK; }
+        // a scratch buffer was reallocated since: the captured launches hold stale pointers
+        (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph);
+        for (Resident &r : e.buffers) c->pool.push_back(r);
+        c->captured.erase(it);
+        return GGML_HIP_OK;
+    }
+    // observed clean before: capture this run (thread-local mode: other threads' HIP calls are none of its business)
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) c->scope_mode = 2;
+    else { (void)hipGetLastError(); e.refused = true; c->scope_mode = 0; }
     return GGML_HIP_OK;
 }
+int ggml_hip_graph_begin(void) { return graph_begin(0); }
+int ggml_hip_graph_begin_keyed(uint64_t key) { return graph_begin(key); }
 int ggml_hip_graph_end(void) {
     Call call;
     int rc = call.begin();
@@ -316,11 +341,64 @@ int ggml_hip_graph_end(void) {
     if (call.ctxs[0]->graph_depth_ <= 0) return fail(GGML_HIP_ERR_ARG, "ggml_hip_graph_end without ggml_hip_graph_begin");
     for (DeviceCtx *c : call.ctxs) {
         int r = c->make_current();
-        if (!r) r = c->pay_and_sync();                   // every node's dst is on the host from here on
+        const bool outer = c->graph_depth_ == 1;
+        const int mode = outer ? c->scope_mode : 0;
+        if (!r && mode == 3) {                           // replay: the whole scope is one launch
+            DeviceCtx::Captured &e = c->captured[c->scope_key];
+            c->scope_mode = 0;
+            ++c->n_replayed;
+            hipError_t he = hipGraphLaunch(e.exec, c->stream);
+            if (he != hipSuccess) r = fail(GGML_HIP_ERR_RUNTIME, "hipGraphLaunch: %s", hipGetErrorString(he));
+            if (!r) r = c->sync_all();
+        } else if (!r && mode == 2) {                    // capture: close it, keep it, run it
+            r = c->pay();                                // (captured like everything else of the scope)
+            c->scope_mode = 0;
+            DeviceCtx::Captured &e = c->captured[c->scope_key];
+            hipGraph_t g = nullptr;
+            hipError_t he = hipStreamEndCapture(c->stream, &g);
+            if (he == hipSuccess && g) he = hipGraphInstantiate(&e.exec, g, nullptr, nullptr, 0);
+            if (he != hipSuccess || !g) {
+                (void)hipGetLastError();
+                if (g) (void)hipGraphDestroy(g);
+                e.exec = nullptr; e.refused = true; ++c->n_refused;
+                if (!r) r = fail(GGML_HIP_ERR_RUNTIME, "graph scope capture failed (%s): the scope's nodes did not run", hipGetErrorString(he));
+            } else {
+                e.graph = g;
+                ++c->n_captured;
+                e.scratch_sig = c->scratch_sig();
+                for (auto &kv : c->resident) e.buffers.push_back(kv.second);     // owned by the entry from here on
+                c->resident.clear();
+                he = hipGraphLaunch(e.exec, c->stream);
+                if (he != hipSuccess && !r) r = fail(GGML_HIP_ERR_RUNTIME, "hipGraphLaunch: %s", hipGetErrorString(he));
+                const int r2 = c->sync_all();
+                if (!r) r = r2;
+            }
+        } else if (!r) {
+            const bool clean = c->scope_clean;           // (the wait below is the scope's end, not part of it)
+            if (mode == 1) c->scope_mode = 0;
+            r = c->pay_and_sync();                       // every node's dst is on the host from here on
+            if (mode == 1) {
+                DeviceCtx::Captured &e = c->captured[c->scope_key];
+                if (clean && !r) { e.seen = 1; ++c->n_observed; }     // (a scope that was not clean is simply observed again next time)
+            }
+        }
+        if (outer) c->scope_mode = 0;
         if (r && !rc) rc = r;
         if (--c->graph_depth_ == 0) c->drain(false);
     }
     return rc;
+}
+void ggml_hip_debug_scope_counters(uint64_t *observed, uint64_t *captured, uint64_t *replayed, uint64_t *refused) {
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        v[0] += c->n_observed; v[1] += c->n_captured; v[2] += c->n_replayed; v[3] += c->n_refused;
+    }
+    if (observed) *observed = v[0];
+    if (captured) *captured = v[1];
+    if (replayed) *replayed = v[2];
+    if (refused) *refused = v[3];
 }
 void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits) {
     uint64_t a = 0, b = 0, h = 0;
@@ -336,6 +414,13 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
 
 /* Seam 1.  Checks mirror the Debug.Asserts of the three drivers (Ggml.cs:6026-6046, 6222-6241, 6477-6504) and of
  * ggml_mul_mat_impl (Ggml.cs:8228-8229); the reference silently drops them in Release, here they are errors. */
+// inside a replayed graph scope the seams have nothing to do: ggml_hip_graph_end launches the captured scope
+static bool scope_replaying() {
+    const int b = bound_slot();
+    DeviceCtx *c = slot(b >= 0 ? b : 0);
+    return c && c->scope_mode == 3;
+}
+
 static bool src1_contig_early(const ggml_tensor *t) { return t->nb[0] == 4 && t->nb[1] == (uint64_t)t->ne[0] * 4; }
 
 struct SeamEpi {                                    // the node after the mul_mat (fused seams below); mode as in mm_epilogue
@@ -354,6 +439,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
     if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     // offload convention of the reference's own dead GPU blocks (Ggml.cs:6510-6521)
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     const int type = src0->type;
     if (type < 0 || type >= GGML_TYPE_COUNT || !weight_type_ok(type))
         return fail(GGML_HIP_ERR_TYPE, "src0 type %d unsupported (Q4_3/Q8_1 null slots; Q4_2/Q5_1 broken storage, SURVEY D7/D8)", type);
@@ -432,6 +518,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
             if (!cacheable && in_graph && ggml_hip_type_size(type) == src0->nb[0] && (type == GGML_TYPE_F32) && contiguous_f32(src0))
                 dev_src = (const uint8_t *)c->resident_lookup(src0->data, (size_t)nelem(src0) * 4);
             if (!dev_src && in_graph) { rc = c->pay_and_sync(); if (rc) return rc; }
+            c->scope_dirty();                             // a weight upload (allocation, staging, a wait) is not replayable
             std::vector<ggml_hip_weight *> slices;
             for (int64_t i03 = 0; i03 < ne03 && !rc; ++i03)
                 for (int64_t i02 = 0; i02 < ne02 && !rc; ++i02) {
@@ -552,6 +639,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                     }
                     continue;
                 }
+                c->scope_dirty();                         // the three-stream pipeline is issued live
                 PipeArgs pa;
                 pa.w = w; pa.x_host = x_host; pa.nb11 = src1->nb[1]; pa.d_host = d_host; pa.nb1 = dst->nb[1];
                 pa.xd = xd; pa.upload = !x_res[(size_t)g]; pa.dd = dd; pa.ldd = ldd;
@@ -601,6 +689,7 @@ int ggml_hip_compute_forward_mul_mat_add(const struct ggml_compute_params *param
                                          const struct ggml_tensor *addend, struct ggml_tensor *add_dst) {
     if (!params || !src0 || !src1 || !mm_dst || !addend || !add_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     const SeamEpi epi = {1, addend, add_dst, 1.0f};
     int rc = seam1(params, src0, src1, mm_dst, &epi);
     if (rc != SEAM_NOT_FUSABLE) return rc;
@@ -616,6 +705,7 @@ int ggml_hip_compute_forward_mul_mat_scale(const struct ggml_compute_params *par
                                            const struct ggml_tensor *scalar, struct ggml_tensor *scale_dst) {
     if (!params || !src0 || !src1 || !mm_dst || !scalar || !scale_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     if (scalar->type != GGML_TYPE_F32 || nelem(scalar) != 1 || !scalar->data) return fail(GGML_HIP_ERR_SHAPE, "scale: src1 must be an F32 scalar (Ggml.cs:6755)");
     bool fusable = scale_dst->data == mm_dst->data && scalar->op == GGML_OP_NONE;   // a view of the product; the scalar a leaf in host memory
     for (int i = 0; i < 4; ++i) fusable = fusable && scale_dst->ne[i] == mm_dst->ne[i];
@@ -639,6 +729,7 @@ int ggml_hip_compute_forward_norm_mul_mat(const struct ggml_compute_params *para
                                           struct ggml_tensor *mm_dst, const struct ggml_tensor *addend, struct ggml_tensor *add_dst) {
     if (!params || !x || !g || !norm_dst || !mul_dst || !src0 || !mm_dst || ((addend == nullptr) != (add_dst == nullptr))) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     SeamEpi epi = {addend ? 1 : 0, addend, add_dst, 1.0f};
     epi.pro_x = x; epi.pro_g = g; epi.pro_norm = norm_dst;
     int rc = seam1(params, src0, mul_dst, mm_dst, &epi);
@@ -654,6 +745,7 @@ int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const
                                  struct ggml_tensor *dst) {
     if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     const int st = src0->type, dt = dst->type;
     if (st != GGML_TYPE_F32 && st != GGML_TYPE_F16) return fail(GGML_HIP_ERR_TYPE, "cpy: src0 must be F32 or F16 (Ggml.cs:4602-4619)");
     if (!wq_ok(dt))
@@ -728,6 +820,7 @@ int ggml_hip_compute_forward_add(const struct ggml_compute_params *params, const
                                  const struct ggml_tensor *src1, struct ggml_tensor *dst) {
     if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     const int t = src0->type;
     if (t == GGML_TYPE_F32) return binary_f32_seam(0, src0, src1, dst);      // ggml_compute_forward_add_f32 (Ggml.cs:4622-4682)
     if (!wq_ok(t))
@@ -772,6 +865,7 @@ int ggml_hip_compute_forward_mul(const struct ggml_compute_params *params, const
                                  const struct ggml_tensor *src1, struct ggml_tensor *dst) {
     if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     return binary_f32_seam(1, src0, src1, dst);
 }
 
@@ -780,6 +874,7 @@ int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, con
                                    const struct ggml_tensor *src1, struct ggml_tensor *dst) {
     if (!params || !src0 || !src1 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     if (src0->type != GGML_TYPE_F32 || src1->type != GGML_TYPE_F32 || dst->type != GGML_TYPE_F32) return fail(GGML_HIP_ERR_TYPE, "scale: F32 only (Ggml.cs:6786-6799)");
     if (nelem(src1) != 1) return fail(GGML_HIP_ERR_SHAPE, "scale: src1 must be a scalar (Ggml.cs:6755)");
     for (int i = 0; i < 4; ++i)
@@ -897,6 +992,7 @@ int ggml_hip_compute_forward_rms_norm_mul(const struct ggml_compute_params *para
                                           const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst) {
     if (!params || !x || !g || !norm_dst || !mul_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     return fused_pair_seam(0, x, g, norm_dst, mul_dst);
 }
 
@@ -905,6 +1001,7 @@ int ggml_hip_compute_forward_silu_mul(const struct ggml_compute_params *params, 
                                       const struct ggml_tensor *b, struct ggml_tensor *silu_dst, struct ggml_tensor *mul_dst) {
     if (!params || !a || !b || !silu_dst || !mul_dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     return fused_pair_seam(1, a, b, silu_dst, mul_dst);
 }
 
@@ -913,6 +1010,7 @@ int ggml_hip_compute_forward_rms_norm(const struct ggml_compute_params *params, 
                                       struct ggml_tensor *dst) {
     if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     return unary_f32_seam(0, src0, dst);
 }
 
@@ -921,6 +1019,7 @@ int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, cons
                                   struct ggml_tensor *dst) {
     if (!params || !src0 || !dst) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
     return unary_f32_seam(1, src0, dst);
 }
 

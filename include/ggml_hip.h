@@ -173,6 +173,19 @@ void ggml_hip_invalidate_all(void);
  * reference guarantees on return from ggml_graph_compute.  Calls nest; buffers are recycled across graphs. */
 int  ggml_hip_graph_begin(void);
 int  ggml_hip_graph_end(void);
+/* The same scope, NAMED: `key` (non-zero) identifies the graph the caller is about to run -- a hash over what decides the
+ * calls it will make: every node's op, the data pointers, types, ne / nb of the node and of its sources, and the scalar
+ * operands it reads on the host (the factor of a SCALE node).  Inside a scope the seams cost the host one kernel launch per
+ * node and the device -> host copies of all results go out together at the end; a named scope that needed nothing else is
+ * captured into a hipGraph the second time it is seen and replayed with ONE launch from the third time on (the seams
+ * return at once; leaf tensors are re-read from host memory by the captured copies, so their CONTENTS may change between
+ * runs -- a decoder's token loop).  Everything the key covers must be unchanged when a key is reused; a weight that is
+ * rewritten must be invalidated as always (ggml_hip_invalidate*), which also drops the captured scopes.  One device slot
+ * only; with several the call is ggml_hip_graph_begin.  (7B decoder layer at batch 1 through ggml_graph_compute: 439 us per
+ * graph with per-node copies, 97 us in a plain scope, see DESIGN 8 for the replayed figure.) */
+int  ggml_hip_graph_begin_keyed(uint64_t key);
+/* Named scopes so far by what became of them: observed clean, captured, replayed, refused (tests, tuning). */
+void ggml_hip_debug_scope_counters(uint64_t *observed, uint64_t *captured, uint64_t *replayed, uint64_t *refused);
 /* Bytes moved over PCIe by seam 1 so far and the number of src1 operands served from a resident dst (tests, tuning). */
 void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits);
 

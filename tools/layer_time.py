@@ -53,4 +53,9 @@ for _ in range(50):
 ts = np.sort(ts)
 print(f"N={N}: {gf.n_nodes} nodes, graph compute median {np.median(ts):.1f} us (p10 {ts[5]:.1f}, p90 {ts[45]:.1f}) = {np.median(ts) / gf.n_nodes:.1f} us per node; "
       f"result checksum {float(np.abs(G.tensor_f32(out)).sum()):.6g}")
+import ctypes as C  # noqa: E402
+from ggmlsharp_amd._lib import lib  # noqa: E402
+v = [C.c_uint64() for _ in range(4)]
+lib().ggml_hip_debug_scope_counters(*[C.byref(x) for x in v])
+print("named scopes: observed %d, captured %d, replayed %d, refused %d" % tuple(x.value for x in v))
 G.ggml_free(ctx)
