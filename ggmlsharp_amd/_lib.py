@@ -29,6 +29,7 @@ TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 20, Q4_1: 24, Q4_2: 10, Q4_3: 12, Q5_0: 22, Q
 
 GGML_OP_NONE, GGML_OP_ADD, GGML_OP_MUL_MAT, GGML_OP_CPY = 0, 2, 20, 22
 GGML_OP_SILU = 17
+GGML_OP_MUL, GGML_OP_RMS_NORM, GGML_OP_SCALE = 4, 19, 21
 GGML_TASK_INIT, GGML_TASK_COMPUTE, GGML_TASK_FINALIZE = 0, 1, 2
 
 OK, ERR_NO_DEVICE, ERR_TYPE, ERR_SHAPE, ERR_ARG, ERR_RUNTIME = 0, -1, -2, -3, -4, -5

@@ -145,12 +145,17 @@ int DeviceCtx::sync_all() {
     return e == hipSuccess ? GGML_HIP_OK : fail(GGML_HIP_ERR_RUNTIME, "stream synchronize: %s", hipGetErrorString(e));
 }
 void *DeviceCtx::take(size_t n) {
+    // best fit: a graph that is computed again asks for the same sizes again and must find every one of them (a first fit
+    // hands a larger buffer to a smaller request and sends the larger request to hipMalloc -- four computes of a decoder layer
+    // until the pool had settled, and an allocation keeps a named scope from being captured)
+    size_t best = pool.size();
     for (size_t i = 0; i < pool.size(); ++i)
-        if (pool[i].bytes >= n && pool[i].bytes <= 2 * n + 4096) {
-            void *p = pool[i].p;
-            pool.erase(pool.begin() + (long)i);
-            return p;
-        }
+        if (pool[i].bytes >= n && pool[i].bytes <= 2 * n + 4096 && (best == pool.size() || pool[i].bytes < pool[best].bytes)) best = i;
+    if (best != pool.size()) {
+        void *p = pool[best].p;
+        pool.erase(pool.begin() + (long)best);
+        return p;
+    }
     scope_dirty();                                 // (an allocation is not something a capture may contain)
     void *p = nullptr;
     if (hipMalloc(&p, n) != hipSuccess) return nullptr;

@@ -893,7 +893,7 @@ int ggml_hip_compute_forward_scale(const struct ggml_compute_params *params, con
         rc = c->make_current();
         if (rc) return rc;
         if (g == 0) {
-            if (in_graph) { rc = c->pay_and_sync(); if (rc) return rc; }      // the scalar is read from host memory
+            if (in_graph) { rc = c->before_host_read(src1->data, 4); if (rc) return rc; }      // the scalar is read from host memory (and is part of a named scope's key)
             v = *(const float *)src1->data;
         }
         // the reference scales dst's own memory: when dst is not a view of src0 that memory is whatever it held before, and

@@ -1,0 +1,164 @@
+"""GPU tests (-m gpu) of the graph scope's host side (include/ggml_hip.h ggml_hip_graph_begin / _begin_keyed): results owed to the
+host and paid together, named scopes captured and replayed -- every run must leave every node's data in host memory, equal bit
+for bit to the node-by-node seams, whatever the scope did behind the scenes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ggmlsharp_amd import ggml as G
+from ggmlsharp_amd import _lib
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ggmlsharp_amd import device
+    device.init(0)
+    return device
+
+
+def _counters():
+    v = [C.c_uint64() for _ in range(4)]
+    _lib.lib().ggml_hip_debug_scope_counters(*[C.byref(x) for x in v])
+    return tuple(int(x.value) for x in v)        # observed, captured, replayed, refused
+
+
+def _layer(ctx, rng, K, M, F, N):
+    """a decoder-layer-shaped graph of the ops on this path; returns (graph, leaves, every node in order)"""
+    def f32(k, n, scale=1.0):
+        t = G.ggml_new_tensor_2d(ctx, G.F32, k, n)
+        G.tensor_f32(t)[:] = (rng.standard_normal((n, k)) * scale).astype(np.float32).reshape(1, 1, n, k)
+        return t
+
+    def q(ty, k, m):
+        t = G.ggml_new_tensor_2d(ctx, ty, k, m)
+        G.tensor_bytes(t)[:] = O.quantize_row(ty, rng.standard_normal((m, k)).astype(np.float32)).reshape(-1)
+        return t
+
+    x, g1, g2 = f32(K, N, 2.0), f32(K, N), f32(K, N)
+    S = G.ggml_new_tensor_1d(ctx, G.F32, 1)
+    G.tensor_f32(S)[:] = 0.25
+    wq, wk, wo = q(G.Q4_0, K, M), q(G.Q8_0, K, M), q(G.Q4_0, M, K)
+    w1, w3, w2 = q(G.Q4_0, K, F), q(G.Q4_0, K, F), q(G.Q5_0, F, K)
+    cur = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, x), g1)
+    qq, kk = G.ggml_mul_mat(ctx, wq, cur), G.ggml_mul_mat(ctx, wk, cur)
+    a = G.ggml_scale(ctx, G.ggml_add(ctx, qq, kk), S)
+    h = G.ggml_add(ctx, G.ggml_mul_mat(ctx, wo, a), x)
+    cur2 = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, h), g2)
+    u, gt = G.ggml_mul_mat(ctx, w1, cur2), G.ggml_mul_mat(ctx, w3, cur2)
+    s = G.ggml_mul(ctx, G.ggml_silu(ctx, u), gt)
+    out = G.ggml_add(ctx, G.ggml_mul_mat(ctx, w2, s), h)
+    gf = G.ggml_build_forward(out)
+    nodes = [gf.nodes[i] for i in range(gf.n_nodes)]
+    return gf, (x, g1, g2, S), nodes
+
+
+def _node_by_node(gf):
+    """the same nodes through the single seams, each call on its own (no scope): the reference for every bit"""
+    L = _lib.lib()
+    p = _lib.ggml_compute_params(_lib.GGML_TASK_COMPUTE, 0, 1, 0, None)
+    for i in range(gf.n_nodes):
+        n = gf.nodes[i].contents
+        op = n.op
+        if op == _lib.GGML_OP_MUL_MAT:
+            rc = L.ggml_hip_compute_forward_mul_mat(C.byref(p), n.src0, n.src1, gf.nodes[i])
+        elif op == _lib.GGML_OP_ADD:
+            rc = L.ggml_hip_compute_forward_add(C.byref(p), n.src0, n.src1, gf.nodes[i])
+        elif op == _lib.GGML_OP_MUL:
+            rc = L.ggml_hip_compute_forward_mul(C.byref(p), n.src0, n.src1, gf.nodes[i])
+        elif op == _lib.GGML_OP_SCALE:
+            rc = L.ggml_hip_compute_forward_scale(C.byref(p), n.src0, n.src1, gf.nodes[i])
+        elif op == _lib.GGML_OP_RMS_NORM:
+            rc = L.ggml_hip_compute_forward_rms_norm(C.byref(p), n.src0, gf.nodes[i])
+        elif op == _lib.GGML_OP_SILU:
+            rc = L.ggml_hip_compute_forward_silu(C.byref(p), n.src0, gf.nodes[i])
+        else:
+            raise AssertionError(op)
+        _lib.check(rc, f"node {i}")
+
+
+def _snapshot(nodes):
+    return [np.array(G.tensor_f32(t), copy=True) for t in nodes]
+
+
+@pytest.mark.parametrize("N", [1, 3, 20])
+def test_named_scope_is_captured_replayed_and_tracks_its_leaves(dev, N):
+    """six computes of one graph with new leaf CONTENTS each time: observed, captured, then replayed -- every node's host
+    data equals the node-by-node seams' bit for bit every time; then a weight is rewritten (invalidate) and it still does."""
+    rng = np.random.default_rng(7 + N)
+    K, M, F = 256, 192, 320
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    try:
+        gf, (x, g1, g2, S), nodes = _layer(ctx, rng, K, M, F, N)
+        c0 = _counters()
+        for it in range(6):
+            G.tensor_f32(x)[:] = (rng.standard_normal((N, K)) * (1 + it)).astype(np.float32).reshape(1, 1, N, K)
+            _lib.lib().ggml_hip_invalidate_range(x.contents.data, N * K * 4)     # (what ggml_set_f32 does; x is no weight: nothing is dropped)
+            G.ggml_graph_compute(ctx, gf)
+            got = _snapshot(nodes)
+            _node_by_node(gf)
+            ref = _snapshot(nodes)
+            for i, (a, b) in enumerate(zip(got, ref)):
+                assert np.array_equal(a, b), (it, i)
+        c1 = _counters()
+        # (the first compute uploads the weights, the node-by-node calls in between grow a scratch buffer once: observed and
+        # captured after that, replayed from then on)
+        assert c1[0] - c0[0] >= 1 and c1[1] - c0[1] >= 1 and c1[2] - c0[2] >= 2 and c1[3] == c0[3], (c0, c1)
+        # the scale factor is read on the host: a new value is a new key (observed again, not replayed with the old factor)
+        G.tensor_f32(S)[:] = 0.5
+        G.ggml_graph_compute(ctx, gf)
+        got = _snapshot(nodes)
+        _node_by_node(gf)
+        for i, (a, b) in enumerate(zip(got, _snapshot(nodes))):
+            assert np.array_equal(a, b), ("scale", i)
+        c2 = _counters()
+        assert c2[2] == c1[2], "a graph with another scale factor must not replay the captured one"
+        G.tensor_f32(S)[:] = 0.25
+        # a weight rewritten in place + invalidate: the captured scope (which holds the old device copy) is dropped
+        w = nodes[2].contents.src0                                   # wq
+        wb = G.tensor_bytes(w)
+        wb[:] = O.quantize_row(G.Q4_0, rng.standard_normal((M, K)).astype(np.float32)).reshape(-1)
+        _lib.lib().ggml_hip_invalidate(w.contents.data)
+        for it in range(4):
+            G.ggml_graph_compute(ctx, gf)
+            got = _snapshot(nodes)
+            _node_by_node(gf)
+            for i, (a, b) in enumerate(zip(got, _snapshot(nodes))):
+                assert np.array_equal(a, b), ("rewritten weight", it, i)
+        c3 = _counters()
+        assert c3[1] - c2[1] == 1 and c3[2] - c2[2] >= 1, (c2, c3)
+    finally:
+        G.ggml_free(ctx)
+
+
+def test_plain_scope_pays_everything_it_owes(dev):
+    """ggml_hip_graph_begin (no key): one launch per node, the host copies together at the end -- including a tensor that is
+    overwritten in place (scale) and a leaf that two nodes read."""
+    rng = np.random.default_rng(3)
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    try:
+        gf, leaves, nodes = _layer(ctx, rng, 128, 96, 160, 2)
+        L = _lib.lib()
+        p = _lib.ggml_compute_params(_lib.GGML_TASK_COMPUTE, 0, 1, 0, None)
+        _lib.check(L.ggml_hip_graph_begin(), "begin")
+        for i in range(gf.n_nodes):
+            n = gf.nodes[i].contents
+            f = {_lib.GGML_OP_MUL_MAT: L.ggml_hip_compute_forward_mul_mat, _lib.GGML_OP_ADD: L.ggml_hip_compute_forward_add,
+                 _lib.GGML_OP_MUL: L.ggml_hip_compute_forward_mul, _lib.GGML_OP_SCALE: L.ggml_hip_compute_forward_scale}.get(n.op)
+            if f is not None:
+                _lib.check(f(C.byref(p), n.src0, n.src1, gf.nodes[i]), f"node {i}")
+            elif n.op == _lib.GGML_OP_RMS_NORM:
+                _lib.check(L.ggml_hip_compute_forward_rms_norm(C.byref(p), n.src0, gf.nodes[i]), f"node {i}")
+            else:
+                _lib.check(L.ggml_hip_compute_forward_silu(C.byref(p), n.src0, gf.nodes[i]), f"node {i}")
+        _lib.check(L.ggml_hip_graph_end(), "end")
+        got = _snapshot(nodes)
+        _node_by_node(gf)
+        for i, (a, b) in enumerate(zip(got, _snapshot(nodes))):
+            assert np.array_equal(a, b), i
+    finally:
+        G.ggml_free(ctx)
