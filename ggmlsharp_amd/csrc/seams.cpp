@@ -291,6 +291,22 @@ void ggml_hip_invalidate_range(const void *host_ptr, size_t bytes) {
     }
 }
 
+/* A CPU node inside a graph scope is about to READ host memory [host_ptr, host_ptr + bytes) (a source produced by an
+ * offloaded node): whatever the scope still owes that range is copied and waited for.  Cheap when nothing is owed. */
+int ggml_hip_host_read(const void *host_ptr, size_t bytes) {
+    if (!host_ptr || bytes == 0) return GGML_HIP_OK;
+    int rc = GGML_HIP_OK;
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        if (c->owed.empty() && !c->d2h_busy) continue;
+        int r = c->make_current();
+        if (!r) r = c->before_host_read(host_ptr, bytes);
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+
 void ggml_hip_invalidate_all(void) {
     for (int i = 0; i < n_slots(); ++i) {
         DeviceCtx *c = slot(i);

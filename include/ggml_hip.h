@@ -173,6 +173,11 @@ void ggml_hip_invalidate_all(void);
  * reference guarantees on return from ggml_graph_compute.  Calls nest; buffers are recycled across graphs. */
 int  ggml_hip_graph_begin(void);
 int  ggml_hip_graph_end(void);
+/* Inside a scope the host copy of a node's result is OWED, not made at once (the copies of a scope go out together: one
+ * launch per node is all a node costs the host).  A node the host computes itself between offloaded ones calls this for each
+ * source it is about to read -- the range is paid and waited for when it is owed or still in flight, else nothing happens --
+ * and ggml_hip_invalidate_range for what it wrote (a resident copy of that range is stale). */
+int  ggml_hip_host_read(const void *host_ptr, size_t bytes);
 /* The same scope, NAMED: `key` (non-zero) identifies the graph the caller is about to run -- a hash over what decides the
  * calls it will make: every node's op, the data pointers, types, ne / nb of the node and of its sources, and the scalar
  * operands it reads on the host (the factor of a SCALE node).  Inside a scope the seams cost the host one kernel launch per

@@ -162,3 +162,37 @@ def test_plain_scope_pays_everything_it_owes(dev):
             assert np.array_equal(a, b), i
     finally:
         G.ggml_free(ctx)
+
+
+def test_host_read_inside_a_scope_pays_what_is_owed(dev):
+    """a node the host computes itself between offloaded nodes: ggml_hip_host_read makes its source current, and what it
+    writes (followed by ggml_hip_invalidate_range) is what the next offloaded node uploads."""
+    rng = np.random.default_rng(11)
+    K, N = 256, 3
+    ctx = G.ggml_init(16 * 1024 * 1024)
+    try:
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        Y = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        x = rng.standard_normal((N, K)).astype(np.float32)
+        y = rng.standard_normal((N, K)).astype(np.float32)
+        G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
+        G.tensor_f32(Y)[:] = y.reshape(1, 1, N, K)
+        t_add = G.ggml_add(ctx, X, Y)
+        t_mul = G.ggml_mul(ctx, t_add, Y)
+        G.tensor_f32(t_add)[:] = -7.0                       # poison: the host copy must really be written
+        L = _lib.lib()
+        p = _lib.ggml_compute_params(_lib.GGML_TASK_COMPUTE, 0, 1, 0, None)
+        _lib.check(L.ggml_hip_graph_begin(), "begin")
+        a = t_add.contents
+        _lib.check(L.ggml_hip_compute_forward_add(C.byref(p), a.src0, a.src1, t_add), "add")
+        _lib.check(L.ggml_hip_host_read(a.data, N * K * 4), "host read")
+        got = np.array(G.tensor_f32(t_add)[0, 0], copy=True)
+        assert np.array_equal(got, x + y)
+        G.tensor_f32(t_add)[:] = (got * 2).reshape(1, 1, N, K)          # the "CPU node": in place
+        L.ggml_hip_invalidate_range(a.data, N * K * 4)
+        m = t_mul.contents
+        _lib.check(L.ggml_hip_compute_forward_mul(C.byref(p), m.src0, m.src1, t_mul), "mul")
+        _lib.check(L.ggml_hip_graph_end(), "end")
+        assert np.array_equal(G.tensor_f32(t_mul)[0, 0], (x + y) * 2 * y)
+    finally:
+        G.ggml_free(ctx)
