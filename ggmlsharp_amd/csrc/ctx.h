@@ -100,12 +100,15 @@ struct DeviceCtx {
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         std::vector<Resident> buffers;             // the scope's resident buffers, owned by the entry while it can be replayed
         uint64_t scratch_sig = 0;                  // the scratch pointers baked into the captured launches
+        std::vector<std::pair<const void *, size_t>> leaves;   // host tensors the scope uploaded when it was observed: prefetched together
         int seen = 0, strikes = 0; bool refused = false;   // refused: a capture failed outright, or was cut short three times
     };
     std::map<uint64_t, Captured> captured;
     uint64_t scope_key = 0;
     int scope_mode = 0;                            // 0 plain, 1 observing, 2 capturing, 3 replaying
     bool scope_clean = true;
+    std::vector<std::pair<const void *, size_t>> scope_leaves;   // (observing) whole host tensors uploaded so far in this scope
+    void note_leaf(const void *host, size_t bytes) { if (scope_mode == 1) scope_leaves.emplace_back(host, bytes); }
     uint64_t n_observed = 0, n_captured = 0, n_replayed = 0, n_refused = 0;   // keyed scopes by what became of them (tests, tuning)
     uint64_t scratch_sig() const;
     void scope_dirty();                            // something other than a compute-stream launch is about to happen

@@ -86,6 +86,7 @@ int operand_f32(DeviceCtx *c, bool in_graph, const ggml_tensor *t, Scratch &scra
         // the upload stays resident for the rest of the scope: a leaf used by several nodes (the residual stream) moves once
         void *keep = c->resident_buffer(t->data, bytes);
         if (!keep) return -1;
+        c->note_leaf(t->data, bytes);
         if (hipMemcpyAsync(keep, t->data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
         c->h2d_bytes += bytes;
         *out = (const float *)keep;
@@ -329,6 +330,7 @@ static int graph_begin(uint64_t key) {
     if (rc) return rc;
     c->scope_key = key;
     c->scope_clean = true;
+    c->scope_leaves.clear();
     c->scope_mode = 1;
     auto it = c->captured.find(key);
     if (it == c->captured.end()) return GGML_HIP_OK;                 // first sight: observe
@@ -345,7 +347,23 @@ static int graph_begin(uint64_t key) {
     }
     // observed clean before: capture this run (thread-local mode: other threads' HIP calls are none of its business)
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) c->scope_mode = 2;
-    else { (void)hipGetLastError(); e.refused = true; c->scope_mode = 0; }
+    else { (void)hipGetLastError(); e.refused = true; c->scope_mode = 0; return GGML_HIP_OK; }
+    // the leaves the scope uploaded one by one when it was observed come down TOGETHER, as the first node of the captured
+    // graph (one launch through the device mapping of the pool instead of a copy node each); the seams then find them resident
+    std::vector<const void *> src; std::vector<void *> dst; std::vector<size_t> nb;
+    for (const auto &lf : e.leaves) {
+        if (lf.second % 4 != 0 || (uintptr_t)lf.first % 4 != 0 || lf.second > (8u << 20)) continue;
+        const void *m = host_range_device_ptr(lf.first, lf.second);
+        if (!m || c->resident_lookup(lf.first, lf.second)) continue;
+        void *d = c->resident_buffer(lf.first, lf.second);
+        if (!d) break;
+        src.push_back(m); dst.push_back(d); nb.push_back(lf.second);
+        c->h2d_bytes += lf.second;
+    }
+    for (size_t i = 0; i < src.size() && c->scope_mode == 2; i += 32) {
+        const int n = (int)(src.size() - i < 32 ? src.size() - i : 32);
+        if (launch_scatter_copy(src.data() + i, dst.data() + i, nb.data() + i, n, c->stream) != hipSuccess) { (void)hipGetLastError(); c->scope_dirty(); }
+    }
     return GGML_HIP_OK;
 }
 int ggml_hip_graph_begin(void) { return graph_begin(0); }
@@ -395,7 +413,7 @@ int ggml_hip_graph_end(void) {
             r = c->pay_and_sync();                       // every node's dst is on the host from here on
             if (mode == 1) {
                 DeviceCtx::Captured &e = c->captured[c->scope_key];
-                if (clean && !r) { e.seen = 1; ++c->n_observed; }     // (a scope that was not clean is simply observed again next time)
+                if (clean && !r) { e.seen = 1; e.leaves = c->scope_leaves; ++c->n_observed; }     // (a scope that was not clean is simply observed again next time)
             }
         }
         if (outer) c->scope_mode = 0;
@@ -635,6 +653,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 if (in_graph && G == 1 && d_res[0] && ne11 <= chunk && (x_res[0] || (epi && epi->pro_x) || src1->nb[1] == (uint64_t)ne10 * 4)) {
                     const bool pro = epi && epi->pro_x;
                     if (!x_res[0] && !pro) {
+                        if (nslice == 1) c->note_leaf(src1->data, (size_t)ne11 * ne10 * 4);
                         e = hipMemcpyAsync(c->src1.p, x_host, (size_t)ne11 * ne10 * 4, hipMemcpyHostToDevice, c->stream);
                         if (e != hipSuccess) break;
                         c->h2d_bytes += (size_t)ne11 * ne10 * 4;
