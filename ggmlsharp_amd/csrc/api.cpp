@@ -807,6 +807,37 @@ int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_
     return ggml_hip_mul_mat_epilogue_dev(w, d_y, N, w->K, d_dst, ldd, d_work, work_bytes, mode, d_addend, ld_add, d_dst2, ldd2, scale, stream);
 }
 
+/* ---- several weight matrices behind ONE activation matrix (q / k / v, gate / up): one launch for N <= 4 ---- */
+static bool multi_ok(const ggml_hip_weight *const *w, int n_w, int64_t N) {
+    if (!w || n_w < 2 || n_w > 4 || !gemv_fused_has_epilogue(N)) return false;
+    for (int i = 0; i < n_w; ++i)
+        if (!w[i] || !is_q(w[i]->type) || w[i]->ext_type != 0 || w[i]->type != w[0]->type || w[i]->K != w[0]->K || w[i]->device != w[0]->device || w[i]->M <= 0)
+            return false;
+    return true;
+}
+int ggml_hip_mul_mat_multi_fused(const ggml_hip_weight *const *w, int n_w, int64_t N) { return multi_ok(w, n_w, N) ? 1 : 0; }
+
+int ggml_hip_mul_mat_multi_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N, float *const *d_dst,
+                               const int64_t *ldd, const float *d_g, int64_t ld_g, float *d_norm, float *d_y, void *stream) {
+    if (!w || !d_src1 || !d_dst || !ldd) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (!multi_ok(w, n_w, N)) return fail(GGML_HIP_ERR_SHAPE, "multi mul_mat: 2..4 quantized matrices of one type and K on one device, N <= 4");
+    for (int i = 0; i < n_w; ++i)
+        if (!d_dst[i] || ldd[i] < w[i]->M) return fail(GGML_HIP_ERR_SHAPE, "multi mul_mat: dst %d missing or its row stride smaller than a row", i);
+    if (ld1 < w[0]->K) return fail(GGML_HIP_ERR_SHAPE, "row stride smaller than a row");
+    int rc = weight_device_current(w[0]);
+    if (rc) return rc;
+    rc = check_src1_alignment(d_src1, ld1);
+    if (rc) return rc;
+    const bool with_pro = d_g != nullptr;
+    if (with_pro) {
+        if (!d_norm || !d_y || ld_g < w[0]->K) return fail(GGML_HIP_ERR_ARG, "prologue: norm / mul outputs missing or g too narrow");
+        if (!prologue_is_fused(w[0], N, d_src1, ld1, d_g, ld_g, d_norm, d_y)) return fail(GGML_HIP_ERR_SHAPE, "prologue: operands must be 16-byte aligned with row strides that are multiples of 4");
+    }
+    const mm_prologue pro = {d_g, ld_g, d_norm, d_y};
+    HIP_TRY(launch_gemv_q_fused_multi(w, n_w, d_src1, ld1, with_pro ? &pro : nullptr, N, d_dst, ldd, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
 int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_norm, float *d_y, int64_t nrows, int64_t k, void *stream) {
     if (nrows <= 0 || k <= 0) return GGML_HIP_OK;
     if (!d_x || !d_g || !d_norm || !d_y) return fail(GGML_HIP_ERR_ARG, "null argument");

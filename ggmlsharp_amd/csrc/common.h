@@ -269,6 +269,19 @@ hipError_t launch_rms_norm_mul_f32(const float *x, const float *g, float *n_out,
 hipError_t launch_silu_mul_f32(const float *a, const float *b, float *s_out, float *y_out, int64_t n, hipStream_t st);
 // gemv.hip / gemm_q.hip / dense.hip
 hipError_t launch_gemv_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+// Up to four weight matrices of one type and K behind ONE activation matrix (the q / k / v or the gate / up projections of a
+// transformer block): the fused mat-vec walks the row tiles of all of them in one launch.  Row tiles [tile_end[i-1], tile_end[i])
+// belong to matrix i; every row's arithmetic is what the single-matrix call does.
+struct mv_set {
+    int n;
+    int tile_end[4];
+    const uint8_t *qs[4];
+    const uint32_t *gs[4];
+    float *dst[4];
+    int64_t M[4], Mpad[4], ldd[4];
+};
+hipError_t launch_gemv_q_fused_multi(const ggml_hip_weight *const *w, int n_w, const float *x, int64_t ld1, const mm_prologue *pro, int64_t N,
+                                     float *const *dst, const int64_t *ldd, hipStream_t st);
 hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t ld1, int64_t N, float *dst, int64_t ldd,
                                hipStream_t st, const mm_epilogue *ep = nullptr);
 bool gemv_fused_has_epilogue(int64_t N);       // the kernel form that serves N applies an mm_epilogue itself

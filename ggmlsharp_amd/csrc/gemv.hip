@@ -14,6 +14,7 @@
 //   only two xor-shuffles plus one LDS pass to combine -- no atomics, fixed summation tree (deterministic).
 //   The Q8 activation vector (written by K1) is staged into LDS once per 128 k-blocks and read as broadcasts.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -287,12 +288,11 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
 // SC: all of K fits one chunk of 128 k-blocks (K <= 4096), a launch-time fact -- two instantiations instead of one kernel
 // that carries both schedules in its registers (the combined form spilled: 24 B of scratch at 128 registers)
 // PRO: the rms_norm -> mul prologue (common.h mm_prologue): the quantized row is (x * rms_scale) * g, computed here.
-template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO = false>
-__global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
-    const uint8_t *__restrict__ qs, const uint32_t *__restrict__ gs,
-                                                                const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
-                                                                int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles,
-                                                                const mm_epilogue ep, const mm_prologue pro) {
+// MULTI: several weight matrices behind one activation matrix (common.h mv_set) -- its own kernels below: with the per-item
+// selects in every kernel the single-matrix call lost 5-12 % (4096 x 4096: 4.6 -> 5.2 us)
+template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO, bool MULTI>
+__device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *__restrict__ x, int64_t ld1, int64_t nbk, int N, int ntiles,
+                                                const mm_epilogue &ep, const mm_prologue &pro) {
     static_assert(GV_ROWS == 16 && GV_NKQ == 4, "lane = (row, k-lane) with 4 k-lanes per wave");
     constexpr int CH = GV_CHUNK;                       // k-blocks per chunk, all waves together
     constexpr int BPL = CH / GV_WORKERS;               // k-blocks per lane per chunk (4)
@@ -330,6 +330,24 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
         // shared -- with the tile-major side image they cost 3-6 % at M >= 11008)
         return (int)blockIdx.x + (w / nchunks) * (int)gridDim.x;
     };
+    // the matrix a global row tile belongs to (common.h mv_set; one matrix: the selects fold to its fields) and the tile in it
+    struct Sel { const uint8_t *qs; const uint32_t *gs; float *dst; int64_t M, Mpad, ldd; int tile; };
+    auto select = [&](int gt) {
+        Sel o;
+        if constexpr (!MULTI) {
+            o.qs = ws.qs[0]; o.gs = ws.gs[0]; o.dst = ws.dst[0]; o.M = ws.M[0]; o.Mpad = ws.Mpad[0]; o.ldd = ws.ldd[0]; o.tile = gt;
+            return o;
+        }
+        const int k = (gt >= ws.tile_end[0]) + (gt >= ws.tile_end[1]) + (gt >= ws.tile_end[2]);
+        o.qs = k == 0 ? ws.qs[0] : k == 1 ? ws.qs[1] : k == 2 ? ws.qs[2] : ws.qs[3];
+        o.gs = k == 0 ? ws.gs[0] : k == 1 ? ws.gs[1] : k == 2 ? ws.gs[2] : ws.gs[3];
+        o.dst = k == 0 ? ws.dst[0] : k == 1 ? ws.dst[1] : k == 2 ? ws.dst[2] : ws.dst[3];
+        o.M = k == 0 ? ws.M[0] : k == 1 ? ws.M[1] : k == 2 ? ws.M[2] : ws.M[3];
+        o.Mpad = k == 0 ? ws.Mpad[0] : k == 1 ? ws.Mpad[1] : k == 2 ? ws.Mpad[2] : ws.Mpad[3];
+        o.ldd = k == 0 ? ws.ldd[0] : k == 1 ? ws.ldd[1] : k == 2 ? ws.ldd[2] : ws.ldd[3];
+        o.tile = gt - (k == 0 ? 0 : k == 1 ? ws.tile_end[0] : k == 2 ? ws.tile_end[1] : ws.tile_end[2]);
+        return o;
+    };
     // (wider batches keep one register set: their activation registers already fill the budget, and the second set cost
     // them a resident workgroup -- 32000 x 4096 x 8: 50.5 us with it against 41.9 without)
     constexpr bool PF = NC == 1 && SC;
@@ -338,7 +356,11 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     uint32_t hb[HAS_H ? BPL : 1], hbn[PF && HAS_H ? BPL : 1];
     // the weight stream of one item (4 x 16 B + scales in flight per lane)
     auto load_item = [&](int w, uint4 *Q, uint4 *Q2, float *DW, float *MW, uint32_t *HB) {
-        const int tl = tile_of(w);
+        const Sel sel = select(tile_of(w));
+        const uint8_t *const qs = sel.qs;
+        const uint32_t *const gs = sel.gs;
+        const int64_t Mpad = sel.Mpad;
+        const int tl = sel.tile;
         const int64_t row = (int64_t)tl * GV_ROWS + r;  // < Mpad by construction
         const int64_t cb = (int64_t)(w % nchunks) * CH;
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
@@ -405,7 +427,10 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
         const int cidx = w % nchunks;
         const int64_t cb = (int64_t)cidx * CH;
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
-        const int tile = tile_of(w);
+        const Sel sel = select(tile_of(w));
+        const int tile = sel.tile;
+        float *const dst = sel.dst;
+        const int64_t M = sel.M, ldd = sel.ldd;
         if (cidx == 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
@@ -575,6 +600,24 @@ __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fu
     }
 }
 
+// one weight matrix: the arguments as they always were (the set of one is built in registers; a kernel that takes the whole
+// mv_set in its argument segment ran the single-matrix call 5 % slower: 4096 x 4096 4.60 -> 4.85 us)
+template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO = false>
+__global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
+    const uint8_t *__restrict__ qs, const uint32_t *__restrict__ gs, const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
+    int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles, const mm_epilogue ep, const mm_prologue pro) {
+    mv_set ws;
+    ws.n = 1; ws.qs[0] = qs; ws.gs[0] = gs; ws.dst[0] = dst; ws.M[0] = M; ws.Mpad[0] = Mpad; ws.ldd[0] = ldd;
+    gemv_fused_body<TYPE, NC, GV_ROWS, SC, PRO, false>(ws, x, ld1, nbk, N, ntiles, ep, pro);
+}
+// several weight matrices behind one activation matrix (common.h mv_set)
+template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO>
+__global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fused_multi_kernel(
+    const mv_set ws, const float *__restrict__ x, int64_t ld1, int64_t nbk, int N, int ntiles, const mm_prologue pro) {
+    const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
+    gemv_fused_body<TYPE, NC, GV_ROWS, SC, PRO, true>(ws, x, ld1, nbk, N, ntiles, ep, pro);
+}
+
 // the prologue of the call in flight on this host thread (launch_gemv_q_fused_pro sets it around the type dispatch)
 thread_local const mm_prologue *t_prologue = nullptr;
 
@@ -650,6 +693,52 @@ hipError_t launch_gemv_q_fused(const ggml_hip_weight *w, const float *x, int64_t
                                hipStream_t st, const mm_epilogue *ep) {
     act_planes none = {nullptr, nullptr, nullptr, 0};
     return launch_any<true>(w, x, ld1, none, N, dst, ldd, st, ep);
+}
+
+namespace {
+template <int TYPE>
+hipError_t launch_multi_typed(const mv_set &ws, const float *x, int64_t ld1, const mm_prologue *pro, int64_t nbk, int64_t N, int ntiles, hipStream_t st) {
+    const mm_prologue none{nullptr, 0, nullptr, nullptr};
+    const bool sc = nbk <= GV_CHUNK;
+    const int cap = (N <= 1 && sc) ? GV_PF_WGS : GV_MAX_WGS;
+    dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
+#define GVM(NC) do { \
+        if (pro) { if (sc) gemv_fused_multi_kernel<TYPE, NC, 16, true, true><<<grid, GV_THREADS, 0, st>>>(ws, x, ld1, nbk, (int)N, ntiles, *pro); \
+                   else gemv_fused_multi_kernel<TYPE, NC, 16, false, true><<<grid, GV_THREADS, 0, st>>>(ws, x, ld1, nbk, (int)N, ntiles, *pro); } \
+        else if (sc) gemv_fused_multi_kernel<TYPE, NC, 16, true, false><<<grid, GV_THREADS, 0, st>>>(ws, x, ld1, nbk, (int)N, ntiles, none); \
+        else gemv_fused_multi_kernel<TYPE, NC, 16, false, false><<<grid, GV_THREADS, 0, st>>>(ws, x, ld1, nbk, (int)N, ntiles, none); } while (0)
+    if (N <= 1) GVM(1);
+    else if (N <= 2) GVM(2);
+    else GVM(4);
+#undef GVM
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_gemv_q_fused_multi(const ggml_hip_weight *const *w, int n_w, const float *x, int64_t ld1, const mm_prologue *pro, int64_t N,
+                                     float *const *dst, const int64_t *ldd, hipStream_t st) {
+    if (n_w < 1 || n_w > 4 || N < 1 || N > 4 || GV_OLD_FUSED) return hipErrorNotSupported;
+    mv_set ws;
+    memset(&ws, 0, sizeof ws);
+    ws.n = n_w;
+    int ntiles = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < n_w) {
+            if (w[i]->type != w[0]->type || w[i]->nbk != w[0]->nbk || w[i]->M <= 0) return hipErrorInvalidValue;
+            ntiles += (int)((w[i]->M + 15) / 16);
+            ws.qs[i] = w[i]->qs; ws.gs[i] = w[i]->gs; ws.dst[i] = dst[i]; ws.M[i] = w[i]->M; ws.Mpad[i] = w[i]->Mpad; ws.ldd[i] = ldd[i];
+        }
+        ws.tile_end[i] = ntiles;
+    }
+    switch (w[0]->type) {
+    case GGML_TYPE_Q4_0: return launch_multi_typed<GGML_TYPE_Q4_0>(ws, x, ld1, pro, w[0]->nbk, N, ntiles, st);
+    case GGML_TYPE_Q4_1: return launch_multi_typed<GGML_TYPE_Q4_1>(ws, x, ld1, pro, w[0]->nbk, N, ntiles, st);
+    case GGML_TYPE_Q5_0: return launch_multi_typed<GGML_TYPE_Q5_0>(ws, x, ld1, pro, w[0]->nbk, N, ntiles, st);
+    case GGML_TYPE_Q4_2: return launch_multi_typed<GGML_TYPE_Q4_2>(ws, x, ld1, pro, w[0]->nbk, N, ntiles, st);
+    case GGML_TYPE_Q5_1: return launch_multi_typed<GGML_TYPE_Q5_1>(ws, x, ld1, pro, w[0]->nbk, N, ntiles, st);
+    case GGML_TYPE_Q8_0: return launch_multi_typed<GGML_TYPE_Q8_0>(ws, x, ld1, pro, w[0]->nbk, N, ntiles, st);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 bool gemv_fused_has_epilogue(int64_t N) { return N >= 1 && N <= 4 && !GV_OLD_FUSED; }

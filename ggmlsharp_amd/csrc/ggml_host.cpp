@@ -12,7 +12,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <vector>
 
 static_assert(sizeof(ggml_object) == 32, "TypeDefinitions.cs:48-56");
 static_assert(sizeof(ggml_context) == 88, "TypeDefinitions.cs:32-46");
@@ -364,7 +363,9 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
     // a gated feed-forward, mul(silu(u), g) -- sits a few nodes further on is run right in front of it, so that the pair goes
     // down as one launch.  The walk puts g's producers between the two; a node may move past them when none of them reads what
     // it writes or writes what it reads or writes.
-    std::vector<ggml_tensor *> order(cgraph->nodes, cgraph->nodes + cgraph->n_nodes);
+    static thread_local ggml_tensor *order[GGML_MAX_NODES];     // (a plain array: the test-support library exports ggml_* only)
+    const int n_order = cgraph->n_nodes;
+    for (int i = 0; i < n_order; ++i) order[i] = cgraph->nodes[i];
     auto range_of = [](const ggml_tensor *t, const uint8_t **a, const uint8_t **b) {
         *a = (const uint8_t *)t->data; *b = *a + ggml_nbytes(t);
     };
@@ -374,38 +375,38 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         range_of(x, &a0, &a1); range_of(y, &b0, &b1);
         return a0 < b1 && b0 < a1;
     };
-    for (int i = 0; i + 2 < (int)order.size(); ++i) {
-        ggml_tensor *s = order[(size_t)i];
+    for (int i = 0; i + 2 < n_order; ++i) {
+        ggml_tensor *s = order[i];
         if (s->op != GGML_OP_SILU || !s->src0 || s->data == s->src0->data) continue;
         int j = -1;
-        for (int k = i + 2; k < (int)order.size() && k <= i + 4; ++k) {
-            ggml_tensor *m = order[(size_t)k];
+        for (int k = i + 2; k < n_order && k <= i + 4; ++k) {
+            ggml_tensor *m = order[k];
             if (m->op == GGML_OP_MUL && (m->src0 == s || m->src1 == s) && m->src0 != m->src1 && m->data != s->data) { j = k; break; }
         }
         if (j < 0) continue;
         bool ok = true;
         for (int k = i + 1; k < j && ok; ++k) {
-            ggml_tensor *t = order[(size_t)k];
+            ggml_tensor *t = order[k];
             ok = t->op != GGML_OP_NONE && t->src0 != s && t->src1 != s && !overlaps(t->src0, s) && !overlaps(t->src1, s) && !overlaps(t, s) &&
                  !overlaps(t, s->src0);
         }
         if (!ok) continue;
-        for (int k = i; k + 1 < j; ++k) order[(size_t)k] = order[(size_t)k + 1];      // s moves to j - 1
-        order[(size_t)j - 1] = s;
+        for (int k = i; k + 1 < j; ++k) order[k] = order[k + 1];      // s moves to j - 1
+        order[j - 1] = s;
     }
     for (int i = 0; i < cgraph->n_nodes; i++) {
-        ggml_tensor *node = order[(size_t)i];
+        ggml_tensor *node = order[i];
         if (node->op == GGML_OP_NONE) continue;
         ggml_compute_params params;
         params.ith = 0; params.nth = node->n_tasks; params.wsize = 0; params.wdata = nullptr;
         // a node and the node right behind it that consumes it go to the device as ONE call when the
         // library has the fused form (both nodes' data are still produced; the unfused seams are the fallback inside).
-        ggml_tensor *next = i + 1 < cgraph->n_nodes ? order[(size_t)i + 1] : nullptr;
+        ggml_tensor *next = i + 1 < cgraph->n_nodes ? order[i + 1] : nullptr;
         // the longest form first: rms_norm, mul, mul_mat [, add] -- the pre-projection chain of a transformer block -- goes down
         // as one call (one LAUNCH for decode-sized batches; the library splits it into pair + mul_mat otherwise)
         if (node->op == GGML_OP_RMS_NORM && i + 2 < cgraph->n_nodes) {
-            ggml_tensor *mul = order[(size_t)i + 1], *mm = order[(size_t)i + 2];
-            ggml_tensor *add = i + 3 < cgraph->n_nodes ? order[(size_t)i + 3] : nullptr;
+            ggml_tensor *mul = order[i + 1], *mm = order[i + 2];
+            ggml_tensor *add = i + 3 < cgraph->n_nodes ? order[i + 3] : nullptr;
             const bool pair = mul->op == GGML_OP_MUL && (mul->src0 == node || mul->src1 == node) && mul->src0 != mul->src1 && mul->data != node->data;
             if (pair && mm->op == GGML_OP_MUL_MAT && mm->src1 == mul && mm->src0 != mul && mm->src0 != node) {
                 const bool with_add = add && add->op == GGML_OP_ADD && add->src0 == mm && add->src1 != mm && add->src1 != mul && add->src1 != node &&

@@ -329,6 +329,16 @@ int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_
                               float *d_norm, float *d_y, float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, int mode,
                               const float *d_addend, int64_t ld_add, float *d_dst2, int64_t ldd2, float scale, void *stream);
 int ggml_hip_norm_mul_mat_fused(const ggml_hip_weight *w, int64_t N);
+/* Several weight matrices behind ONE activation matrix -- the q / k / v or the gate / up projections of a transformer block
+ * (each its own MUL_MAT node with the same src1, Ggml.cs:6714) -- as one launch for N <= 4: 2..4 resident matrices of one
+ * quantized type and K; dst[i] receives matrix i's product ([N][M_i], row stride ldd[i]); every row is bit for bit what
+ * ggml_hip_mul_mat_dev gives.  With d_g the launch also computes the rms_norm -> mul pair in front (d_src1 is then the
+ * norm's input x; d_norm / d_y receive both nodes' data, as in ggml_hip_norm_mul_mat_dev).  ggml_hip_mul_mat_multi_fused
+ * says whether the form exists for these matrices and N (else: one call per matrix). */
+int ggml_hip_mul_mat_multi_fused(const ggml_hip_weight *const *w, int n_w, int64_t N);
+int ggml_hip_mul_mat_multi_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N,
+                               float *const *d_dst, const int64_t *ldd, const float *d_g, int64_t ld_g, float *d_norm,
+                               float *d_y, void *stream);
 /* The pair kernel alone on contiguous device rows: d_norm = rms_norm(d_x) (Ggml.cs:5858-5920), d_y = d_norm * d_g. */
 int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_norm, float *d_y, int64_t nrows, int64_t k, void *stream);
 /* Device form of the epilogue: mode 1 add (d_dst keeps the product, d_dst2 = product + d_addend), mode 2 scale (d_dst =

@@ -196,3 +196,41 @@ def test_chain_device_form_one_launch_for_decode_batches(dev):
             prod = dev.mul_mat(W, y)                       # the separate mul_mat on the same y
             assert torch.equal(d1, prod), (t, N)
             assert torch.equal(d2, prod + r), (t, N)
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q5_1, O.Q8_0])
+def test_multi_weight_device_form_is_bitwise_the_single_calls(dev, t):
+    """2..4 weight matrices behind one activation matrix in one launch (ggml_hip_mul_mat_multi_dev), with and without the
+    rms_norm -> mul prologue: every dst equals the single-matrix call's, the norm / mul nodes equal the pair kernel's."""
+    from ggmlsharp_amd._lib import lib, check
+    L = lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (Ms, K, N) in (((96, 130), 256, 1), ((64, 64, 200), 512, 3), ((33, 500, 16, 129), 256, 4), ((4096, 4096, 4096), 4096, 1), ((300, 40), 4352, 2)):
+        Ws = [dev.Weight.from_host(t, O.quantize_row(t, _rand((M, K))), K) for M in Ms]
+        x = torch.from_numpy(_rand((N, K), 2.0)).cuda()
+        g = torch.from_numpy(_rand((N, K))).cuda()
+        hw = (C.c_void_p * len(Ws))(*[w.handle for w in Ws])
+        assert L.ggml_hip_mul_mat_multi_fused(hw, len(Ws), N) == 1
+        assert L.ggml_hip_mul_mat_multi_fused(hw, len(Ws), 5) == 0
+        singles = [dev.mul_mat(w, x) for w in Ws]
+        outs = [torch.full((N, M + 4), -2.0, device="cuda") for M in Ms]
+        dp = (C.c_void_p * len(Ws))(*[o.data_ptr() for o in outs])
+        ld = (C.c_int64 * len(Ws))(*[M + 4 for M in Ms])
+        check(L.ggml_hip_mul_mat_multi_dev(hw, len(Ws), C.c_void_p(x.data_ptr()), K, N, dp, ld, None, 0, None, None, st), "multi")
+        for o, s, M in zip(outs, singles, Ms):
+            assert torch.equal(o[:, :M], s) and torch.all(o[:, M:] == -2.0), (t, Ms, K, N)
+        # with the prologue
+        nrm, y = torch.empty((N, K), device="cuda"), torch.empty((N, K), device="cuda")
+        n_ref, y_ref = torch.empty((N, K), device="cuda"), torch.empty((N, K), device="cuda")
+        check(L.ggml_hip_rms_norm_mul_rows_dev(C.c_void_p(x.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(n_ref.data_ptr()), C.c_void_p(y_ref.data_ptr()),
+                                               N, K, st), "pair")
+        singles = [dev.mul_mat(w, y_ref) for w in Ws]
+        for o in outs:
+            o.fill_(-2.0)
+        check(L.ggml_hip_mul_mat_multi_dev(hw, len(Ws), C.c_void_p(x.data_ptr()), K, N, dp, ld, C.c_void_p(g.data_ptr()), K, C.c_void_p(nrm.data_ptr()),
+                                           C.c_void_p(y.data_ptr()), st), "multi + prologue")
+        assert torch.equal(nrm, n_ref) and torch.equal(y, y_ref), (t, Ms, K, N)
+        for o, s, M in zip(outs, singles, Ms):
+            assert torch.equal(o[:, :M], s) and torch.all(o[:, M:] == -2.0), (t, Ms, K, N, "prologue")
+        for w in Ws:
+            w.free()
