@@ -152,6 +152,7 @@ HIP_SYMBOLS = {
     "ggml_hip_compute_forward_mul_mat_add": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T, _T]),
     "ggml_hip_compute_forward_mul_mat_scale": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T, _T]),
     "ggml_hip_compute_forward_norm_mul_mat": (C.c_int, [C.POINTER(ggml_compute_params), _T, _T, _T, _T, _T, _T, _T, _T]),
+    "ggml_hip_compute_forward_mul_mat_multi": (C.c_int, [C.POINTER(ggml_compute_params), C.c_int, C.POINTER(_T), _T, C.POINTER(_T), _T, _T, _T]),
     "ggml_hip_norm_mul_mat_dev": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, _P, C.c_size_t, C.c_int, _P,
                                              C.c_int64, _P, C.c_int64, C.c_float, _P]),
     "ggml_hip_norm_mul_mat_fused": (C.c_int, [_P, C.c_int64]),

@@ -394,6 +394,44 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         for (int k = i; k + 1 < j; ++k) order[k] = order[k + 1];      // s moves to j - 1
         order[j - 1] = s;
     }
+    // MUL_MAT nodes that read the SAME src1 through quantized leaves of one type (q / k / v, gate / up) are brought together
+    // behind the first of them -- they go down as one call (ggml_hip_compute_forward_mul_mat_multi).  A node moves up past
+    // the nodes in between when it does not depend on them and nobody there touches what it reads or writes.
+    auto groupable = [](const ggml_tensor *t, const ggml_tensor *first) {
+        if (!t || t->op != GGML_OP_MUL_MAT || !t->src0 || !t->src1 || t->src0->op != GGML_OP_NONE) return false;
+        const int ty = t->src0->type;
+        if (!(ty == GGML_TYPE_Q4_0 || ty == GGML_TYPE_Q4_1 || ty == GGML_TYPE_Q5_0 || ty == GGML_TYPE_Q5_1 || ty == GGML_TYPE_Q8_0)) return false;
+        if (t->src1->ne[1] > 4 || t->src1->ne[2] != 1 || t->src1->ne[3] != 1 || t->src0->ne[2] != 1 || t->src0->ne[3] != 1) return false;
+        return !first || (t->src1 == first->src1 && ty == first->src0->type && t->src0->ne[0] == first->src0->ne[0] && t != first);
+    };
+    for (int i = 0; i + 1 < n_order; ++i) {
+        ggml_tensor *first = order[i];
+        if (!groupable(first, nullptr)) continue;
+        int cnt = 1, pos = i + 1;
+        for (int j = i + 1; j < n_order && j <= i + 16 && cnt < 4; ++j) {
+            ggml_tensor *t = order[j];
+            if (!groupable(t, first)) continue;
+            bool ok = true;
+            for (int k = pos; k < j && ok; ++k) {
+                ggml_tensor *u = order[k];
+                ok = u->op != GGML_OP_NONE && t->src0 != u && t->src1 != u && !overlaps(u, t->src0) && !overlaps(u, t->src1) && !overlaps(u, t) &&
+                     !overlaps(u->src0, t) && !overlaps(u->src1, t);
+            }
+            if (!ok) continue;
+            for (int k = j; k > pos; --k) order[k] = order[k - 1];
+            order[pos++] = t;
+            ++cnt;
+        }
+        i = pos - 1;
+    }
+    auto group_at = [&](int at, const ggml_tensor *src1, const ggml_tensor **w, ggml_tensor **d) {   // members from order[at] on
+        int g = 0;
+        while (g < 4 && at + g < n_order && groupable(order[at + g], nullptr) && order[at + g]->src1 == src1 &&
+               (g == 0 || (order[at + g]->src0->type == order[at]->src0->type && order[at + g]->src0->ne[0] == order[at]->src0->ne[0]))) {
+            w[g] = order[at + g]->src0; d[g] = order[at + g]; ++g;
+        }
+        return g;
+    };
     for (int i = 0; i < cgraph->n_nodes; i++) {
         ggml_tensor *node = order[i];
         if (node->op == GGML_OP_NONE) continue;
@@ -409,6 +447,21 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
             ggml_tensor *add = i + 3 < cgraph->n_nodes ? order[i + 3] : nullptr;
             const bool pair = mul->op == GGML_OP_MUL && (mul->src0 == node || mul->src1 == node) && mul->src0 != mul->src1 && mul->data != node->data;
             if (pair && mm->op == GGML_OP_MUL_MAT && mm->src1 == mul && mm->src0 != mul && mm->src0 != node) {
+                const ggml_tensor *gw[4];
+                ggml_tensor *gd[4];
+                const int gn = group_at(i + 2, mul, gw, gd);
+                if (gn >= 2) {                        // the pair and every projection that reads it: one call
+                    ggml_tensor *g = mul->src0 == node ? mul->src1 : mul->src0;
+                    for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {
+                        params.type = phase;
+                        int rc = ggml_hip_compute_forward_mul_mat_multi(&params, gn, gw, mul, gd, node->src0, g, node);
+                        if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }
+                    }
+                    node->perf_runs++; mul->perf_runs++;
+                    for (int k = 0; k < gn; ++k) gd[k]->perf_runs++;
+                    i += 1 + gn;
+                    continue;
+                }
                 const bool with_add = add && add->op == GGML_OP_ADD && add->src0 == mm && add->src1 != mm && add->src1 != mul && add->src1 != node &&
                                       add->src1->type == GGML_TYPE_F32;
                 ggml_tensor *g = mul->src0 == node ? mul->src1 : mul->src0;
@@ -421,6 +474,21 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
                 node->perf_runs++; mul->perf_runs++; mm->perf_runs++;
                 if (with_add) add->perf_runs++;
                 i += with_add ? 3 : 2;
+                continue;
+            }
+        }
+        if (node->op == GGML_OP_MUL_MAT) {
+            const ggml_tensor *gw[4];
+            ggml_tensor *gd[4];
+            const int gn = group_at(i, node->src1, gw, gd);
+            if (gn >= 2) {
+                for (int phase = GGML_TASK_INIT; phase <= GGML_TASK_FINALIZE; ++phase) {
+                    params.type = phase;
+                    int rc = ggml_hip_compute_forward_mul_mat_multi(&params, gn, gw, node->src1, gd, nullptr, nullptr, nullptr);
+                    if (rc != GGML_HIP_OK) { (void)ggml_hip_graph_end(); return rc; }
+                }
+                for (int k = 0; k < gn; ++k) gd[k]->perf_runs++;
+                i += gn - 1;
                 continue;
             }
         }

@@ -775,6 +775,90 @@ int ggml_hip_compute_forward_norm_mul_mat(const struct ggml_compute_params *para
     return seam1(params, src0, mul_dst, mm_dst, nullptr);
 }
 
+/* Several MUL_MAT nodes with the SAME src1 (q / k / v, gate / up; optionally the rms_norm -> mul pair that produces that src1
+ * in front) as one call: one launch inside a graph scope on one slot for N <= 4 when every weight is a cached leaf of one
+ * quantized type and K and every tensor is contiguous; anything else runs the nodes through their own seams, one after the
+ * other (which also fills the weight cache, so the next compute of the graph takes the fused form).  pro_x == NULL: no pair. */
+int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *params, int n, const struct ggml_tensor *const *src0,
+                                           const struct ggml_tensor *src1, struct ggml_tensor *const *dst, const struct ggml_tensor *pro_x,
+                                           const struct ggml_tensor *pro_g, struct ggml_tensor *pro_norm) {
+    if (!params || !src0 || !src1 || !dst || n < 1 || n > 4) return fail(GGML_HIP_ERR_ARG, "bad argument (1..4 nodes)");
+    for (int i = 0; i < n; ++i)
+        if (!src0[i] || !dst[i]) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if ((pro_x == nullptr) != (pro_g == nullptr) || (pro_x == nullptr) != (pro_norm == nullptr)) return fail(GGML_HIP_ERR_ARG, "prologue: x, g and the norm node go together");
+    if (params->ith != 0 || params->type != GGML_TASK_COMPUTE) return GGML_HIP_OK;
+    if (scope_replaying()) return GGML_HIP_OK;
+    auto one_by_one = [&]() {
+        int rc = pro_x ? ggml_hip_compute_forward_norm_mul_mat(params, pro_x, pro_g, pro_norm, const_cast<ggml_tensor *>(src1), src0[0], dst[0], nullptr, nullptr)
+                       : seam1(params, src0[0], src1, dst[0], nullptr);
+        for (int i = 1; i < n && !rc; ++i) rc = seam1(params, src0[i], src1, dst[i], nullptr);
+        return rc;
+    };
+    if (n < 2) return one_by_one();
+    const int type = src0[0]->type;
+    const int64_t K = src1->ne[0], N = src1->ne[1];
+    bool ok = type >= 0 && type < GGML_TYPE_COUNT && is_q(type) && weight_type_ok(type) && src1->type == GGML_TYPE_F32 && N >= 1 && N <= 4 &&
+              src1->ne[2] == 1 && src1->ne[3] == 1 && src1->data && contiguous_f32(src1) && K % QK == 0;
+    for (int i = 0; i < n && ok; ++i) {
+        const ggml_tensor *w = src0[i], *d = dst[i];
+        ok = w->type == type && w->op == GGML_OP_NONE && w->data && w->ne[0] == K && w->ne[2] == 1 && w->ne[3] == 1 && w->ne[1] > 0 &&
+             w->nb[0] == TSIZE[type] && w->nb[0] <= w->nb[1] && d->type == GGML_TYPE_F32 && d->data && contiguous_f32(d) && d->ne[0] == w->ne[1] &&
+             d->ne[1] == N && d->ne[2] == 1 && d->ne[3] == 1;
+        for (int j = 0; j < i && ok; ++j) ok = dst[j]->data != d->data;
+    }
+    if (ok && pro_x) {
+        const ggml_tensor *ts[3] = {pro_x, pro_g, pro_norm};
+        for (const ggml_tensor *t : ts)
+            ok = ok && t->data && t->type == GGML_TYPE_F32 && contiguous_f32(t) && t->ne[0] == K && t->ne[1] == N && t->ne[2] == 1 && t->ne[3] == 1;
+        ok = ok && pro_norm->data != src1->data;
+    }
+    if (!ok) return one_by_one();
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    if (call.G() != 1 || !call.in_graph()) return one_by_one();
+    DeviceCtx *c = call.ctxs[0];
+    rc = c->make_current();
+    if (rc) return rc;
+    const ggml_hip_weight *W[4];
+    for (int i = 0; i < n; ++i) {
+        const ggml_tensor *w = src0[i];
+        const CacheKey key{w->data, type, w->ne[0], w->ne[1], w->ne[2], w->ne[3], w->nb[1], w->nb[2], w->nb[3], (int64_t)0, w->ne[1]};
+        auto it = c->cache.find(key);
+        if (it == c->cache.end() || it->second.slices.size() != 1) return one_by_one();      // (uploads and caches them: fused next time)
+        W[i] = it->second.slices[0];
+    }
+    if (!ggml_hip_mul_mat_multi_fused(W, n, N)) return one_by_one();
+    for (int i = 0; i < n; ++i) note_host_write(call, dst[i], true);
+    const float *xd = nullptr, *gd = nullptr;
+    float *nd = nullptr, *yd = nullptr;
+    if (pro_x) {
+        if (operand_f32(c, true, pro_x, c->aux[0], &xd) || operand_f32(c, true, pro_g, c->aux[1], &gd)) return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: operand staging failed");
+        note_host_write(call, pro_norm, true);
+        note_host_write(call, src1, true);
+        nd = result_f32(c, true, pro_norm, c->aux[2]);
+        yd = result_f32(c, true, src1, c->aux[3]);
+        if (!nd || !yd) return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: hipMalloc failed");
+    } else if (operand_f32(c, true, src1, c->src1, &xd)) {
+        return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: operand staging failed");
+    }
+    float *dd[4];
+    int64_t ldd[4];
+    for (int i = 0; i < n; ++i) {
+        dd[i] = result_f32(c, true, dst[i], c->dst);
+        if (!dd[i]) return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: hipMalloc failed for a resident dst");
+        ldd[i] = dst[i]->ne[0];
+    }
+    rc = ggml_hip_mul_mat_multi_dev(W, n, xd, K, N, dd, ldd, gd, K, nd, yd, c->stream);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) c->owe(dst[i]->data, dd[i], (size_t)N * dst[i]->ne[0] * 4);
+    if (pro_x) {
+        c->owe(pro_norm->data, nd, (size_t)N * K * 4);
+        c->owe(src1->data, yd, (size_t)N * K * 4);
+    }
+    return GGML_HIP_OK;
+}
+
 /* ggml_compute_forward_cpy, quantizing branch of dup_f32 / dup_f16 (Ggml.cs:4339-4363, 3935-3966) */
 int ggml_hip_compute_forward_cpy(const struct ggml_compute_params *params, const struct ggml_tensor *src0,
                                  struct ggml_tensor *dst) {

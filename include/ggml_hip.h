@@ -323,6 +323,14 @@ int ggml_hip_compute_forward_norm_mul_mat(const struct ggml_compute_params *para
                                           const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst,
                                           const struct ggml_tensor *src0, struct ggml_tensor *mm_dst,
                                           const struct ggml_tensor *addend, struct ggml_tensor *add_dst);
+/* Several MUL_MAT nodes with the SAME src1 (the q / k / v or gate / up projections), optionally with the rms_norm -> mul pair
+ * that produces that src1 in front (pro_x / pro_g / pro_norm as x / g / norm_dst above, src1 = the mul node; NULL: no pair):
+ * ONE launch inside a graph scope for batches of up to 4 rows when every src0 is a cached quantized leaf of one type and K;
+ * otherwise the nodes run through their own seams one after the other.  Every node's data is produced either way. */
+int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *params, int n, const struct ggml_tensor *const *src0,
+                                           const struct ggml_tensor *src1, struct ggml_tensor *const *dst,
+                                           const struct ggml_tensor *pro_x, const struct ggml_tensor *pro_g,
+                                           struct ggml_tensor *pro_norm);
 /* Device form of the prologue + epilogue: d_norm = rms_norm(d_x), d_y = d_norm * d_g (both [N][K] contiguous), then the
  * product of w and d_y with the epilogue `mode` (0 none).  ggml_hip_norm_mul_mat_fused: 1 when it is one launch. */
 int ggml_hip_norm_mul_mat_dev(const ggml_hip_weight *w, const float *d_x, int64_t ld_x, const float *d_g, int64_t ld_g, int64_t N,
