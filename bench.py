@@ -253,6 +253,63 @@ def seam1_host_config(M, K, N, iters):
         G.ggml_free(ctx)
 
 
+def dropin_decode_layer(N, iters):
+    """The DROP-IN path at decode size: one LLaMA-7B-shaped decoder layer (D = 4096, F = 11008, Q4_0; the attention itself is
+    replaced by adds -- soft_max / rope are outside this path) at batch N through ggml_graph_compute of the host mirror, host
+    tensors in the registered context pool.  What is timed is the wall clock of a whole graph compute (17 nodes): the seams,
+    the launches, the device -> host copies that leave every node's data in host memory."""
+    import ctypes as C
+    from ggmlsharp_amd import ggml as G
+    from ggmlsharp_amd._lib import lib
+    D, F = 4096, 11008
+    rng = np.random.default_rng(1)
+    ctx = G.ggml_init(700 * 1024 * 1024)
+    try:
+        def qweight(K, M):
+            t = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
+            b = G.tensor_bytes(t).reshape(M * (K // 32), 20)
+            b[:, 4:] = rng.integers(0, 256, (M * (K // 32), 16), dtype=np.uint8)
+            b[:, :4] = (rng.random(M * (K // 32), dtype=np.float32) * 0.02 + 0.001).view(np.uint8).reshape(-1, 4)
+            return t
+
+        def f32(K, n):
+            t = G.ggml_new_tensor_2d(ctx, G.F32, K, n)
+            G.tensor_f32(t)[:] = rng.standard_normal((n, K)).astype(np.float32).reshape(1, 1, n, K)
+            return t
+
+        x, g1, g2 = f32(D, N), f32(D, N), f32(D, N)
+        wq, wk, wv, wo = (qweight(D, D) for _ in range(4))
+        w1, w3, w2 = qweight(D, F), qweight(D, F), qweight(F, D)
+        cur = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, x), g1)
+        q, k, v = G.ggml_mul_mat(ctx, wq, cur), G.ggml_mul_mat(ctx, wk, cur), G.ggml_mul_mat(ctx, wv, cur)
+        a = G.ggml_add(ctx, G.ggml_add(ctx, q, k), v)
+        h = G.ggml_add(ctx, G.ggml_mul_mat(ctx, wo, a), x)
+        cur2 = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, h), g2)
+        u, gt = G.ggml_mul_mat(ctx, w1, cur2), G.ggml_mul_mat(ctx, w3, cur2)
+        s = G.ggml_mul(ctx, G.ggml_silu(ctx, u), gt)
+        out = G.ggml_add(ctx, G.ggml_mul_mat(ctx, w2, s), h)
+        gf = G.ggml_build_forward(out)
+        for _ in range(5):
+            G.ggml_graph_compute(ctx, gf)
+        ts = []
+        for i in range(iters):
+            G.tensor_f32(x)[0, 0, 0, 0] = float(i)          # a new token every time: the captured scope re-reads its leaves
+            t0 = time.perf_counter()
+            G.ggml_graph_compute(ctx, gf)
+            ts.append((time.perf_counter() - t0) * 1e6)
+        cnt = [C.c_uint64() for _ in range(4)]
+        lib().ggml_hip_debug_scope_counters(*[C.byref(c) for c in cnt])
+        wbytes = (4 * D * D + 3 * D * F) // 32 * 20
+        t = float(np.median(ts))
+        return {"workload": f"7B-shaped decoder layer (Q4_0, 7 mul_mat + 10 element-wise nodes), batch {N}, host tensors through ggml_graph_compute",
+                "us_per_graph": round(t, 1), "p10_us": round(float(np.percentile(ts, 10)), 1), "p90_us": round(float(np.percentile(ts, 90)), 1),
+                "nodes": int(gf.n_nodes), "weight_bytes": wbytes, "weight_stream_GBs": round(wbytes / t / 1e3, 1),
+                "hbm_frac": round(wbytes / t / 1e3 / HBM_PEAK_GBS, 4),
+                "named_scopes": {"observed": cnt[0].value, "captured": cnt[1].value, "replayed": cnt[2].value, "refused": cnt[3].value}}
+    finally:
+        G.ggml_free(ctx)
+
+
 def pcie_probe():
     """Pinned host <-> device copy rates of this box (what bounds the drop-in path)."""
     n = 64 << 20
@@ -571,6 +628,7 @@ def main():
                     c["pcie_bound_ms"] = round(bound, 4)
                     c["step_over_pcie_bound"] = round(c["ms_per_step"] / bound, 3)
                 out["other_configs"].update(s1)
+                out["other_configs"]["dropin_decode_layer_batch1"] = dropin_decode_layer(1, 200)
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
                 out["other_configs"]["seam1_host_error"] = f"{type(e).__name__}: {e}"[:300]
         if not args.no_cpu_baseline:
