@@ -15,6 +15,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -105,6 +106,7 @@ struct DeviceCtx {
     };
     std::map<uint64_t, Captured> captured;
     uint64_t scope_key = 0;
+    std::thread::id scope_owner;                   // the thread that opened the named scope: only ITS seam calls are the scope's
     int scope_mode = 0;                            // 0 plain, 1 observing, 2 capturing, 3 replaying
     bool scope_clean = true;
     std::vector<std::pair<const void *, size_t>> scope_leaves;   // (observing) whole host tensors uploaded so far in this scope

@@ -329,6 +329,7 @@ static int graph_begin(uint64_t key) {
     rc = c->make_current();
     if (rc) return rc;
     c->scope_key = key;
+    c->scope_owner = std::this_thread::get_id();
     c->scope_clean = true;
     c->scope_leaves.clear();
     c->scope_mode = 1;
@@ -452,7 +453,7 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
 static bool scope_replaying() {
     const int b = bound_slot();
     DeviceCtx *c = slot(b >= 0 ? b : 0);
-    return c && c->scope_mode == 3;
+    return c && c->scope_mode == 3 && c->scope_owner == std::this_thread::get_id();
 }
 
 static bool src1_contig_early(const ggml_tensor *t) { return t->nb[0] == 4 && t->nb[1] == (uint64_t)t->ne[0] * 4; }
