@@ -264,6 +264,7 @@ int ggml_hip_unregister_host_pool(void *ptr) {
         DeviceCtx *c = slot(i);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         if (c->make_current() == GGML_HIP_OK) (void)c->pay_and_sync();
+        c->drop_captured();                             // captured scopes hold the pool's device mapping
         c->invalidate(ptr, bytes);
         c->drop_overlapping(ptr, bytes, false);
     }
@@ -334,7 +335,10 @@ static int graph_begin(uint64_t key) {
     c->scope_leaves.clear();
     c->scope_mode = 1;
     auto it = c->captured.find(key);
-    if (it == c->captured.end()) return GGML_HIP_OK;                 // first sight: observe
+    if (it == c->captured.end()) {                                   // first sight: observe
+        if (c->captured.size() >= 256) c->drop_captured();           // (a host that never repeats a graph: do not collect its keys)
+        return GGML_HIP_OK;
+    }
     DeviceCtx::Captured &e = it->second;
     if (e.refused) { c->scope_mode = 0; return GGML_HIP_OK; }
     if (!e.exec && e.seen == 0) return GGML_HIP_OK;                  // not observed clean yet: keep observing

@@ -196,3 +196,22 @@ def test_host_read_inside_a_scope_pays_what_is_owed(dev):
         assert np.array_equal(G.tensor_f32(t_mul)[0, 0], (x + y) * 2 * y)
     finally:
         G.ggml_free(ctx)
+
+
+def test_a_freed_pool_takes_its_captured_scopes_with_it(dev):
+    """ggml_free + ggml_init usually hand out the same addresses again, i.e. the same key: the captured scope of the old pool (its
+    device mapping, its resident buffers) must be gone -- the new graph is observed and captured afresh and is right."""
+    rng = np.random.default_rng(21)
+    for round_ in range(3):
+        ctx = G.ggml_init(32 * 1024 * 1024)
+        try:
+            gf, (x, g1, g2, S), nodes = _layer(ctx, rng, 128, 96, 160, 1)
+            for it in range(4):
+                G.tensor_f32(x)[:] = rng.standard_normal((1, 128)).astype(np.float32).reshape(1, 1, 1, 128)
+                G.ggml_graph_compute(ctx, gf)
+                got = _snapshot(nodes)
+                _node_by_node(gf)
+                for i, (a, b) in enumerate(zip(got, _snapshot(nodes))):
+                    assert np.array_equal(a, b), (round_, it, i)
+        finally:
+            G.ggml_free(ctx)
