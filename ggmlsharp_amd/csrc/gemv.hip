@@ -350,7 +350,9 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
     };
     // (wider batches keep one register set: their activation registers already fill the budget, and the second set cost
     // them a resident workgroup -- 32000 x 4096 x 8: 50.5 us with it against 41.9 without)
-    constexpr bool PF = NC == 1 && SC;
+    // (the look-ahead form: one column, and three / four -- 11008 x 4096 x 4 15.6 -> 12.6 us, 32000 x 4096 x 4 29.6 -> 23.3 with
+    // one workgroup per CU; two columns measured level to worse: 11008 x 4096 x 2 8.3 -> 9.1 us)
+    constexpr bool PF = SC && (NC == 1 || NC == 4);
     uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1], qn[PF ? BPL : 1], q2n[PF && TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
     float dw[BPL], mw[HAS_M ? BPL : 1], dwn[PF ? BPL : 1], mwn[PF && HAS_M ? BPL : 1];
     uint32_t hb[HAS_H ? BPL : 1], hbn[PF && HAS_H ? BPL : 1];
@@ -628,7 +630,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
     const int ntiles = (int)((w->M + ROWS - 1) / ROWS);
     dim3 grid((unsigned)(ntiles < GV_MAX_WGS ? ntiles : GV_MAX_WGS));
     if constexpr (FUSED && !GV_OLD_FUSED) {
-        if (N <= 1 && w->nbk <= GV_CHUNK && ntiles > GV_PF_WGS) grid = dim3((unsigned)GV_PF_WGS);
+        if ((N <= 1 || N >= 3) && w->nbk <= GV_CHUNK && ntiles > GV_PF_WGS) grid = dim3((unsigned)GV_PF_WGS);
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
@@ -700,7 +702,7 @@ template <int TYPE>
 hipError_t launch_multi_typed(const mv_set &ws, const float *x, int64_t ld1, const mm_prologue *pro, int64_t nbk, int64_t N, int ntiles, hipStream_t st) {
     const mm_prologue none{nullptr, 0, nullptr, nullptr};
     const bool sc = nbk <= GV_CHUNK;
-    const int cap = (N <= 1 && sc) ? GV_PF_WGS : GV_MAX_WGS;
+    const int cap = ((N <= 1 || N >= 3) && sc) ? GV_PF_WGS : GV_MAX_WGS;
     dim3 grid((unsigned)(ntiles < cap ? ntiles : cap));
 #define GVM(NC) do { \
         if (pro) { if (sc) gemv_fused_multi_kernel<TYPE, NC, 16, true, true><<<grid, GV_THREADS, 0, st>>>(ws, x, ld1, nbk, (int)N, ntiles, *pro); \
