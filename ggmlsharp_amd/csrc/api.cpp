@@ -169,9 +169,27 @@ const void *DeviceCtx::resident_lookup(const void *host, size_t bytes) {
 // a write to host range [host, host + bytes) makes every OTHER resident copy that overlaps it stale (a view with an
 // offset gets its own entry; the parent's device copy must not be served afterwards)
 void DeviceCtx::owe(void *host, const void *dev, size_t bytes) {
+    if (bytes >= OWE_EARLY_BYTES) {
+        // a large result goes home at once, by DMA on the copy stream, beside the kernels that follow (a prompt-sized batch
+        // owes tens of MB per decoder layer: PCIe time that has to overlap the compute, not follow it); such a scope is
+        // issued live (a captured graph runs its branches one after the other)
+        scope_dirty();
+        for (size_t i = 0; i < owed.size(); ++i)
+            if (owed[i].host == host) { owed.erase(owed.begin() + (long)i); break; }
+        hipError_t e = hipEventRecord(ev_ready, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_d2h, ev_ready, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s_d2h);
+        if (e == hipSuccess) { d2h_busy = true; d2h_bytes += bytes; return; }
+        (void)hipGetLastError();                   // could not: owe it like a small one
+    }
     for (Owed &o : owed)
         if (o.host == host) { o.dev = dev; o.bytes = bytes; return; }
     owed.push_back(Owed{host, dev, bytes});
+}
+// a buffer is about to be reused while a copy on the copy stream may still read it: later kernels wait for that stream
+void DeviceCtx::join_copies() {
+    if (!d2h_busy) return;
+    if (hipEventRecord(ev_d2h, s_d2h) != hipSuccess || hipStreamWaitEvent(stream, ev_d2h, 0) != hipSuccess) (void)hipGetLastError();
 }
 int DeviceCtx::pay(const void *only_dev) {
     if (owed.empty()) return GGML_HIP_OK;
@@ -217,6 +235,7 @@ void DeviceCtx::drop_overlapping(const void *host, size_t bytes, bool keep_exact
         const bool overlap = x < b && a < y;
         if (overlap && !(keep_exact && it->first == host)) {
             (void)pay(it->second.p);               // its host copy goes out (stream-ordered) before the buffer is reused
+            join_copies();
             pool.push_back(it->second);
             it = resident.erase(it);
         } else {
@@ -230,6 +249,7 @@ void *DeviceCtx::resident_buffer(const void *host, size_t bytes) {
     if (old != resident.end()) {
         if (old->second.bytes >= bytes) return old->second.p;      // the same tensor computed again: reuse its buffer
         (void)pay(old->second.p);
+        join_copies();
         pool.push_back(old->second);
         resident.erase(old);
     }

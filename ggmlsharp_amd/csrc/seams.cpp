@@ -655,7 +655,9 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 // nothing else -- no fork / join over the copy streams, no device -> host copy of its own (DeviceCtx::owe:
                 // the host copies of a scope's results go out together).  17 nodes of a 7B decoder layer at batch 1:
                 // 439 -> see DESIGN 8 us per graph compute.
-                if (in_graph && G == 1 && d_res[0] && ne11 <= chunk && (x_res[0] || (epi && epi->pro_x) || src1->nb[1] == (uint64_t)ne10 * 4)) {
+                // (a batch of any size when src1 is already in HBM: there is no upload for chunks to overlap; the result's way
+                // home overlaps the NEXT nodes' kernels -- DeviceCtx::owe sends a large one at once on the copy stream)
+                if (in_graph && G == 1 && d_res[0] && (x_res[0] || (epi && epi->pro_x) || (ne11 <= chunk && src1->nb[1] == (uint64_t)ne10 * 4))) {
                     const bool pro = epi && epi->pro_x;
                     if (!x_res[0] && !pro) {
                         if (nslice == 1) c->note_leaf(src1->data, (size_t)ne11 * ne10 * 4);
