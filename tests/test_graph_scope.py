@@ -215,3 +215,49 @@ def test_a_freed_pool_takes_its_captured_scopes_with_it(dev):
                     assert np.array_equal(a, b), (round_, it, i)
         finally:
             G.ggml_free(ctx)
+
+
+def test_two_stacked_layers_with_shared_projections(dev):
+    """two decoder-layer-shaped blocks in one graph (the second reads the first's output), three projections reading one
+    tensor in each: the host mirror's reordering (projections brought together, SILU moved to its consumer) and the fused
+    calls it makes must leave every node's data equal to the node-by-node seams', through observe / capture / replay."""
+    rng = np.random.default_rng(31)
+    K, M, F, N = 256, 256, 384, 2
+    ctx = G.ggml_init(96 * 1024 * 1024)
+    try:
+        def f32(k, n, scale=1.0):
+            t = G.ggml_new_tensor_2d(ctx, G.F32, k, n)
+            G.tensor_f32(t)[:] = (rng.standard_normal((n, k)) * scale).astype(np.float32).reshape(1, 1, n, k)
+            return t
+
+        def q(ty, k, m):
+            t = G.ggml_new_tensor_2d(ctx, ty, k, m)
+            G.tensor_bytes(t)[:] = O.quantize_row(ty, rng.standard_normal((m, k)).astype(np.float32)).reshape(-1)
+            return t
+
+        x = f32(K, N, 2.0)
+        h = x
+        for layer in range(2):
+            g1, g2 = f32(K, N), f32(K, N)
+            wq, wk, wv, wo = q(G.Q4_0, K, M), q(G.Q4_0, K, M), q(G.Q4_0, K, M), q(G.Q4_0, M, K)
+            w1, w3, w2 = q(G.Q8_0, K, F), q(G.Q8_0, K, F), q(G.Q4_1, F, K)
+            cur = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, h), g1)
+            qq, kk, vv = G.ggml_mul_mat(ctx, wq, cur), G.ggml_mul_mat(ctx, wk, cur), G.ggml_mul_mat(ctx, wv, cur)
+            a = G.ggml_add(ctx, G.ggml_mul(ctx, qq, kk), vv)             # (stand-in for the attention: the projections' consumers interleave)
+            h = G.ggml_add(ctx, G.ggml_mul_mat(ctx, wo, a), h)
+            cur2 = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, h), g2)
+            u, gt = G.ggml_mul_mat(ctx, w1, cur2), G.ggml_mul_mat(ctx, w3, cur2)
+            s = G.ggml_mul(ctx, G.ggml_silu(ctx, u), gt)
+            h = G.ggml_add(ctx, G.ggml_mul_mat(ctx, w2, s), h)
+        gf = G.ggml_build_forward(h)
+        nodes = [gf.nodes[i] for i in range(gf.n_nodes)]
+        assert gf.n_nodes == 34
+        for it in range(5):
+            G.tensor_f32(x)[:] = (rng.standard_normal((N, K)) * (1 + it)).astype(np.float32).reshape(1, 1, N, K)
+            G.ggml_graph_compute(ctx, gf)
+            got = _snapshot(nodes)
+            _node_by_node(gf)
+            for i, (a_, b_) in enumerate(zip(got, _snapshot(nodes))):
+                assert np.array_equal(a_, b_), (it, i)
+    finally:
+        G.ggml_free(ctx)
