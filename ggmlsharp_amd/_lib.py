@@ -127,6 +127,7 @@ HIP_SYMBOLS = {
     "ggml_hip_graph_begin": (C.c_int, []),
     "ggml_hip_graph_begin_keyed": (C.c_int, [C.c_uint64]),
     "ggml_hip_host_read": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ggml_hip_graph_outputs": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "ggml_hip_debug_scope_counters": (None, [C.POINTER(C.c_uint64)] * 4),
     "ggml_hip_graph_end": (C.c_int, []),
     "ggml_hip_debug_transfer_counters": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -169,7 +169,7 @@ const void *DeviceCtx::resident_lookup(const void *host, size_t bytes) {
 // a write to host range [host, host + bytes) makes every OTHER resident copy that overlaps it stale (a view with an
 // offset gets its own entry; the parent's device copy must not be served afterwards)
 void DeviceCtx::owe(void *host, const void *dev, size_t bytes) {
-    if (bytes >= OWE_EARLY_BYTES) {
+    if (bytes >= OWE_EARLY_BYTES && wanted(host)) {
         // a large result goes home at once, by DMA on the copy stream, beside the kernels that follow (a prompt-sized batch
         // owes tens of MB per decoder layer: PCIe time that has to overlap the compute, not follow it); such a scope is
         // issued live (a captured graph runs its branches one after the other)

@@ -90,6 +90,15 @@ struct DeviceCtx {
     // together -- one scatter kernel writing through the device mapping of the registered pool -- when the scope ends, when a
     // buffer is about to be recycled, or before anything reads host memory that may be owed.
     struct Owed { void *host; const void *dev; size_t bytes; };
+    // opt-in (ggml_hip_graph_outputs): only the listed tensors are owed to the caller at scope end; the others are still
+    // copied when the LIBRARY needs them in host memory (a recycled buffer, an upload of an overlapping range), never otherwise
+    bool outputs_only = false;
+    std::vector<const void *> outputs;
+    bool wanted(const void *host) const {
+        if (!outputs_only) return true;
+        for (const void *p : outputs) if (p == host) return true;
+        return false;
+    }
     std::vector<Owed> owed;
     static constexpr size_t OWE_EARLY_BYTES = 1u << 20;      // results this large are copied at once, on the copy stream (7B layer, batch 32 = 512-KB results: 468 us captured and paid at the end, 550 us with early copies; batch 512: 4.97 -> 4.26 ms)
     void owe(void *host, const void *dev, size_t bytes);      // (replaces an entry for the same host pointer)

@@ -148,6 +148,7 @@ struct PipeArgs {
     const float *addend = nullptr;                 // [N][Ms] on the device (mode 1)
     float *dst2 = nullptr; uint8_t *d2_host = nullptr; uint64_t nb1_2 = 0;   // the add node's result, device and host
     float scale = 1.0f;                            // mode 2
+    bool owe_dst = false;                          // graph scope, outputs-only: dst is resident and the caller does not want it -- owed, not copied
     // the rms_norm -> mul pair in front of the mul_mat, computed by the mat-vec's prologue (common.h mm_prologue): src1 IS the
     // mul node; x / g are its inputs on the device, pro_n / pro_y receive both nodes' results ([N][K]), n_host / y_host their tensors
     const float *pro_x = nullptr, *pro_g = nullptr;
@@ -184,6 +185,7 @@ int issue_chunks(DeviceCtx *c, const PipeArgs &a) {
                                                a.addend ? a.addend + (size_t)r * a.Ms : nullptr, a.Ms, a.dst2 ? a.dst2 + (size_t)r * a.Ms : nullptr, a.Ms,
                                                a.scale, c->stream);
         if (rc) return rc;
+        if (a.owe_dst) continue;
         e = hipEventRecord(c->ev_k[ke], c->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->s_d2h, c->ev_k[ke], 0);
         if (e == hipSuccess) {
@@ -381,6 +383,11 @@ int ggml_hip_graph_end(void) {
     for (DeviceCtx *c : call.ctxs) {
         int r = c->make_current();
         const bool outer = c->graph_depth_ == 1;
+        if (outer && c->outputs_only) {                  // the caller asked for these tensors only (ggml_hip_graph_outputs)
+            std::vector<DeviceCtx::Owed> keep;
+            for (const DeviceCtx::Owed &o : c->owed) if (c->wanted(o.host)) keep.push_back(o);
+            c->owed.swap(keep);
+        }
         const int mode = outer ? c->scope_mode : 0;
         if (!r && mode == 3) {                           // replay: the whole scope is one launch
             DeviceCtx::Captured &e = c->captured[c->scope_key];
@@ -421,11 +428,26 @@ int ggml_hip_graph_end(void) {
                 if (clean && !r) { e.seen = 1; e.leaves = c->scope_leaves; ++c->n_observed; }     // (a scope that was not clean is simply observed again next time)
             }
         }
-        if (outer) c->scope_mode = 0;
+        if (outer) { c->scope_mode = 0; c->outputs_only = false; c->outputs.clear(); }
         if (r && !rc) rc = r;
         if (--c->graph_depth_ == 0) c->drain(false);
     }
     return rc;
+}
+/* Opt-in, and a DEVIATION from the reference's contract: inside the open graph scope, declare that only these tensors (by
+ * data pointer) have to be in host memory when the scope ends.  Every other result stays on the device: its host memory is
+ * NOT updated (the reference leaves every node's data there).  What the library itself needs on the host is still copied. */
+int ggml_hip_graph_outputs(const void *const *host_ptrs, int n) {
+    if (n < 0 || (n > 0 && !host_ptrs)) return fail(GGML_HIP_ERR_ARG, "bad argument");
+    Call call;
+    int rc = call.begin();
+    if (rc) return rc;
+    if (!call.in_graph()) return fail(GGML_HIP_ERR_ARG, "ggml_hip_graph_outputs outside a graph scope");
+    for (DeviceCtx *c : call.ctxs) {
+        c->outputs_only = true;
+        c->outputs.assign(host_ptrs, host_ptrs + n);
+    }
+    return GGML_HIP_OK;
 }
 void ggml_hip_debug_scope_counters(uint64_t *observed, uint64_t *captured, uint64_t *replayed, uint64_t *refused) {
     uint64_t v[4] = {0, 0, 0, 0};
@@ -691,6 +713,10 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                     pa.upload = false;
                     pa.pro_x = pro_x; pa.pro_g = pro_g; pa.pro_n = pro_n; pa.pro_y = pro_y;
                     pa.n_host = (uint8_t *)epi->pro_norm->data; pa.y_host = (uint8_t *)src1->data;
+                }
+                if (in_graph && G == 1 && d_res[0] && !epi && !c->wanted(dst->data) && dst_contig) {
+                    pa.owe_dst = true;                     // (kept for the library's own needs, dropped at scope end)
+                    c->owe(d_host, dd, (size_t)ne11 * ne01 * 4);
                 }
                 if (epi) {
                     pa.epi_mode = epi->mode; pa.scale = epi->scale;

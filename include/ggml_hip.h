@@ -178,6 +178,13 @@ int  ggml_hip_graph_end(void);
  * source it is about to read -- the range is paid and waited for when it is owed or still in flight, else nothing happens --
  * and ggml_hip_invalidate_range for what it wrote (a resident copy of that range is stale). */
 int  ggml_hip_host_read(const void *host_ptr, size_t bytes);
+/* OPT-IN, and a deviation from the reference's contract (which leaves EVERY node's data in host memory, Ggml.cs:3539-3704):
+ * called inside an open scope, before its nodes, it names the tensors (by data pointer) whose data the caller will read after
+ * ggml_hip_graph_end; no other result of the scope is copied to the host -- its host memory keeps whatever it held.  The
+ * library still copies what IT needs on the host (a buffer that is recycled, a source it has to upload again).  At prompt-sized
+ * batches the copies are the whole cost of a graph: 7B decoder layer at batch 512, 4.26 ms with every node's data, see DESIGN 8
+ * with the last node's only.  The key of a named scope must cover the list (the host mirror never calls this). */
+int  ggml_hip_graph_outputs(const void *const *host_ptrs, int n);
 /* The same scope, NAMED: `key` (non-zero) identifies the graph the caller is about to run -- a hash over what decides the
  * calls it will make: every node's op, the data pointers, types, ne / nb of the node and of its sources, and the scalar
  * operands it reads on the host (the factor of a SCALE node).  Inside a scope the seams cost the host one kernel launch per

@@ -261,3 +261,48 @@ def test_two_stacked_layers_with_shared_projections(dev):
                 assert np.array_equal(a_, b_), (it, i)
     finally:
         G.ggml_free(ctx)
+
+
+@pytest.mark.parametrize("N", [2, 300])
+def test_outputs_only_scope_copies_what_was_asked_for(dev, N):
+    """ggml_hip_graph_outputs (opt-in, not the reference's contract): the named tensor is right, the others' host memory is
+    left alone, and far fewer bytes cross PCIe."""
+    rng = np.random.default_rng(41)
+    ctx = G.ggml_init(256 * 1024 * 1024)
+    try:
+        gf, leaves, nodes = _layer(ctx, rng, 256, 192, 320, N)
+        _node_by_node(gf)
+        ref = _snapshot(nodes)
+        for t in nodes:
+            G.tensor_f32(t)[:] = -9.0
+        L = _lib.lib()
+        p = _lib.ggml_compute_params(_lib.GGML_TASK_COMPUTE, 0, 1, 0, None)
+        c0 = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        c1 = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        L.ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c0])
+        _lib.check(L.ggml_hip_graph_begin(), "begin")
+        want = (C.c_void_p * 1)(nodes[-1].contents.data)
+        _lib.check(L.ggml_hip_graph_outputs(want, 1), "outputs")
+        for i in range(gf.n_nodes):
+            n = gf.nodes[i].contents
+            f = {_lib.GGML_OP_MUL_MAT: L.ggml_hip_compute_forward_mul_mat, _lib.GGML_OP_ADD: L.ggml_hip_compute_forward_add,
+                 _lib.GGML_OP_MUL: L.ggml_hip_compute_forward_mul, _lib.GGML_OP_SCALE: L.ggml_hip_compute_forward_scale}.get(n.op)
+            if f is not None:
+                _lib.check(f(C.byref(p), n.src0, n.src1, gf.nodes[i]), f"node {i}")
+            elif n.op == _lib.GGML_OP_RMS_NORM:
+                _lib.check(L.ggml_hip_compute_forward_rms_norm(C.byref(p), n.src0, gf.nodes[i]), f"node {i}")
+            else:
+                _lib.check(L.ggml_hip_compute_forward_silu(C.byref(p), n.src0, gf.nodes[i]), f"node {i}")
+        _lib.check(L.ggml_hip_graph_end(), "end")
+        L.ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c1])
+        got = _snapshot(nodes)
+        assert np.array_equal(got[-1], ref[-1])
+        untouched = sum(bool(np.all(g == -9.0)) for g in got[:-1])
+        assert untouched >= len(nodes) - 3, untouched          # (an in-place view shares its parent's memory)
+        assert c1[1].value - c0[1].value <= 2 * got[-1].nbytes
+        # and the scope after it is an ordinary one again
+        G.ggml_graph_compute(ctx, gf)
+        for i, (a, b) in enumerate(zip(_snapshot(nodes), ref)):
+            assert np.array_equal(a, b), i
+    finally:
+        G.ggml_free(ctx)
