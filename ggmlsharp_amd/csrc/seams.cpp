@@ -121,6 +121,9 @@ int eltwise_slots(const Call &call) { return call.in_graph() ? call.G() : 1; }
 
 // Seam-1 pipeline: src1 rows per chunk.  A function of N and K only (never of M or the slot count), so a row shard and the
 // unsplit matrix run the same kernel forms on the same chunks: bit-identical results for any split.
+#ifndef SEAM_MIN_CHUNK
+#define SEAM_MIN_CHUNK 128            // (A/B 256 / 512 rows: 4096 x 4096 x 512 0.349 -> 0.365 / 0.373 ms, x 4096 1.71 -> 1.76 / 1.73: no gain)
+#endif
 int64_t seam_chunk_rows(int64_t N, int64_t K, bool pinned) {
     if (!pinned) return N;                              // pageable memory: the runtime stages synchronously, nothing overlaps
     const int64_t x_bytes = N * K * 4;
@@ -130,7 +133,7 @@ int64_t seam_chunk_rows(int64_t N, int64_t K, bool pinned) {
     // (measured on MI355X / PCIe 5, 4096 x 4096 x {4096, 512}: 8 chunks 1.71 / 0.36 ms (two chunks at 512), 16 chunks 1.75 / 0.39 ms;
     // the box moves 94 GB/s with both directions busy: 1.42 ms for the 134 MB of the first shape)
     int64_t rows = ((N + 7) / 8 + 31) / 32 * 32;
-    if (rows < 128) rows = 128;
+    if (rows < SEAM_MIN_CHUNK) rows = SEAM_MIN_CHUNK;
     return rows;
 }
 
