@@ -86,6 +86,7 @@ int operand_f32(DeviceCtx *c, bool in_graph, const ggml_tensor *t, Scratch &scra
         // the upload stays resident for the rest of the scope: a leaf used by several nodes (the residual stream) moves once
         void *keep = c->resident_buffer(t->data, bytes);
         if (!keep) return -1;
+        if (!host_range_pinned(t->data, bytes)) c->scope_dirty();   // a copy from pageable memory is staged by the runtime: not something a capture may hold
         c->note_leaf(t->data, bytes);
         if (hipMemcpyAsync(keep, t->data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
         c->h2d_bytes += bytes;
@@ -333,7 +334,7 @@ static int graph_begin(uint64_t key) {
     DeviceCtx *c = call.ctxs[0];
     if (key == 0 || call.G() != 1 || c->graph_depth_ != 1) return GGML_HIP_OK;
     rc = c->make_current();
-    if (rc) return rc;
+    if (rc) { --c->graph_depth_; return rc; }            // (no scope was opened)
     c->scope_key = key;
     c->scope_owner = std::this_thread::get_id();
     c->scope_clean = true;
@@ -482,7 +483,9 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
 static bool scope_replaying() {
     const int b = bound_slot();
     DeviceCtx *c = slot(b >= 0 ? b : 0);
-    return c && c->scope_mode == 3 && c->scope_owner == std::this_thread::get_id();
+    if (!c) return false;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    return c->scope_mode == 3 && c->scope_owner == std::this_thread::get_id();
 }
 
 static bool src1_contig_early(const ggml_tensor *t) { return t->nb[0] == 4 && t->nb[1] == (uint64_t)t->ne[0] * 4; }
@@ -685,6 +688,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 if (in_graph && G == 1 && d_res[0] && (x_res[0] || (epi && epi->pro_x) || (ne11 <= chunk && src1->nb[1] == (uint64_t)ne10 * 4))) {
                     const bool pro = epi && epi->pro_x;
                     if (!x_res[0] && !pro) {
+                        if (!pinned) c->scope_dirty();
                         if (nslice == 1) c->note_leaf(src1->data, (size_t)ne11 * ne10 * 4);
                         e = hipMemcpyAsync(c->src1.p, x_host, (size_t)ne11 * ne10 * 4, hipMemcpyHostToDevice, c->stream);
                         if (e != hipSuccess) break;
