@@ -306,3 +306,31 @@ def test_outputs_only_scope_copies_what_was_asked_for(dev, N):
             assert np.array_equal(a, b), i
     finally:
         G.ggml_free(ctx)
+
+
+def test_an_unregistered_pool_is_never_captured(dev):
+    """a context pool too small to be registered for DMA (pageable host memory): the graph is computed live every time."""
+    rng = np.random.default_rng(51)
+    ctx = G.ggml_init(48 * 1024)                      # below the mirror's registration threshold
+    try:
+        K, M, N = 64, 32, 2
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        Y = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        W = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
+        G.tensor_bytes(W)[:] = O.quantize_row(G.Q4_0, rng.standard_normal((M, K)).astype(np.float32)).reshape(-1)
+        G.tensor_f32(Y)[:] = rng.standard_normal((N, K)).astype(np.float32).reshape(1, 1, N, K)
+        out = G.ggml_mul_mat(ctx, W, G.ggml_mul(ctx, X, Y))
+        gf = G.ggml_build_forward(out)
+        nodes = [gf.nodes[i] for i in range(gf.n_nodes)]
+        c0 = _counters()
+        for it in range(5):
+            G.tensor_f32(X)[:] = rng.standard_normal((N, K)).astype(np.float32).reshape(1, 1, N, K)
+            G.ggml_graph_compute(ctx, gf)
+            got = _snapshot(nodes)
+            _node_by_node(gf)
+            for i, (a, b) in enumerate(zip(got, _snapshot(nodes))):
+                assert np.array_equal(a, b), (it, i)
+        c1 = _counters()
+        assert c1[1] == c0[1] and c1[2] == c0[2], (c0, c1)
+    finally:
+        G.ggml_free(ctx)
