@@ -508,6 +508,10 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     return hipGetLastError();
 }
 
+#ifndef MX_SMALL_FB
+#define MX_SMALL_FB 2                  // weight fragment look-ahead of the small-batch forms (A/B 4: 4096 x 4096 x {16, 64} 13.2 us either way,
+                                       // 32000 x 4096 x 32 32 -> 66 us: these forms are bound by their latency chain, not by the prefetch depth)
+#endif
 template <int TYPE>
 hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     // the largest tile that still gives the chip ~2 workgroups per CU; small problems get more, smaller workgroups
@@ -537,9 +541,9 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
         const int h = var == 12 ? 128 : var == 15 ? 64 : var == 13 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || TYPE != GGML_TYPE_Q4_0) ? 64 : 128);
         if constexpr (TYPE == GGML_TYPE_Q4_0)
-            if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
-        if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
-        return launch_cfg<TYPE, 1, 2, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+            if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
+        if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
+        return launch_cfg<TYPE, 1, 2, 1, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
     }
     // 129 .. 256 rows: the four-way tree as well.  Really split (8 waves per 64-row tile) while the tiles are few -- 4096 x 4096 x 256
     // 28.5 -> 21 us, 4096 x 11008 x 256 62 -> 42 us -- and for larger M, where the split costs (11008 x 4096 x 256: 41.5 -> 52 us), two wave
