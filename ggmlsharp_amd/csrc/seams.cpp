@@ -371,9 +371,19 @@ static int graph_begin(uint64_t key) {
         src.push_back(m); dst.push_back(d); nb.push_back(lf.second);
         c->h2d_bytes += lf.second;
     }
-    for (size_t i = 0; i < src.size() && c->scope_mode == 2; i += 32) {
+    // (the launches are good live as well: should one of the buffer requests above have ended the capture -- an allocation --
+    // the leaves still come down; a leaf whose copy could not be issued loses its resident entry again and is uploaded by the
+    // node that reads it)
+    for (size_t i = 0; i < src.size(); i += 32) {
         const int n = (int)(src.size() - i < 32 ? src.size() - i : 32);
-        if (launch_scatter_copy(src.data() + i, dst.data() + i, nb.data() + i, n, c->stream) != hipSuccess) { (void)hipGetLastError(); c->scope_dirty(); }
+        if (launch_scatter_copy(src.data() + i, dst.data() + i, nb.data() + i, n, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            c->scope_dirty();
+            for (size_t k = i; k < src.size(); ++k)
+                for (auto it = c->resident.begin(); it != c->resident.end(); ++it)
+                    if (it->second.p == dst[k]) { c->pool.push_back(it->second); c->resident.erase(it); break; }
+            break;
+        }
     }
     return GGML_HIP_OK;
 }
