@@ -85,7 +85,7 @@ struct Cfg {
     static_assert((KB * 2 * TN) % NT == 0 && (KB * TN) % NT == 0, "DMA rounds");
     static constexpr int A16_ROUNDS = KB * 2 * TN / NT, A8_ROUNDS = KB * TN / NT;
     static constexpr int SC_CHUNKS = KB * TN / 4;          // 16-byte pieces per plane
-    static_assert(SC_CHUNKS % 64 == 0 && SC_CHUNKS <= NT, "scale DMA is whole waves");
+    static_assert((SC_CHUNKS % 64 == 0 || SC_CHUNKS == 32) && SC_CHUNKS <= NT, "scale DMA is whole waves (or the first half of one: 32-column tiles)");
     static constexpr int NPIECE = A16_ROUNDS + A8_ROUNDS + 1;
     // DMA pieces per tile: one where the stage has enough tiles (the pieces must all be issued before the drain point in the
     // middle of the stage's last k-block), two for the small wave tiles
@@ -173,11 +173,13 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         } else if constexpr (i < C::A16_ROUNDS + C::A8_ROUNDS) {
             constexpr int i8 = i - C::A16_ROUNDS, u = 2 * P * i8;
             blds16(rA, sp + C::A16_BYTES + (size_t)(wave * 64 + C::NT * i8) * 16, voff8, s0 + (u >> 1) * a_blk);
-        } else if (wave < C::SC_CHUNKS / 64) {                           // uniform per wave
+        } else if (wave * 64 < C::SC_CHUNKS) {                           // uniform per wave
             const uint32_t sS0 = (uint32_t)s * KB * (uint32_t)(Npad * 4);
-            blds16(rAd, sp + C::A16_BYTES + C::A8_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
-            if (TYPE == GGML_TYPE_Q4_1)
-                blds16(rAs, sp + C::A16_BYTES + C::A8_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            if (C::SC_CHUNKS % 64 == 0 || lane < C::SC_CHUNKS % 64) {   // (32-column tiles: half a wave of 16-byte pieces; the DMA honours exec)
+                blds16(rAd, sp + C::A16_BYTES + C::A8_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+                if (TYPE == GGML_TYPE_Q4_1)
+                    blds16(rAs, sp + C::A16_BYTES + C::A8_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            }
         }
     };
 
@@ -539,6 +541,13 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         // The 16-wave form only for Q4_0: Q4_1 spills in the 128 registers of a 1024-thread workgroup and measures no faster
         // (32000 x 4096 x 64: 43.5 against 42 us on 64-row tiles).
         const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+        // up to 32 rows: 32-column tiles (the 64-column tile spends half of its MFMAs and scale-accumulates on padding columns
+        // there); same four-way tree, same bits; 32- or 64-row tiles by tile count
+        if (N <= 32 && var != 25) {
+            const int h32 = var == 13 ? 32 : var == 15 || var == 12 ? 64 : (t64 < 160 ? 32 : 64);
+            if (h32 >= 64) return launch_cfg<TYPE, 1, 1, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+            return launch_cfg<TYPE, 1, 1, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+        }
         const int h = var == 12 ? 128 : var == 15 ? 64 : var == 13 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || TYPE != GGML_TYPE_Q4_0) ? 64 : 128);
         if constexpr (TYPE == GGML_TYPE_Q4_0)
             if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
