@@ -134,7 +134,7 @@ struct Cfg {
     static_assert(A_CHUNKS % NT == 0, "DMA rounds");
     static constexpr int A_ROUNDS = A_CHUNKS / NT;
     static constexpr int SC_CHUNKS = KB * TN / 4;          // 16-byte pieces per plane
-    static_assert(SC_CHUNKS % 64 == 0 && SC_CHUNKS <= NT, "scale DMA is whole waves");
+    static_assert((SC_CHUNKS % 64 == 0 || SC_CHUNKS == 32) && SC_CHUNKS <= NT, "scale DMA is whole waves (or the first half of one: 32-column tiles)");
     static constexpr int WPS = 2;                          // waves per SIMD aimed at (256 registers each)
 };
 
@@ -213,10 +213,12 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         if constexpr (i < C::A_ROUNDS) {
             constexpr int bb = (P * i) >> 2, pan = (P * i) & 3;
             blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voffA, (uint32_t)s * KB * a_blk + bb * a_blk + pan * a_pan);
-        } else if (wave < C::SC_CHUNKS / 64) {                           // uniform per wave
+        } else if (wave * 64 < C::SC_CHUNKS) {                           // uniform per wave
             const uint32_t sS0 = (uint32_t)s * KB * (uint32_t)(Npad * 4);
-            blds16(rAd, sp + C::A_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
-            if (WT<TYPE>::MIN) blds16(rAs, sp + C::A_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            if (C::SC_CHUNKS % 64 == 0 || lane < C::SC_CHUNKS % 64) {   // (32-column tiles: half a wave of 16-byte pieces; the DMA honours exec)
+                blds16(rAd, sp + C::A_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+                if (WT<TYPE>::MIN) blds16(rAs, sp + C::A_BYTES + C::SC_BYTES + (size_t)(wave * 64) * 16, voffS, sS0);
+            }
         }
     };
 
@@ -528,6 +530,12 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         // 16-wave form not for the min-term types: registers)
         static const int tile = dev_env_int("GGML_HIP_Q16_TILE", 0);   // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
         const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
+        // up to 32 rows: 32-column tiles (gemm_qmx.hip: half of the 64-column tile's work is on padding columns there); same tree
+        if (N <= 32 && tile != 4) {
+            const int h32 = tile == 2 ? 32 : tile == 1 || tile == 3 ? 64 : (t64 < 160 ? 32 : 64);
+            if (h32 >= 64) return launch_cfg<TYPE, 1, 1, 2, 1, 4, 4>(w, p, N, dst, ldd, st);
+            return launch_cfg<TYPE, 1, 1, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
+        }
         const int h = tile == 1 ? 128 : tile == 3 ? 64 : tile == 2 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || WT<TYPE>::MIN) ? 64 : 128);
         if constexpr (!WT<TYPE>::MIN)
             if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st);
