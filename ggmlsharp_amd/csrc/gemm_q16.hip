@@ -335,6 +335,9 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
                 // (a BUILTIN, so that hipcc pads its own reads of the result -- it splits the tuple with v_mov; the inline-asm readers
                 // are a tile step away: the dummy operand of this step's third scale-accumulate group keeps the MFMA above it)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_s, mpair, acc[i][j], 0, 0, 0);
+                // one tile per k-block (32-column forms): the SAME accumulators take the previous tile's scale-accumulates right
+                // behind this MFMA: its 16 passes + 4 wait states are spent here (tests/test_isa_audit.py)
+                if constexpr (WMT * WNT == 1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][j]));
             }
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             if constexpr (j == WNT - 1) {

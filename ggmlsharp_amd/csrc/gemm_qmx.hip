@@ -266,8 +266,13 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             // issued a whole tile step (32 VALU instructions) before and after the scale-accumulates that touch them.  A BUILTIN, so
             // that hipcc pads its own reads of the result (it splits the tuple with v_mov); the inline-asm readers are kept a
             // step away by an empty volatile statement on the tuple ahead of the previous tile's scale-accumulates (below).
-            if constexpr (TYPE == GGML_TYPE_Q4_1 && (bb & 1))
+            if constexpr (TYPE == GGML_TYPE_Q4_1 && (bb & 1)) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_s, mcur[i], acc[i][j], 0, 0, 0);
+                // one tile per k-block (32-column forms): the SAME accumulators take the previous tile's scale-accumulates right
+                // behind this MFMA: its 16 passes + 4 wait states are spent here (tests/test_isa_audit.py found the asm 6 slots
+                // behind it; twenty idle cycles per pair of k-blocks)
+                if constexpr (NTILE == 1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][j]));
+            }
             if constexpr (i == WMT - 1 && bb * WNT + j + 1 < KB * WNT && !(GGML_MX_DBG & (2 | 64))) fetch_af(std::integral_constant<int, bb * WNT + j + 1>{});
             // the fragment of m-tile i is dead once the MFMA of the block's last n-tile is issued: reload it for kb + 2
             // (this group's k-blocks: the stage after s is sn)
