@@ -486,6 +486,229 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     }
 }
 
+// ---- K3s: batches of up to 32 rows (a batched decoder's step), Q4_0 / Q4_1 -------------------------------------------------
+// The staged kernel above is a latency chain here: one 32 x 32 tile per wave and k-block, a stage of four k-blocks between two
+// barriers, and at every stage's drain point the wave waits for everything it has in flight -- one memory round trip per stage,
+// eight of them for K = 4096.  With the weights cold in HBM (a decoder walks through gigabytes of them) that is 17 us for
+// 4096 x 4096 x 32 where the 15 MB of bf6 planes are 3 us of HBM time.
+// This form has no stages: a workgroup is one 32-row weight tile and KS waves that each take a CONTIGUOUS range of k-blocks,
+// in PAIRS.  A wave requests everything its first NP pairs need before anything else -- for K <= 4096 that is its whole range:
+// all of the matrix is in flight at once across the grid; longer K refills a pair's slots as soon as its MFMAs have issued --
+// in the order it will consume it (loads return in order: the wait in front of a pair is exactly for that pair's data).
+//   * weights: the MX operand wants a block's fragment in BOTH lane halves (the halves are the two digit groups of the
+//     activations).  Loading it twice doubles the traffic through the texture path, so lanes 0..31 fetch block i and lanes
+//     32..63 block i + 1 of the same rows in ONE instruction, and v_permlane32_swap hands each half the other's copy: half the
+//     load instructions, half the registers that wait for data.
+//   * activations: straight from the K1 image in L2 into registers (no reuse between waves that LDS would serve);
+//   * row scales: the wave's own slice, loaded by itself into its own LDS slice -- no barrier before the end;
+//   * the waves' sums are added in wave order through LDS: a KS-way tree, fixed by N and K like every other form's.
+// Arithmetic per block as above: one MX MFMA, then acc += (sumi * d1) * d0 (Ggml.cs:1158); Q4_1's min term per pair of blocks as
+// a 32x32x2 f32 MFMA in front of the pair's scale-accumulates.  Everything is builtins and plain C: the compiler counts the
+// loads and pads the MFMA hazards.
+#ifdef K3S_TRACE            // tools/k3s_trace.hip: time stamps (100 MHz) of wave 0 / wave KS-1 of every workgroup at the phase ends
+__device__ unsigned long long k3s_trace_buf[2048 * 2 * 8];
+#define K3S_STAMP(k) do { if (lane == 0 && (wave == 0 || wave == KS - 1) && blockIdx.x < 2048) \
+        k3s_trace_buf[((size_t)blockIdx.x * 2 + (wave != 0)) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define K3S_STAMP(k) do { } while (0)
+#endif
+template <int TYPE, int KS, int NP, bool ROT, int WMT>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                           const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
+                           const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp,
+                           int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, uint32_t ad_bytes,
+                           const mm_epilogue ep) {
+    static_assert(TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1, "one weight digit per block");
+    constexpr bool Q41 = TYPE == GGML_TYPE_Q4_1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    K3S_STAMP(0);
+    const int m0 = blockIdx.x * 32 * WMT;                   // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
+    const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (nloc even; the planes are zero
+    const int npair = nloc >> 1;                            // past the end of K, the descriptors' range check covers the rest)
+    // ---- descriptors and per-lane offsets (planes [nbk][Mpad][16 | 8 | 4]; image per k-block [half][Npad][16] then [half][Npad][8]) ----
+    const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
+    const rsrc_t rWm = make_rsrc(Q41 ? (const void *)wm : (const void *)wd, wd_bytes);
+    const rsrc_t rA = make_rsrc(a6, a_bytes), rAs = make_rsrc(Q41 ? asd : ad, ad_bytes);
+    const uint32_t voffS = (uint32_t)((hh * Npad + l31) * 4);
+    const int mrow = m0 + l31;
+    const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4);
+    // lane half hh takes block (pair's first) + hh
+    const uint32_t offA = (uint32_t)(mrow * 16) + hh * wa_blk, offB = (uint32_t)(mrow * 8) + hh * wb_blk, offD = (uint32_t)(mrow * 4) + hh * d_blk;
+    const uint32_t a_blk = (uint32_t)Npad * 48u;
+    const uint32_t voff16 = (uint32_t)((hh * Npad + l31) * 16), voff8 = (uint32_t)(32 * Npad + (hh * Npad + l31) * 8);
+
+    struct WP { u32x4 lo[WMT]; u32x2 hi[WMT]; float d[WMT]; float mn[WMT]; float s; };   // lanes 0..31: the pair's first block, lanes 32..63: its second
+    struct AF { u32x4 lo; u32x2 hi; };
+    WP wp[NP];
+    AF af[2 * NP];
+    auto load_pair = [&](WP &f, AF &a0, AF &a1, int pr) {   // pair pr of this wave (clamped to its last: never another wave's blocks)
+        const int kb = kb0 + 2 * (pr < npair ? pr : npair - 1);
+        a0.lo = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff16, (int)((uint32_t)kb * a_blk), 0);
+        a0.hi = __builtin_amdgcn_raw_buffer_load_b64(rA, (int)voff8, (int)((uint32_t)kb * a_blk), 0);
+        a1.lo = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)voff16, (int)((uint32_t)(kb + 1) * a_blk), 0);
+        a1.hi = __builtin_amdgcn_raw_buffer_load_b64(rA, (int)voff8, (int)((uint32_t)(kb + 1) * a_blk), 0);
+#pragma unroll
+        for (int t = 0; t < WMT; ++t) {                      // (tiles are 32 rows apart: a constant the instruction's offset field takes)
+            f.lo[t] = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)(offA + 512u * t), (int)((uint32_t)kb * wa_blk), 0);
+            f.hi[t] = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)(offB + 256u * t), (int)((uint32_t)kb * wb_blk), 0);
+            f.d[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)(offD + 128u * t), (int)((uint32_t)kb * d_blk), 0));
+            if constexpr (Q41) f.mn[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)(offD + 128u * t), (int)((uint32_t)kb * d_blk), 0));
+        }
+        if constexpr (Q41) {
+            // d1 * sum(a) of column l31, block kb + hh (K1's second plane): the A operand of the pair's min-term MFMA.  A slot that
+            // repeats the wave's last pair must add nothing: its offset points past the plane, the range check returns 0.
+            f.s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAs, (int)voffS, pr < npair ? (int)((uint32_t)kb * (uint32_t)(Npad * 4)) : 0x7FFFFFF0, 0));
+        }
+    };
+
+    // ---- this wave's slice of the row scales: rows x 32 floats, straight into its own LDS slice.
+    //      Rows past the wave's range are ZERO: a slot that holds a clamped (repeated) pair then adds (sumi * 0) * d0 = +0. ----
+    const int trows = ROT ? nloc : 2 * NP;
+    float *const tabD = (float *)smem + (size_t)wave * trows * 32;
+    constexpr int TP = 8;                                   // float4 pieces per lane and plane (nloc <= 64)
+    f32x4 td[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int idx = lane + 64 * j, b = idx >> 3, c4 = idx & 7;
+        const bool ok = b < nloc && kb0 + b < nbkp;
+        const size_t e = (size_t)(kb0 + (ok ? b : 0)) * Npad + 4 * c4;
+        td[j] = ok ? *(const f32x4 *)(ad + e) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    static_for<NP>([&](auto uc) { constexpr int u = decltype(uc)::value; load_pair(wp[u], af[2 * u], af[2 * u + 1], u); });
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < trows * 8) {
+            *(f32x4 *)(tabD + 4 * idx) = td[j];
+        }
+    }
+    // (same wave wrote and reads: LDS operations of one wave complete in order; the compiler needs the fence)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    K3S_STAMP(1);
+    f32x16 acc[WMT];
+#pragma unroll
+    for (int t = 0; t < WMT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int scale_a = hh ? 127 : 131;                     // E8M0: K group 0 (the ah digits) carries 2^4
+
+    // v_permlane32_swap: x in both operands -> {x's lower half in both halves, x's upper half in both halves}
+    auto both = [](uint32_t x, uint32_t &b0, uint32_t &b1) {
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        b0 = r[0]; b1 = r[1];
+    };
+    // pair pr of the wave (blocks i = 2 pr, i + 1) out of slot u: [min term of the pair,] block i, block i + 1
+    auto pair = [&](int pr, auto uc) {
+        constexpr int u = decltype(uc)::value;
+        WP &w = wp[u];
+        AF &a0 = af[2 * u], &a1 = af[2 * u + 1];
+        const i32x8 A0 = {(int)a0.lo[0], (int)a0.lo[1], (int)a0.lo[2], (int)a0.lo[3], (int)a0.hi[0], (int)a0.hi[1], 0, 0};
+        const i32x8 A1 = {(int)a1.lo[0], (int)a1.lo[1], (int)a1.lo[2], (int)a1.lo[3], (int)a1.hi[0], (int)a1.hi[1], 0, 0};
+        const int i = 2 * pr;
+        f32x16 t0[WMT], t1[WMT];
+        float d0[WMT], d1[WMT];
+#pragma unroll
+        for (int t = 0; t < WMT; ++t) {
+            uint32_t b0[6], b1[6];
+            both(w.lo[t][0], b0[0], b1[0]); both(w.lo[t][1], b0[1], b1[1]); both(w.lo[t][2], b0[2], b1[2]); both(w.lo[t][3], b0[3], b1[3]);
+            both(w.hi[t][0], b0[4], b1[4]); both(w.hi[t][1], b0[5], b1[5]);
+            uint32_t d0u, d1u;
+            both(__builtin_bit_cast(uint32_t, w.d[t]), d0u, d1u);
+            d0[t] = __builtin_bit_cast(float, d0u); d1[t] = __builtin_bit_cast(float, d1u);
+            const i32x8 B0 = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b0[4], (int)b0[5], 0, 0};
+            const i32x8 B1 = {(int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3], (int)b1[4], (int)b1[5], 0, 0};
+            t0[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, B0, zero, 3, 3, 0, scale_a, 0, 127);
+            t1[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, B1, zero, 3, 3, 0, scale_a, 0, 127);
+            if constexpr (Q41) {
+                // + (m0 + 8 d0) * (d1 * sum(a)) per block (Ggml.cs:1190-1196 factorised; nib = (nib - 8) + 8): the two blocks of the
+                // pair are the K = 2 of one f32 MFMA -- block i in lane half 0, block i + 1 in lane half 1, which is how they were loaded
+                const float m8 = fmaf(8.0f, w.d[t], w.mn[t]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.s, m8, acc[t], 0, 0, 0);
+            }
+        }
+        if constexpr (ROT) load_pair(w, a0, a1, pr + NP);   // the fragments are in the MFMAs' hands: the slot takes the pair NP further on
+        const float *dp0 = tabD + i * 32 + 4 * hh, *dp1 = dp0 + 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 da = *(const f32x4 *)(dp0 + 8 * q);
+#pragma unroll
+            for (int t = 0; t < WMT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = t0[t][4 * q + e] * da[e];
+                    acc[t][4 * q + e] = __builtin_fmaf(x, d0[t], acc[t][4 * q + e]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 da = *(const f32x4 *)(dp1 + 8 * q);
+#pragma unroll
+            for (int t = 0; t < WMT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = t1[t][4 * q + e] * da[e];
+                    acc[t][4 * q + e] = __builtin_fmaf(x, d1[t], acc[t][4 * q + e]);
+                }
+        }
+    };
+    if constexpr (!ROT) {                                    // the whole range sits in the slots (npair <= NP; slots past it: zero table rows)
+        static_for<NP>([&](auto pc) { pair(decltype(pc)::value, pc); });
+    } else {
+        // whole rounds of NP pairs, then the rest (a guard around every pair would cost the exact waits: the compiler merges the
+        // counters of the two paths at every join)
+        int base = 0;
+        for (; base + NP <= npair; base += NP)
+            static_for<NP>([&](auto pc) { pair(base + decltype(pc)::value, pc); });
+        static_for<NP>([&](auto pc) { if (base + decltype(pc)::value < npair) pair(base + decltype(pc)::value, pc); });
+    }
+
+    // ---- the waves' sums, added in wave order (the tables are dead: every wave is past its loop at the first barrier).  Every wave
+    //      takes its share of the result rows a lane holds: the additions of one element are the same, in the same order, whoever
+    //      makes them (one wave adding all of it: 1.4 us after the barrier; this way 0.5) ----
+#ifdef K3S_TRACE
+    asm volatile("" : "+v"(acc[0]));
+    K3S_STAMP(2);
+#endif
+    __syncthreads();
+    K3S_STAMP(3);
+    float *xch = (float *)smem + lane;
+#pragma unroll
+    for (int t = 0; t < WMT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(size_t)((wave * WMT + t) * 16 + r) * 64] = acc[t][r];
+    __syncthreads();
+    K3S_STAMP(4);
+    static_assert((16 * WMT) % KS == 0 && 16 % (16 * WMT / KS) == 0, "rows per wave");
+    constexpr int RW = 16 * WMT / KS;
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        const int rr = wave * RW + k, t = rr / 16, r = rr % 16;   // (uniform)
+        float v = xch[(size_t)(t * 16 + r) * 64];
+#pragma unroll
+        for (int g = 1; g < KS; ++g) v += xch[(size_t)((g * WMT + t) * 16 + r) * 64];
+        // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31] ----
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * hh, m = m0 + 32 * t + l31;
+        if (n < N && m < M) {
+            if (ep.mode == 2) {
+                dst[(size_t)n * ldd + m] = v * ep.scale;
+            } else {
+                dst[(size_t)n * ldd + m] = v;
+                if (ep.mode == 1) ep.dst2[(size_t)n * ep.ld2 + m] = v + ep.addend[(size_t)n * ep.ld_add + m];
+            }
+        }
+    }
+    K3S_STAMP(6);
+}
+
 // the epilogue of the call in flight on this host thread (set by launch_gemm_qmx around launch_typed: the tile-form selection
 // below has a dozen call sites, the epilogue concerns none of them)
 thread_local mm_epilogue t_epilogue = {0, nullptr, 0, nullptr, 0, 1.0f};
@@ -512,6 +735,47 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     kern<<<grid, C::NT * KSP, C::TOTAL * KSP, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M,
                                         (int)N, (int)w->Mpad, (int)p.Npad, nstages, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes,
                                         (uint32_t)wd_bytes, (uint32_t)a_bytes, (uint32_t)ad_bytes, (uint32_t)dst_bytes, t_epilogue);
+    return hipGetLastError();
+}
+
+// K3s launch: KS = 8 waves per 32-row tile, each a contiguous eighth of K in pairs of blocks; the slots hold a wave's whole range
+// for K <= 4096 (8 pairs) and K <= 2048 (4 pairs), longer K refills them in turn.  Chosen by N and K alone.
+template <int TYPE>
+hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    constexpr int KS = 8;
+    if (!w->q6a || !w->q6b || p.Npad < 32) return hipErrorInvalidValue;
+    const int nbkp = (int)pad_kblocks(w->nbk);
+    int nloc = (nbkp + KS - 1) / KS;
+    nloc += nloc & 1;                                       // pairs of blocks stay inside one wave
+    if (nloc > 64) return hipErrorNotSupported;             // (the table pieces a lane holds: K <= 16384)
+    const uint64_t nba = (uint64_t)nbkp;
+    const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4;
+    const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
+    if (wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+    const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
+    // More 32-row tiles than CUs: two of them per workgroup.  Every workgroup pulls the whole activation image through its CU's
+    // vector memory path (196 KB for K = 4096, against 115 KB of weights per tile) and a CU sustains some 70 GB/s from far
+    // memory: twice the weights behind the same activation fragments.  Same blocks in the same order per element: the same bits
+    // (only the geometry follows M).
+    static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 = one tile per workgroup always, 2 = two always
+    const bool two = geo == 2 || (geo != 1 && (w->M + 31) / 32 > 256);
+    const int tab = KS * rows * 32 * 4, xch = KS * (two ? 2 : 1) * 16 * 64 * 4;
+    const int lds = tab > xch ? tab : xch;
+    dim3 grid((unsigned)((w->M + (two ? 63 : 31)) / (two ? 64 : 32)));
+    if (two && w->Mpad % 64 != 0) return hipErrorInvalidValue;
+#define K3S_GO(NP, ROT, WMT) do { \
+        auto kern = gemm_qmx_small_kernel<TYPE, KS, NP, ROT, WMT>; \
+        static PerDeviceOnce once; \
+        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
+        if (attr != hipSuccess) return attr; \
+        kern<<<grid, KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M, (int)N, \
+                                      (int)w->Mpad, (int)p.Npad, nbkp, nloc, (int)ldd, (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, \
+                                      (uint32_t)ad_bytes, t_epilogue); } while (0)
+    if (two) { if (nloc <= 8) K3S_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(3, true, 2); else K3S_GO(4, true, 2); }
+    else if (nloc <= 8) K3S_GO(4, false, 1);
+    else if (nloc <= 16) K3S_GO(8, false, 1);
+    else { if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(4, true, 1); else K3S_GO(8, true, 1); }   // (Q4_1 carries three more registers per pair)
+#undef K3S_GO
     return hipGetLastError();
 }
 
@@ -548,6 +812,16 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
         // up to 32 rows: 32-column tiles (the 64-column tile spends half of its MFMAs and scale-accumulates on padding columns
         // there); same four-way tree, same bits; 32- or 64-row tiles by tile count
+        if constexpr (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) {
+            // up to 32 rows, K >= 2048: the stage-free form (K3s above).  Weights cold in HBM, compute kernel in us, staged form | K3s:
+            // 4096 x 4096 x 32 16.8 | 12.3, 8192 x 4096 17.6 | 13.2, 11008 x 4096 20.1 | 19.3, 16384 x 4096 21.3 | 20.3, 32000 x 4096
+            // 31.1 | 36.1 (the one loss: 500 workgroups, two rounds), 4096 x 11008 36.7 | 24.8, 4096 x 2048 10.4 | 8.2; K = 1024 7.2 | 7.7:
+            // shorter K stays on the staged form.  The choice is by N and K alone (GGML_HIP_MX_TILE=26: the staged form, A/B).
+            if (N <= 32 && w->nbk >= 64 && var != 25 && var != 26) {
+                const hipError_t e = launch_small<TYPE>(w, p, N, dst, ldd, st);
+                if (e != hipErrorNotSupported) return e;
+            }
+        }
         if (N <= 32 && var != 25) {
             const int h32 = var == 13 ? 32 : var == 15 || var == 12 ? 64 : (t64 < 160 ? 32 : 64);
             if (h32 >= 64) return launch_cfg<TYPE, 1, 1, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
