@@ -33,7 +33,8 @@ def _params(phase=_lib.GGML_TASK_COMPUTE):
 def test_epilogue_device_form_is_bitwise_product_then_node(dev, t):
     from ggmlsharp_amd._lib import lib, check
     L = lib()
-    for (M, K, N) in ((96, 256, 1), (130, 512, 3), (64, 256, 4), (200, 256, 6), (515, 512, 40), (260, 1024, 300), (128, 256, 1100)):
+    for (M, K, N) in ((96, 256, 1), (130, 512, 3), (64, 256, 4), (200, 256, 6), (515, 512, 40), (260, 1024, 300), (128, 256, 1100),
+                      (130, 2048, 12), (260, 4096 + 64, 32)):      # (the last two: the batched-decode form, gemm_qmx.hip K3s)
         wq = O.quantize_row(t, _rand((M, K)))
         W = dev.Weight.from_host(t, wq, K)
         x = torch.from_numpy(_rand((N, K))).cuda()

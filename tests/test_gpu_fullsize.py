@@ -186,6 +186,26 @@ def test_small_batch_tile_forms_agree_bitwise(dev, N):
         W.free()
 
 
+@pytest.mark.parametrize("N", [9, 20, 32])
+def test_batched_decode_form_follows_M_only_in_its_geometry(dev, N):
+    """Batches of up to 32 rows, K >= 2048 (gemm_qmx.hip K3s): eight waves with a contiguous eighth of K each, their sums added
+    in wave order -- fixed by N and K.  One 32-row tile per workgroup while there are at most 256 tiles, two above: a shard is
+    bit for bit the matching columns of the unsplit result.  K = 2048 holds a wave's range in its slots, 4096 + 64 and 6144
+    refill them in turn."""
+    for (t, M, K) in ((Q4_0, 16384 + 40, 2048), (3, 8192 + 300, 4096 + 64), (Q4_0, 300, 6144), (3, 100, 2048 + 32)):
+        rows, x = _make(dev, t, M, K, N, seed=11 + t + N)
+        W = dev.Weight.from_device(t, rows, K)
+        full = dev.mul_mat(W, x)
+        _check_fp64(dev, t, rows, x, full, K)
+        for (r0, r1) in ((0, 2048), (M - 77, M), (0, min(M, 8192)), (31, 290)):
+            if r1 > M:
+                continue
+            Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+            assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, M, K, N, r0, r1)
+            Ws.free()
+        W.free()
+
+
 @pytest.mark.parametrize("N", [100, 300])
 def test_dense_f16_tile_forms_agree_bitwise(dev, N):
     """F16 weights: the K split of a batch (four ways up to 128 rows, two ways up to 512) is fixed by N and K, the tile shape by
