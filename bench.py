@@ -598,7 +598,7 @@ def main():
         if not args.no_side_configs:
             out["other_configs"] = {
                 "batch1": side_config(device, 4096, 4096, 1, copies=32, iters=200),
-                "batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100),      # a batched decoder's step: INIT + the 32-column MX form
+                "batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100),      # a batched decoder's step: INIT + the stage-free MX form (gemm_qmx.hip K3s)
                 "prompt512": side_config(device, 4096, 4096, 512, copies=32, iters=100),
                 "batch1_M32000": side_config(device, 32000, 4096, 1, copies=8, iters=100),   # the same mat-vec kernel on an 82 MB matrix
                 # BASELINE.json configs[3] (the reference has no k-quants: its 5-bit type Q5_0 stands in) and
