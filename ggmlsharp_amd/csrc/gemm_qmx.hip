@@ -614,6 +614,47 @@ void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__res
         const i32x8 A0 = {(int)a0.lo[0], (int)a0.lo[1], (int)a0.lo[2], (int)a0.lo[3], (int)a0.hi[0], (int)a0.hi[1], 0, 0};
         const i32x8 A1 = {(int)a1.lo[0], (int)a1.lo[1], (int)a1.lo[2], (int)a1.lo[3], (int)a1.hi[0], (int)a1.hi[1], 0, 0};
         const int i = 2 * pr;
+        if constexpr (WMT >= 4) {
+            // four tiles behind one activation fragment (more than 512 tiles): a tile's two MFMAs, then its scale-accumulates, tile by
+            // tile -- the products of all four at once would be 128 registers; the row scales of the pair stay in registers instead
+            const float *dp = tabD + i * 32 + 4 * hh;
+            f32x4 da0[4], da1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { da0[q] = *(const f32x4 *)(dp + 8 * q); da1[q] = *(const f32x4 *)(dp + 32 + 8 * q); }
+#pragma unroll
+            for (int t = 0; t < WMT; ++t) {
+                uint32_t b0[6], b1[6];
+                both(w.lo[t][0], b0[0], b1[0]); both(w.lo[t][1], b0[1], b1[1]); both(w.lo[t][2], b0[2], b1[2]); both(w.lo[t][3], b0[3], b1[3]);
+                both(w.hi[t][0], b0[4], b1[4]); both(w.hi[t][1], b0[5], b1[5]);
+                uint32_t d0u, d1u;
+                both(__builtin_bit_cast(uint32_t, w.d[t]), d0u, d1u);
+                const float e0 = __builtin_bit_cast(float, d0u), e1 = __builtin_bit_cast(float, d1u);
+                const i32x8 B0 = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b0[4], (int)b0[5], 0, 0};
+                const i32x8 B1 = {(int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3], (int)b1[4], (int)b1[5], 0, 0};
+                const f32x16 x0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, B0, zero, 3, 3, 0, scale_a, 0, 127);
+                const f32x16 x1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, B1, zero, 3, 3, 0, scale_a, 0, 127);
+                if constexpr (Q41) {
+                    const float m8 = fmaf(8.0f, w.d[t], w.mn[t]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.s, m8, acc[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = x0[4 * q + e] * da0[q][e];
+                        acc[t][4 * q + e] = __builtin_fmaf(x, e0, acc[t][4 * q + e]);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = x1[4 * q + e] * da1[q][e];
+                        acc[t][4 * q + e] = __builtin_fmaf(x, e1, acc[t][4 * q + e]);
+                    }
+            }
+            if constexpr (ROT) load_pair(w, a0, a1, pr + NP);
+            return;
+        }
         f32x16 t0[WMT], t1[WMT];
         float d0[WMT], d1[WMT];
 #pragma unroll
@@ -753,16 +794,19 @@ hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
     if (wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
     const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
-    // More 32-row tiles than CUs: two of them per workgroup.  Every workgroup pulls the whole activation image through its CU's
-    // vector memory path (196 KB for K = 4096, against 115 KB of weights per tile) and a CU sustains some 70 GB/s from far
-    // memory: twice the weights behind the same activation fragments.  Same blocks in the same order per element: the same bits
-    // (only the geometry follows M).
-    static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 = one tile per workgroup always, 2 = two always
-    const bool two = geo == 2 || (geo != 1 && (w->M + 31) / 32 > 256);
-    const int tab = KS * rows * 32 * 4, xch = KS * (two ? 2 : 1) * 16 * 64 * 4;
+    // More 32-row tiles than CUs: two of them per workgroup, four beyond 512 tiles.  Every workgroup pulls the whole activation
+    // image through its CU's vector memory path (196 KB for K = 4096, against 115 KB of weights per tile), and that path is what
+    // bounds the form: two / four times the weights behind the same activation fragments (32000 x 4096 x 32: 41.5 | 36.1 | 30.1 us
+    // with one | two | four tiles).  Same blocks in the same order per element: the same bits (only the geometry follows M).
+    static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 / 2 / 4 = that many tiles per workgroup whatever M
+    const int64_t t32 = (w->M + 31) / 32;
+    // (four tiles: Q4_0 only -- Q4_1's min-term registers do not fit beside four accumulator tiles)
+    const int wmt = geo == 1 ? 1 : geo == 2 || TYPE == GGML_TYPE_Q4_1 ? (geo == 2 || geo == 4 || t32 > 256 ? 2 : 1) : geo == 4 ? 4 : (t32 <= 256 ? 1 : t32 <= 512 ? 2 : 4);
+    const bool two = wmt == 2;
+    const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
     const int lds = tab > xch ? tab : xch;
-    dim3 grid((unsigned)((w->M + (two ? 63 : 31)) / (two ? 64 : 32)));
-    if (two && w->Mpad % 64 != 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((w->M + 32 * wmt - 1) / (32 * wmt)));
+    if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
 #define K3S_GO(NP, ROT, WMT) do { \
         auto kern = gemm_qmx_small_kernel<TYPE, KS, NP, ROT, WMT>; \
         static PerDeviceOnce once; \
@@ -771,7 +815,8 @@ hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float
         kern<<<grid, KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M, (int)N, \
                                       (int)w->Mpad, (int)p.Npad, nbkp, nloc, (int)ldd, (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, \
                                       (uint32_t)ad_bytes, t_epilogue); } while (0)
-    if (two) { if (nloc <= 8) K3S_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(3, true, 2); else K3S_GO(4, true, 2); }
+    if (wmt == 4) { if constexpr (TYPE == GGML_TYPE_Q4_0) K3S_GO(2, true, 4); }
+    else if (two) { if (nloc <= 8) K3S_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(3, true, 2); else K3S_GO(4, true, 2); }
     else if (nloc <= 8) K3S_GO(4, false, 1);
     else if (nloc <= 16) K3S_GO(8, false, 1);
     else { if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(4, true, 1); else K3S_GO(8, true, 1); }   // (Q4_1 carries three more registers per pair)
@@ -814,8 +859,8 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         // there); same four-way tree, same bits; 32- or 64-row tiles by tile count
         if constexpr (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) {
             // up to 32 rows, K >= 2048: the stage-free form (K3s above).  Weights cold in HBM, compute kernel in us, staged form | K3s:
-            // 4096 x 4096 x 32 16.8 | 12.3, 8192 x 4096 17.6 | 13.2, 11008 x 4096 20.1 | 19.3, 16384 x 4096 21.3 | 20.3, 32000 x 4096
-            // 31.1 | 36.1 (the one loss: 500 workgroups, two rounds), 4096 x 11008 36.7 | 24.8, 4096 x 2048 10.4 | 8.2; K = 1024 7.2 | 7.7:
+            // 4096 x 4096 x 32 16.8 | 12.3, 8192 x 4096 17.6 | 13.2, 11008 x 4096 20.1 | 18.5-19.3, 16384 x 4096 21.3 | 20.3, 32000 x 4096
+            // 31.1 | 30.1 (four tiles per workgroup; two: 36.1), 4096 x 11008 36.7 | 24.8, 4096 x 2048 10.4 | 8.2; K = 1024 7.2 | 7.7:
             // shorter K stays on the staged form.  The choice is by N and K alone (GGML_HIP_MX_TILE=26: the staged form, A/B).
             if (N <= 32 && w->nbk >= 64 && var != 25 && var != 26) {
                 const hipError_t e = launch_small<TYPE>(w, p, N, dst, ldd, st);

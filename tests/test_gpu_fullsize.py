@@ -189,10 +189,11 @@ def test_small_batch_tile_forms_agree_bitwise(dev, N):
 @pytest.mark.parametrize("N", [9, 20, 32])
 def test_batched_decode_form_follows_M_only_in_its_geometry(dev, N):
     """Batches of up to 32 rows, K >= 2048 (gemm_qmx.hip K3s): eight waves with a contiguous eighth of K each, their sums added
-    in wave order -- fixed by N and K.  One 32-row tile per workgroup while there are at most 256 tiles, two above: a shard is
-    bit for bit the matching columns of the unsplit result.  K = 2048 holds a wave's range in its slots, 4096 + 64 and 6144
+    in wave order -- fixed by N and K.  One 32-row tile per workgroup while there are at most 256 tiles, two above, four (Q4_0)
+    above 512: a shard is bit for bit the matching columns of the unsplit result.  K = 2048 holds a wave's range in its slots, 4096 + 64 and 6144
     refill them in turn."""
-    for (t, M, K) in ((Q4_0, 16384 + 40, 2048), (3, 8192 + 300, 4096 + 64), (Q4_0, 300, 6144), (3, 100, 2048 + 32)):
+    # (16424 rows = 514 tiles: four per workgroup for Q4_0; 8492 rows: two)
+    for (t, M, K) in ((Q4_0, 16384 + 40, 2048), (3, 8192 + 300, 4096 + 64), (Q4_0, 8192 + 300, 2048), (Q4_0, 300, 6144), (3, 100, 2048 + 32)):
         rows, x = _make(dev, t, M, K, N, seed=11 + t + N)
         W = dev.Weight.from_device(t, rows, K)
         full = dev.mul_mat(W, x)

@@ -28,14 +28,16 @@ int main(int argc, char **argv) {
     CK(hipMemset(a6, 0, ab)); CK(hipMemset(ad, 0, adb));
     const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
     const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
-    const int tab = KS * rows * 32 * 4, xch = KS * 2 * 16 * 64 * 4, lds = std::max(tab, xch);
-    const bool two = getenv("K3S_TWO") ? atoi(getenv("K3S_TWO")) != 0 : (M + 31) / 32 > 256;
-    const int grid = two ? (M + 63) / 64 : (M + 31) / 32;
+    const int tab = KS * rows * 32 * 4, xch = KS * 4 * 16 * 64 * 4, lds = std::max(tab, xch);
+    const int t32 = (M + 31) / 32;
+    const int wmt = getenv("K3S_TILES") ? atoi(getenv("K3S_TILES")) : (t32 <= 256 ? 1 : t32 <= 512 ? 2 : 4);   // tiles per workgroup (1 | 2 | 4)
+    const bool two = wmt == 2;
+    const int grid = (M + 32 * wmt - 1) / (32 * wmt);
     auto go = [&](int c) {
 #define GO(NP, ROT, WMT) do { auto kern = gemm_qmx_small_kernel<GGML_TYPE_Q4_0, 8, NP, ROT, WMT>; \
         CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         kern<<<grid, KS * 64, lds>>>(A[c], B[c], D[c], D[c], a6, ad, ad, dst, M, N, Mpad, Npad, nbkp, nloc, M, (uint32_t)wa, (uint32_t)wdb, (uint32_t)ab, (uint32_t)adb, ep); } while (0)
-        if (two) { if (nloc <= 8) GO(4, false, 2); else GO(4, true, 2); } else if (nloc <= 8) GO(4, false, 1); else if (nloc <= 16) GO(8, false, 1); else GO(8, true, 1);
+        if (wmt == 4) GO(2, true, 4); else if (two) { if (nloc <= 8) GO(4, false, 2); else GO(4, true, 2); } else if (nloc <= 8) GO(4, false, 1); else if (nloc <= 16) GO(8, false, 1); else GO(8, true, 1);
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int c = 0; c < copies; ++c) go(c);
