@@ -124,6 +124,8 @@ HIP_SYMBOLS = {
     "ggml_hip_mul_mat_multi_fused": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),
     "ggml_hip_mul_mat_multi_dev": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ggml_hip_mul_mat_multi_work_dev": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
+                                                  C.POINTER(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]),
     "ggml_hip_graph_begin": (C.c_int, []),
     "ggml_hip_graph_begin_keyed": (C.c_int, [C.c_uint64]),
     "ggml_hip_host_read": (C.c_int, [C.c_void_p, C.c_size_t]),

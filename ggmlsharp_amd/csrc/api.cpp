@@ -858,6 +858,47 @@ int ggml_hip_mul_mat_multi_dev(const ggml_hip_weight *const *w, int n_w, const f
     return GGML_HIP_OK;
 }
 
+/* the same for any N, with the work buffer a batch needs: src1 is quantized ONCE (the INIT phase, Ggml.cs:6641-6654, is the same for
+ * every matrix of one type and K) and the matrices follow -- in one launch where gemm_qmx.hip has the form (9 <= N <= 32), else one
+ * COMPUTE after the other behind the shared image.  Every row is bit for bit what ggml_hip_mul_mat_dev gives for that matrix. */
+int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N, float *const *d_dst,
+                                    const int64_t *ldd, void *d_work, size_t work_bytes, void *stream) {
+    if (!w || !d_src1 || !d_dst || !ldd) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (n_w < 1 || n_w > 4) return fail(GGML_HIP_ERR_ARG, "multi mul_mat: 1..4 matrices");
+    if (N <= 0) return GGML_HIP_OK;
+    for (int i = 0; i < n_w; ++i) {
+        if (!w[i] || !d_dst[i]) return fail(GGML_HIP_ERR_ARG, "multi mul_mat: matrix or dst %d missing", i);
+        if (!is_q(w[i]->type) || w[i]->type != w[0]->type || w[i]->ext_type != w[0]->ext_type || w[i]->K != w[0]->K || w[i]->device != w[0]->device)
+            return fail(GGML_HIP_ERR_SHAPE, "multi mul_mat: quantized matrices of one type and K on one device");
+        if (ldd[i] < w[i]->M) return fail(GGML_HIP_ERR_SHAPE, "multi mul_mat: dst %d row stride smaller than a row", i);
+    }
+    if (n_w >= 2 && multi_ok(w, n_w, N)) return ggml_hip_mul_mat_multi_dev(w, n_w, d_src1, ld1, N, d_dst, ldd, nullptr, 0, nullptr, nullptr, stream);
+    // one image for all of them?  (the image kind of a type follows N and K; M enters for shapes beyond the 32-bit offsets only)
+    bool shared = N > gemv_rows_max(w[0]->type) && w[0]->ext_type == 0;
+    const int kind = act_image_kind(w[0]->type, w[0]->M, w[0]->K, N);
+    for (int i = 1; i < n_w && shared; ++i) shared = act_image_kind(w[i]->type, w[i]->M, w[i]->K, N) == kind;
+    if (!shared) {
+        for (int i = 0; i < n_w; ++i) {
+            const int rc = ggml_hip_mul_mat_dev(w[i], d_src1, N, ld1, d_dst[i], ldd[i], d_work, work_bytes, stream);
+            if (rc) return rc;
+        }
+        return GGML_HIP_OK;
+    }
+    int rc = ggml_hip_mul_mat_init_dev(w[0], d_src1, N, ld1, d_work, work_bytes, stream);
+    if (rc) return rc;
+    if (kind == 3 && n_w >= 2) {
+        for (int i = 1; i < n_w; ++i) { rc = weight_device_current(w[i]); if (rc) return rc; }
+        const hipError_t e = launch_gemm_qmx_multi(w, n_w, act_carve(d_work, w[0]->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream);
+        if (e == hipSuccess) return GGML_HIP_OK;
+        if (e != hipErrorNotSupported) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: %s", hipGetErrorString(e)); }
+    }
+    for (int i = 0; i < n_w; ++i) {
+        rc = ggml_hip_mul_mat_compute_dev(w[i], N, d_dst[i], ldd[i], d_work, work_bytes, stream);
+        if (rc) return rc;
+    }
+    return GGML_HIP_OK;
+}
+
 int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_norm, float *d_y, int64_t nrows, int64_t k, void *stream) {
     if (nrows <= 0 || k <= 0) return GGML_HIP_OK;
     if (!d_x || !d_g || !d_norm || !d_y) return fail(GGML_HIP_ERR_ARG, "null argument");

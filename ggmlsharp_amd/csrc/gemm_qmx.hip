@@ -512,13 +512,14 @@ __device__ unsigned long long k3s_trace_buf[2048 * 2 * 8];
 #else
 #define K3S_STAMP(k) do { } while (0)
 #endif
+// (wg = the workgroup's index inside its matrix: blockIdx.x for one matrix, see the multi-matrix entry below)
 template <int TYPE, int KS, int NP, bool ROT, int WMT>
-__global__ __launch_bounds__(KS * 64, 1)
-void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
-                           const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
-                           const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp,
-                           int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, uint32_t ad_bytes,
-                           const mm_epilogue ep) {
+__device__ __forceinline__
+void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                         const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
+                         const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp,
+                         int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, uint32_t ad_bytes,
+                         const mm_epilogue &ep, int wg) {
     static_assert(TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1, "one weight digit per block");
     constexpr bool Q41 = TYPE == GGML_TYPE_Q4_1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -527,7 +528,7 @@ void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__res
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     K3S_STAMP(0);
-    const int m0 = blockIdx.x * 32 * WMT;                   // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
+    const int m0 = wg * 32 * WMT;                           // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
     const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (nloc even; the planes are zero
     const int npair = nloc >> 1;                            // past the end of K, the descriptors' range check covers the rest)
     // ---- descriptors and per-lane offsets (planes [nbk][Mpad][16 | 8 | 4]; image per k-block [half][Npad][16] then [half][Npad][8]) ----
@@ -750,6 +751,39 @@ void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__res
     K3S_STAMP(6);
 }
 
+template <int TYPE, int KS, int NP, bool ROT, int WMT>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                           const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
+                           const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp,
+                           int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, uint32_t ad_bytes,
+                           const mm_epilogue ep) {
+    gemm_qmx_small_body<TYPE, KS, NP, ROT, WMT>(w6a, w6b, wd, wm, a6, ad, asd, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, w6a_bytes, wd_bytes, a_bytes,
+                                                ad_bytes, ep, (int)blockIdx.x);
+}
+
+// Several weight matrices behind ONE activation image (q / k / v, gate / up of a batched decoder's step): the workgroups of all of
+// them in one launch -- 4096 rows are 128 tiles, half of the chip; three such matrices fill it.  A workgroup picks its matrix from
+// its index (uniform, once); everything after that is the single-matrix kernel, so every matrix gets the bits of its own call.
+struct mxs_set {
+    int n; int wg_end[4];                                   // workgroups [wg_end[i - 1], wg_end[i]) belong to matrix i
+    const uint8_t *a[4], *b[4]; const float *d[4], *m[4]; float *dst[4];
+    int M[4], Mpad[4], ldd[4]; uint32_t wa_bytes[4], wd_bytes[4];
+};
+template <int TYPE, int KS, int NP, bool ROT, int WMT>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_qmx_small_multi_kernel(const mxs_set ws, const uint8_t *__restrict__ a6, const float *__restrict__ ad, const float *__restrict__ asd,
+                                 int N, int Npad, int nbkp, int nloc, uint32_t a_bytes, uint32_t ad_bytes) {
+    const int b = (int)blockIdx.x;
+    const int k = (b >= ws.wg_end[0]) + (b >= ws.wg_end[1]) + (b >= ws.wg_end[2]);
+    const int first = k == 0 ? 0 : k == 1 ? ws.wg_end[0] : k == 2 ? ws.wg_end[1] : ws.wg_end[2];
+#define MXS(f) (k == 0 ? ws.f[0] : k == 1 ? ws.f[1] : k == 2 ? ws.f[2] : ws.f[3])
+    const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
+    gemm_qmx_small_body<TYPE, KS, NP, ROT, WMT>(MXS(a), MXS(b), MXS(d), MXS(m), a6, ad, asd, MXS(dst), MXS(M), N, MXS(Mpad), Npad, nbkp, nloc, MXS(ldd),
+                                                MXS(wa_bytes), MXS(wd_bytes), a_bytes, ad_bytes, ep, b - first);
+#undef MXS
+}
+
 // the epilogue of the call in flight on this host thread (set by launch_gemm_qmx around launch_typed: the tile-form selection
 // below has a dozen call sites, the epilogue concerns none of them)
 thread_local mm_epilogue t_epilogue = {0, nullptr, 0, nullptr, 0, 1.0f};
@@ -821,6 +855,55 @@ hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float
     else if (nloc <= 16) K3S_GO(8, false, 1);
     else { if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(4, true, 1); else K3S_GO(8, true, 1); }   // (Q4_1 carries three more registers per pair)
 #undef K3S_GO
+    return hipGetLastError();
+}
+
+// K3s for several matrices of one type and K behind one activation image: hipErrorNotSupported where the single-matrix form would
+// not run either (the caller then computes them one after the other).  Tiles per workgroup by the tiles of all of them together.
+template <int TYPE>
+hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
+    constexpr int KS = 8;
+    const int nbkp = (int)pad_kblocks(w[0]->nbk);
+    int nloc = (nbkp + KS - 1) / KS;
+    nloc += nloc & 1;
+    if (w[0]->nbk < 64 || nloc > 64 || p.Npad < 32) return hipErrorNotSupported;
+    const uint64_t nba = (uint64_t)nbkp;
+    const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
+    if (a_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+    int64_t t32 = 0;
+    for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32;
+    const int wmt = t32 <= 256 ? 1 : t32 <= 512 || TYPE == GGML_TYPE_Q4_1 ? 2 : 4;
+    mxs_set ws = {};
+    ws.n = n_w;
+    int wgs = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < n_w) {
+            const ggml_hip_weight *x = w[i];
+            const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)x->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)x->Mpad * 4;
+            if (!x->q6a || !x->q6b || x->nbk != w[0]->nbk || x->Mpad % (32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+            wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt));
+            ws.a[i] = x->q6a; ws.b[i] = x->q6b; ws.d[i] = x->d; ws.m[i] = x->m; ws.dst[i] = dst[i];
+            ws.M[i] = (int)x->M; ws.Mpad[i] = (int)x->Mpad; ws.ldd[i] = (int)ldd[i]; ws.wa_bytes[i] = (uint32_t)wq_bytes; ws.wd_bytes[i] = (uint32_t)wd_bytes;
+        }
+        ws.wg_end[i] = wgs;
+    }
+    const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
+    const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
+    const int lds = tab > xch ? tab : xch;
+    dim3 grid((unsigned)wgs);
+#define K3M_GO(NP, ROT, WMT) do { \
+        auto kern = gemm_qmx_small_multi_kernel<TYPE, KS, NP, ROT, WMT>; \
+        static PerDeviceOnce once; \
+        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
+        if (attr != hipSuccess) return attr; \
+        kern<<<grid, KS * 64, lds, st>>>(ws, (const uint8_t *)p.a8, p.ad, (const float *)p.as, (int)N, (int)p.Npad, nbkp, nloc, (uint32_t)a_bytes, \
+                                      (uint32_t)ad_bytes); } while (0)
+    if (wmt == 4) { if constexpr (TYPE == GGML_TYPE_Q4_0) K3M_GO(2, true, 4); }
+    else if (wmt == 2) { if (nloc <= 8) K3M_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3M_GO(3, true, 2); else K3M_GO(4, true, 2); }
+    else if (nloc <= 8) K3M_GO(4, false, 1);
+    else if (nloc <= 16) K3M_GO(8, false, 1);
+    else { if constexpr (TYPE == GGML_TYPE_Q4_1) K3M_GO(4, true, 1); else K3M_GO(8, true, 1); }
+#undef K3M_GO
     return hipGetLastError();
 }
 
@@ -917,6 +1000,17 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
 }
 
 }  // namespace
+
+hipError_t launch_gemm_qmx_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
+    if (n_w < 2 || n_w > 4 || N < 9 || N > 32) return hipErrorNotSupported;
+    for (int i = 0; i < n_w; ++i)
+        if (!w[i] || w[i]->type != w[0]->type || w[i]->M <= 0 || (uint64_t)32 * (uint64_t)ldd[i] * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
+    switch (w[0]->type) {
+    case GGML_TYPE_Q4_0: return launch_small_multi<GGML_TYPE_Q4_0>(w, n_w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_small_multi<GGML_TYPE_Q4_1>(w, n_w, p, N, dst, ldd, st);
+    default: return hipErrorNotSupported;
+    }
+}
 
 hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
                            const mm_epilogue *ep) {

@@ -401,7 +401,7 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         if (!t || t->op != GGML_OP_MUL_MAT || !t->src0 || !t->src1 || t->src0->op != GGML_OP_NONE) return false;
         const int ty = t->src0->type;
         if (!(ty == GGML_TYPE_Q4_0 || ty == GGML_TYPE_Q4_1 || ty == GGML_TYPE_Q5_0 || ty == GGML_TYPE_Q5_1 || ty == GGML_TYPE_Q8_0)) return false;
-        if (t->src1->ne[1] > 4 || t->src1->ne[2] != 1 || t->src1->ne[3] != 1 || t->src0->ne[2] != 1 || t->src0->ne[3] != 1) return false;
+        if (t->src1->ne[1] > 32 || t->src1->ne[2] != 1 || t->src1->ne[3] != 1 || t->src0->ne[2] != 1 || t->src0->ne[3] != 1) return false;
         return !first || (t->src1 == first->src1 && ty == first->src0->type && t->src0->ne[0] == first->src0->ne[0] && t != first);
     };
     for (int i = 0; i + 1 < n_order; ++i) {

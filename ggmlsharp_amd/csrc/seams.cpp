@@ -849,7 +849,7 @@ int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *par
     if (n < 2) return one_by_one();
     const int type = src0[0]->type;
     const int64_t K = src1->ne[0], N = src1->ne[1];
-    bool ok = type >= 0 && type < GGML_TYPE_COUNT && is_q(type) && weight_type_ok(type) && src1->type == GGML_TYPE_F32 && N >= 1 && N <= 4 &&
+    bool ok = type >= 0 && type < GGML_TYPE_COUNT && is_q(type) && weight_type_ok(type) && src1->type == GGML_TYPE_F32 && N >= 1 && N <= 32 &&
               src1->ne[2] == 1 && src1->ne[3] == 1 && src1->data && contiguous_f32(src1) && K % QK == 0;
     for (int i = 0; i < n && ok; ++i) {
         const ggml_tensor *w = src0[i], *d = dst[i];
@@ -880,7 +880,10 @@ int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *par
         if (it == c->cache.end() || it->second.slices.size() != 1) return one_by_one();      // (uploads and caches them: fused next time)
         W[i] = it->second.slices[0];
     }
-    if (!ggml_hip_mul_mat_multi_fused(W, n, N)) return one_by_one();
+    // up to 4 rows: the fused mat-vec takes them (and the prologue) in one launch; 9..32 rows: one INIT for all of them and one launch
+    // where gemm_qmx.hip has the form (ggml_hip_mul_mat_multi_work_dev), the norm -> mul pair in front as its own kernel
+    const bool fused_rows = ggml_hip_mul_mat_multi_fused(W, n, N) != 0;
+    if (!fused_rows && (N <= 8 || !ggml_hip_mul_mat_epilogue_fused(W[0], N))) return one_by_one();
     for (int i = 0; i < n; ++i) note_host_write(call, dst[i], true);
     const float *xd = nullptr, *gd = nullptr;
     float *nd = nullptr, *yd = nullptr;
@@ -901,7 +904,14 @@ int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *par
         if (!dd[i]) return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: hipMalloc failed for a resident dst");
         ldd[i] = dst[i]->ne[0];
     }
-    rc = ggml_hip_mul_mat_multi_dev(W, n, xd, K, N, dd, ldd, gd, K, nd, yd, c->stream);
+    if (fused_rows) {
+        rc = ggml_hip_mul_mat_multi_dev(W, n, xd, K, N, dd, ldd, gd, K, nd, yd, c->stream);
+    } else {
+        const size_t w_bytes = ggml_hip_mul_mat_work_size(type, K, N);
+        if (c->work.ensure(w_bytes ? w_bytes : 16)) return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: hipMalloc failed for scratch");
+        if (pro_x) rc = ggml_hip_rms_norm_mul_rows_dev(xd, gd, nd, yd, N, K, c->stream);
+        if (!rc) rc = ggml_hip_mul_mat_multi_work_dev(W, n, pro_x ? yd : xd, K, N, dd, ldd, c->work.p, c->work.cap, c->stream);
+    }
     if (rc) return rc;
     for (int i = 0; i < n; ++i) c->owe(dst[i]->data, dd[i], (size_t)N * dst[i]->ne[0] * 4);
     if (pro_x) {

@@ -354,6 +354,13 @@ int ggml_hip_mul_mat_multi_fused(const ggml_hip_weight *const *w, int n_w, int64
 int ggml_hip_mul_mat_multi_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N,
                                float *const *d_dst, const int64_t *ldd, const float *d_g, int64_t ld_g, float *d_norm,
                                float *d_y, void *stream);
+/* The same for a batch of any size, with the scratch a batch needs (ggml_hip_mul_mat_work_size(type, K, N) bytes): src1 is
+ * quantized once -- the INIT phase (Ggml.cs:6641-6654) is the same for every matrix of one type and K -- and the 1..4 matrices
+ * follow, in ONE launch where the library has the form (9 <= N <= 32, Q4_0 / Q4_1, K >= 2048: three 4096-row projections fill
+ * the chip that one of them half uses), else one COMPUTE after the other behind the shared image.  Every row is bit for bit
+ * what ggml_hip_mul_mat_dev gives for that matrix. */
+int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N,
+                                    float *const *d_dst, const int64_t *ldd, void *d_work, size_t work_bytes, void *stream);
 /* The pair kernel alone on contiguous device rows: d_norm = rms_norm(d_x) (Ggml.cs:5858-5920), d_y = d_norm * d_g. */
 int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_norm, float *d_y, int64_t nrows, int64_t k, void *stream);
 /* Device form of the epilogue: mode 1 add (d_dst keeps the product, d_dst2 = product + d_addend), mode 2 scale (d_dst =

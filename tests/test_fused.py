@@ -235,3 +235,81 @@ def test_multi_weight_device_form_is_bitwise_the_single_calls(dev, t):
             assert torch.equal(o[:, :M], s) and torch.all(o[:, M:] == -2.0), (t, Ms, K, N, "prologue")
         for w in Ws:
             w.free()
+
+
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0])
+def test_multi_weight_batch_form_is_bitwise_the_single_calls(dev, t):
+    """ggml_hip_mul_mat_multi_work_dev: 1..4 matrices behind ONE quantization of src1 for a batch of any size -- one launch where
+    gemm_qmx.hip has the form (9..32 rows, Q4_0 / Q4_1, K >= 2048: one / two / four tiles per workgroup by the tiles of all the
+    matrices together), else one COMPUTE after the other.  Every dst equals the single-matrix call's, bit for bit."""
+    from ggmlsharp_amd._lib import lib, check
+    L = lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (Ms, K, N) in (((96, 130), 2048, 12), ((4096, 4096, 4096), 2048, 32), ((300, 8200, 40), 2048 + 64, 9), ((8192, 8192 + 300), 2048, 20),
+                       ((64, 200), 512, 20), ((130, 70, 33), 2048, 3), ((100, 60), 2048, 7), ((128, 96), 4096 + 128, 70), ((77,), 2048, 16)):
+        Ws = [dev.Weight.from_host(t, O.quantize_row(t, _rand((M, K))), K) for M in Ms]
+        x = torch.from_numpy(_rand((N, K), 2.0)).cuda()
+        hw = (C.c_void_p * len(Ws))(*[w.handle for w in Ws])
+        singles = [dev.mul_mat(w, x) for w in Ws]
+        outs = [torch.full((N, M + 4), -2.0, device="cuda") for M in Ms]
+        dp = (C.c_void_p * len(Ws))(*[o.data_ptr() for o in outs])
+        ld = (C.c_int64 * len(Ws))(*[M + 4 for M in Ms])
+        work = dev.alloc_work(t, K, N)
+        check(L.ggml_hip_mul_mat_multi_work_dev(hw, len(Ws), C.c_void_p(x.data_ptr()), K, N, dp, ld, C.c_void_p(work.data_ptr()), work.numel(), st),
+              "multi with work")
+        for o, s, M in zip(outs, singles, Ms):
+            assert torch.equal(o[:, :M], s) and torch.all(o[:, M:] == -2.0), (t, Ms, K, N)
+        for w in Ws:
+            w.free()
+
+
+@pytest.mark.parametrize("N", [12, 32])
+def test_projection_groups_of_a_batch_go_down_together(dev, N):
+    """q / k / v and gate / up of a batched decoder's step through ggml_graph_compute (K = 2048: the one-launch form) against the
+    same nodes one by one through the single seams: identical bytes for every node, over an observed, a captured and two
+    replayed computes."""
+    rng = np.random.default_rng(40 + N)
+    K, M, F = 2048, 96, 160
+    ctx = G.ggml_init(128 * 1024 * 1024)
+    try:
+        def qw(t, k, m):
+            w = G.ggml_new_tensor_2d(ctx, t, k, m)
+            G.tensor_bytes(w)[:] = O.quantize_row(t, (rng.standard_normal((m, k)) * 0.3).astype(np.float32)).reshape(-1)
+            return w
+        x = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        g1 = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        G.tensor_f32(g1)[:] = rng.standard_normal((N, K)).astype(np.float32).reshape(1, 1, N, K)
+        cur = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, x), g1)
+        q, k, v = (G.ggml_mul_mat(ctx, qw(G.Q4_0, K, M), cur) for _ in range(3))
+        a = G.ggml_add(ctx, G.ggml_add(ctx, q, k), v)
+        u, gt = G.ggml_mul_mat(ctx, qw(G.Q4_1, K, F), x), G.ggml_mul_mat(ctx, qw(G.Q4_1, K, F), x)
+        s = G.ggml_mul(ctx, G.ggml_silu(ctx, u), gt)
+        out = G.ggml_add(ctx, G.ggml_mul_mat(ctx, qw(G.Q4_0, F, M), s), a)
+        gf = G.ggml_build_forward(out)
+        L = _lib.lib()
+        p = _params()
+
+        def one_by_one():
+            for i in range(gf.n_nodes):
+                n = gf.nodes[i].contents
+                if n.op == _lib.GGML_OP_MUL_MAT:
+                    rc = L.ggml_hip_compute_forward_mul_mat(C.byref(p), n.src0, n.src1, gf.nodes[i])
+                elif n.op == _lib.GGML_OP_ADD:
+                    rc = L.ggml_hip_compute_forward_add(C.byref(p), n.src0, n.src1, gf.nodes[i])
+                elif n.op == _lib.GGML_OP_MUL:
+                    rc = L.ggml_hip_compute_forward_mul(C.byref(p), n.src0, n.src1, gf.nodes[i])
+                elif n.op == _lib.GGML_OP_RMS_NORM:
+                    rc = L.ggml_hip_compute_forward_rms_norm(C.byref(p), n.src0, gf.nodes[i])
+                else:
+                    rc = L.ggml_hip_compute_forward_silu(C.byref(p), n.src0, gf.nodes[i])
+                _lib.check(rc, f"node {i}")
+        for it in range(4):
+            G.tensor_f32(x)[:] = (rng.standard_normal((N, K)) * (1 + it)).astype(np.float32).reshape(1, 1, N, K)
+            L.ggml_hip_invalidate_range(x.contents.data, N * K * 4)
+            G.ggml_graph_compute(ctx, gf)
+            got = [np.array(G.tensor_f32(gf.nodes[i]), copy=True) for i in range(gf.n_nodes)]
+            one_by_one()
+            for i in range(gf.n_nodes):
+                assert np.array_equal(got[i].view(np.uint32), G.tensor_f32(gf.nodes[i]).view(np.uint32)), (N, it, i, gf.nodes[i].contents.op)
+    finally:
+        G.ggml_free(ctx)
