@@ -408,6 +408,67 @@ def make_runner(device, gdist, M_total, K, N, world, rank, exchange, chunks, see
     return gdist.RowSplitMulMat(W, N, world, rank, M_total=M_total, chunks=chunks if world > 1 else 1, exchange=exchange), W
 
 
+def projection_group_config(device, Ms, K, N, sets=12, reps=20):
+    """q / k / v (or gate / up) of a batched decoder's step: the matrices of one group behind ONE quantization of src1 and one
+    launch (ggml_hip_mul_mat_multi_work_dev) next to one ggml_hip_mul_mat_dev per matrix; a ring of weight sets larger than the
+    caches, each form inside a replayed hipGraph."""
+    import ctypes as C
+    from ggmlsharp_amd._lib import check, lib
+    L = lib()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    rows = [device.quantize_rows(Q4_0, torch.randn((M, K), generator=g, device="cuda")) for M in Ms]
+    W = [[device.Weight.from_device(Q4_0, r, K) for r in rows] for _ in range(sets)]
+    x = torch.randn((N, K), generator=g, device="cuda")
+    outs = [torch.empty((N, M), device="cuda") for M in Ms]
+    work = device.alloc_work(Q4_0, K, N)
+    dp = (C.c_void_p * len(Ms))(*[o.data_ptr() for o in outs])
+    ld = (C.c_int64 * len(Ms))(*Ms)
+    s = torch.cuda.Stream()
+    res = {}
+    try:
+        for mode in ("single_calls", "one_call"):
+            with torch.cuda.stream(s):
+                st = C.c_void_p(s.cuda_stream)
+
+                def body():
+                    for ws in W:
+                        if mode == "one_call":
+                            hw = (C.c_void_p * len(Ms))(*[w.handle for w in ws])
+                            check(L.ggml_hip_mul_mat_multi_work_dev(hw, len(Ms), C.c_void_p(x.data_ptr()), K, N, dp, ld, C.c_void_p(work.data_ptr()),
+                                                                    work.numel(), st), "multi")
+                        else:
+                            for w, o, M in zip(ws, outs, Ms):
+                                check(L.ggml_hip_mul_mat_dev(w.handle, C.c_void_p(x.data_ptr()), N, K, C.c_void_p(o.data_ptr()), M,
+                                                             C.c_void_p(work.data_ptr()), work.numel(), st), "single")
+                body()
+                s.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=s):
+                    body()
+                gr.replay()
+                s.synchronize()
+                ts = []
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s)
+                    gr.replay()
+                    e1.record(s)
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1) / sets)
+            res[mode] = stats(ts)
+    finally:
+        for ws in W:
+            for w in ws:
+                w.free()
+    wbytes = sum(M * (K // 32) * 20 for M in Ms)
+    t = res["one_call"]["median_ms"]
+    return {"workload": f"Q4_0 {len(Ms)} x mul_mat M={Ms[0]} K={K} N={N} behind one src1 (a projection group of a batched decoder's step)",
+            "ms_per_group": round(t, 5), "p10_ms": res["one_call"]["p10_ms"], "p90_ms": res["one_call"]["p90_ms"],
+            "ms_as_single_calls": round(res["single_calls"]["median_ms"], 5), "weight_sets_rotated": sets,
+            "algorithmic_GBs": round(wbytes / (t * 1e-3) / 1e9, 1), "hbm_frac": round(wbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def pick_exchange(device, gdist, world, rank, requested, K):
     """Which exchange form runs: "rccl" always works; "push" (direct peer stores through IPC-shared dst buffers) is used
     when every rank could set it up AND its result is bit for bit the RCCL form's on a small problem."""
@@ -630,6 +691,7 @@ def main():
                     c["step_over_pcie_bound"] = round(c["ms_per_step"] / bound, 3)
                 out["other_configs"].update(s1)
                 out["other_configs"]["dropin_decode_layer_batch1"] = dropin_decode_layer(1, 200)
+                out["other_configs"]["batch32_qkv_group"] = projection_group_config(device, (4096, 4096, 4096), 4096, 32)
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
                 out["other_configs"]["seam1_host_error"] = f"{type(e).__name__}: {e}"[:300]
         if not args.no_cpu_baseline:
