@@ -76,7 +76,11 @@ int gemm_force() {
 
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
-    if (N <= GEMV_MAX_N || force == 1) return 0;
+    if (N <= 4 || force == 1) return 0;
+    // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
+    // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them (a 7B
+    // decoder layer through ggml_graph_compute: batch 9 192 us against batch 8 232 us on the mat-vec)
+    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= 64)) return 0;
     if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
@@ -705,7 +709,7 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     int rc = weight_device_current(w);
     if (rc) return rc;
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
-    if (N <= gemv_rows_max(w->type))
+    if (N <= gemv_rows_max(w->type) && act_image_kind(w->type, w->M, w->K, N) == 0)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else if (act_image_kind(w->type, w->M, w->K, N) == 3)
         HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));
@@ -734,7 +738,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
-    if (N <= GEMV_MAX_N && w->ext_type == 0) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
+    if (N <= GEMV_MAX_N && w->ext_type == 0 && act_image_kind(w->type, w->M, w->K, N) == 0) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
         rc = check_src1_alignment(d_src1, ld1);     // (float4 loads of the activation rows)
         if (rc) return rc;
         HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream));
@@ -749,8 +753,9 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
 // (Q4_0 / Q4_1, N > 8); every other form runs the epilogue as its own launch behind the mat-mul.
 static bool epilogue_is_fused(const ggml_hip_weight *w, int64_t N) {
     if (!is_q(w->type) || w->ext_type != 0) return false;
-    if (N <= GEMV_MAX_N) return gemv_fused_has_epilogue(N);
-    return act_image_kind(w->type, w->M, w->K, N) == 3;
+    const int kind = act_image_kind(w->type, w->M, w->K, N);
+    if (N <= GEMV_MAX_N && kind == 0) return gemv_fused_has_epilogue(N);
+    return kind == 3;
 }
 
 int ggml_hip_mul_mat_epilogue_fused(const ggml_hip_weight *w, int64_t N) { return w && epilogue_is_fused(w, N) ? 1 : 0; }
@@ -769,7 +774,7 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
         int rc = weight_device_current(w);
         if (rc) return rc;
-        if (N <= GEMV_MAX_N) {
+        if (N <= GEMV_MAX_N && act_image_kind(w->type, w->M, w->K, N) == 0) {
             rc = check_src1_alignment(d_src1, ld1);
             if (rc) return rc;
             HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream, &ep));
@@ -874,8 +879,8 @@ int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, co
     }
     if (n_w >= 2 && multi_ok(w, n_w, N)) return ggml_hip_mul_mat_multi_dev(w, n_w, d_src1, ld1, N, d_dst, ldd, nullptr, 0, nullptr, nullptr, stream);
     // one image for all of them?  (the image kind of a type follows N and K; M enters for shapes beyond the 32-bit offsets only)
-    bool shared = N > gemv_rows_max(w[0]->type) && w[0]->ext_type == 0;
     const int kind = act_image_kind(w[0]->type, w[0]->M, w[0]->K, N);
+    bool shared = !(N <= gemv_rows_max(w[0]->type) && kind == 0) && w[0]->ext_type == 0;
     for (int i = 1; i < n_w && shared; ++i) shared = act_image_kind(w[i]->type, w[i]->M, w[i]->K, N) == kind;
     if (!shared) {
         for (int i = 0; i < n_w; ++i) {

@@ -1002,7 +1002,7 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
 }  // namespace
 
 hipError_t launch_gemm_qmx_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
-    if (n_w < 2 || n_w > 4 || N < 9 || N > 32) return hipErrorNotSupported;
+    if (n_w < 2 || n_w > 4 || N < 5 || N > 32) return hipErrorNotSupported;
     for (int i = 0; i < n_w; ++i)
         if (!w[i] || w[i]->type != w[0]->type || w[i]->M <= 0 || (uint64_t)32 * (uint64_t)ldd[i] * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
     switch (w[0]->type) {

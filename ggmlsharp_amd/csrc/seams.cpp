@@ -880,10 +880,10 @@ int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *par
         if (it == c->cache.end() || it->second.slices.size() != 1) return one_by_one();      // (uploads and caches them: fused next time)
         W[i] = it->second.slices[0];
     }
-    // up to 4 rows: the fused mat-vec takes them (and the prologue) in one launch; 9..32 rows: one INIT for all of them and one launch
+    // up to 4 rows: the fused mat-vec takes them (and the prologue) in one launch; 5..32 rows (Q4_0 / Q4_1): one INIT for all of them and one launch
     // where gemm_qmx.hip has the form (ggml_hip_mul_mat_multi_work_dev), the norm -> mul pair in front as its own kernel
     const bool fused_rows = ggml_hip_mul_mat_multi_fused(W, n, N) != 0;
-    if (!fused_rows && (N <= 8 || !ggml_hip_mul_mat_epilogue_fused(W[0], N))) return one_by_one();
+    if (!fused_rows && (N <= 4 || !ggml_hip_mul_mat_epilogue_fused(W[0], N))) return one_by_one();
     for (int i = 0; i < n; ++i) note_host_write(call, dst[i], true);
     const float *xd = nullptr, *gd = nullptr;
     float *nd = nullptr, *yd = nullptr;
