@@ -864,7 +864,7 @@ int ggml_hip_mul_mat_multi_dev(const ggml_hip_weight *const *w, int n_w, const f
 }
 
 /* the same for any N, with the work buffer a batch needs: src1 is quantized ONCE (the INIT phase, Ggml.cs:6641-6654, is the same for
- * every matrix of one type and K) and the matrices follow -- in one launch where gemm_qmx.hip has the form (5 <= N <= 32), else one
+ * every matrix of one type and K) and the matrices follow -- in one launch where gemm_qmx.hip has the form (5 <= N <= 64), else one
  * COMPUTE after the other behind the shared image.  Every row is bit for bit what ggml_hip_mul_mat_dev gives for that matrix. */
 int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N, float *const *d_dst,
                                     const int64_t *ldd, void *d_work, size_t work_bytes, void *stream) {

@@ -519,7 +519,7 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
                          const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
                          const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp,
                          int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, uint32_t ad_bytes,
-                         const mm_epilogue &ep, int wg) {
+                         const mm_epilogue &ep, int wg, int ntw) {
     static_assert(TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1, "one weight digit per block");
     constexpr bool Q41 = TYPE == GGML_TYPE_Q4_1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -528,20 +528,21 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     K3S_STAMP(0);
-    const int m0 = wg * 32 * WMT;                           // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
+    const int m0 = (wg % ntw) * 32 * WMT;                   // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
+    const int n0 = (wg / ntw) * 32;                         // ... and one 32-column slice of src1 (33..64 rows: two workgroups per tile group)
     const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (nloc even; the planes are zero
     const int npair = nloc >> 1;                            // past the end of K, the descriptors' range check covers the rest)
     // ---- descriptors and per-lane offsets (planes [nbk][Mpad][16 | 8 | 4]; image per k-block [half][Npad][16] then [half][Npad][8]) ----
     const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
     const rsrc_t rWm = make_rsrc(Q41 ? (const void *)wm : (const void *)wd, wd_bytes);
     const rsrc_t rA = make_rsrc(a6, a_bytes), rAs = make_rsrc(Q41 ? asd : ad, ad_bytes);
-    const uint32_t voffS = (uint32_t)((hh * Npad + l31) * 4);
+    const uint32_t voffS = (uint32_t)((hh * Npad + n0 + l31) * 4);
     const int mrow = m0 + l31;
     const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4);
     // lane half hh takes block (pair's first) + hh
     const uint32_t offA = (uint32_t)(mrow * 16) + hh * wa_blk, offB = (uint32_t)(mrow * 8) + hh * wb_blk, offD = (uint32_t)(mrow * 4) + hh * d_blk;
     const uint32_t a_blk = (uint32_t)Npad * 48u;
-    const uint32_t voff16 = (uint32_t)((hh * Npad + l31) * 16), voff8 = (uint32_t)(32 * Npad + (hh * Npad + l31) * 8);
+    const uint32_t voff16 = (uint32_t)((hh * Npad + n0 + l31) * 16), voff8 = (uint32_t)(32 * Npad + (hh * Npad + n0 + l31) * 8);
 
     struct WP { u32x4 lo[WMT]; u32x2 hi[WMT]; float d[WMT]; float mn[WMT]; float s; };   // lanes 0..31: the pair's first block, lanes 32..63: its second
     struct AF { u32x4 lo; u32x2 hi; };
@@ -577,7 +578,7 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     for (int j = 0; j < TP; ++j) {
         const int idx = lane + 64 * j, b = idx >> 3, c4 = idx & 7;
         const bool ok = b < nloc && kb0 + b < nbkp;
-        const size_t e = (size_t)(kb0 + (ok ? b : 0)) * Npad + 4 * c4;
+        const size_t e = (size_t)(kb0 + (ok ? b : 0)) * Npad + n0 + 4 * c4;
         td[j] = ok ? *(const f32x4 *)(ad + e) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     static_for<NP>([&](auto uc) { constexpr int u = decltype(uc)::value; load_pair(wp[u], af[2 * u], af[2 * u + 1], u); });
@@ -738,7 +739,7 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 #pragma unroll
         for (int g = 1; g < KS; ++g) v += xch[(size_t)((g * WMT + t) * 16 + r) * 64];
         // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31] ----
-        const int n = (r & 3) + 8 * (r >> 2) + 4 * hh, m = m0 + 32 * t + l31;
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hh, m = m0 + 32 * t + l31;
         if (n < N && m < M) {
             if (ep.mode == 2) {
                 dst[(size_t)n * ldd + m] = v * ep.scale;
@@ -757,9 +758,9 @@ void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__res
                            const float *__restrict__ wm, const uint8_t *__restrict__ a6, const float *__restrict__ ad,
                            const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp,
                            int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, uint32_t ad_bytes,
-                           const mm_epilogue ep) {
+                           const mm_epilogue ep, int ntw) {
     gemm_qmx_small_body<TYPE, KS, NP, ROT, WMT>(w6a, w6b, wd, wm, a6, ad, asd, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, w6a_bytes, wd_bytes, a_bytes,
-                                                ad_bytes, ep, (int)blockIdx.x);
+                                                ad_bytes, ep, (int)blockIdx.x, ntw);
 }
 
 // Several weight matrices behind ONE activation image (q / k / v, gate / up of a batched decoder's step): the workgroups of all of
@@ -773,14 +774,14 @@ struct mxs_set {
 template <int TYPE, int KS, int NP, bool ROT, int WMT>
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_qmx_small_multi_kernel(const mxs_set ws, const uint8_t *__restrict__ a6, const float *__restrict__ ad, const float *__restrict__ asd,
-                                 int N, int Npad, int nbkp, int nloc, uint32_t a_bytes, uint32_t ad_bytes) {
+                                 int N, int Npad, int nbkp, int nloc, uint32_t a_bytes, uint32_t ad_bytes, int ncol) {
     const int b = (int)blockIdx.x;
     const int k = (b >= ws.wg_end[0]) + (b >= ws.wg_end[1]) + (b >= ws.wg_end[2]);
     const int first = k == 0 ? 0 : k == 1 ? ws.wg_end[0] : k == 2 ? ws.wg_end[1] : ws.wg_end[2];
 #define MXS(f) (k == 0 ? ws.f[0] : k == 1 ? ws.f[1] : k == 2 ? ws.f[2] : ws.f[3])
     const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
     gemm_qmx_small_body<TYPE, KS, NP, ROT, WMT>(MXS(a), MXS(b), MXS(d), MXS(m), a6, ad, asd, MXS(dst), MXS(M), N, MXS(Mpad), Npad, nbkp, nloc, MXS(ldd),
-                                                MXS(wa_bytes), MXS(wd_bytes), a_bytes, ad_bytes, ep, b - first);
+                                                MXS(wa_bytes), MXS(wd_bytes), a_bytes, ad_bytes, ep, b - first, ((k == 0 ? ws.wg_end[0] : k == 1 ? ws.wg_end[1] : k == 2 ? ws.wg_end[2] : ws.wg_end[3]) - first) / ncol);
 #undef MXS
 }
 
@@ -818,7 +819,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
 template <int TYPE>
 hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     constexpr int KS = 8;
-    if (!w->q6a || !w->q6b || p.Npad < 32) return hipErrorInvalidValue;
+    if (!w->q6a || !w->q6b) return hipErrorInvalidValue;
     const int nbkp = (int)pad_kblocks(w->nbk);
     int nloc = (nbkp + KS - 1) / KS;
     nloc += nloc & 1;                                       // pairs of blocks stay inside one wave
@@ -833,13 +834,16 @@ hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // bounds the form: two / four times the weights behind the same activation fragments (32000 x 4096 x 32: 41.5 | 36.1 | 30.1 us
     // with one | two | four tiles).  Same blocks in the same order per element: the same bits (only the geometry follows M).
     static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 / 2 / 4 = that many tiles per workgroup whatever M
-    const int64_t t32 = (w->M + 31) / 32;
+    const int ncol = (int)((N + 31) / 32);                  // 32-column slices of src1: one workgroup per tile group and slice
+    if (p.Npad < 32 * ncol) return hipErrorInvalidValue;
+    const int64_t t32 = (w->M + 31) / 32 * ncol;
     // (four tiles: Q4_0 only -- Q4_1's min-term registers do not fit beside four accumulator tiles)
     const int wmt = geo == 1 ? 1 : geo == 2 || TYPE == GGML_TYPE_Q4_1 ? (geo == 2 || geo == 4 || t32 > 256 ? 2 : 1) : geo == 4 ? 4 : (t32 <= 256 ? 1 : t32 <= 512 ? 2 : 4);
     const bool two = wmt == 2;
     const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
     const int lds = tab > xch ? tab : xch;
-    dim3 grid((unsigned)((w->M + 32 * wmt - 1) / (32 * wmt)));
+    const int ntw = (int)((w->M + 32 * wmt - 1) / (32 * wmt));
+    dim3 grid((unsigned)(ntw * ncol));
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
 #define K3S_GO(NP, ROT, WMT) do { \
         auto kern = gemm_qmx_small_kernel<TYPE, KS, NP, ROT, WMT>; \
@@ -848,7 +852,7 @@ hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float
         if (attr != hipSuccess) return attr; \
         kern<<<grid, KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M, (int)N, \
                                       (int)w->Mpad, (int)p.Npad, nbkp, nloc, (int)ldd, (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, \
-                                      (uint32_t)ad_bytes, t_epilogue); } while (0)
+                                      (uint32_t)ad_bytes, t_epilogue, ntw); } while (0)
     if (wmt == 4) { if constexpr (TYPE == GGML_TYPE_Q4_0) K3S_GO(2, true, 4); }
     else if (two) { if (nloc <= 8) K3S_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3S_GO(3, true, 2); else K3S_GO(4, true, 2); }
     else if (nloc <= 8) K3S_GO(4, false, 1);
@@ -866,12 +870,14 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
     const int nbkp = (int)pad_kblocks(w[0]->nbk);
     int nloc = (nbkp + KS - 1) / KS;
     nloc += nloc & 1;
-    if (w[0]->nbk < 64 || nloc > 64 || p.Npad < 32) return hipErrorNotSupported;
+    if (w[0]->nbk < 64 || nloc > 64) return hipErrorNotSupported;
     const uint64_t nba = (uint64_t)nbkp;
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
     if (a_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+    const int ncol = (int)((N + 31) / 32);
+    if (p.Npad < 32 * ncol) return hipErrorNotSupported;
     int64_t t32 = 0;
-    for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32;
+    for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32 * ncol;
     const int wmt = t32 <= 256 ? 1 : t32 <= 512 || TYPE == GGML_TYPE_Q4_1 ? 2 : 4;
     mxs_set ws = {};
     ws.n = n_w;
@@ -881,7 +887,7 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
             const ggml_hip_weight *x = w[i];
             const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)x->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)x->Mpad * 4;
             if (!x->q6a || !x->q6b || x->nbk != w[0]->nbk || x->Mpad % (32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
-            wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt));
+            wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt)) * ncol;
             ws.a[i] = x->q6a; ws.b[i] = x->q6b; ws.d[i] = x->d; ws.m[i] = x->m; ws.dst[i] = dst[i];
             ws.M[i] = (int)x->M; ws.Mpad[i] = (int)x->Mpad; ws.ldd[i] = (int)ldd[i]; ws.wa_bytes[i] = (uint32_t)wq_bytes; ws.wd_bytes[i] = (uint32_t)wd_bytes;
         }
@@ -897,7 +903,7 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<grid, KS * 64, lds, st>>>(ws, (const uint8_t *)p.a8, p.ad, (const float *)p.as, (int)N, (int)p.Npad, nbkp, nloc, (uint32_t)a_bytes, \
-                                      (uint32_t)ad_bytes); } while (0)
+                                      (uint32_t)ad_bytes, ncol); } while (0)
     if (wmt == 4) { if constexpr (TYPE == GGML_TYPE_Q4_0) K3M_GO(2, true, 4); }
     else if (wmt == 2) { if (nloc <= 8) K3M_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3M_GO(3, true, 2); else K3M_GO(4, true, 2); }
     else if (nloc <= 8) K3M_GO(4, false, 1);
@@ -941,11 +947,15 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
         // up to 32 rows: 32-column tiles (the 64-column tile spends half of its MFMAs and scale-accumulates on padding columns
         // there); same four-way tree, same bits; 32- or 64-row tiles by tile count
         if constexpr (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) {
-            // up to 32 rows, K >= 2048: the stage-free form (K3s above).  Weights cold in HBM, compute kernel in us, staged form | K3s:
+            // up to 32 rows (64: below), K >= 2048: the stage-free form (K3s above).  Weights cold in HBM, compute kernel in us, staged form | K3s:
             // 4096 x 4096 x 32 16.8 | 12.3, 8192 x 4096 17.6 | 13.2, 11008 x 4096 20.1 | 18.5-19.3, 16384 x 4096 21.3 | 20.3, 32000 x 4096
             // 31.1 | 30.1 (four tiles per workgroup; two: 36.1), 4096 x 11008 36.7 | 24.8, 4096 x 2048 10.4 | 8.2; K = 1024 7.2 | 7.7:
             // shorter K stays on the staged form.  The choice is by N and K alone (GGML_HIP_MX_TILE=26: the staged form, A/B).
-            if (N <= 32 && w->nbk >= 64 && var != 25 && var != 26) {
+            // 33..64 rows: two workgroups per tile group, one per 32-column slice of src1 (the weights come twice, the second time mostly
+            // from L2): COMPUTE in us, staged 64-column form | K3s -- 4096 x 4096 x 64 19.8 | 12.2, 8192 x 4096 20.4 | 17.9, 11008 x 4096 23.0 |
+            // 23.0, 4096 x 11008 42.8 | 24.2, 4096 x 2048 12.1 | 8.4; 32000 x 4096 42.0 | 51.2 (the one loss: a vocabulary projection)
+            static const int ncmax = dev_env_int("GGML_HIP_K3S_COLS", 2);   // developer A/B switch: 1 = K3s up to 32 rows only
+            if (N <= 32 * ncmax && w->nbk >= 64 && var != 25 && var != 26) {
                 const hipError_t e = launch_small<TYPE>(w, p, N, dst, ldd, st);
                 if (e != hipErrorNotSupported) return e;
             }
@@ -1002,7 +1012,7 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
 }  // namespace
 
 hipError_t launch_gemm_qmx_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
-    if (n_w < 2 || n_w > 4 || N < 5 || N > 32) return hipErrorNotSupported;
+    if (n_w < 2 || n_w > 4 || N < 5 || N > 64) return hipErrorNotSupported;
     for (int i = 0; i < n_w; ++i)
         if (!w[i] || w[i]->type != w[0]->type || w[i]->M <= 0 || (uint64_t)32 * (uint64_t)ldd[i] * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
     switch (w[0]->type) {

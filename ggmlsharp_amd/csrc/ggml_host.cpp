@@ -401,6 +401,8 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
         if (!t || t->op != GGML_OP_MUL_MAT || !t->src0 || !t->src1 || t->src0->op != GGML_OP_NONE) return false;
         const int ty = t->src0->type;
         if (!(ty == GGML_TYPE_Q4_0 || ty == GGML_TYPE_Q4_1 || ty == GGML_TYPE_Q5_0 || ty == GGML_TYPE_Q5_1 || ty == GGML_TYPE_Q8_0)) return false;
+        // (up to 32 rows: beyond, every result is a megabyte going home by DMA beside the next node's kernel -- a 7B layer at batch 64:
+        // 800 us node by node, 862 us with q / k / v finishing together; the library's group call itself takes up to 64 rows)
         if (t->src1->ne[1] > 32 || t->src1->ne[2] != 1 || t->src1->ne[3] != 1 || t->src0->ne[2] != 1 || t->src0->ne[3] != 1) return false;
         return !first || (t->src1 == first->src1 && ty == first->src0->type && t->src0->ne[0] == first->src0->ne[0] && t != first);
     };

@@ -849,7 +849,7 @@ int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *par
     if (n < 2) return one_by_one();
     const int type = src0[0]->type;
     const int64_t K = src1->ne[0], N = src1->ne[1];
-    bool ok = type >= 0 && type < GGML_TYPE_COUNT && is_q(type) && weight_type_ok(type) && src1->type == GGML_TYPE_F32 && N >= 1 && N <= 32 &&
+    bool ok = type >= 0 && type < GGML_TYPE_COUNT && is_q(type) && weight_type_ok(type) && src1->type == GGML_TYPE_F32 && N >= 1 && N <= 64 &&
               src1->ne[2] == 1 && src1->ne[3] == 1 && src1->data && contiguous_f32(src1) && K % QK == 0;
     for (int i = 0; i < n && ok; ++i) {
         const ggml_tensor *w = src0[i], *d = dst[i];
@@ -880,7 +880,7 @@ int ggml_hip_compute_forward_mul_mat_multi(const struct ggml_compute_params *par
         if (it == c->cache.end() || it->second.slices.size() != 1) return one_by_one();      // (uploads and caches them: fused next time)
         W[i] = it->second.slices[0];
     }
-    // up to 4 rows: the fused mat-vec takes them (and the prologue) in one launch; 5..32 rows (Q4_0 / Q4_1): one INIT for all of them and one launch
+    // up to 4 rows: the fused mat-vec takes them (and the prologue) in one launch; 5..64 rows (Q4_0 / Q4_1): one INIT for all of them and one launch
     // where gemm_qmx.hip has the form (ggml_hip_mul_mat_multi_work_dev), the norm -> mul pair in front as its own kernel
     const bool fused_rows = ggml_hip_mul_mat_multi_fused(W, n, N) != 0;
     if (!fused_rows && (N <= 4 || !ggml_hip_mul_mat_epilogue_fused(W[0], N))) return one_by_one();

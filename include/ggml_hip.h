@@ -356,7 +356,7 @@ int ggml_hip_mul_mat_multi_dev(const ggml_hip_weight *const *w, int n_w, const f
                                float *d_y, void *stream);
 /* The same for a batch of any size, with the scratch a batch needs (ggml_hip_mul_mat_work_size(type, K, N) bytes): src1 is
  * quantized once -- the INIT phase (Ggml.cs:6641-6654) is the same for every matrix of one type and K -- and the 1..4 matrices
- * follow, in ONE launch where the library has the form (5 <= N <= 32, Q4_0 / Q4_1, K >= 2048: three 4096-row projections fill
+ * follow, in ONE launch where the library has the form (5 <= N <= 64, Q4_0 / Q4_1, K >= 2048: three 4096-row projections fill
  * the chip that one of them half uses), else one COMPUTE after the other behind the shared image.  Every row is bit for bit
  * what ggml_hip_mul_mat_dev gives for that matrix. */
 int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, const float *d_src1, int64_t ld1, int64_t N,

@@ -34,7 +34,7 @@ def test_epilogue_device_form_is_bitwise_product_then_node(dev, t):
     from ggmlsharp_amd._lib import lib, check
     L = lib()
     for (M, K, N) in ((96, 256, 1), (130, 512, 3), (64, 256, 4), (200, 256, 6), (515, 512, 40), (260, 1024, 300), (128, 256, 1100),
-                      (130, 2048, 12), (260, 4096 + 64, 32), (96, 2048, 6)):      # (the last three: the batched-decode form, gemm_qmx.hip K3s)
+                      (130, 2048, 12), (260, 4096 + 64, 32), (96, 2048, 6), (200, 2048, 40), (130, 2048, 64)):      # (the last three: the batched-decode form, gemm_qmx.hip K3s)
         wq = O.quantize_row(t, _rand((M, K)))
         W = dev.Weight.from_host(t, wq, K)
         x = torch.from_numpy(_rand((N, K))).cuda()
@@ -246,7 +246,7 @@ def test_multi_weight_batch_form_is_bitwise_the_single_calls(dev, t):
     L = lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for (Ms, K, N) in (((96, 130), 2048, 12), ((4096, 4096, 4096), 2048, 32), ((300, 8200, 40), 2048 + 64, 9), ((8192, 8192 + 300), 2048, 20),
-                       ((64, 200), 512, 20), ((130, 70, 33), 2048, 3), ((100, 60), 2048, 7), ((128, 96), 4096 + 128, 70), ((77,), 2048, 16)):
+                       ((64, 200), 512, 20), ((130, 70, 33), 2048, 3), ((100, 60), 2048, 7), ((128, 96), 4096 + 128, 70), ((77,), 2048, 16), ((4096, 300, 4096), 2048, 50), ((8192 + 40, 200), 2048 + 64, 64)):
         Ws = [dev.Weight.from_host(t, O.quantize_row(t, _rand((M, K))), K) for M in Ms]
         x = torch.from_numpy(_rand((N, K), 2.0)).cuda()
         hw = (C.c_void_p * len(Ws))(*[w.handle for w in Ws])
@@ -263,7 +263,7 @@ def test_multi_weight_batch_form_is_bitwise_the_single_calls(dev, t):
             w.free()
 
 
-@pytest.mark.parametrize("N", [12, 32])
+@pytest.mark.parametrize("N", [6, 12, 32, 50])
 def test_projection_groups_of_a_batch_go_down_together(dev, N):
     """q / k / v and gate / up of a batched decoder's step through ggml_graph_compute (K = 2048: the one-launch form) against the
     same nodes one by one through the single seams: identical bytes for every node, over an observed, a captured and two

@@ -186,9 +186,9 @@ def test_small_batch_tile_forms_agree_bitwise(dev, N):
         W.free()
 
 
-@pytest.mark.parametrize("N", [5, 9, 20, 32])
+@pytest.mark.parametrize("N", [5, 9, 20, 32, 40, 64])
 def test_batched_decode_form_follows_M_only_in_its_geometry(dev, N):
-    """Batches of 5 to 32 rows, K >= 2048 (gemm_qmx.hip K3s): eight waves with a contiguous eighth of K each, their sums added
+    """Batches of 5 to 64 rows (two 32-column slices above 32), K >= 2048 (gemm_qmx.hip K3s): eight waves with a contiguous eighth of K each, their sums added
     in wave order -- fixed by N and K.  One 32-row tile per workgroup while there are at most 256 tiles, two above, four (Q4_0)
     above 512: a shard is bit for bit the matching columns of the unsplit result.  K = 2048 holds a wave's range in its slots, 4096 + 64 and 6144
     refill them in turn."""

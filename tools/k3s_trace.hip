@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     auto go = [&](int c) {
 #define GO(NP, ROT, WMT) do { auto kern = gemm_qmx_small_kernel<GGML_TYPE_Q4_0, 8, NP, ROT, WMT>; \
         CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        kern<<<grid, KS * 64, lds>>>(A[c], B[c], D[c], D[c], a6, ad, ad, dst, M, N, Mpad, Npad, nbkp, nloc, M, (uint32_t)wa, (uint32_t)wdb, (uint32_t)ab, (uint32_t)adb, ep); } while (0)
+        kern<<<grid, KS * 64, lds>>>(A[c], B[c], D[c], D[c], a6, ad, ad, dst, M, N, Mpad, Npad, nbkp, nloc, M, (uint32_t)wa, (uint32_t)wdb, (uint32_t)ab, (uint32_t)adb, ep, grid); } while (0)
         if (wmt == 4) GO(2, true, 4); else if (two) { if (nloc <= 8) GO(4, false, 2); else GO(4, true, 2); } else if (nloc <= 8) GO(4, false, 1); else if (nloc <= 16) GO(8, false, 1); else GO(8, true, 1);
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
