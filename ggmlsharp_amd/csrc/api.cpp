@@ -74,8 +74,14 @@ int gemm_force() {
 }
 }  // namespace
 
+// Q8_0, 5..64 rows, 2048 <= K <= 4096: the stage-free batched-decode form on the int8 matrix cores (gemm_q.hip gemm_q8_small_kernel) -- image 0
+static bool q8_small_serves(int type, int64_t K, int64_t N) {
+    return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 128 && gemm_force() == 0;
+}
+
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
+    if (q8_small_serves(type, K, N)) return 0;
     if (N <= 4 || force == 1) return 0;
     // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
     // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them (a 7B
@@ -709,6 +715,9 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     int rc = weight_device_current(w);
     if (rc) return rc;
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
+    if (w->ext_type == 0 && q8_small_serves(w->type, w->K, N) && launch_gemm_q8_small(w, p, N, d_dst, ldd, (hipStream_t)stream, nullptr) == hipSuccess)
+        return GGML_HIP_OK;
+    (void)hipGetLastError();
     if (N <= gemv_rows_max(w->type) && act_image_kind(w->type, w->M, w->K, N) == 0)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else if (act_image_kind(w->type, w->M, w->K, N) == 3)
@@ -738,7 +747,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
-    if (N <= GEMV_MAX_N && w->ext_type == 0 && act_image_kind(w->type, w->M, w->K, N) == 0) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
+    if (N <= GEMV_MAX_N && w->ext_type == 0 && act_image_kind(w->type, w->M, w->K, N) == 0 && !q8_small_serves(w->type, w->K, N)) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
         rc = check_src1_alignment(d_src1, ld1);     // (float4 loads of the activation rows)
         if (rc) return rc;
         HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream));
@@ -749,10 +758,11 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     return ggml_hip_mul_mat_compute_dev(w, N, d_dst, ldd, d_work, work_bytes, stream);
 }
 
-// does a kernel form with a fused store-phase epilogue serve this (weight, N)?  The fused mat-vec (N <= 4) and the MX mat-mat
-// (Q4_0 / Q4_1, N > 8); every other form runs the epilogue as its own launch behind the mat-mul.
+// does a kernel form with a fused store-phase epilogue serve this (weight, N)?  The fused mat-vec (N <= 4), the MX mat-mat (Q4_0 / Q4_1:
+// N > 8, and from 5 rows where K >= 2048) and Q8_0's batched-decode form; every other form runs the epilogue as its own launch behind the mat-mul.
 static bool epilogue_is_fused(const ggml_hip_weight *w, int64_t N) {
     if (!is_q(w->type) || w->ext_type != 0) return false;
+    if (q8_small_serves(w->type, w->K, N)) return true;
     const int kind = act_image_kind(w->type, w->M, w->K, N);
     if (N <= GEMV_MAX_N && kind == 0) return gemv_fused_has_epilogue(N);
     return kind == 3;
@@ -774,7 +784,7 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
         int rc = weight_device_current(w);
         if (rc) return rc;
-        if (N <= GEMV_MAX_N && act_image_kind(w->type, w->M, w->K, N) == 0) {
+        if (N <= GEMV_MAX_N && act_image_kind(w->type, w->M, w->K, N) == 0 && !q8_small_serves(w->type, w->K, N)) {
             rc = check_src1_alignment(d_src1, ld1);
             if (rc) return rc;
             HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream, &ep));
@@ -782,7 +792,8 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         }
         rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
         if (rc) return rc;
-        HIP_TRY(launch_gemm_qmx(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep));
+        if (q8_small_serves(w->type, w->K, N)) HIP_TRY(launch_gemm_q8_small(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep));
+        else HIP_TRY(launch_gemm_qmx(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep));
         return GGML_HIP_OK;
     }
     // no fused form for this kernel: the product, then the node's own kernel row by row (same values)
@@ -880,7 +891,7 @@ int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, co
     if (n_w >= 2 && multi_ok(w, n_w, N)) return ggml_hip_mul_mat_multi_dev(w, n_w, d_src1, ld1, N, d_dst, ldd, nullptr, 0, nullptr, nullptr, stream);
     // one image for all of them?  (the image kind of a type follows N and K; M enters for shapes beyond the 32-bit offsets only)
     const int kind = act_image_kind(w[0]->type, w[0]->M, w[0]->K, N);
-    bool shared = !(N <= gemv_rows_max(w[0]->type) && kind == 0) && w[0]->ext_type == 0;
+    bool shared = (!(N <= gemv_rows_max(w[0]->type) && kind == 0) || q8_small_serves(w[0]->type, w[0]->K, N)) && w[0]->ext_type == 0;
     for (int i = 1; i < n_w && shared; ++i) shared = act_image_kind(w[i]->type, w[i]->M, w[i]->K, N) == kind;
     if (!shared) {
         for (int i = 0; i < n_w; ++i) {

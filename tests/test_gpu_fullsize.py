@@ -193,7 +193,8 @@ def test_batched_decode_form_follows_M_only_in_its_geometry(dev, N):
     above 512: a shard is bit for bit the matching columns of the unsplit result.  K = 2048 holds a wave's range in its slots, 4096 + 64 and 6144
     refill them in turn."""
     # (16424 rows = 514 tiles: four per workgroup for Q4_0; 8492 rows: two)
-    for (t, M, K) in ((Q4_0, 16384 + 40, 2048), (3, 8192 + 300, 4096 + 64), (Q4_0, 8192 + 300, 2048), (Q4_0, 300, 6144), (3, 100, 2048 + 32)):
+    for (t, M, K) in ((Q4_0, 16384 + 40, 2048), (3, 8192 + 300, 4096 + 64), (Q4_0, 8192 + 300, 2048), (Q4_0, 300, 6144), (3, 100, 2048 + 32),
+                      (Q8_0, 8192 + 300, 2048), (Q8_0, 300, 4096), (Q8_0, 130, 2048 + 64)):   # (Q8_0: the int8 form of the same, gemm_q.hip)
         rows, x = _make(dev, t, M, K, N, seed=11 + t + N)
         W = dev.Weight.from_device(t, rows, K)
         full = dev.mul_mat(W, x)
