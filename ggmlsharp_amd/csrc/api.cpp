@@ -908,6 +908,12 @@ int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, co
         if (e == hipSuccess) return GGML_HIP_OK;
         if (e != hipErrorNotSupported) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: %s", hipGetErrorString(e)); }
     }
+    if (kind == 0 && n_w >= 2 && q8_small_serves(w[0]->type, w[0]->K, N)) {
+        for (int i = 1; i < n_w; ++i) { rc = weight_device_current(w[i]); if (rc) return rc; }
+        const hipError_t e = launch_gemm_q8_small_multi(w, n_w, act_carve(d_work, w[0]->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream);
+        if (e == hipSuccess) return GGML_HIP_OK;
+        if (e != hipErrorNotSupported) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: %s", hipGetErrorString(e)); }
+    }
     for (int i = 0; i < n_w; ++i) {
         rc = ggml_hip_mul_mat_compute_dev(w[i], N, d_dst[i], ldd[i], d_work, work_bytes, stream);
         if (rc) return rc;

@@ -465,15 +465,14 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
 // slice of the row scales in its own LDS slice; the waves' sums are added in wave order, every wave taking its share of the rows.
 // Arithmetic per block as in the kernel above: acc = fma((float)sumi, d1 * d0, acc) (Ggml.cs:1377-1378).
 template <int KS, int NB, bool ROT, int WMT>
-__global__ __launch_bounds__(KS * 64, 1)
-void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
-                          float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
-                          uint32_t w_bytes, uint32_t a_bytes) {
+__device__ __forceinline__
+void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                        float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
+                        uint32_t w_bytes, uint32_t a_bytes, int wg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int wg = (int)blockIdx.x;
     const int m0 = (wg % ntw) * 32 * WMT, n0 = (wg / ntw) * 32;
     const int kb0 = wave * nloc;
     // a slot past the wave's range (or past the end of K) repeats a valid block: its table row is zero, so it adds (sumi * 0) = +0
@@ -585,6 +584,74 @@ void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restric
     }
 }
 
+template <int KS, int NB, bool ROT, int WMT>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                          float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
+                          uint32_t w_bytes, uint32_t a_bytes) {
+    gemm_q8_small_body<KS, NB, ROT, WMT>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
+}
+
+// several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
+struct q8s_set {
+    int n; int wg_end[4];
+    const uint8_t *qs[4]; const float *d[4]; float *dst[4];
+    int M[4], Mpad[4]; int64_t ldd[4]; uint32_t w_bytes[4];
+};
+template <int KS, int NB, bool ROT, int WMT>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_q8_small_multi_kernel(const q8s_set ws, const int8_t *__restrict__ a8, const float *__restrict__ ad, int N, int Npad, int nbkp, int nloc,
+                                uint32_t a_bytes, int ncol) {
+    const int b = (int)blockIdx.x;
+    const int k = (b >= ws.wg_end[0]) + (b >= ws.wg_end[1]) + (b >= ws.wg_end[2]);
+    const int first = k == 0 ? 0 : k == 1 ? ws.wg_end[0] : k == 2 ? ws.wg_end[1] : ws.wg_end[2];
+#define Q8S(f) (k == 0 ? ws.f[0] : k == 1 ? ws.f[1] : k == 2 ? ws.f[2] : ws.f[3])
+    const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
+    gemm_q8_small_body<KS, NB, ROT, WMT>(Q8S(qs), Q8S(d), a8, ad, Q8S(dst), Q8S(M), N, Q8S(Mpad), Npad, nbkp, nloc, Q8S(ldd), ep, (Q8S(wg_end) - first) / ncol,
+                                         Q8S(w_bytes), a_bytes, b - first);
+#undef Q8S
+}
+
+hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
+    constexpr int KS = 8;
+    const int nbkp = (int)pad_kblocks(w[0]->nbk);
+    const int nloc = (nbkp + KS - 1) / KS;
+    const int ncol = (int)((N + 31) / 32);
+    if (nloc > 16 || p.Npad < 32 * ncol) return hipErrorNotSupported;
+    int64_t t32 = 0;
+    for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32 * ncol;
+    const int wmt = t32 <= 256 || nloc > 8 ? 1 : 2;
+    const uint64_t aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
+    if (aq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+    q8s_set ws = {};
+    ws.n = n_w;
+    int wgs = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < n_w) {
+            const ggml_hip_weight *x = w[i];
+            const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)x->Mpad * 16;
+            if (x->type != GGML_TYPE_Q8_0 || !x->qs || !x->d || x->nbk != w[0]->nbk || x->Mpad % (32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+            wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt)) * ncol;
+            ws.qs[i] = x->qs; ws.d[i] = x->d; ws.dst[i] = dst[i]; ws.M[i] = (int)x->M; ws.Mpad[i] = (int)x->Mpad; ws.ldd[i] = ldd[i]; ws.w_bytes[i] = (uint32_t)wq_bytes;
+        }
+        ws.wg_end[i] = wgs;
+    }
+    const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;
+    const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
+    const int lds = tab > xch ? tab : xch;
+    dim3 grid((unsigned)wgs);
+#define Q8M_GO(NB, WMT) do { \
+        auto kern = gemm_q8_small_multi_kernel<KS, NB, false, WMT>; \
+        static PerDeviceOnce once; \
+        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
+        if (attr != hipSuccess) return attr; \
+        kern<<<grid, KS * 64, lds, st>>>(ws, p.a8, p.ad, (int)N, (int)p.Npad, nbkp, nloc, (uint32_t)aq_bytes, ncol); } while (0)
+    if (nloc <= 8) { if (wmt == 2) Q8M_GO(8, 2); else Q8M_GO(8, 1); }
+    else Q8M_GO(16, 1);
+#undef Q8M_GO
+    return hipGetLastError();
+}
+
 hipError_t launch_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     constexpr int KS = 8;
     const int nbkp = (int)pad_kblocks(w->nbk);
@@ -623,6 +690,13 @@ hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, act_planes p, int64_t 
     if (N <= 0 || w->M <= 0) return hipSuccess;
     const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
     return launch_q8_small(w, p, N, dst, ldd, st, ep ? *ep : none);
+}
+
+hipError_t launch_gemm_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
+    if (n_w < 2 || n_w > 4 || N < 5 || N > 64) return hipErrorNotSupported;
+    for (int i = 0; i < n_w; ++i)
+        if (!w[i] || w[i]->type != GGML_TYPE_Q8_0 || w[i]->M <= 0) return hipErrorNotSupported;
+    return launch_q8_small_multi(w, n_w, p, N, dst, ldd, st);
 }
 
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {

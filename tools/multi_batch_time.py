@@ -16,7 +16,7 @@ from ggmlsharp_amd._lib import check, lib  # noqa: E402
 device.init(0)
 L = lib()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-T = 2
+T = int(os.environ.get("MULTI_TYPE", "2"))      # 2 = Q4_0, 8 = Q8_0
 
 
 def run(Ms, K, sets=12, reps=20):
