@@ -74,9 +74,9 @@ int gemm_force() {
 }
 }  // namespace
 
-// Q8_0, 5..64 rows, 2048 <= K <= 4096: the stage-free batched-decode form on the int8 matrix cores (gemm_q.hip gemm_q8_small_kernel) -- image 0
+// Q8_0, 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
 static bool q8_small_serves(int type, int64_t K, int64_t N) {
-    return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 128 && gemm_force() == 0;
+    return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && gemm_force() == 0;
 }
 
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
@@ -715,9 +715,11 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     int rc = weight_device_current(w);
     if (rc) return rc;
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
-    if (w->ext_type == 0 && q8_small_serves(w->type, w->K, N) && launch_gemm_q8_small(w, p, N, d_dst, ldd, (hipStream_t)stream, nullptr) == hipSuccess)
-        return GGML_HIP_OK;
-    (void)hipGetLastError();
+    if (w->ext_type == 0 && q8_small_serves(w->type, w->K, N)) {
+        const hipError_t e = launch_gemm_q8_small(w, p, N, d_dst, ldd, (hipStream_t)stream, nullptr);
+        if (e == hipSuccess) return GGML_HIP_OK;
+        if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported = planes beyond the 32-bit offsets: the staged int8 kernel below)
+    }
     if (N <= gemv_rows_max(w->type) && act_image_kind(w->type, w->M, w->K, N) == 0)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else if (act_image_kind(w->type, w->M, w->K, N) == 3)

@@ -289,7 +289,7 @@ bool gemv_fused_has_epilogue(int64_t N);       // the kernel form that serves N 
 hipError_t launch_gemv_q_fused_pro(const ggml_hip_weight *w, const float *x, int64_t ld1, const mm_prologue &pro, int64_t N, float *dst,
                                    int64_t ldd, hipStream_t st, const mm_epilogue *ep = nullptr);
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
-// Q8_0, 5 <= N <= 64, K >= 2048: the stage-free batched-decode form on the int8 matrix cores (gemm_q.hip; image 0 of K1); ep: add / scale in the store phase
+// Q8_0, 5 <= N <= 64, K >= 2048: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip; image 0 of K1); ep: add / scale in the store phase
 hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue *ep);
 hipError_t launch_gemm_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st);
 hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);

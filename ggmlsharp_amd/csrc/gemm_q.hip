@@ -456,248 +456,7 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
 }
 
-// ---- K3s for Q8_0: batches of 5 .. 64 rows, K >= 2048 (the stage-free form of gemm_qmx.hip on the int8 matrix cores) --------------------
-// Q8_0's resident planes ARE int8 MFMA operands -- [k-block][half][row][16 B], the halves holding the even and the odd elements, the way K1
-// writes the activations (image 0) -- so a k-block is one 16-byte load per operand and lane and one v_mfma_i32_32x32x32_i8, no digits and
-// nothing to expand: 36 B per 32 weights through the CU's memory path where the bf6 planes of Q4_0 carry 28 and its activation image 48.
-// Structure as K3s: a workgroup = WMT 32-row weight tiles x one 32-column slice of src1 x KS waves with a contiguous range of k-blocks each;
-// a wave requests its first NB blocks before anything else (K <= 4096: all of them; longer K: round after round), keeps its
-// slice of the row scales in its own LDS slice; the waves' sums are added in wave order, every wave taking its share of the rows.
-// Arithmetic per block as in the kernel above: acc = fma((float)sumi, d1 * d0, acc) (Ggml.cs:1377-1378).
-template <int KS, int NB, bool ROT, int WMT>
-__device__ __forceinline__
-void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
-                        float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
-                        uint32_t w_bytes, uint32_t a_bytes, int wg) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int m0 = (wg % ntw) * 32 * WMT, n0 = (wg / ntw) * 32;
-    const int kb0 = wave * nloc;
-    // a slot past the wave's range (or past the end of K) repeats a valid block: its table row is zero, so it adds (sumi * 0) = +0
-    auto blk = [&](int i) { const int kb = kb0 + (i < nloc ? i : nloc - 1); return kb < nbkp ? kb : nbkp - 1; };
-
-    struct WB { i32x4 q[WMT]; float d[WMT]; };
-    WB wb[NB];
-    i32x4 ab[NB];
-    // raw buffer addressing: one 32-bit offset per lane and plane, the k-block in the scalar offset (planes past their end read 0)
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(qs), 0, (int)w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wd), 0, (int)(w_bytes / 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a8), 0, (int)a_bytes, 0x00020000);
-    const uint32_t offW = (uint32_t)((hh * Mpad + m0 + l31) * 16), offD = (uint32_t)((m0 + l31) * 4), offA = (uint32_t)((hh * Npad + n0 + l31) * 16);
-    const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
-    auto load_blk = [&](WB &f, i32x4 &a, int i) {
-        const uint32_t kb = (uint32_t)blk(i);
-        a = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)offA, (int)(kb * a_blk), 0));
-#pragma unroll
-        for (int t = 0; t < WMT; ++t) {
-            f.q[t] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(offW + 512u * t), (int)(kb * w_blk), 0));
-            f.d[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(offD + 128u * t), (int)(kb * d_blk), 0));
-        }
-    };
-
-    // ---- this wave's slice of the row scales: rows x 32 floats, straight into its own LDS slice (rows past its range: zero) ----
-    const int trows = (nloc + NB - 1) / NB * NB;            // whole rounds of NB slots: rows past the wave's range are zero
-    float *const tabD = (float *)smem8 + (size_t)wave * trows * 32;
-    constexpr int TP = 8;                                   // float4 pieces per lane (nloc <= 64)
-    f32x4 td[TP];
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int idx = lane + 64 * j, b = idx >> 3, c4 = idx & 7;
-        const bool ok = b < nloc && kb0 + b < nbkp;
-        td[j] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; load_blk(wb[u], ab[u], u); });
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int idx = lane + 64 * j;
-        if (idx < trows * 8) *(f32x4 *)(tabD + 4 * idx) = td[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    float acc[WMT][16];
-#pragma unroll
-    for (int t = 0; t < WMT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto block = [&](int i, auto uc) {                      // block i of the wave out of slot u
-        constexpr int u = decltype(uc)::value;
-        WB &w = wb[u];
-        i32x16 t[WMT];
-        float dw[WMT];
-#pragma unroll
-        for (int k = 0; k < WMT; ++k) { t[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ab[u], w.q[k], zero, 0, 0, 0); dw[k] = w.d[k]; }
-        const float *dp = tabD + i * 32 + 4 * hh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 da = *(const f32x4 *)(dp + 8 * q);
-#pragma unroll
-            for (int k = 0; k < WMT; ++k)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[k][4 * q + e] = fmaf((float)t[k][4 * q + e], da[e] * dw[k], acc[k][4 * q + e]);
-        }
-    };
-    if constexpr (!ROT) {
-        static_for<NB>([&](auto uc) { block(decltype(uc)::value, uc); });
-    } else {
-        // longer K: rounds of NB blocks, a round's loads issued together behind the previous round's last MFMA (a slot refilled as soon
-        // as its own MFMA had issued -- the form of gemm_qmx.hip -- spilled here: 256 registers + 200 B of scratch)
-        static_for<NB>([&](auto uc) { block(decltype(uc)::value, uc); });
-        for (int base = NB; base < nloc; base += NB) {
-            __builtin_amdgcn_sched_barrier(0);              // (a round's loads stay behind the previous round's arithmetic: hoisted, they double the live slots)
-            static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; load_blk(wb[u], ab[u], base + u); });
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<NB>([&](auto uc) { block(base + decltype(uc)::value, uc); });
-        }
-    }
-
-    // ---- the waves' sums in wave order, every wave its share of the rows ----
-    __syncthreads();
-    float *xch = (float *)smem8 + lane;
-#pragma unroll
-    for (int t = 0; t < WMT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(size_t)((wave * WMT + t) * 16 + r) * 64] = acc[t][r];
-    __syncthreads();
-    constexpr int RW = 16 * WMT / KS;
-    static_assert((16 * WMT) % KS == 0, "rows per wave");
-#pragma unroll
-    for (int k = 0; k < RW; ++k) {
-        const int rr = wave * RW + k, t = rr / 16, r = rr % 16;
-        float v = xch[(size_t)(t * 16 + r) * 64];
-#pragma unroll
-        for (int g = 1; g < KS; ++g) v += xch[(size_t)((g * WMT + t) * 16 + r) * 64];
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hh, m = m0 + 32 * t + l31;
-        if (n < N && m < M) {
-            if (ep.mode == 2) {
-                dst[(size_t)n * ldd + m] = v * ep.scale;
-            } else {
-                dst[(size_t)n * ldd + m] = v;
-                if (ep.mode == 1) ep.dst2[(size_t)n * ep.ld2 + m] = v + ep.addend[(size_t)n * ep.ld_add + m];
-            }
-        }
-    }
-}
-
-template <int KS, int NB, bool ROT, int WMT>
-__global__ __launch_bounds__(KS * 64, 1)
-void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
-                          float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbkp, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
-                          uint32_t w_bytes, uint32_t a_bytes) {
-    gemm_q8_small_body<KS, NB, ROT, WMT>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
-}
-
-// several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
-struct q8s_set {
-    int n; int wg_end[4];
-    const uint8_t *qs[4]; const float *d[4]; float *dst[4];
-    int M[4], Mpad[4]; int64_t ldd[4]; uint32_t w_bytes[4];
-};
-template <int KS, int NB, bool ROT, int WMT>
-__global__ __launch_bounds__(KS * 64, 1)
-void gemm_q8_small_multi_kernel(const q8s_set ws, const int8_t *__restrict__ a8, const float *__restrict__ ad, int N, int Npad, int nbkp, int nloc,
-                                uint32_t a_bytes, int ncol) {
-    const int b = (int)blockIdx.x;
-    const int k = (b >= ws.wg_end[0]) + (b >= ws.wg_end[1]) + (b >= ws.wg_end[2]);
-    const int first = k == 0 ? 0 : k == 1 ? ws.wg_end[0] : k == 2 ? ws.wg_end[1] : ws.wg_end[2];
-#define Q8S(f) (k == 0 ? ws.f[0] : k == 1 ? ws.f[1] : k == 2 ? ws.f[2] : ws.f[3])
-    const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
-    gemm_q8_small_body<KS, NB, ROT, WMT>(Q8S(qs), Q8S(d), a8, ad, Q8S(dst), Q8S(M), N, Q8S(Mpad), Npad, nbkp, nloc, Q8S(ldd), ep, (Q8S(wg_end) - first) / ncol,
-                                         Q8S(w_bytes), a_bytes, b - first);
-#undef Q8S
-}
-
-hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
-    constexpr int KS = 8;
-    const int nbkp = (int)pad_kblocks(w[0]->nbk);
-    const int nloc = (nbkp + KS - 1) / KS;
-    const int ncol = (int)((N + 31) / 32);
-    if (nloc > 16 || p.Npad < 32 * ncol) return hipErrorNotSupported;
-    int64_t t32 = 0;
-    for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32 * ncol;
-    const int wmt = t32 <= 256 || nloc > 8 ? 1 : 2;
-    const uint64_t aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
-    if (aq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
-    q8s_set ws = {};
-    ws.n = n_w;
-    int wgs = 0;
-    for (int i = 0; i < 4; ++i) {
-        if (i < n_w) {
-            const ggml_hip_weight *x = w[i];
-            const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)x->Mpad * 16;
-            if (x->type != GGML_TYPE_Q8_0 || !x->qs || !x->d || x->nbk != w[0]->nbk || x->Mpad % (32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
-            wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt)) * ncol;
-            ws.qs[i] = x->qs; ws.d[i] = x->d; ws.dst[i] = dst[i]; ws.M[i] = (int)x->M; ws.Mpad[i] = (int)x->Mpad; ws.ldd[i] = ldd[i]; ws.w_bytes[i] = (uint32_t)wq_bytes;
-        }
-        ws.wg_end[i] = wgs;
-    }
-    const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;
-    const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
-    const int lds = tab > xch ? tab : xch;
-    dim3 grid((unsigned)wgs);
-#define Q8M_GO(NB, WMT) do { \
-        auto kern = gemm_q8_small_multi_kernel<KS, NB, false, WMT>; \
-        static PerDeviceOnce once; \
-        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
-        if (attr != hipSuccess) return attr; \
-        kern<<<grid, KS * 64, lds, st>>>(ws, p.a8, p.ad, (int)N, (int)p.Npad, nbkp, nloc, (uint32_t)aq_bytes, ncol); } while (0)
-    if (nloc <= 8) { if (wmt == 2) Q8M_GO(8, 2); else Q8M_GO(8, 1); }
-    else Q8M_GO(16, 1);
-#undef Q8M_GO
-    return hipGetLastError();
-}
-
-hipError_t launch_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
-    constexpr int KS = 8;
-    const int nbkp = (int)pad_kblocks(w->nbk);
-    const int nloc = (nbkp + KS - 1) / KS;
-    const int ncol = (int)((N + 31) / 32);
-    if (w->type != GGML_TYPE_Q8_0 || !w->qs || !w->d || nloc > 64 || p.Npad < 32 * ncol) return hipErrorNotSupported;
-    const int64_t t32 = (w->M + 31) / 32 * ncol;
-    if (nloc > 16) return hipErrorNotSupported;
-    const int wmt = t32 <= 256 || nloc > 8 ? 1 : 2;
-    if (w->Mpad % (32 * wmt) != 0) return hipErrorNotSupported;
-    const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
-    if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
-    const int ntw = (int)((w->M + 32 * wmt - 1) / (32 * wmt));
-    const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;
-    const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
-    const int lds = tab > xch ? tab : xch;
-    dim3 grid((unsigned)(ntw * ncol));
-#define Q8S_GO(NB, ROT, WMT) do { \
-        auto kern = gemm_q8_small_kernel<KS, NB, ROT, WMT>; \
-        static PerDeviceOnce once; \
-        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
-        if (attr != hipSuccess) return attr; \
-        kern<<<grid, KS * 64, lds, st>>>(w->qs, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, nbkp, nloc, ldd, ep, ntw, \
-                                      (uint32_t)wq_bytes, (uint32_t)aq_bytes); } while (0)
-    // (K <= 4096 only: the looped forms for longer K spill -- 256 registers + 0.5..1.4 KB of scratch whatever the refill order; such
-    // shapes stay on the staged f16 form, see api.cpp act_image_kind)
-    if (nloc <= 8) { if (wmt == 2) Q8S_GO(8, false, 2); else Q8S_GO(8, false, 1); }
-    else Q8S_GO(16, false, 1);
-#undef Q8S_GO
-    return hipGetLastError();
-}
-
 }  // namespace
-
-hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue *ep) {
-    if (N <= 0 || w->M <= 0) return hipSuccess;
-    const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
-    return launch_q8_small(w, p, N, dst, ldd, st, ep ? *ep : none);
-}
-
-hipError_t launch_gemm_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
-    if (n_w < 2 || n_w > 4 || N < 5 || N > 64) return hipErrorNotSupported;
-    for (int i = 0; i < n_w; ++i)
-        if (!w[i] || w[i]->type != GGML_TYPE_Q8_0 || w[i]->M <= 0) return hipErrorNotSupported;
-    return launch_q8_small_multi(w, n_w, p, N, dst, ldd, st);
-}
 
 hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;

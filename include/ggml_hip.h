@@ -313,7 +313,7 @@ int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, cons
  *   mul_mat_add    mm_dst = mul_mat(src0, src1), add_dst = mm_dst + addend        the add is applied to the accumulators in
  *   mul_mat_scale  mm_dst = scale_dst = mul_mat(src0, src1) * scalar (in place)   the store phase of the mat-mul kernels
  * (epilogue forms exist in the fused mat-vec, N <= 4, in the MX mat-mat of Q4_0 / Q4_1 -- N > 8, and 5..8 rows where K >= 2048 --
- * and in the batched-decode form of Q8_0, 5..64 rows with 2048 <= K <= 4096:
+ * and in the batched-decode form of Q8_0, 5..64 rows with 2048 <= K <= 16384:
  * ggml_hip_mul_mat_epilogue_fused; elsewhere the node's own kernel runs behind the mat-mul inside the same call). */
 int ggml_hip_compute_forward_rms_norm_mul(const struct ggml_compute_params *params, const struct ggml_tensor *x,
                                           const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst);

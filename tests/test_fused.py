@@ -42,7 +42,7 @@ def test_epilogue_device_form_is_bitwise_product_then_node(dev, t):
         prod = dev.mul_mat(W, x)
         work = dev.alloc_work(t, K, N)
         fused = L.ggml_hip_mul_mat_epilogue_fused(W.handle, N)
-        assert fused == (1 if (N <= 4 or ((N > 8 or K >= 2048) and t in (O.Q4_0, O.Q4_1)) or (t == O.Q8_0 and 5 <= N <= 64 and 2048 <= K <= 4096)) else 0), (t, N)
+        assert fused == (1 if (N <= 4 or ((N > 8 or K >= 2048) and t in (O.Q4_0, O.Q4_1)) or (t == O.Q8_0 and 5 <= N <= 64 and 2048 <= K <= 16384)) else 0), (t, N)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         d1 = torch.full((N, M + 8), -3.0, device="cuda")
         d2 = torch.full((N, M + 4), -4.0, device="cuda")

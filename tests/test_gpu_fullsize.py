@@ -194,7 +194,7 @@ def test_batched_decode_form_follows_M_only_in_its_geometry(dev, N):
     refill them in turn."""
     # (16424 rows = 514 tiles: four per workgroup for Q4_0; 8492 rows: two)
     for (t, M, K) in ((Q4_0, 16384 + 40, 2048), (3, 8192 + 300, 4096 + 64), (Q4_0, 8192 + 300, 2048), (Q4_0, 300, 6144), (3, 100, 2048 + 32),
-                      (Q8_0, 8192 + 300, 2048), (Q8_0, 300, 4096), (Q8_0, 130, 2048 + 64)):   # (Q8_0: the int8 form of the same, gemm_q.hip)
+                      (Q8_0, 8192 + 300, 2048), (Q8_0, 300, 4096), (Q8_0, 130, 2048 + 64), (Q8_0, 8192 + 300, 4096 + 64), (Q8_0, 200, 11008)):   # (Q8_0: the int8 form of the same, gemm_q.hip)
         rows, x = _make(dev, t, M, K, N, seed=11 + t + N)
         W = dev.Weight.from_device(t, rows, K)
         full = dev.mul_mat(W, x)
@@ -254,3 +254,20 @@ def test_short_wide_shard_runs_the_one_tile_form_with_the_unsplit_bits(dev):
         for (r0, r1) in ((0, 512), (1536, 2048), (3600, 4096)):
             Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
             assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, r0, r1)
+
+
+@pytest.mark.parametrize("t", [Q4_0, 3, Q5_0, Q8_0])
+def test_scratch_contents_never_reach_the_result(dev, t):
+    """The work buffer is the caller's scratch: whatever it held before -- here every byte 0xFF, i.e. NaN where a kernel would read a
+    float -- must not show in dst.  K that is not a whole number of 4-block stages leaves padded k-blocks in the planes, which a
+    kernel either gets zero-filled from INIT or must not read (the int8 image's are not written)."""
+    for (M, K, N) in ((130, 2048 + 64, 6), (300, 4096 + 64, 20), (96, 2048 + 32, 64), (200, 2048 + 96, 200), (64, 11008, 33), (128, 96, 12)):
+        rows, x = _make(dev, t, M, K, N, seed=3 + t + N)
+        W = dev.Weight.from_device(t, rows, K)
+        ref = dev.mul_mat(W, x, work=torch.zeros_like(dev.alloc_work(t, K, N)))
+        work = dev.alloc_work(t, K, N)
+        work.fill_(0xFF)
+        got = dev.mul_mat(W, x, work=work)
+        assert torch.isfinite(got).all(), (t, M, K, N)
+        assert torch.equal(got, ref), (t, M, K, N)
+        W.free()
