@@ -11,7 +11,9 @@ from ggmlsharp_amd._lib import lib  # noqa: E402
 device.init(0)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
-SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29), (4096, 4096, 64), (777, 11008, 128), (16384, 1024, 100)]
+SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29), (4096, 4096, 64), (777, 11008, 128), (16384, 1024, 100),
+          # the batched-decode forms (K3s / K3s-i8): one, two and four tiles per workgroup, one and two column slices, K in slots and in rounds
+          (4096, 4096, 6), (4096, 4096, 32), (8492, 4160, 50), (20000, 2048, 20), (300, 11008, 64), (4096, 2112, 9)]
 nbad = 0
 for (M, K, N) in SHAPES:
     for t in TYPES:
