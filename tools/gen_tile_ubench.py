@@ -25,6 +25,16 @@ def group(t, g):
     return o
 
 
+def group_dpp(t, g):
+    """the row scale of accumulator register r comes from lane r of the lane's own row of 16 (one register holds all 16 scales)"""
+    o = []
+    for r in range(4):
+        o.append(f"v_mul_f32_dpp v{TMP + r}, v{DA}, v{t + 4 * g + r} row_newbcast:{4 * g + r} row_mask:0xf bank_mask:0xf")
+    for r in range(4):
+        o.append(f"v_fmac_f32 v{ACC + 4 * g + r}, v{TMP + r}, v{DW}")
+    return o
+
+
 def group_pk(t, g):
     o = []
     for r in (0, 2):
@@ -65,6 +75,13 @@ def tile(kind, cur, nxt):
         ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b128 v[{LD + 4}:{LD + 7}], v{LD + 12} offset:1024",
               f"ds_read_b64 v[{LD + 8}:{LD + 9}], v{LD + 12} offset:2048"]
         return [mm] + ld + g[0] + g[1] + g[2] + ["s_waitcnt lgkmcnt(0)"] + g[3]
+    if kind in ("mxd", "mxd_real"):
+        mm = f"v_mfma_scale_f32_32x32x64_f8f6f4 v[{nxt}:{nxt + 15}], v[{A0}:{A0 + 5}], v[{B0}:{B0 + 5}], 0, v{SCL}, v{SCL} op_sel_hi:[0,0,0] cbsz:3 blgp:3"
+        gd = [group_dpp(cur, i) for i in range(4)]
+        if kind == "mxd":
+            return [mm] + sum(gd, [])
+        ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b64 v[{LD + 8}:{LD + 9}], v{LD + 12} offset:2048", f"ds_read_b32 v{LD + 10}, v{LD + 12} offset:1024"]
+        return [mm] + ld + gd[0] + gd[1] + gd[2] + ["s_waitcnt lgkmcnt(0)"] + gd[3]
     if kind in ("mxp", "mxp_real", "mxp_only"):
         # S = MX MFMA; P = (weight scales) (x) (activation scales) as a K=6 bf16 MFMA; acc += S * P: 16 VALU instead of 32
         ps, pn = (P0, P1) if cur == T0 else (P1, P0)
@@ -95,7 +112,7 @@ def tile(kind, cur, nxt):
     raise ValueError(kind)
 
 
-KINDS = ["valu", "mfma", "mx_only", "mx", "mx_real", "mxp_only", "mxp", "mxp_real", "mxq", "mxq_real"]
+KINDS = ["valu", "mfma", "mx_only", "mx", "mx_real", "mxd", "mxd_real", "mxp_only", "mxp", "mxp_real", "mxq", "mxq_real"]
 src = ['// generated by tools/gen_tile_ubench.py -- do not edit', '#include <hip/hip_runtime.h>', '#include <cstdio>', '']
 for k in KINDS:
     body = tile(k, T0, T1) if k.startswith("mxq") else tile(k, T0, T1) + tile(k, T1, T0)
