@@ -11,6 +11,24 @@ std::mutex g_table_mu;
 DeviceCtx *g_slots[MAX_SLOTS] = {};
 std::atomic<int> g_nslots{0};
 
+// An error reported while the calling thread has a NAMED graph scope open: the host falls back to its own code for
+// that node, so the scope must never be captured -- a replay would skip the seams, the fallback with them, and
+// the node's data would never be produced.  The key is refused for good; a capture in progress is ended and issued live.
+static void poison_open_scope() {
+    const int b = bound_slot();
+    DeviceCtx *c = slot(b >= 0 ? b : 0);
+    if (!c) return;
+    std::unique_lock<std::recursive_mutex> lk(c->mu, std::try_to_lock);
+    if (!lk.owns_lock()) return;
+    if ((c->scope_mode != 1 && c->scope_mode != 2) || c->scope_owner != std::this_thread::get_id()) return;
+    const uint64_t key = c->scope_key;
+    if (c->scope_mode == 2) c->scope_dirty();
+    else c->scope_clean = false;
+    DeviceCtx::Captured &e = c->captured[key];
+    e.seen = 0;
+    if (!e.refused) { e.refused = true; ++c->n_refused; }
+}
+
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -18,6 +36,7 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     t_err = buf;
+    if (code != GGML_HIP_OK) poison_open_scope();
     return code;
 }
 
@@ -79,9 +98,15 @@ static bool q8_small_serves(int type, int64_t K, int64_t N) {
     return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && gemm_force() == 0;
 }
 
+// Q8_0 / Q5_0, 257..512 rows, K >= 2048: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type, N and K alone
+// (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against 58).
+static bool q8_mid_serves(int type, int64_t K, int64_t N) {
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N > 256 && N <= 512 && K / QK >= 64 && gemm_force() == 0;
+}
+
 int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     const int force = gemm_force();
-    if (q8_small_serves(type, K, N)) return 0;
+    if (q8_small_serves(type, K, N) || q8_mid_serves(type, K, N)) return 0;
     if (N <= 4 || force == 1) return 0;
     // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
     // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them (a 7B
@@ -412,7 +437,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
     w->ext_type = q5k ? GGML_HIP_TYPE_Q5_K : 0;
     static std::atomic<uint64_t> next_uid{1};
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
-    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, off_gs = 0, total = 0;
+    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, off_gs = 0, off_i8 = 0, total = 0;
     bool with6 = false;
     size_t off_p16 = 0;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
@@ -433,6 +458,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         off_gs = total; total += (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (gemm_force() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
+        if (type == GGML_TYPE_Q5_0) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
         if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
@@ -456,6 +482,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         w->gs = (uint32_t *)((uint8_t *)base + off_gs);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
         if (q5k) w->khdr = (uint8_t *)base + off_kh;
+        if (type == GGML_TYPE_Q5_0) w->i8p = (uint8_t *)base + off_i8;
     }
     *out = w;
     return GGML_HIP_OK;
@@ -532,6 +559,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
         e = launch_repack_to_planar(type, dev_rows, nb01, row_begin, rows_n, w, st);
     }
     if (e == hipSuccess) e = launch_nibbles_to_bf6(w, st);
+    if (e == hipSuccess) e = launch_q5_to_i8(w, st);
     if (e == hipSuccess) e = launch_gemv_side_image(w, st);
     if (e == hipSuccess) e = launch_f16_rows_to_panels(w, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -719,6 +747,12 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
         const hipError_t e = launch_gemm_q8_small(w, p, N, d_dst, ldd, (hipStream_t)stream, nullptr);
         if (e == hipSuccess) return GGML_HIP_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported = planes beyond the 32-bit offsets: the staged int8 kernel below)
+    }
+    if (w->ext_type == 0 && q8_mid_serves(w->type, w->K, N)) {
+        const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
+        const hipError_t e = launch_gemm_q8_mid(w, p, N, d_dst, ldd, (hipStream_t)stream, none);
+        if (e == hipSuccess) return GGML_HIP_OK;
+        if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported: the staged int8 kernel below reads the same image)
     }
     if (N <= gemv_rows_max(w->type) && act_image_kind(w->type, w->M, w->K, N) == 0)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));

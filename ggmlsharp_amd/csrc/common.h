@@ -61,6 +61,9 @@ struct ggml_hip_weight {
     uint8_t *q6a;     // bf6 (e3m2) digit codes, [nbk][NF][Mpad][16 B] = the first 16 bytes of each 24-byte MFMA fragment
     uint8_t *q6b;     //   (element e at bits [6e, 6e+5]) and [nbk][NF][Mpad][8 B] = the last 8; NF = 1 (Q4_0, Q4_1: nib - 8)
                       //   or 2 (Q5_0, Q8_0: w = 16 * wh + wl, fragment 0 = wl, fragment 1 = wh) -- gemm_qmx.hip
+    uint8_t *i8p;     // Q5_0 only: int8 operand planes of the int8 matrix cores, [nbk][2][Mpad][16 B] like Q8_0's qs -- plane h byte j =
+                      //   element 2j + h, value (nib | bit << 4) - 16 (Ggml.cs:1285-1289); built once at upload (layout.hip), 1 B / weight
+                      //   beside the 0.69 B / weight of the format, for prompt-sized batches (gemm_qmp.hip)
     void    *dense;
     uint8_t *p16;     // F16 only: k-panel-major copy [Kpad/8 + spare][Mpad][16 B] for dense16.hip
     uint32_t *gs;     // mat-vec side image (gemv.hip): the per-block words a 16-row tile needs beside its nibbles, tile-major
@@ -229,6 +232,7 @@ hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, 
                                    ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st);
+hipError_t launch_q5_to_i8(ggml_hip_weight *w, hipStream_t st);     // Q5_0 nibble + fifth-bit planes -> w->i8p
 // up to 32 device buffers -> device-visible (mapped host) destinations in one launch; sizes and addresses multiples of 4
 hipError_t launch_scatter_copy(const void *const *src, void *const *dst, const size_t *bytes, int n, hipStream_t st);
 hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st);   // d / m / qh planes -> w->gs (after every write of the planes)
@@ -298,6 +302,10 @@ hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, fl
 hipError_t launch_gemm_qmx_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st);
 hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
                            const mm_epilogue *ep = nullptr);
+// Q4_0, prompt-sized batches, K >= 2048 (gemm_qmp.hip K3p); hipErrorNotSupported where the form does not apply
+hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep);
+// the same form on the int8 matrix cores: Q8_0, image 0 (gemm_qmp.hip)
+hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep);
 hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st);
 

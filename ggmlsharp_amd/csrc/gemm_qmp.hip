@@ -1,0 +1,431 @@
+// gemm_qmp.hip -- K3p: quantized mat-mat for prompt-sized batches (a few hundred src1 rows) on the MX matrix path, Q4_0.
+//
+// COMPUTE phase of ggml_compute_forward_mul_mat_q_f32 (Ggml.cs:6676-6698) with the block arithmetic of gemm_qmx.hip: one exact
+// v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile and quant block (weights and both activation digits as bf6), then
+// acc += (sumi * d1) * d0 in f32 (ggml_vec_dot_q4_0_q8_0, Ggml.cs:1136-1159).
+//
+// Why another form.  4096 x 4096 x 512 is 2048 output tiles for 256 CUs: eight tiles per CU.  The staged kernel of gemm_qmx.hip
+// runs it on 64 x 64 workgroup tiles (two tiles per wave and k-block) and pulls 1.7 KB through the CU's vector memory path per tile
+// and k-block -- each weight fragment serves two MFMAs, each activation stage two waves -- which is what bounds it (PMC,
+// profiles/r03_pmc_c345_baseline.txt: 38 % of wave-cycles parked, 32 % VALU; 1400 W at 2.13 GHz, profiles/r03_power.txt): the path
+// delivers about 70 GB/s per CU.  Here a WAVE owns a 128 x 64 output tile (4 x 2 MFMA tiles: 0.86 KB per tile and k-block, the
+// least eight tiles allow) and the eight waves of a workgroup split K into eight contiguous ranges -- the structure of the
+// batched-decode form K3s (gemm_qmx.hip) with eight tiles behind every fragment instead of one:
+//   * no LDS stages, no barrier inside the K loop: every wave streams its own operands L2 -> registers one k-block ahead;
+//   * weights: lanes 0..31 fetch the rows of m-tile 2p and lanes 32..63 those of m-tile 2p + 1 in ONE instruction (the MX
+//     operand wants a block in both lane halves) and v_permlane32_swap hands each half the other's copy;
+//   * activations: the K1b image (kind 3) straight from L2, both digit groups of a column in the two lane halves;
+//   * row scales: the wave's slice of the scale plane in its own LDS slice (broadcast ds_read_b128);
+//   * the eight partial tiles are added in wave order through LDS (two rounds of four tiles), every wave storing its share of
+//     the rows: an eight-way tree fixed by K alone, so a row shard computes the bits of the unsplit matrix.
+#include "common.h"
+#include <utility>
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+#ifdef K3P_TRACE            // tools/k3p_trace.hip: per-wave time stamps (s_memrealtime, 100 MHz) at the phase ends + shader cycles of the K loop
+__device__ unsigned long long k3p_trace_buf[4096 * 8];
+#define K3P_STAMP(k) do { if (lane == 0 && (size_t)blockIdx.x * 8 + wave < 4096) k3p_trace_buf[((size_t)blockIdx.x * 8 + wave) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define K3P_STAMP(k) do { } while (0)
+#endif
+
+constexpr int KS = 8;          // waves per workgroup = K ranges
+constexpr int WMT = 4;         // 32-row weight tiles per wave (two lane-half pairs)
+constexpr int WNT = 2;         // 32-column tiles of src1 per wave
+
+// XCD-aware tile order (speed only): workgroups b, b + 8, ... share an XCD and its L2; an XCD takes a contiguous run of the tile
+// list ordered "n fastest", so the workgroups that stream the same weight rows sit behind one L2.
+__device__ __forceinline__ void tile_origin(int tiles_m, int tiles_n, int &m0, int &n0) {
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    m0 = (t_lin / tiles_n) * (32 * WMT);
+    n0 = (t_lin % tiles_n) * (32 * WNT);
+}
+
+// This wave's slice of the row scales: nloc rows x 64 floats into its own LDS slice.  Rows at or past nbk_valid are ZERO, so a
+// k-block past the end of K adds (sumi * 0) * d0 = +0 whatever the operand registers hold.  Same wave writes and reads: no barrier.
+__device__ __forceinline__ void load_scale_table(float *tabD, const float *__restrict__ ad, int kb0, int nloc, int nbk_valid, int Npad, int n0, int lane) {
+    const int npiece = nloc * (32 * WNT / 4);               // float4 pieces
+    for (int base = 0; base < npiece; base += 64 * 4) {
+        f32x4 td[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + lane + 64 * u, b = idx / (8 * WNT), c4 = idx % (8 * WNT);
+            const bool ok = idx < npiece && kb0 + b < nbk_valid;
+            td[u] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + lane + 64 * u;
+            if (idx < npiece) *(f32x4 *)(tabD + 4 * idx) = td[u];
+        }
+    }
+}
+
+// The waves' sums, added in wave order, four of the eight tiles per round (128 KB of LDS in 16-byte pieces); every wave takes its
+// share of the pieces, so the additions of one element are the same, in the same order, whoever makes them.
+__device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[WMT][WNT], uint8_t *smem, float *__restrict__ dst, int M, int N, int ldd, int m0, int n0,
+                                                 int wave, int lane, const mm_epilogue &ep) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int lda = (int)ep.ld_add, ld2 = (int)ep.ld2;
+    f32x4 *xch = (f32x4 *)smem + lane;                       // [wave][tile of the round][q][lane] pieces of four accumulator registers
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        __syncthreads();                                     // (round 0: every wave is past its scale table; round 1: past its reads)
+        if (rnd == 0) K3P_STAMP(3); else K3P_STAMP(4);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = 4 * rnd + tt, j = t / WMT, i = t % WMT;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xch[(size_t)((wave * 4 + tt) * 4 + q) * 64] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                        // 4 tiles x 4 register groups = 16 pieces of 64 lanes x 16 B, 2 per wave
+            const int pc = wave * 2 + k, tt = pc / 4, q = pc % 4;
+            const int t = 4 * rnd + tt, j = t / WMT, i = t % WMT;
+            f32x4 v = xch[(size_t)(tt * 4 + q) * 64];
+#pragma unroll
+            for (int g = 1; g < KS; ++g) {
+                const f32x4 o = xch[(size_t)((g * 4 + tt) * 4 + q) * 64];
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+            // dst[n][m]: D[row = (r & 3) + 8 (r >> 2) + 4 hh][col = lane & 31], r = 4 q + e
+            const int m = m0 + 32 * i + l31;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + 32 * j + e + 8 * q + 4 * hh;
+                if (n < N && m < M) {
+                    if (ep.mode == 2) {
+                        dst[(size_t)n * ldd + m] = v[e] * ep.scale;
+                    } else {
+                        dst[(size_t)n * ldd + m] = v[e];
+                        if (ep.mode == 1) ep.dst2[(size_t)n * ld2 + m] = v[e] + ep.addend[(size_t)n * lda + m];
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct WFrag { u32x4 lo[WMT / 2]; u32x2 hi[WMT / 2]; float d[WMT / 2]; };   // lanes 0..31: m-tile 2p, lanes 32..63: m-tile 2p + 1
+struct AFrag { u32x4 lo[WNT]; u32x2 hi[WNT]; };
+
+__global__ __launch_bounds__(KS * 64, 2)
+void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                         const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad,
+                         int Npad, int nbkp, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w6a_bytes, uint32_t wd_bytes,
+                         uint32_t a_bytes, const mm_epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    K3P_STAMP(0);
+
+    int m0, n0;
+    tile_origin(tiles_m, tiles_n, m0, n0);
+    const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (planes and image read 0 past their end)
+
+    const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
+    const rsrc_t rA = make_rsrc(a6, a_bytes);
+    const int mrow = m0 + 32 * hh + l31;                    // pair p: + 64 p rows (the instruction's immediate offset)
+    const uint32_t offA = (uint32_t)(mrow * 16), offB = (uint32_t)(mrow * 8), offD = (uint32_t)(mrow * 4);
+    const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4);
+    const uint32_t a_blk = (uint32_t)Npad * 48u;
+    const uint32_t voff16 = (uint32_t)((hh * Npad + n0 + l31) * 16), voff8 = (uint32_t)(32 * Npad + (hh * Npad + n0 + l31) * 8);
+
+    auto load_w = [&](WFrag &f, int kb) {
+#pragma unroll
+        for (int p = 0; p < WMT / 2; ++p) {
+            f.lo[p] = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)(offA + 1024u * p), (int)((uint32_t)kb * wa_blk), 0);
+            f.hi[p] = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)(offB + 512u * p), (int)((uint32_t)kb * wb_blk), 0);
+            f.d[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)(offD + 256u * p), (int)((uint32_t)kb * d_blk), 0));
+        }
+    };
+    auto load_a = [&](AFrag &f, int kb) {
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            f.lo[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(voff16 + 512u * j), (int)((uint32_t)kb * a_blk), 0);
+            f.hi[j] = __builtin_amdgcn_raw_buffer_load_b64(rA, (int)(voff8 + 256u * j), (int)((uint32_t)kb * a_blk), 0);
+        }
+    };
+
+    float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
+    load_scale_table(tabD, ad, kb0, nloc, nbkp, Npad, n0, lane);   // (K1b writes the k-blocks K is padded to as zeros)
+    WFrag wl;                                               // the NEXT k-block's weights, as loaded (lane halves = the m-tiles of a pair)
+    AFrag af;                                               // activation fragments: column tile j is refetched as soon as its last MFMA has issued
+    load_w(wl, kb0);
+    load_a(af, kb0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int scale_a = hh ? 127 : 131;                     // E8M0: K group 0 (the ah digits) carries 2^4
+
+    // v_permlane32_swap: x in both operands -> {x's lower half in both halves, x's upper half in both halves}
+    auto both = [](uint32_t x, uint32_t &b0, uint32_t &b1) {
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        b0 = r[0]; b1 = r[1];
+    };
+
+    // ---- K loop: one k-block per trip.  The weights of the block are spread to both lane halves (their load registers are free
+    //      again and take the next block's: a whole block of look-ahead for the stream that comes from HBM); eight tiles, the MFMA of
+    //      tile t + 1 issued before the scale-accumulate of tile t; column tile j's fragment is refetched right behind its last MFMA.
+    //      (The look-ahead of the last trip reads the next wave's first block, or zeros past the planes: never used.) ----
+    K3P_STAMP(1);
+#ifdef K3P_TRACE
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    for (int b = 0; b < nloc; ++b) {
+        // Two waves share a SIMD and the older one wins every arbitration: left alone, waves 0..3 finish their K range a quarter
+        // early and waves 4..7 run the rest at one wave per SIMD (tools/k3p_trace.hip: 15.8 against 21.5 us).  The younger half
+        // takes priority on every other k-block, so both halves finish together.
+        if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        i32x8 B[WMT];
+        float dw[WMT];
+#pragma unroll
+        for (int p = 0; p < WMT / 2; ++p) {
+            uint32_t b0[6], b1[6], d0u, d1u;
+            both(wl.lo[p][0], b0[0], b1[0]); both(wl.lo[p][1], b0[1], b1[1]); both(wl.lo[p][2], b0[2], b1[2]); both(wl.lo[p][3], b0[3], b1[3]);
+            both(wl.hi[p][0], b0[4], b1[4]); both(wl.hi[p][1], b0[5], b1[5]);
+            both(__builtin_bit_cast(uint32_t, wl.d[p]), d0u, d1u);
+            B[2 * p] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b0[4], (int)b0[5], 0, 0};
+            B[2 * p + 1] = i32x8{(int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3], (int)b1[4], (int)b1[5], 0, 0};
+            dw[2 * p] = __builtin_bit_cast(float, d0u); dw[2 * p + 1] = __builtin_bit_cast(float, d1u);
+        }
+        load_w(wl, kb0 + b + 1);
+        const float *dp = tabD + b * (32 * WNT) + 4 * hh;
+        f32x16 x[2];
+        {
+            const i32x8 A0 = {(int)af.lo[0][0], (int)af.lo[0][1], (int)af.lo[0][2], (int)af.lo[0][3], (int)af.hi[0][0], (int)af.hi[0][1], 0, 0};
+            x[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, B[0], zero, 3, 3, 0, scale_a, 0, 127);
+        }
+        static_for<WMT * WNT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, j = t / WMT, i = t % WMT;
+            if constexpr (t + 1 < WMT * WNT) {
+                constexpr int j1 = (t + 1) / WMT, i1 = (t + 1) % WMT;
+                const i32x8 A1 = {(int)af.lo[j1][0], (int)af.lo[j1][1], (int)af.lo[j1][2], (int)af.lo[j1][3], (int)af.hi[j1][0], (int)af.hi[j1][1], 0, 0};
+                x[(t + 1) & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, B[i1], zero, 3, 3, 0, scale_a, 0, 127);
+                if constexpr (i1 == WMT - 1) {              // the last MFMA that reads column tile j1's fragment has issued
+                    af.lo[j1] = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(voff16 + 512u * j1), (int)((uint32_t)(kb0 + b + 1) * a_blk), 0);
+                    af.hi[j1] = __builtin_amdgcn_raw_buffer_load_b64(rA, (int)(voff8 + 256u * j1), (int)((uint32_t)(kb0 + b + 1) * a_blk), 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 da = *(const f32x4 *)(dp + 32 * j + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = x[t & 1][4 * q + e] * da[e];                               // (sumi * d1) ...
+                    acc[i][j][4 * q + e] = __builtin_fmaf(v, dw[i], acc[i][j][4 * q + e]);      // ... * d0, Ggml.cs:1158
+                }
+            }
+        });
+    }
+
+#ifdef K3P_TRACE
+    asm volatile("" : "+v"(acc[0][0]));
+    if (lane == 0 && (size_t)blockIdx.x * 8 + wave < 4096) k3p_trace_buf[((size_t)blockIdx.x * 8 + wave) * 8 + 7] = __builtin_readcyclecounter() - clk0;
+#endif
+    K3P_STAMP(2);
+    // ---- the waves' sums, added in wave order, four of the eight tiles per round (128 KB of LDS); every wave takes its share of the
+    //      result rows a lane holds, so the additions of one element are the same, in the same order, whoever makes them ----
+    __builtin_amdgcn_s_setprio(0);
+    reduce_and_store(acc, smem, dst, M, N, ldd, m0, n0, wave, lane, ep);
+    K3P_STAMP(5);
+}
+
+// ---- K3p on the int8 matrix cores: Q8_0 and Q5_0 (COMPUTE phase with ggml_vec_dot_q8_0_q8_0, Ggml.cs:1351-1381, and
+//      ggml_vec_dot_q5_0_q8_0, Ggml.cs:1258-1301) ----------------------------------------------------------------------------------------
+// Q8_0's resident planes ARE v_mfma_i32_32x32x32_i8 operands -- [k-block][half][row][16 B], the halves holding the even and the odd
+// elements, the order K1's image 0 gives the activations -- so a k-block is one 16-byte load per operand, tile and lane: nothing to
+// expand, nothing to spread across lane halves.  Q5_0 gets planes of the same form at upload (ggml_hip_weight::i8p, layout.hip).
+// Per block, Q8_0: acc = fma((float)sumi, d1 * d0, acc) (gemm_q8s.hip, the batched-decode form of the same arithmetic); Q5_0:
+// acc = fma(d0 * (float)sumi, d1, acc) -- the reference's a = d * sxy, t = a * y.d (Ggml.cs:1296-1298).  Structure as above; the weights of block b + 1 are requested at the start of block b into a second
+// register set (the sets take turns: two k-blocks per trip, nloc even).
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+struct WI8 { i32x4 q[WMT]; float d[WMT]; };
+
+template <int TYPE>
+__global__ __launch_bounds__(KS * 64, 2)
+void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                        float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int ldd, int tiles_m, int tiles_n,
+                        uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    K3P_STAMP(0);
+    int m0, n0;
+    tile_origin(tiles_m, tiles_n, m0, n0);
+    const int kb0 = wave * nloc;
+
+    const rsrc_t rW = make_rsrc(qs, w_bytes), rD = make_rsrc(wd, w_bytes / 8), rA = make_rsrc(a8, a_bytes);
+    const uint32_t offW = (uint32_t)((hh * Mpad + m0 + l31) * 16), offD = (uint32_t)((m0 + l31) * 4), offA = (uint32_t)((hh * Npad + n0 + l31) * 16);
+    const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
+    auto load_w = [&](WI8 &f, int kb) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+            f.q[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(offW + 512u * i), (int)((uint32_t)kb * w_blk), 0));
+            f.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
+        }
+    };
+    float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
+    load_scale_table(tabD, ad, kb0, nloc, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
+    WI8 w0, w1;
+    i32x4 af[WNT];
+    load_w(w0, kb0);
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) af[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j), (int)((uint32_t)kb0 * a_blk), 0));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // one k-block: local index b, weights in w; the next block's go into wn; column tile j's fragment is refetched behind its last MFMA
+    auto block = [&](int b, WI8 &w, WI8 &wn) {
+        if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }   // (see the MX kernel)
+        load_w(wn, kb0 + b + 1);
+        const float *dp = tabD + b * (32 * WNT) + 4 * hh;
+        i32x16 x[2];
+        x[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], w.q[0], zero, 0, 0, 0);
+        static_for<WMT * WNT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, j = t / WMT, i = t % WMT;
+            if constexpr (t + 1 < WMT * WNT) {
+                constexpr int j1 = (t + 1) / WMT, i1 = (t + 1) % WMT;
+                // Order pin (empty statement, no instruction): the MFMA of tile t + 1 may not issue before the scale-accumulate of
+                // tile t - 1 has finished -- left alone the compiler issues all eight MFMAs of a block up front (128 registers of
+                // products: 860 bytes of scratch).
+                if constexpr (t >= 1) {
+                    constexpr int jp = (t - 1) / WMT, ip = (t - 1) % WMT;
+                    asm volatile("" : "+v"(w.q[i1]), "+v"(acc[ip][jp]));
+                }
+                x[(t + 1) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j1], w.q[i1], zero, 0, 0, 0);
+                if constexpr (i1 == WMT - 1)
+                    af[j1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j1), (int)((uint32_t)(kb0 + b + 1) * a_blk), 0));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 da = *(const f32x4 *)(dp + 32 * j + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if constexpr (TYPE == GGML_TYPE_Q8_0)
+                        acc[i][j][4 * q + e] = __builtin_fmaf((float)x[t & 1][4 * q + e], da[e] * w.d[i], acc[i][j][4 * q + e]);   // Ggml.cs:1377-1378
+                    else
+                        acc[i][j][4 * q + e] = __builtin_fmaf(w.d[i] * (float)x[t & 1][4 * q + e], da[e], acc[i][j][4 * q + e]);   // Ggml.cs:1296-1298
+            }
+        });
+    };
+    K3P_STAMP(1);
+#ifdef K3P_TRACE
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    for (int b = 0; b < nloc; b += 2) {                     // (the look-ahead of the last trip reads past the wave's range: never used)
+        block(b, w0, w1);
+        block(b + 1, w1, w0);
+    }
+#ifdef K3P_TRACE
+    asm volatile("" : "+v"(acc[0][0]));
+    if (lane == 0 && (size_t)blockIdx.x * 8 + wave < 4096) k3p_trace_buf[((size_t)blockIdx.x * 8 + wave) * 8 + 7] = __builtin_readcyclecounter() - clk0;
+#endif
+    K3P_STAMP(2);
+    __builtin_amdgcn_s_setprio(0);
+    reduce_and_store(acc, smem, dst, M, N, ldd, m0, n0, wave, lane, ep);
+    K3P_STAMP(5);
+}
+
+}  // namespace
+
+// Q8_0 / Q5_0, at least 8 k-blocks per wave: hipErrorNotSupported otherwise (the caller falls back to the staged int8 kernel, same image)
+hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
+    const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : w->type == GGML_TYPE_Q5_0 ? w->i8p : nullptr;
+    if (!planes || !w->d) return hipErrorNotSupported;
+    const int nbkp = (int)pad_kblocks(w->nbk);
+    int nloc = (nbkp + KS - 1) / KS;
+    nloc += nloc & 1;                                       // two k-blocks per trip
+    if (nloc < 8) return hipErrorNotSupported;
+    const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
+    if ((uint64_t)(KS * nloc + 2) * 2 * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 2 * (uint64_t)p.Npad * 16 > 0xFFFFFFFFull) return hipErrorNotSupported;
+    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorNotSupported;
+    const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
+    const size_t tab = (size_t)KS * nloc * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
+    const size_t lds = tab > xch ? tab : xch;
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    (void)hipGetLastError();
+#define Q8MID_GO(T) do { \
+        auto kern = gemm_q8_mid_kernel<T>; \
+        static PerDeviceOnce once; \
+        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
+        if (attr != hipSuccess) return attr; \
+        kern<<<dim3((unsigned)(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, \
+                                                                        (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep); } while (0)
+    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else Q8MID_GO(GGML_TYPE_Q5_0);
+#undef Q8MID_GO
+    return hipGetLastError();
+}
+
+// Serves Q4_0 with at least 8 k-blocks per wave; hipErrorNotSupported otherwise (the caller falls back to the staged forms).
+hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
+    if (w->type != GGML_TYPE_Q4_0 || !w->q6a || !w->q6b) return hipErrorNotSupported;
+    const int nbkp = (int)pad_kblocks(w->nbk);
+    int nloc = (nbkp + KS - 1) / KS;
+    if (nloc < 8) return hipErrorNotSupported;
+    const uint64_t nba = (uint64_t)nbkp;
+    const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4;
+    const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad;
+    // (32-bit buffer offsets, the look-ahead past a wave's range included)
+    if ((uint64_t)(KS * nloc + 2) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 48 * (uint64_t)p.Npad > 0xFFFFFFFFull) return hipErrorNotSupported;
+    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorNotSupported;
+    const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
+    const size_t tab = (size_t)KS * nloc * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
+    const size_t lds = tab > xch ? tab : xch;
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    static PerDeviceOnce once;
+    const hipError_t attr = once.max_dynamic_lds((const void *)gemm_qmx_mid_kernel, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    (void)hipGetLastError();
+    gemm_qmx_mid_kernel<<<dim3((unsigned)(tiles_m * tiles_n)), KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N,
+                                                                                     (int)w->Mpad, (int)p.Npad, nbkp, nloc, (int)ldd, tiles_m, tiles_n,
+                                                                                     (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, ep);
+    return hipGetLastError();
+}

@@ -70,6 +70,10 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+#ifdef K3M_CLOCK            // tools/k3m_clock.hip: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) every wave spends in the K loop
+__device__ unsigned long long k3m_clock_buf[8192 * 2];
+#endif
+
 // WMT x WNT 32x32 tiles per wave, WGM x WGN waves per workgroup, KB k-blocks per LDS stage
 template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
 struct Cfg {
@@ -355,6 +359,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     f32x16 sav[VS > 1 ? WMT : 1][VS > 1 ? WNT : 1];         // sum of this wave group's finished passes
     const int niter = VS * ((nstages + KV - 1) / KV);
     int sc = s_first, pass = 0;
+#ifdef K3M_CLOCK
+    const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
+#endif
     for (int it = 0; it < niter; ++it) {
         int sn = sc + KV, pn = pass;
         if (VS > 1 && sn >= nstages) { pn = pass + 1; sn = pn < VS ? grp * VS + pn : nstages; }
@@ -376,6 +383,14 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         }
         sc = sn; pass = pn;
     }
+#ifdef K3M_CLOCK
+    {
+        asm volatile("" : "+v"(acc[0][0]));
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+        const size_t slot = (size_t)blockIdx.x * (WGM * WGN * KSP) + wave_all;
+        if (lane == 0 && slot < 8192) { k3m_clock_buf[2 * slot] = c1 - clk_c0; k3m_clock_buf[2 * slot + 1] = r1 - clk_r0; }
+    }
+#endif
 
     // ---- K split: groups 1 .. KSP-1 hand their accumulators to group 0 through LDS (the stage buffers are free now); group 0
     //      adds them in group order, so the summation tree is fixed ----
@@ -987,6 +1002,15 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // 11008 x 4096 x 256: 53 -> 38 us, 32000 x 4096 x 256: 119 -> 107 us; 4096 x 4096 x 512 unchanged; var 17 = the 128-row form)
     // the largest grids keep the 128-row form (32000 x 4096 x 512: 171 us against 179 us)
     if (N <= 512 && w->nbk >= 8 && var != 3) {
+        // 257 .. 512 rows, K >= 2048, Q4_0: K3p (gemm_qmp.hip) -- 128 x 64 tiles per WAVE, K split eight ways over the waves of a workgroup,
+        // no stages: half the bytes per tile and k-block through the CU's memory path.  By N and K alone (GGML_HIP_K3P=1: the staged form, A/B).
+        if constexpr (TYPE == GGML_TYPE_Q4_0) {
+            static const int k3p = dev_env_int("GGML_HIP_K3P", 0);
+            if (k3p != 1) {
+                const hipError_t e = launch_gemm_qmx_mid(w, p, N, dst, ldd, st, t_epilogue);
+                if (e != hipErrorNotSupported) return e;
+            }
+        }
         // (the same two-way tree run by ONE wave group on unsplit 128 x 64 tiles measured level: 32000 x 4096 x 512 161 | 161 us,
         // 11008 x 4096 x 512 74 | 79, 16384 x 4096 x 512 114 | 110)
         // (weight fragments a whole stage ahead, FB = 4, with weights cold in HBM: 4096 x 4096 x 512 35.7 -> 34.9 us, the others level)

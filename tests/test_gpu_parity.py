@@ -245,6 +245,9 @@ SHAPES = [  # (M, K, N): ragged M / N, all kernels (N <= 8 fused mat-vec, above 
     (1, 32, 9), (31, 64, 33), (257, 96, 257), (129, 32, 65),   # one k-block (three pad blocks per stage), one-row weights
     (128, 4096, 16), (130, 4096 + 64, 13), (200, 288, 10), (17, 2080, 12),   # 9..16 rows: wide mat-vec form (Q4_2 / Q5_1), several LDS chunks of K
     (100, 512, 70), (96, 1056, 128), (40, 4096, 100),                       # 32-row tiles with the four-way K split (nbk >= 16, N <= 128)
+    # K3p (gemm_qmp.hip): K >= 2048, Q4_0 257..512 rows / Q8_0 65..512 rows -- eight K ranges per workgroup, ragged M and N,
+    # K / 32 = 65 (ranges of 10 with the last one short), 73 (pad blocks inside the last range)
+    (200, 2048, 300), (129, 4160, 257), (96, 2336, 512), (300, 2080, 65), (130, 2048, 130),
 ]
 
 

@@ -334,3 +334,41 @@ def test_an_unregistered_pool_is_never_captured(dev):
         assert c1[1] == c0[1] and c1[2] == c0[2], (c0, c1)
     finally:
         G.ggml_free(ctx)
+
+
+def test_an_error_inside_a_named_scope_is_reported_every_time(dev):
+    """a seam that fails inside a named scope (the host then runs its own code for that node) must
+    keep failing -- five computes of one keyed scope with one node of a rejected type (Q4_3: a null slot in the reference,
+    Ggml.cs:248) return the error five times; the scope is never captured or replayed, the good node's data is right every time."""
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    ctx = G.ggml_init(8 * 1024 * 1024)
+    try:
+        K, M, N = 128, 64, 3
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        W = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
+        Wbad = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
+        for w in (W, Wbad):
+            G.tensor_bytes(w)[:] = O.quantize_row(G.Q4_0, rng.standard_normal((M, K)).astype(np.float32)).reshape(-1)
+        y1, y2 = G.ggml_mul_mat(ctx, W, X), G.ggml_mul_mat(ctx, Wbad, X)
+        Wbad.contents.type = 5                                  # GGML_TYPE_Q4_3: no quantize_fns slot, the seam rejects it
+        p = _lib.ggml_compute_params(_lib.GGML_TASK_COMPUTE, 0, 1, 0, None)
+        c0 = _counters()
+        for it in range(5):
+            G.tensor_f32(X)[:] = rng.standard_normal((N, K)).astype(np.float32).reshape(1, 1, N, K)
+            L.ggml_hip_invalidate_range(X.contents.data, N * K * 4)
+            G.tensor_f32(y1)[:] = -5.0
+            _lib.check(L.ggml_hip_graph_begin_keyed(0xBADC0DE), "begin")
+            rc1 = L.ggml_hip_compute_forward_mul_mat(C.byref(p), y1.contents.src0, y1.contents.src1, y1)
+            rc2 = L.ggml_hip_compute_forward_mul_mat(C.byref(p), y2.contents.src0, y2.contents.src1, y2)
+            _lib.check(L.ggml_hip_graph_end(), "end")
+            assert rc1 == 0, (it, rc1)
+            assert rc2 != 0, f"compute {it}: the rejected node reported success"
+            ref = O.mul_mat(O.Q4_0, np.array(G.tensor_bytes(W)), np.array(G.tensor_f32(X)).reshape(N, K), M, K, N)[0, 0]
+            got = np.array(G.tensor_f32(y1)).reshape(N, M)
+            rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+            assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms), it
+        c1 = _counters()
+        assert c1[1] == c0[1] and c1[2] == c0[2], f"a scope with a failing node was captured / replayed: {c0} -> {c1}"
+    finally:
+        G.ggml_free(ctx)

@@ -8,7 +8,7 @@ NAME=$1; FILE=$2; EXTRA=$3
 make -s all
 mkdir -p ../lib/dbg ../lib/obj_dbg
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -DGGML_HIP_DEV -Wno-unused-function -Wno-unused-variable"
-case $FILE in gemm_q16.hip|gemm_qmx.hip|gemm_q8s.hip) FL="$FL -fno-slp-vectorize";; esac
+case $FILE in gemm_q16.hip|gemm_qmx.hip|gemm_q8s.hip|gemm_qmp.hip) FL="$FL -fno-slp-vectorize";; esac
 case $FILE in *.cpp) FL="$FL -x hip";; esac
 /opt/rocm/bin/hipcc $FL $EXTRA -c $FILE -o ../lib/obj_dbg/$NAME.o
 OBJS=$(ls ../lib/obj/*.o | grep -v "/$FILE.o")
