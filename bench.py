@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x BF16 per clock, ~5 PF dense.  The MX kernel issues bf6 MFMAs
                             # (4x BF16 per clock, ~10 PF) over twice the algorithmic K (two digits per Q8 activation): the same
                             # 5 PF ceiling in algorithmic FLOPs.
-PROFILE_TRAFFIC = ("r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
+PROFILE_TRAFFIC = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
 def algorithmic_bytes(M, K, N, blk=20):
@@ -115,31 +115,50 @@ def physical_cores():
     return max(1, min(n, allowed)), logical, allowed, model
 
 
-def cpu_baseline_leg(M, K, n_cols, threads):
+def cpu_baseline_leg(M, K, n_cols, threads, reps=3):
+    """`reps` repetitions of the oracle's mul_mat on the first n_cols src1 rows; returns (median GFLOP/s, all wall times)."""
     import oracle_lib as O
     rng = np.random.default_rng(0)
     w = rng.standard_normal((M, K)).astype(np.float32)
     x = rng.standard_normal((n_cols, K)).astype(np.float32)
     wq = O.quantize_row(O.Q4_0, w)
     O.mul_mat(O.Q4_0, wq[:64], x[:8], 64, K, 8, nth=1)  # warm the library
-    t0 = time.perf_counter()
-    O.mul_mat(O.Q4_0, wq, x, M, K, n_cols, nth=threads)
-    dt = time.perf_counter() - t0
-    return round(2.0 * M * K * n_cols / dt / 1e9, 2), dt
+    dts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.mul_mat(O.Q4_0, wq, x, M, K, n_cols, nth=threads)
+        dts.append(time.perf_counter() - t0)
+    dt = float(np.median(dts))
+    return round(2.0 * M * K * n_cols / dt / 1e9, 2), dts
 
 
-def cpu_baseline(M, K):
+def cpu_baseline(M, K, N):
     """The reference's CPU algorithm (oracle = C port, scalar block dots, INIT on one thread, rows split over T threads,
-    Ggml.cs:6641-6698), timed on the host cores on bounded samples of the same workload: T = 1 and T = physical cores."""
+    Ggml.cs:6641-6698), timed on the host cores as BASELINE.md section 2 states it: three repetitions, the median -- all N src1
+    rows at T = physical cores (a few seconds), and a stated sample of the rows at T = 1."""
     cores, logical, allowed, model = physical_cores()
-    v1, dt1 = cpu_baseline_leg(M, K, 384, 1)
-    nT = 2048 if cores >= 8 else 384
-    vT, dtT = cpu_baseline_leg(M, K, nT, cores)
+    nT = N if cores >= 8 else 384                     # (a host with a handful of cores: a bounded sample there too)
+    vT, dtsT = cpu_baseline_leg(M, K, nT, cores)
+    n1 = 256
+    v1, dts1 = cpu_baseline_leg(M, K, n1, 1)
+    fmt = lambda ds: " / ".join(f"{d:.2f}" for d in ds)   # noqa: E731
     return {"value": vT, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"Q4_0 mul_mat M={M} K={K}, first {nT} of 4096 src1 rows on T={cores} threads ({dtT:.2f} s wall); "
-                      f"oracle/ggml_oracle.c scalar path; host: {model}, {logical} logical CPUs, {allowed} usable",
+            "sample": f"Q4_0 mul_mat M={M} K={K}, {'all' if nT == N else 'first'} {nT} of {N} src1 rows on T={cores} threads, median of 3 repetitions "
+                      f"({fmt(dtsT)} s wall); oracle/ggml_oracle.c scalar path; host: {model}, {logical} logical CPUs, {allowed} usable",
             "single_thread": {"value": v1, "unit": "GFLOP/s", "cores": 1,
-                              "sample": f"first 384 of 4096 src1 rows, {dt1:.2f} s wall"}}
+                              "sample": f"first {n1} of {N} src1 rows, median of 3 repetitions ({fmt(dts1)} s wall)"}}
+
+
+def compute_kernel_name(qtype, K, N):
+    """which COMPUTE kernel serves (type, K, N): the selection is by type, N and K alone (csrc/api.cpp act_image_kind, gemm_qmx.hip launch_typed)"""
+    if N <= 8:
+        return "gemv_fused_kernel (gemv.hip)"
+    if K >= 2048 and 256 < N <= 512 and qtype in (Q4_0, Q8_0, Q5_0):
+        return ("gemm_qmx_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, MX bf6 MFMA (gemm_qmp.hip)" if qtype == Q4_0 else
+                "gemm_q8_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, v_mfma_i32_32x32x32_i8 off resident int8 planes (gemm_qmp.hip)")
+    if qtype == Q4_0:
+        return "gemm_qmx_small_kernel: K3s (gemm_qmx.hip)" if (N <= 64 and K >= 2048) else "gemm_qmx_kernel: K3m staged MX form (gemm_qmx.hip)"
+    return "gemm_q16_kernel / gemm_q_kernel (f16 / int8 staged forms)"
 
 
 def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
@@ -194,6 +213,10 @@ def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
            "timing": f"median over {reps} hipGraph replays of {nodes} calls rotating over the weight copies (dependent launches: includes the inter-kernel boundary)"}
     if t_comp is not None:
         res["compute_kernel_ms"] = round(t_comp, 5)
+        # the binding roof of the mat-mat shapes is the matrix unit: the COMPUTE kernel alone against the dense int8-class peak
+        tops = flops / (t_comp * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(tops / I8_MFMA_PEAK_TOPS, 4),
+                           "kernel_ms": round(t_comp, 5), "kernel": compute_kernel_name(qtype, K, N)}
     for w in ws:
         w.free()
     return res
@@ -666,6 +689,9 @@ def main():
                 # configs[4] on ONE GPU (the row split is `--gpus 8`: other_configs.config5_vocab512 of that line)
                 "q8_0_ffn512": side_config(device, 4096, 11008, 512, copies=6, iters=60, qtype=Q8_0),
                 "q5_0_ffn512": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_0),
+                # config 4 in its other orientation ("bench both orientations"): the up projection, M = 11008, K = 4096
+                "q8_0_ffn512_up": side_config(device, 11008, 4096, 512, copies=6, iters=60, qtype=Q8_0),
+                "q5_0_ffn512_up": side_config(device, 11008, 4096, 512, copies=8, iters=60, qtype=Q5_0),
                 # ... and Q5_K itself as an UNPINNED EXTRA (upstream format, no oracle in the reference; ggml_hip.h GGML_HIP_TYPE_Q5_K)
                 "q5_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_K),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
@@ -695,7 +721,7 @@ def main():
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
                 out["other_configs"]["seam1_host_error"] = f"{type(e).__name__}: {e}"[:300]
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(M, K)
+            out["cpu_baseline"] = cpu_baseline(M, K, N)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -217,9 +217,15 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 #pragma unroll
         for (int p = 0; p < WMT / 2; ++p) {
             uint32_t b0[6], b1[6], d0u, d1u;
+#ifdef K3P_NOSWAP          // timing experiment only (wrong operands): what do the 14 swaps + their copies cost?
+            b0[0] = wl.lo[p][0]; b0[1] = wl.lo[p][1]; b0[2] = wl.lo[p][2]; b0[3] = wl.lo[p][3]; b0[4] = wl.hi[p][0]; b0[5] = wl.hi[p][1];
+            b1[0] = wl.lo[p][1]; b1[1] = wl.lo[p][0]; b1[2] = wl.lo[p][3]; b1[3] = wl.lo[p][2]; b1[4] = wl.hi[p][1]; b1[5] = wl.hi[p][0];
+            d0u = d1u = __builtin_bit_cast(uint32_t, wl.d[p]);
+#else
             both(wl.lo[p][0], b0[0], b1[0]); both(wl.lo[p][1], b0[1], b1[1]); both(wl.lo[p][2], b0[2], b1[2]); both(wl.lo[p][3], b0[3], b1[3]);
             both(wl.hi[p][0], b0[4], b1[4]); both(wl.hi[p][1], b0[5], b1[5]);
             both(__builtin_bit_cast(uint32_t, wl.d[p]), d0u, d1u);
+#endif
             B[2 * p] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b0[4], (int)b0[5], 0, 0};
             B[2 * p + 1] = i32x8{(int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3], (int)b1[4], (int)b1[5], 0, 0};
             dw[2 * p] = __builtin_bit_cast(float, d0u); dw[2 * p + 1] = __builtin_bit_cast(float, d1u);
@@ -322,7 +328,12 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    // one k-block: local index b, weights in w; the next block's go into wn; column tile j's fragment is refetched behind its last MFMA
+    // one k-block: local index b, weights in w; the next block's go into wn; column tile j's fragment is refetched behind its last MFMA.
+    // The 16 row scales of a column tile are read during the LAST tile of the column tile before it (the order pins below are
+    // scheduling boundaries: a read issued where it is used costs its LDS latency twice per tile).
+    f32x4 da[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) da[q] = *(const f32x4 *)(tabD + 4 * hh + 8 * q);
     auto block = [&](int b, WI8 &w, WI8 &wn) {
         if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }   // (see the MX kernel)
         load_w(wn, kb0 + b + 1);
@@ -344,15 +355,23 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
                 if constexpr (i1 == WMT - 1)
                     af[j1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j1), (int)((uint32_t)(kb0 + b + 1) * a_blk), 0));
             }
+            f32x4 dn[4];
+            if constexpr (i == WMT - 1) {                   // the next column tile's scales (j + 1, or tile 0 of the next k-block: 64 floats on)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dn[q] = *(const f32x4 *)(dp + 32 * (j + 1) + 8 * q);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 da = *(const f32x4 *)(dp + 32 * j + 8 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if constexpr (TYPE == GGML_TYPE_Q8_0)
-                        acc[i][j][4 * q + e] = __builtin_fmaf((float)x[t & 1][4 * q + e], da[e] * w.d[i], acc[i][j][4 * q + e]);   // Ggml.cs:1377-1378
+                        acc[i][j][4 * q + e] = __builtin_fmaf((float)x[t & 1][4 * q + e], da[q][e] * w.d[i], acc[i][j][4 * q + e]);   // Ggml.cs:1377-1378
                     else
-                        acc[i][j][4 * q + e] = __builtin_fmaf(w.d[i] * (float)x[t & 1][4 * q + e], da[e], acc[i][j][4 * q + e]);   // Ggml.cs:1296-1298
+                        acc[i][j][4 * q + e] = __builtin_fmaf(w.d[i] * (float)x[t & 1][4 * q + e], da[q][e], acc[i][j][4 * q + e]);   // Ggml.cs:1296-1298
+            }
+            if constexpr (i == WMT - 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) da[q] = dn[q];
             }
         });
     };

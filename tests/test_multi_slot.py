@@ -288,3 +288,93 @@ def test_reinit_on_another_device_set_is_refused(slots):
     assert L.ggml_hip_init(0) == 0                               # the same device again is fine
     if L.ggml_hip_device_count() > 1:
         assert L.ggml_hip_init(1) == -4
+
+
+# ---------------------------------------------------------------- G = 8 without a node
+# BASELINE config 5's exact partition (Q4_0 32000 x 4096 x 512 -> eight shards of 4000 rows) and the strong-scaling partition of
+# the headline (4096^3 -> eight shards of 512 rows), both on the ONE GPU of the test box: eight device slots of one process
+# (the form the C# host uses), and the two exchange forms' data movement with eight ranks' worth of shards in one process.
+G8_CASES = [("config 5", 32000, 4096, 512), ("headline 4096^3", 4096, 4096, 4096)]
+
+
+def _q4_rows_on_device(M, K, seed):
+    from ggmlsharp_amd import device
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((512, K), generator=g, device="cuda")
+    return device.quantize_rows(O.Q4_0, w), x
+
+
+@pytest.mark.parametrize("name,M,K,N", G8_CASES)
+def test_eight_slots_on_one_device_exact_partition_is_bitwise_the_unsplit_result(slots, name, M, K, N):
+    from ggmlsharp_amd import device
+    from ggmlsharp_amd._lib import lib, check
+    L = lib()
+    slots([0])
+    rows, x512 = _q4_rows_on_device(M, K, seed=M + N)
+    x = x512 if N == 512 else torch.randn((N, K), device="cuda")
+    W = device.Weight.from_device(O.Q4_0, rows, K)
+    single = device.mul_mat(W, x).clone()
+    torch.cuda.synchronize()
+    W.free()
+    host_rows = rows.cpu().numpy()
+    G = 8
+    slots([0] * G)
+    h = C.c_void_p()
+    check(L.ggml_hip_split_weight_upload(O.Q4_0, host_rows.ctypes.data_as(C.c_void_p), K, M, host_rows.shape[1], C.byref(h)), "split upload")
+    dr = (M + G - 1) // G
+    for g in range(G):                                           # the reference's thread partition, Ggml.cs:6665-6672
+        a, b = C.c_int64(), C.c_int64()
+        check(L.ggml_hip_split_weight_rows(h, g, C.byref(a), C.byref(b)), "rows")
+        assert (a.value, b.value) == (dr * g, min(dr * (g + 1), M)), (name, g)
+    assert dr == (4000 if M == 32000 else 512)
+    outs = [torch.full((N, M), -5.0, device="cuda") for _ in range(G)]
+    torch.cuda.synchronize()
+    xs = (C.c_void_p * G)(*[x.data_ptr()] * G)
+    ds = (C.c_void_p * G)(*[o.data_ptr() for o in outs])
+    check(L.ggml_hip_set_exchange(0), "set_exchange")           # peer copies (the in-process RCCL form refuses slots that share a device)
+    check(L.ggml_hip_mul_mat_split_dev(h, xs, N, K, ds, M), "split mul_mat")
+    check(L.ggml_hip_sync_slots(), "sync")
+    for g, o in enumerate(outs):
+        assert torch.equal(o, single), f"{name}: slot {g}'s copy of dst differs from the unsplit result"
+    L.ggml_hip_split_weight_free(h)
+
+
+@pytest.mark.parametrize("name,M,K,N", G8_CASES)
+def test_both_exchange_forms_move_eight_ranks_shards_into_the_unsplit_result(name, M, K, N):
+    """One process per GPU (ggmlsharp_amd/dist.py): rank r computes rows [dr r, dr (r + 1)) into a [N][Ms] shard; "rccl" = all-gather
+    to [G][N][Ms] + ggml_hip_relayout_gathered_dev, "push" = ggml_hip_push_columns_dev into every rank's [N][M].  Here the eight
+    ranks' shards are computed one after the other on the one GPU (row_begin / row_end weights: exactly what a rank holds) and both
+    kernels must assemble the unsplit result bit for bit, in each of eight destination buffers."""
+    from ggmlsharp_amd import device
+    from ggmlsharp_amd import dist as gdist
+    from ggmlsharp_amd._lib import lib, check
+    device.init(0)
+    L = lib()
+    G = 8
+    rows, x512 = _q4_rows_on_device(M, K, seed=M + N + 1)
+    x = x512 if N == 512 else torch.randn((N, K), device="cuda")
+    W = device.Weight.from_device(O.Q4_0, rows, K)
+    full = device.mul_mat(W, x).clone()
+    W.free()
+    Ms = gdist.shard_width(M, G)
+    gathered = torch.zeros((G, N, Ms), device="cuda")
+    shards = []
+    for r in range(G):
+        r0, r1 = gdist.shard_rows(M, G, r)
+        Wr = device.Weight.from_device(O.Q4_0, rows, K, row_begin=r0, row_end=r1)
+        device.mul_mat(Wr, x, out=gathered[r, :, : r1 - r0])
+        shards.append((r0, r1))
+        Wr.free()
+    # "rccl": what ncclAllGather leaves on every rank, then the re-layout kernel
+    out = device.relayout_gathered(gathered, G, N, Ms, M)
+    assert torch.equal(out, full), f"{name}: re-layout of eight gathered shards differs from the unsplit result"
+    # "push": every rank stores its columns into every rank's dst
+    peers = [torch.full((N, M), -3.0, device="cuda") for _ in range(G)]
+    pp = (C.c_void_p * G)(*[p.data_ptr() for p in peers])
+    for r, (r0, r1) in enumerate(shards):
+        check(L.ggml_hip_push_columns_dev(C.c_void_p(gathered[r].data_ptr()), Ms, N, r1 - r0, pp, G, M, r0, None), "push")
+    torch.cuda.synchronize()
+    for r, p in enumerate(peers):
+        assert torch.equal(p, full), f"{name}: rank {r}'s pushed dst differs from the unsplit result"

@@ -14,20 +14,22 @@
 
 int main(int argc, char **argv) {
     const int M = argc > 3 ? atoi(argv[1]) : 4096, K = argc > 3 ? atoi(argv[2]) : 4096, N = argc > 3 ? atoi(argv[3]) : 512;
+    const bool i8 = argc > 4 && !strcmp(argv[4], "i8");      // Q8_0 on the int8 form instead of Q4_0 on the MX form
     const int nbk = K / 32, nbkp = (int)pad_kblocks(nbk), Mpad = (int)pad_rows(M), Npad = (int)pad_act(N);
     const size_t wa = (size_t)(nbkp + K_LOOKAHEAD) * Mpad * 16, wb = wa / 2, wdb = (size_t)(nbkp + K_LOOKAHEAD) * Mpad * 4;
     const size_t ab = (size_t)nbkp * 48 * Npad, adb = (size_t)nbkp * Npad * 4;
     const int copies = 16;
     std::vector<ggml_hip_weight> W(copies);
-    std::vector<uint8_t> h(std::max(wa, ab)); uint32_t s = 12345;
+    std::vector<uint8_t> h(std::max(2 * wa, ab)); uint32_t s = 12345;
     auto fill = [&](void *d, size_t n) { for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = (uint8_t)(s >> 24); } CK(hipMemcpy(d, h.data(), n, hipMemcpyHostToDevice)); };
     std::vector<float> f(std::max(wdb, adb) / 4);
     auto fillf = [&](void *d, size_t n) { for (size_t i = 0; i < n / 4; ++i) { s = s * 1664525u + 1013904223u; f[i] = 0.5f + (float)(s >> 8) / 33554432.0f; } CK(hipMemcpy(d, f.data(), n, hipMemcpyHostToDevice)); };
     for (auto &w : W) {
         memset(&w, 0, sizeof(w));
-        w.type = GGML_TYPE_Q4_0; w.M = M; w.K = K; w.Mpad = Mpad; w.nbk = nbk;
-        CK(hipMalloc(&w.q6a, wa)); CK(hipMalloc(&w.q6b, wb)); CK(hipMalloc(&w.d, wdb));
-        fill(w.q6a, wa); fill(w.q6b, wb); fillf(w.d, wdb);
+        w.type = i8 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_0; w.M = M; w.K = K; w.Mpad = Mpad; w.nbk = nbk;
+        CK(hipMalloc(&w.q6a, 2 * wa)); CK(hipMalloc(&w.q6b, wb)); CK(hipMalloc(&w.d, wdb));
+        fill(w.q6a, 2 * wa); fill(w.q6b, wb); fillf(w.d, wdb);
+        w.qs = w.q6a;                                         // (int8 planes: 32 B per row and k-block)
     }
     uint8_t *a6; float *ad, *dst;
     CK(hipMalloc(&a6, ab)); CK(hipMalloc(&ad, adb)); CK(hipMalloc(&dst, (size_t)N * M * 4));
@@ -35,11 +37,11 @@ int main(int argc, char **argv) {
     act_planes p; p.a8 = (int8_t *)a6; p.ad = ad; p.as = (int32_t *)ad; p.Npad = Npad;
     const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int it = 0; it < 200; ++it) CK(launch_gemm_qmx_mid(&W[it % copies], p, N, dst, M, 0, ep));
+    for (int it = 0; it < 200; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], p, N, dst, M, 0, ep));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     const int iters = 2000;
-    for (int it = 0; it < iters; ++it) CK(launch_gemm_qmx_mid(&W[it % copies], p, N, dst, M, 0, ep));
+    for (int it = 0; it < iters; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], p, N, dst, M, 0, ep));
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const int nwg = ((M + 127) / 128) * ((N + 63) / 64);
