@@ -661,7 +661,7 @@ def main():
                    1: ("gemm_q16_kernel<Q4_0,2,4,4,1>", "2 x v_mfma_f32_32x32x16_f16 per tile and block + f32 block-scale epilogue on the VALU"),
                    3: ("gemm_qmx_kernel<Q4_0,2,4,4,1>", "1 x v_mfma_scale_f32_32x32x64_f8f6f4 (bf6 digits, exact) per tile and block + f32 block-scale epilogue on the VALU")}
         from ggmlsharp_amd._lib import lib
-        kname, kdesc = kernels.get(lib().ggml_hip_act_image_kind(Q4_0, M, K, N), kernels[0])
+        kname, kdesc = kernels.get(lib().ggml_hip_act_image_kind(Q4_0, K, N), kernels[0])
         for fn in PROFILE_TRAFFIC:
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:

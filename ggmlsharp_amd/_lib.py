@@ -133,7 +133,7 @@ HIP_SYMBOLS = {
     "ggml_hip_debug_scope_counters": (None, [C.POINTER(C.c_uint64)] * 4),
     "ggml_hip_graph_end": (C.c_int, []),
     "ggml_hip_debug_transfer_counters": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "ggml_hip_act_image_kind": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "ggml_hip_act_image_kind": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
     "ggml_hip_debug_force_gemm": (None, [C.c_int]),
     "ggml_hip_quantize_act_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ggml_hip_mul_mat_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),

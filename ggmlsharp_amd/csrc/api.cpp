@@ -80,16 +80,14 @@ bool has_qh_plane(int t) { return t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
 // (two MFMAs per tile and block); it measured no faster than the kernels above, so its digit planes
 // (1.5 B / weight) are only built for weights uploaded while "mx" is forced.
 // Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip, 3 = the bf6 image of gemm_qmx.hip.
-std::atomic<int> g_force_gemm{-1};   // -1: not set yet; 0 auto, 1 int8, 2 f16, 3 MX
+thread_local int t_force_gemm = -1;   // -1: not set yet; 0 auto, 1 int8, 2 f16, 3 MX.  Per calling thread: a test hook never reaches another thread's calls
 
 int gemm_force() {
-    int force = g_force_gemm.load();
-    if (force < 0) {
+    if (t_force_gemm < 0) {
         const char *e = dev_env_str("GGML_HIP_GEMM");
-        force = !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'm' ? 3 : 0)));
-        g_force_gemm.store(force);
+        t_force_gemm = !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'm' ? 3 : 0)));
     }
-    return force;
+    return t_force_gemm;
 }
 }  // namespace
 
@@ -104,7 +102,9 @@ static bool q8_mid_serves(int type, int64_t K, int64_t N) {
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N > 256 && N <= 512 && K / QK >= 64 && gemm_force() == 0;
 }
 
-int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
+// The K1 image -- hence the kernel family -- for (type, K, N).  NOT a function of the number of weight rows: a row shard runs the
+// kernel form of the unsplit matrix (the signature has no M to consult).
+int act_image_kind(int type, int64_t K, int64_t N) {
     const int force = gemm_force();
     if (q8_small_serves(type, K, N) || q8_mid_serves(type, K, N)) return 0;
     if (N <= 4 || force == 1) return 0;
@@ -115,7 +115,7 @@ int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
-    if ((nba + K_LOOKAHEAD) * (uint64_t)pad_rows(M) * 32 > 0xFFFFFFFFull || nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
+    if (nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
     if (force == 2) return gemm_q16_image_kind(type);
     if (type == GGML_TYPE_Q5_1 && force == 3) return 0;                 // no MX form: the forced choice falls back to the int8 kernel
     if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
@@ -126,6 +126,14 @@ int act_image_kind(int type, int64_t M, int64_t K, int64_t N) {
     // 64 x 64 tiles balance the chip better.  Decided from N and K only, like the K split itself: never from M, so a row shard
     // runs the kernel form of the unsplit matrix.
     return ((N <= 512 || N >= 1024) && K / QK >= 8) ? gemm_q16_image_kind(type) : 0;
+}
+
+// ... for ONE weight: the stated exception -- planes that do not fit 32-bit buffer offsets (> 4 GiB per plane) are served by the
+// int8 kernel and its image, whatever the type.  INIT and COMPUTE both come through here, so they agree.
+int weight_image_kind(const ggml_hip_weight *w, int64_t N) {
+    const uint64_t nba = (uint64_t)pad_kblocks(w->K / QK);
+    if ((nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 32 > 0xFFFFFFFFull) return 0;
+    return act_image_kind(w->type, w->K, N);
 }
 
 // ---------------- DeviceCtx ----------------
@@ -707,13 +715,13 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     rc = weight_device_current(w);
     if (rc) return rc;
     act_planes p = act_carve(d_work, w->K, pad_act(N));
-    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, act_image_kind(w->type, w->M, w->K, N), (hipStream_t)stream,
+    HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, weight_image_kind(w, N), (hipStream_t)stream,
                                 w->ext_type == GGML_HIP_TYPE_Q5_K));     // k-quant weights: the Q8_K rule (one scale per 256)
     return GGML_HIP_OK;
 }
 
-int ggml_hip_act_image_kind(int type, int64_t M, int64_t K, int64_t N) { return act_image_kind(type == GGML_HIP_TYPE_Q5_K ? GGML_TYPE_Q5_1 : type, M, K, N); }
-void ggml_hip_debug_force_gemm(int which) { g_force_gemm.store(which < 0 || which > 3 ? 0 : which); }
+int ggml_hip_act_image_kind(int type, int64_t K, int64_t N) { return act_image_kind(type == GGML_HIP_TYPE_Q5_K ? GGML_TYPE_Q5_1 : type, K, N); }
+void ggml_hip_debug_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 : which; }
 
 int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
                               int image_kind, void *stream) {
@@ -754,11 +762,11 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
         if (e == hipSuccess) return GGML_HIP_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported: the staged int8 kernel below reads the same image)
     }
-    if (N <= gemv_rows_max(w->type) && act_image_kind(w->type, w->M, w->K, N) == 0)
+    if (N <= gemv_rows_max(w->type) && weight_image_kind(w, N) == 0)
         HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (act_image_kind(w->type, w->M, w->K, N) == 3)
+    else if (weight_image_kind(w, N) == 3)
         HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (act_image_kind(w->type, w->M, w->K, N) != 0)
+    else if (weight_image_kind(w, N) != 0)
         HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
     else
         HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
@@ -783,7 +791,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
-    if (N <= GEMV_MAX_N && w->ext_type == 0 && act_image_kind(w->type, w->M, w->K, N) == 0 && !q8_small_serves(w->type, w->K, N)) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
+    if (N <= GEMV_MAX_N && w->ext_type == 0 && weight_image_kind(w, N) == 0 && !q8_small_serves(w->type, w->K, N)) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
         rc = check_src1_alignment(d_src1, ld1);     // (float4 loads of the activation rows)
         if (rc) return rc;
         HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream));
@@ -799,7 +807,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
 static bool epilogue_is_fused(const ggml_hip_weight *w, int64_t N) {
     if (!is_q(w->type) || w->ext_type != 0) return false;
     if (q8_small_serves(w->type, w->K, N)) return true;
-    const int kind = act_image_kind(w->type, w->M, w->K, N);
+    const int kind = weight_image_kind(w, N);
     if (N <= GEMV_MAX_N && kind == 0) return gemv_fused_has_epilogue(N);
     return kind == 3;
 }
@@ -820,7 +828,7 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
         int rc = weight_device_current(w);
         if (rc) return rc;
-        if (N <= GEMV_MAX_N && act_image_kind(w->type, w->M, w->K, N) == 0 && !q8_small_serves(w->type, w->K, N)) {
+        if (N <= GEMV_MAX_N && weight_image_kind(w, N) == 0 && !q8_small_serves(w->type, w->K, N)) {
             rc = check_src1_alignment(d_src1, ld1);
             if (rc) return rc;
             HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream, &ep));
@@ -926,9 +934,9 @@ int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, co
     }
     if (n_w >= 2 && multi_ok(w, n_w, N)) return ggml_hip_mul_mat_multi_dev(w, n_w, d_src1, ld1, N, d_dst, ldd, nullptr, 0, nullptr, nullptr, stream);
     // one image for all of them?  (the image kind of a type follows N and K; M enters for shapes beyond the 32-bit offsets only)
-    const int kind = act_image_kind(w[0]->type, w[0]->M, w[0]->K, N);
+    const int kind = weight_image_kind(w[0], N);
     bool shared = (!(N <= gemv_rows_max(w[0]->type) && kind == 0) || q8_small_serves(w[0]->type, w[0]->K, N)) && w[0]->ext_type == 0;
-    for (int i = 1; i < n_w && shared; ++i) shared = act_image_kind(w[i]->type, w[i]->M, w[i]->K, N) == kind;
+    for (int i = 1; i < n_w && shared; ++i) shared = weight_image_kind(w[i], N) == kind;
     if (!shared) {
         for (int i = 0; i < n_w; ++i) {
             const int rc = ggml_hip_mul_mat_dev(w[i], d_src1, N, ld1, d_dst[i], ldd[i], d_work, work_bytes, stream);

@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 
-#include "../../include/ggml_hip.h"
+#include "../../include/ggml_hip_ext.h"
 
 #define QK 32
 

@@ -38,7 +38,8 @@ int vec_dot_type(int t);                           // Ggml.cs:219-290
 inline size_t row_bytes_of(int t, int64_t k) { return TSIZE[t] * (size_t)(k / BLCK[t]); }
 inline int64_t nelem(const ggml_tensor *t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
 bool contiguous_f32(const ggml_tensor *t);
-int act_image_kind(int type, int64_t M, int64_t K, int64_t N);
+int act_image_kind(int type, int64_t K, int64_t N);              // by type, K and N alone
+int weight_image_kind(const ggml_hip_weight *w, int64_t N);         // ... for one weight (kind 0 when its planes exceed 32-bit offsets)
 
 struct Scratch {
     void *p = nullptr;

@@ -19,7 +19,7 @@
 #ifndef GGML_HOST_MIRROR_H
 #define GGML_HOST_MIRROR_H
 
-#include "ggml_hip.h"
+#include "ggml_hip_ext.h"
 
 #ifdef __cplusplus
 extern "C" {

@@ -189,7 +189,7 @@ def test_quantize_act_planes_match_oracle(dev, t, force):
         ref = O.quantize_row(O.Q8_0, x).reshape(N, nbk, 36)
         ref_d = ref[:, :, :4].copy().view(np.float32).reshape(N, nbk)
         ref_q = ref[:, :, 4:].copy().view(np.int8).astype(np.int32)
-        kind = lib().ggml_hip_act_image_kind(t, 4, K, N)
+        kind = lib().ggml_hip_act_image_kind(t, K, N)
         if force == "f16":     # the f16 images serve big grids only: write them through the explicit-layout entry
             kind = 0 if N <= 8 else (2 if t == O.Q8_0 else 1)
             if kind:

@@ -21,7 +21,7 @@ for cfg in sys.argv[1:]:
     for kernel in (0, 1, 2, 3, 0):
         lib().ggml_hip_debug_force_gemm(kernel)
         W = device.Weight.from_device(t, rows, K)      # the MX digit planes of Q5_0 / Q8_0 exist only for weights uploaded under force 3
-        kind = lib().ggml_hip_act_image_kind(t, M, K, N)
+        kind = lib().ggml_hip_act_image_kind(t, K, N)
         work = device.alloc_work(t, K, N)
         try:
             device.mul_mat_init(W, x, work)
