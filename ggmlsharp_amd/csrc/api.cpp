@@ -2,6 +2,7 @@
 // device-resident data, the row functions (Seam 2).  seams.cpp holds the host-pointer seams, multi.cpp the row split
 // over several devices.  No CPU fallback anywhere: without a device every compute entry returns GGML_HIP_ERR_NO_DEVICE.
 #include "ctx.h"
+#include <algorithm>
 
 namespace ghip {
 
@@ -234,10 +235,13 @@ void DeviceCtx::join_copies() {
     if (!d2h_busy) return;
     if (hipEventRecord(ev_d2h, s_d2h) != hipSuccess || hipStreamWaitEvent(stream, ev_d2h, 0) != hipSuccess) (void)hipGetLastError();
 }
-int DeviceCtx::pay(const void *only_dev) {
+int DeviceCtx::pay(const void *only_dev, size_t only_bytes) {
     if (owed.empty()) return GGML_HIP_OK;
     std::vector<Owed> now, keep;
-    for (const Owed &o : owed) (only_dev == nullptr || o.dev == only_dev ? now : keep).push_back(o);
+    // (a product with ne02 > 1 owes one entry per 2-D slice, all inside one resident buffer: every entry that lies in
+    // [only_dev, only_dev + only_bytes) goes out before that buffer is recycled, not just the one at its base)
+    const uint8_t *lo = (const uint8_t *)only_dev, *hi = lo + (only_bytes ? only_bytes : 1);
+    for (const Owed &o : owed) (only_dev == nullptr || ((const uint8_t *)o.dev >= lo && (const uint8_t *)o.dev < hi) ? now : keep).push_back(o);
     owed.swap(keep);
     if (now.empty()) return GGML_HIP_OK;
     d2h_busy = true;
@@ -277,7 +281,7 @@ void DeviceCtx::drop_overlapping(const void *host, size_t bytes, bool keep_exact
         const uint8_t *x = (const uint8_t *)it->first, *y = x + it->second.bytes;
         const bool overlap = x < b && a < y;
         if (overlap && !(keep_exact && it->first == host)) {
-            (void)pay(it->second.p);               // its host copy goes out (stream-ordered) before the buffer is reused
+            (void)pay(it->second.p, it->second.bytes);   // its host copies go out (stream-ordered) before the buffer is reused
             join_copies();
             pool.push_back(it->second);
             it = resident.erase(it);
@@ -291,7 +295,7 @@ void *DeviceCtx::resident_buffer(const void *host, size_t bytes) {
     auto old = resident.find(host);
     if (old != resident.end()) {
         if (old->second.bytes >= bytes) return old->second.p;      // the same tensor computed again: reuse its buffer
-        (void)pay(old->second.p);
+        (void)pay(old->second.p, old->second.bytes);
         join_copies();
         pool.push_back(old->second);
         resident.erase(old);
@@ -368,7 +372,9 @@ int create_slot_locked(int i, int device) {
     return GGML_HIP_OK;
 }
 
-void destroy_slot_locked(DeviceCtx *c) {
+std::vector<DeviceCtx *> g_graveyard;              // contexts of shut-down slots: resources released, the object kept for late lockers
+
+void release_slot_resources_locked(DeviceCtx *c) {
     (void)hipSetDevice(c->device);
     (void)c->sync_all();
     c->free_cache();
@@ -383,6 +389,10 @@ void destroy_slot_locked(DeviceCtx *c) {
         if (ev) (void)hipEventDestroy(ev);
     for (hipStream_t s : {c->stream, c->s_h2d, c->s_d2h})
         if (s) (void)hipStreamDestroy(s);
+    c->stream = c->s_h2d = c->s_d2h = nullptr;
+}
+void destroy_slot_locked(DeviceCtx *c) {            // (a slot that never became visible: failed initialisation)
+    release_slot_resources_locked(c);
     delete c;
 }
 
@@ -634,10 +644,19 @@ void ggml_hip_shutdown(void) {
     if (n == 0) return;
     g_nslots.store(0, std::memory_order_release);
     for (int i = 0; i < n; ++i) {
-        { std::lock_guard<std::recursive_mutex> l2(g_slots[i]->mu); }   // let a seam that is still inside finish
-        destroy_slot_locked(g_slots[i]);
-        g_slots[i] = nullptr;
+        DeviceCtx *c = g_slots[i];
+        {
+            // a seam that is still inside finishes first; one that fetched the pointer before n_slots dropped to 0 but has not
+            // locked yet finds `dead` set when it does (Call::begin, scope_replaying) and returns "not initialised"
+            std::lock_guard<std::recursive_mutex> l2(c->mu);
+            c->dead = true;
+            g_slots[i] = nullptr;
+            release_slot_resources_locked(c);
+        }
+        g_graveyard.push_back(c);          // the object (its mutex) outlives late lockers; freed at the next shutdown / process end
     }
+    for (size_t k = 0; k + 64 < g_graveyard.size(); ++k) { delete g_graveyard[k]; g_graveyard[k] = nullptr; }
+    g_graveyard.erase(std::remove(g_graveyard.begin(), g_graveyard.end(), nullptr), g_graveyard.end());
     rccl_shutdown();
 }
 
@@ -836,9 +855,13 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         }
         rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
         if (rc) return rc;
-        if (q8_small_serves(w->type, w->K, N)) HIP_TRY(launch_gemm_q8_small(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep));
-        else HIP_TRY(launch_gemm_qmx(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep));
-        return GGML_HIP_OK;
+        const hipError_t e = q8_small_serves(w->type, w->K, N) ? launch_gemm_q8_small(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep)
+                                                                : launch_gemm_qmx(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep);
+        if (e == hipSuccess) return GGML_HIP_OK;
+        // not supported = operands beyond the 32-bit offsets of these kernels (planes, or ld_add / ld2 past 4 GiB): the same product
+        // succeeds without an epilogue (ggml_hip_mul_mat_compute_dev falls back), so it does with one -- the unfused path below
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+        (void)hipGetLastError();
     }
     // no fused form for this kernel: the product, then the node's own kernel row by row (same values)
     int rc = ggml_hip_mul_mat_dev(w, d_src1, N, ld1, d_dst, ldd, d_work, work_bytes, stream);

@@ -104,7 +104,7 @@ struct DeviceCtx {
     static constexpr size_t OWE_EARLY_BYTES = 1u << 20;      // results this large are copied at once, on the copy stream (7B layer, batch 32 = 512-KB results: 468 us captured and paid at the end, 550 us with early copies; batch 512: 4.97 -> 4.26 ms)
     void owe(void *host, const void *dev, size_t bytes);      // (replaces an entry for the same host pointer)
     void join_copies();
-    int pay(const void *only_dev = nullptr);                  // issue the copies on `stream` (all, or the one reading `only_dev`)
+    int pay(const void *only_dev = nullptr, size_t only_bytes = 0);   // issue the copies on `stream` (all, or those reading [only_dev, only_dev + only_bytes))
     int pay_and_sync();                                       // ... and wait: host memory is current afterwards
     // Keyed graph scopes (ggml_hip_graph_begin_keyed): the caller names the graph it is about to run.  A scope that needed
     // nothing but launches on the compute stream (observed once) is captured into a hipGraph the second time and REPLAYED with one
@@ -119,6 +119,7 @@ struct DeviceCtx {
     std::map<uint64_t, Captured> captured;
     uint64_t scope_key = 0;
     std::thread::id scope_owner;                   // the thread that opened the named scope: only ITS seam calls are the scope's
+    bool dead = false;                             // ggml_hip_shutdown released this slot while the caller was waiting for its lock
     int scope_mode = 0;                            // 0 plain, 1 observing, 2 capturing, 3 replaying
     bool scope_clean = true;
     std::vector<std::pair<const void *, size_t>> scope_leaves;   // (observing) whole host tensors uploaded so far in this scope

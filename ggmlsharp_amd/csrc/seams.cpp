@@ -50,6 +50,10 @@ struct Call {
         for (DeviceCtx *c : ctxs) {
             if (!c) return fail(GGML_HIP_ERR_RUNTIME, "library was shut down during the call");
             locks.emplace_back(c->mu);                 // slot order: no lock-order inversion between callers
+            if (c->dead) return fail(GGML_HIP_ERR_RUNTIME, "library was shut down during the call");   // (ggml_hip_shutdown won the race for this slot's lock)
+            // another thread is capturing a named scope on this slot's stream: this call's launches are none of that graph's
+            // business -- the capture is ended and issued live (its owner carries on live), then this call runs
+            if (c->scope_mode == 2 && c->scope_owner != std::this_thread::get_id()) c->scope_dirty();
         }
         return GGML_HIP_OK;
     }
@@ -497,7 +501,7 @@ static bool scope_replaying() {
     DeviceCtx *c = slot(b >= 0 ? b : 0);
     if (!c) return false;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    return c->scope_mode == 3 && c->scope_owner == std::this_thread::get_id();
+    return !c->dead && c->scope_mode == 3 && c->scope_owner == std::this_thread::get_id();
 }
 
 static bool src1_contig_early(const ggml_tensor *t) { return t->nb[0] == 4 && t->nb[1] == (uint64_t)t->ne[0] * 4; }
