@@ -174,11 +174,11 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     };
 
     float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
-    load_scale_table(tabD, ad, kb0, nloc, nbkp, Npad, n0, lane);   // (K1b writes the k-blocks K is padded to as zeros)
     WFrag wl;                                               // the NEXT k-block's weights, as loaded (lane halves = the m-tiles of a pair)
     AFrag af;                                               // activation fragments: column tile j is refetched as soon as its last MFMA has issued
-    load_w(wl, kb0);
+    load_w(wl, kb0);                                        // (requested first: the weights come from HBM, the table from L2)
     load_a(af, kb0);
+    load_scale_table(tabD, ad, kb0, nloc, nbkp, Npad, n0, lane);   // (K1b writes the k-blocks K is padded to as zeros)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -309,12 +309,12 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
         }
     };
     float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
-    load_scale_table(tabD, ad, kb0, nloc, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
     WI8 w0, w1;
     i32x4 af[WNT];
-    load_w(w0, kb0);
+    load_w(w0, kb0);                                        // (requested first: the weights come from HBM, the table from L2)
 #pragma unroll
     for (int j = 0; j < WNT; ++j) af[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j), (int)((uint32_t)kb0 * a_blk), 0));
+    load_scale_table(tabD, ad, kb0, nloc, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun): bash tools/profile_round.sh r02  -- bench line + rocprofv3 kernel stats + PMC passes
-T=${1:-r02}
+T=${1:-r03}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -14,3 +14,9 @@ done
 # dense f16 path: MFMA utilisation of dense16_kernel (SQ_VALU_MFMA_BUSY_CYCLES / 4 SIMD-cycles vs SQ_BUSY...)
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmc_${T}_dense16 -- python3 $R/tools/kbench.py --cfg f16:4096:4096:4096 --iters 5 > $R/gpurun_out/pmc_${T}_dense16.log 2>&1 || exit 4
 echo ok
+# round 3: the other BASELINE configs, one set of passes each (summaries: tools/summarize_cfgs.py <tag> <name> <kernel regex>)
+bash $R/tools/pmc_cfgs.sh ${T}c3 q4_0:4096:4096:512 || exit 5
+bash $R/tools/pmc_cfgs.sh ${T}c4q8 q8_0:4096:11008:512 || exit 6
+bash $R/tools/pmc_cfgs.sh ${T}c4q5 q5_0:4096:11008:512 || exit 7
+bash $R/tools/pmc_cfgs.sh ${T}c5 q4_0:32000:4096:512 || exit 8
+echo ok-configs
