@@ -56,9 +56,11 @@ constexpr int WNT = 2;         // 32-column tiles of src1 per wave
 
 // XCD-aware tile order (speed only): workgroups b, b + 8, ... share an XCD and its L2; an XCD takes a contiguous run of the tile
 // list ordered "n fastest", so the workgroups that stream the same weight rows sit behind one L2.
-__device__ __forceinline__ void tile_origin(int tiles_m, int tiles_n, int &m0, int &n0) {
+// (tile = blockIdx.x + r * gridDim.x for the r-th tile of a persistent workgroup; the grid is a multiple of 8 whenever r > 0, so a
+// workgroup stays in its XCD's run of the list)
+__device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, int &m0, int &n0) {
     const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int bid = tile, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     m0 = (t_lin / tiles_n) * (32 * WMT);
     n0 = (t_lin % tiles_n) * (32 * WNT);
@@ -145,17 +147,25 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     const int l31 = lane & 31, hh = lane >> 5;
     K3P_STAMP(0);
 
+    // A workgroup is PERSISTENT: it takes tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the grid is one workgroup per CU once there
+    // are more tiles than CUs).  The first operands of the next tile are requested before the reduction of the current one.
+    const int nwg = tiles_m * tiles_n;
+    int tile = blockIdx.x;
     int m0, n0;
-    tile_origin(tiles_m, tiles_n, m0, n0);
+    tile_origin(tile, tiles_m, tiles_n, m0, n0);
     const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (planes and image read 0 past their end)
 
     const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
     const rsrc_t rA = make_rsrc(a6, a_bytes);
-    const int mrow = m0 + 32 * hh + l31;                    // pair p: + 64 p rows (the instruction's immediate offset)
-    const uint32_t offA = (uint32_t)(mrow * 16), offB = (uint32_t)(mrow * 8), offD = (uint32_t)(mrow * 4);
+    uint32_t offA, offB, offD, voff16, voff8;               // per-lane offsets of the current tile's operands
+    auto set_offsets = [&](int m0_, int n0_) {
+        const int mrow = m0_ + 32 * hh + l31;               // pair p: + 64 p rows (the instruction's immediate offset)
+        offA = (uint32_t)(mrow * 16); offB = (uint32_t)(mrow * 8); offD = (uint32_t)(mrow * 4);
+        voff16 = (uint32_t)((hh * Npad + n0_ + l31) * 16); voff8 = (uint32_t)(32 * Npad + (hh * Npad + n0_ + l31) * 8);
+    };
+    set_offsets(m0, n0);
     const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4);
     const uint32_t a_blk = (uint32_t)Npad * 48u;
-    const uint32_t voff16 = (uint32_t)((hh * Npad + n0 + l31) * 16), voff8 = (uint32_t)(32 * Npad + (hh * Npad + n0 + l31) * 8);
 
     auto load_w = [&](WFrag &f, int kb) {
 #pragma unroll
@@ -178,6 +188,9 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     AFrag af;                                               // activation fragments: column tile j is refetched as soon as its last MFMA has issued
     load_w(wl, kb0);                                        // (requested first: the weights come from HBM, the table from L2)
     load_a(af, kb0);
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (bool first = true;; first = false) {
+    if (!first) __syncthreads();                            // (the previous tile's reduction has read its last partial sums: the tables may go over them)
     load_scale_table(tabD, ad, kb0, nloc, nbkp, Npad, n0, lane);   // (K1b writes the k-blocks K is padded to as zeros)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -190,7 +203,6 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
         for (int j = 0; j < WNT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int scale_a = hh ? 127 : 131;                     // E8M0: K group 0 (the ah digits) carries 2^4
 
     // v_permlane32_swap: x in both operands -> {x's lower half in both halves, x's upper half in both halves}
@@ -268,7 +280,17 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     // ---- the waves' sums, added in wave order, four of the eight tiles per round (128 KB of LDS); every wave takes its share of the
     //      result rows a lane holds, so the additions of one element are the same, in the same order, whoever makes them ----
     __builtin_amdgcn_s_setprio(0);
-    reduce_and_store(acc, smem, dst, M, N, ldd, m0, n0, wave, lane, ep);
+    const int m0c = m0, n0c = n0;
+    tile += (int)gridDim.x;
+    if (tile < nwg) {                                       // the next tile's first operands travel while this one is reduced and stored
+        tile_origin(tile, tiles_m, tiles_n, m0, n0);
+        set_offsets(m0, n0);
+        load_w(wl, kb0);
+        load_a(af, kb0);
+    }
+    reduce_and_store(acc, smem, dst, M, N, ldd, m0c, n0c, wave, lane, ep);
+    if (tile >= nwg) break;
+  }
     K3P_STAMP(5);
 }
 
@@ -294,12 +316,18 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     K3P_STAMP(0);
+    const int nwg = tiles_m * tiles_n;                      // (persistent workgroups: see the MX kernel)
+    int tile = blockIdx.x;
     int m0, n0;
-    tile_origin(tiles_m, tiles_n, m0, n0);
+    tile_origin(tile, tiles_m, tiles_n, m0, n0);
     const int kb0 = wave * nloc;
 
     const rsrc_t rW = make_rsrc(qs, w_bytes), rD = make_rsrc(wd, w_bytes / 8), rA = make_rsrc(a8, a_bytes);
-    const uint32_t offW = (uint32_t)((hh * Mpad + m0 + l31) * 16), offD = (uint32_t)((m0 + l31) * 4), offA = (uint32_t)((hh * Npad + n0 + l31) * 16);
+    uint32_t offW, offD, offA;
+    auto set_offsets = [&](int m0_, int n0_) {
+        offW = (uint32_t)((hh * Mpad + m0_ + l31) * 16); offD = (uint32_t)((m0_ + l31) * 4); offA = (uint32_t)((hh * Npad + n0_ + l31) * 16);
+    };
+    set_offsets(m0, n0);
     const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
     auto load_w = [&](WI8 &f, int kb) {
 #pragma unroll
@@ -311,9 +339,15 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
     WI8 w0, w1;
     i32x4 af[WNT];
-    load_w(w0, kb0);                                        // (requested first: the weights come from HBM, the table from L2)
+    auto load_first = [&]() {
+        load_w(w0, kb0);                                    // (requested first: the weights come from HBM, the table from L2)
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) af[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j), (int)((uint32_t)kb0 * a_blk), 0));
+        for (int j = 0; j < WNT; ++j) af[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j), (int)((uint32_t)kb0 * a_blk), 0));
+    };
+    load_first();
+    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (bool first = true;; first = false) {
+    if (!first) __syncthreads();                            // (the previous tile's reduction has read its last partial sums)
     load_scale_table(tabD, ad, kb0, nloc, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -326,7 +360,6 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
         for (int j = 0; j < WNT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // one k-block: local index b, weights in w; the next block's go into wn; column tile j's fragment is refetched behind its last MFMA.
     // The 16 row scales of a column tile are read during the LAST tile of the column tile before it (the order pins below are
@@ -389,13 +422,37 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
 #endif
     K3P_STAMP(2);
     __builtin_amdgcn_s_setprio(0);
-    reduce_and_store(acc, smem, dst, M, N, ldd, m0, n0, wave, lane, ep);
+    const int m0c = m0, n0c = n0;
+    tile += (int)gridDim.x;
+    if (tile < nwg) {                                       // the next tile's first operands travel while this one is reduced and stored
+        tile_origin(tile, tiles_m, tiles_n, m0, n0);
+        set_offsets(m0, n0);
+        load_first();
+    }
+    reduce_and_store(acc, smem, dst, M, N, ldd, m0c, n0c, wave, lane, ep);
+    if (tile >= nwg) break;
+  }
     K3P_STAMP(5);
 }
 
 }  // namespace
 
 // Q8_0 / Q5_0, at least 8 k-blocks per wave: hipErrorNotSupported otherwise (the caller falls back to the staged int8 kernel, same image)
+// workgroups of a launch: every tile its own while they fit the chip, else one persistent workgroup per CU (a multiple of 8: XCD order)
+static unsigned persistent_grid(int tiles) {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int n = cus[dev & 63].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        n = n / 8 * 8;
+        if (n < 8) n = 8;
+        cus[dev & 63].store(n, std::memory_order_relaxed);
+    }
+    return (unsigned)(tiles <= n ? tiles : n);
+}
+
 hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : w->type == GGML_TYPE_Q5_0 ? w->i8p : nullptr;
     if (!planes || !w->d) return hipErrorNotSupported;
@@ -416,7 +473,7 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N,
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
-        kern<<<dim3((unsigned)(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, \
+        kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, \
                                                                         (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep); } while (0)
     if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else Q8MID_GO(GGML_TYPE_Q5_0);
 #undef Q8MID_GO
@@ -443,7 +500,7 @@ hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, act_planes p, int64_t N
     const hipError_t attr = once.max_dynamic_lds((const void *)gemm_qmx_mid_kernel, 160 * 1024);
     if (attr != hipSuccess) return attr;
     (void)hipGetLastError();
-    gemm_qmx_mid_kernel<<<dim3((unsigned)(tiles_m * tiles_n)), KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N,
+    gemm_qmx_mid_kernel<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N,
                                                                                      (int)w->Mpad, (int)p.Npad, nbkp, nloc, (int)ldd, tiles_m, tiles_n,
                                                                                      (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, ep);
     return hipGetLastError();
