@@ -13,7 +13,9 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
 SHAPES = [(5000, 2048, 2000), (4096, 4096, 4096), (4096, 1024, 512), (777, 352, 130), (4096, 4096, 1), (32000, 1024, 5), (300, 11008, 513), (4096, 4096, 16), (1000, 2080, 29), (4096, 4096, 64), (777, 11008, 128), (16384, 1024, 100),
           # the batched-decode forms (K3s / K3s-i8): one, two and four tiles per workgroup, one and two column slices, K in slots and in rounds
-          (4096, 4096, 6), (4096, 4096, 32), (8492, 4160, 50), (20000, 2048, 20), (300, 11008, 64), (4096, 2112, 9)]
+          (4096, 4096, 6), (4096, 4096, 32), (8492, 4160, 50), (20000, 2048, 20), (300, 11008, 64), (4096, 2112, 9),
+          # K3p (gemm_qmp.hip): one round, several rounds of persistent workgroups, ragged M / N, K ranges with a short last one
+          (4096, 4096, 512), (4096, 11008, 300), (33000, 2048, 512), (700, 2336, 257), (11008, 4096, 400)]
 nbad = 0
 for (M, K, N) in SHAPES:
     for t in TYPES:
