@@ -357,7 +357,11 @@ int ggml_graph_compute(ggml_context *ctx, ggml_cgraph *cgraph) {
             uint32_t bits; memcpy(&bits, node->src1->data, 4); mix(bits);
         }
     }
+#ifdef GGML_MIRROR_PLAIN_SCOPE                 // (experiment build, tools/experiments/node_cost.py: every graph issued live, never captured)
+    int grc = ggml_hip_graph_begin();
+#else
     int grc = ggml_hip_graph_begin_keyed(key ? key : 1);
+#endif
     if (grc != GGML_HIP_OK) return grc;
     // Execution order: the graph's own (Ggml.cs:7559-7619 is a depth-first walk), except that a SILU whose consumer -- the MUL of
     // a gated feed-forward, mul(silu(u), g) -- sits a few nodes further on is run right in front of it, so that the pair goes
