@@ -276,7 +276,7 @@ def seam1_host_config(M, K, N, iters):
         G.ggml_free(ctx)
 
 
-def dropin_decode_layer(N, iters):
+def dropin_decode_layer(N, iters, layers=1):
     """The DROP-IN path at decode size: one LLaMA-7B-shaped decoder layer (D = 4096, F = 11008, Q4_0; the attention itself is
     replaced by adds -- soft_max / rope are outside this path) at batch N through ggml_graph_compute of the host mirror, host
     tensors in the registered context pool.  What is timed is the wall clock of a whole graph compute (17 nodes): the seams,
@@ -286,7 +286,7 @@ def dropin_decode_layer(N, iters):
     from ggmlsharp_amd._lib import lib
     D, F = 4096, 11008
     rng = np.random.default_rng(1)
-    ctx = G.ggml_init(700 * 1024 * 1024)
+    ctx = G.ggml_init((200 + 500 * layers) * 1024 * 1024)
     try:
         def qweight(K, M):
             t = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
@@ -300,17 +300,20 @@ def dropin_decode_layer(N, iters):
             G.tensor_f32(t)[:] = rng.standard_normal((n, K)).astype(np.float32).reshape(1, 1, n, K)
             return t
 
-        x, g1, g2 = f32(D, N), f32(D, N), f32(D, N)
-        wq, wk, wv, wo = (qweight(D, D) for _ in range(4))
-        w1, w3, w2 = qweight(D, F), qweight(D, F), qweight(F, D)
-        cur = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, x), g1)
-        q, k, v = G.ggml_mul_mat(ctx, wq, cur), G.ggml_mul_mat(ctx, wk, cur), G.ggml_mul_mat(ctx, wv, cur)
-        a = G.ggml_add(ctx, G.ggml_add(ctx, q, k), v)
-        h = G.ggml_add(ctx, G.ggml_mul_mat(ctx, wo, a), x)
-        cur2 = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, h), g2)
-        u, gt = G.ggml_mul_mat(ctx, w1, cur2), G.ggml_mul_mat(ctx, w3, cur2)
-        s = G.ggml_mul(ctx, G.ggml_silu(ctx, u), gt)
-        out = G.ggml_add(ctx, G.ggml_mul_mat(ctx, w2, s), h)
+        x = f32(D, N)
+        out = x
+        for _ in range(layers):             # (several layers in ONE graph: the fixed cost of a graph compute is paid once, as in a real decoder)
+            xin, g1, g2 = out, f32(D, N), f32(D, N)
+            wq, wk, wv, wo = (qweight(D, D) for _ in range(4))
+            w1, w3, w2 = qweight(D, F), qweight(D, F), qweight(F, D)
+            cur = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, xin), g1)
+            q, k, v = G.ggml_mul_mat(ctx, wq, cur), G.ggml_mul_mat(ctx, wk, cur), G.ggml_mul_mat(ctx, wv, cur)
+            a = G.ggml_add(ctx, G.ggml_add(ctx, q, k), v)
+            h = G.ggml_add(ctx, G.ggml_mul_mat(ctx, wo, a), xin)
+            cur2 = G.ggml_mul(ctx, G.ggml_rms_norm(ctx, h), g2)
+            u, gt = G.ggml_mul_mat(ctx, w1, cur2), G.ggml_mul_mat(ctx, w3, cur2)
+            s = G.ggml_mul(ctx, G.ggml_silu(ctx, u), gt)
+            out = G.ggml_add(ctx, G.ggml_mul_mat(ctx, w2, s), h)
         gf = G.ggml_build_forward(out)
         for _ in range(5):
             G.ggml_graph_compute(ctx, gf)
@@ -322,10 +325,10 @@ def dropin_decode_layer(N, iters):
             ts.append((time.perf_counter() - t0) * 1e6)
         cnt = [C.c_uint64() for _ in range(4)]
         lib().ggml_hip_debug_scope_counters(*[C.byref(c) for c in cnt])
-        wbytes = (4 * D * D + 3 * D * F) // 32 * 20
+        wbytes = (4 * D * D + 3 * D * F) // 32 * 20 * layers
         t = float(np.median(ts))
-        return {"workload": f"7B-shaped decoder layer (Q4_0, 7 mul_mat + 10 element-wise nodes), batch {N}, host tensors through ggml_graph_compute",
-                "us_per_graph": round(t, 1), "p10_us": round(float(np.percentile(ts, 10)), 1), "p90_us": round(float(np.percentile(ts, 90)), 1),
+        return {"workload": f"{layers} x 7B-shaped decoder layer (Q4_0, 7 mul_mat + 10 element-wise nodes each) in one graph, batch {N}, host tensors through ggml_graph_compute",
+                "us_per_graph": round(t, 1), "us_per_layer": round(t / layers, 1), "p10_us": round(float(np.percentile(ts, 10)), 1), "p90_us": round(float(np.percentile(ts, 90)), 1),
                 "nodes": int(gf.n_nodes), "weight_bytes": wbytes, "weight_stream_GBs": round(wbytes / t / 1e3, 1),
                 "hbm_frac": round(wbytes / t / 1e3 / HBM_PEAK_GBS, 4),
                 "named_scopes": {"observed": cnt[0].value, "captured": cnt[1].value, "replayed": cnt[2].value, "refused": cnt[3].value}}
@@ -717,6 +720,9 @@ def main():
                     c["step_over_pcie_bound"] = round(c["ms_per_step"] / bound, 3)
                 out["other_configs"].update(s1)
                 out["other_configs"]["dropin_decode_layer_batch1"] = dropin_decode_layer(1, 200)
+                # four such layers as ONE graph (what a decoder computes per token is all its layers in one graph: the fixed cost of a
+                # graph compute -- launch, copies home, synchronise -- is paid once)
+                out["other_configs"]["dropin_decode_4layers_batch1"] = dropin_decode_layer(1, 100, layers=4)
                 out["other_configs"]["batch32_qkv_group"] = projection_group_config(device, (4096, 4096, 4096), 4096, 32)
             except Exception as e:  # noqa: BLE001 -- a side measurement must not take the headline line down
                 out["other_configs"]["seam1_host_error"] = f"{type(e).__name__}: {e}"[:300]
