@@ -825,7 +825,7 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
 // N > 8, and from 5 rows where K >= 2048) and Q8_0's batched-decode form; every other form runs the epilogue as its own launch behind the mat-mul.
 static bool epilogue_is_fused(const ggml_hip_weight *w, int64_t N) {
     if (!is_q(w->type) || w->ext_type != 0) return false;
-    if (q8_small_serves(w->type, w->K, N)) return true;
+    if (q8_small_serves(w->type, w->K, N) || q8_mid_serves(w->type, w->K, N)) return true;
     const int kind = weight_image_kind(w, N);
     if (N <= GEMV_MAX_N && kind == 0) return gemv_fused_has_epilogue(N);
     return kind == 3;
@@ -855,8 +855,10 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         }
         rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
         if (rc) return rc;
-        const hipError_t e = q8_small_serves(w->type, w->K, N) ? launch_gemm_q8_small(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep)
-                                                                : launch_gemm_qmx(w, act_carve(d_work, w->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream, &ep);
+        const act_planes pl = act_carve(d_work, w->K, pad_act(N));
+        const hipError_t e = q8_small_serves(w->type, w->K, N) ? launch_gemm_q8_small(w, pl, N, d_dst, ldd, (hipStream_t)stream, &ep)
+                             : q8_mid_serves(w->type, w->K, N) ? launch_gemm_q8_mid(w, pl, N, d_dst, ldd, (hipStream_t)stream, ep)
+                                                               : launch_gemm_qmx(w, pl, N, d_dst, ldd, (hipStream_t)stream, &ep);
         if (e == hipSuccess) return GGML_HIP_OK;
         // not supported = operands beyond the 32-bit offsets of these kernels (planes, or ld_add / ld2 past 4 GiB): the same product
         // succeeds without an epilogue (ggml_hip_mul_mat_compute_dev falls back), so it does with one -- the unfused path below

@@ -34,7 +34,8 @@ def test_epilogue_device_form_is_bitwise_product_then_node(dev, t):
     from ggmlsharp_amd._lib import lib, check
     L = lib()
     for (M, K, N) in ((96, 256, 1), (130, 512, 3), (64, 256, 4), (200, 256, 6), (515, 512, 40), (260, 1024, 300), (128, 256, 1100),
-                      (130, 2048, 12), (260, 4096 + 64, 32), (96, 2048, 6), (200, 2048, 40), (130, 2048, 64)):      # (the last three: the batched-decode form, gemm_qmx.hip K3s)
+                      (130, 2048, 12), (260, 4096 + 64, 32), (96, 2048, 6), (200, 2048, 40), (130, 2048, 64),      # (the last three: the batched-decode form, gemm_qmx.hip K3s)
+                      (260, 2048, 300), (130, 2336, 512)):                                                          # (K3p, gemm_qmp.hip: the epilogue in its reduction's store phase)
         wq = O.quantize_row(t, _rand((M, K)))
         W = dev.Weight.from_host(t, wq, K)
         x = torch.from_numpy(_rand((N, K))).cuda()
@@ -42,7 +43,7 @@ def test_epilogue_device_form_is_bitwise_product_then_node(dev, t):
         prod = dev.mul_mat(W, x)
         work = dev.alloc_work(t, K, N)
         fused = L.ggml_hip_mul_mat_epilogue_fused(W.handle, N)
-        assert fused == (1 if (N <= 4 or ((N > 8 or K >= 2048) and t in (O.Q4_0, O.Q4_1)) or (t == O.Q8_0 and 5 <= N <= 64 and 2048 <= K <= 16384)) else 0), (t, N)
+        assert fused == (1 if (N <= 4 or ((N > 8 or K >= 2048) and t in (O.Q4_0, O.Q4_1)) or (t == O.Q8_0 and 5 <= N <= 64 and 2048 <= K <= 16384) or (t == O.Q8_0 and 256 < N <= 512 and K >= 2048)) else 0), (t, N)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         d1 = torch.full((N, M + 8), -3.0, device="cuda")
         d2 = torch.full((N, M + 4), -4.0, device="cuda")
