@@ -75,6 +75,14 @@ def tile(kind, cur, nxt):
         ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b128 v[{LD + 4}:{LD + 7}], v{LD + 12} offset:1024",
               f"ds_read_b64 v[{LD + 8}:{LD + 9}], v{LD + 12} offset:2048"]
         return [mm] + ld + g[0] + g[1] + g[2] + ["s_waitcnt lgkmcnt(0)"] + g[3]
+    if kind in ("mxk", "mxk_real"):      # MX MFMA + PACKED f32 epilogue (8 v_pk_mul + 8 v_pk_fma): half the VALU instructions, each twice as wide
+        mm = f"v_mfma_scale_f32_32x32x64_f8f6f4 v[{nxt}:{nxt + 15}], v[{A0}:{A0 + 5}], v[{B0}:{B0 + 5}], 0, v{SCL}, v{SCL} op_sel_hi:[0,0,0] cbsz:3 blgp:3"
+        gp = [group_pk(cur, i) for i in range(4)]
+        if kind == "mxk":
+            return [mm] + sum(gp, [])
+        ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b128 v[{LD + 4}:{LD + 7}], v{LD + 12} offset:1024",
+              f"ds_read_b64 v[{LD + 8}:{LD + 9}], v{LD + 12} offset:2048"]
+        return [mm] + ld + gp[0] + gp[1] + gp[2] + ["s_waitcnt lgkmcnt(0)"] + gp[3]
     if kind in ("mxd", "mxd_real"):
         mm = f"v_mfma_scale_f32_32x32x64_f8f6f4 v[{nxt}:{nxt + 15}], v[{A0}:{A0 + 5}], v[{B0}:{B0 + 5}], 0, v{SCL}, v{SCL} op_sel_hi:[0,0,0] cbsz:3 blgp:3"
         gd = [group_dpp(cur, i) for i in range(4)]
@@ -82,6 +90,18 @@ def tile(kind, cur, nxt):
             return [mm] + sum(gd, [])
         ld = [f"ds_read_b128 v[{LD}:{LD + 3}], v{LD + 12}", f"ds_read_b64 v[{LD + 8}:{LD + 9}], v{LD + 12} offset:2048", f"ds_read_b32 v{LD + 10}, v{LD + 12} offset:1024"]
         return [mm] + ld + gd[0] + gd[1] + gd[2] + ["s_waitcnt lgkmcnt(0)"] + gd[3]
+    if kind in ("mxp_b2", "mxp_b22", "mxp_n"):
+        # register-bank variants of mxp (all three v_fmac operands sit at the same index mod 4 there): _b2 = P two registers up,
+        # _b22 = S and P two registers up; _n = mxp's registers with the kernel's order (MX, wait, 16 v_fmac, P MFMA; ONE P buffer)
+        sb = 2 if kind == "mxp_b22" else 0
+        pb = (PQ + 2, PQ + 18) if kind != "mxp_n" else (P1, P1)
+        ps, pn = pb if cur == T0 else (pb[1], pb[0])
+        mm = f"v_mfma_scale_f32_32x32x64_f8f6f4 v[{nxt + sb}:{nxt + sb + 15}], v[{A0}:{A0 + 5}], v[{B0}:{B0 + 5}], 0, v{SCL}, v{SCL} op_sel_hi:[0,0,0] cbsz:3 blgp:3"
+        pp = f"v_mfma_f32_32x32x16_bf16 v[{pn}:{pn + 15}], v[{PA}:{PA + 3}], v[{PB}:{PB + 3}], 0"
+        f = [f"v_fmac_f32 v{ACC + r}, v{cur + sb + r}, v{ps + r}" for r in range(16)]
+        if kind == "mxp_n":
+            return [mm, "s_nop 7"] + f + [pp]
+        return [mm] + f[:8] + [pp] + f[8:]
     if kind in ("mxp", "mxp_real", "mxp_only"):
         # S = MX MFMA; P = (weight scales) (x) (activation scales) as a K=6 bf16 MFMA; acc += S * P: 16 VALU instead of 32
         ps, pn = (P0, P1) if cur == T0 else (P1, P0)
@@ -112,7 +132,7 @@ def tile(kind, cur, nxt):
     raise ValueError(kind)
 
 
-KINDS = ["valu", "mfma", "mx_only", "mx", "mx_real", "mxd", "mxd_real", "mxp_only", "mxp", "mxp_real", "mxq", "mxq_real"]
+KINDS = ["valu", "mfma", "mx_only", "mx", "mx_real", "mxk", "mxk_real", "mxd", "mxd_real", "mxp_only", "mxp", "mxp_real", "mxp_b2", "mxp_b22", "mxp_n", "mxq", "mxq_real"]
 src = ['// generated by tools/gen_tile_ubench.py -- do not edit', '#include <hip/hip_runtime.h>', '#include <cstdio>', '']
 for k in KINDS:
     body = tile(k, T0, T1) if k.startswith("mxq") else tile(k, T0, T1) + tile(k, T1, T0)
@@ -143,11 +163,11 @@ for k in KINDS:
             for r in (PA, PA + 1, PA + 2, PB, PB + 1, PB + 2):
                 init += rnd(r, 0x007F007F, 0x3F803F80, 0x61c88647 + 2 * r) + [f"v_cndmask_b32 v{r}, 0, v{r}, vcc"]
         init += [f"v_mov_b32 v{SCL}, 0x7f7f7f7f"]
-    clob = ", ".join(f'"v{i}"' for i in range(0, 184 if k.startswith("mxq") else NV)) + ', "vcc"'
+    clob = ", ".join(f'"v{i}"' for i in range(0, 184 if k.startswith("mxq") or k.startswith("mxp_") else NV)) + ', "vcc"'
     asm = "\\n\\t".join(init + ["s_mov_b32 s20, %1", "s_memtime s[22:23]", "s_waitcnt lgkmcnt(0)", "1:"] + body +
                         ["s_sub_u32 s20, s20, 1", "s_cmp_lg_u32 s20, 0", "s_cbranch_scc1 1b", "s_nop 15", "s_nop 15", "s_memtime s[24:25]",
                          "s_waitcnt lgkmcnt(0)", "s_sub_u32 %0, s24, s22", f"v_mov_b32 %2, v{ACC}"])
-    lb = "__launch_bounds__(512) " if k.startswith("mxq") else ""
+    lb = "__launch_bounds__(512) " if k.startswith("mxq") or k.startswith("mxp_") else ""
     src += [f'__global__ void {lb}k_{k}(float *out, unsigned *cyc, int n) {{', '    __shared__ float lds[1024];', '    lds[threadIdx.x & 1023] = 1.0f;',
             '    __syncthreads();', '    unsigned dt; float r;',
             f'    asm volatile("v_mov_b32 v{LD + 13}, %3\\n\\t{asm}" : "=s"(dt), "+s"(n), "=v"(r) : "v"(threadIdx.x) : {clob}, "s20", "s22", "s23", "s24", "s25", "scc", "memory");',
@@ -180,7 +200,7 @@ src += ['template <typename K> void run(const char *name, K kern, int w, float *
         '    printf("%-8s waves/SIMD %d: %8.1f us  %7.1f cyc/tile/wave  %7.1f cyc/tile/SIMD  %6.2f ns/tile/SIMD  clock %.2f GHz\\n", name, w, ms * 1e3,',
         '           cyc / (2.0 * iters), cyc / (2.0 * iters) / w, ms * 1e6 / (2.0 * iters) / w, cyc / (ms * 1e6));', '}', '',
         'int main() {', '    float *o; unsigned *c; hipMalloc(&o, 256 * 1024 * 4); hipMalloc(&c, 4);', '    for (int w = 1; w <= 4; ++w) {']
-src += [(f'        if (w <= 2) run("{k}", k_{k}, w, o, c);' if k.startswith("mxq") else f'        run("{k}", k_{k}, w, o, c);') for k in KINDS]
+src += [(f'        if (w <= 2) run("{k}", k_{k}, w, o, c);' if k.startswith("mxq") or k.startswith("mxp_") else f'        run("{k}", k_{k}, w, o, c);') for k in KINDS]
 src += ['    }',
         '    { const int iters = 4000; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;',
         '      auto t = [&](const char *nm, auto kern) { kern<<<256, 512>>>(o, c, 100); hipDeviceSynchronize(); hipEventRecord(e0); kern<<<256, 512>>>(o, c, iters); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);',
