@@ -24,6 +24,7 @@ namespace {
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 
 typedef __attribute__((address_space(3))) void lds_void;
 using rsrc_t = __amdgpu_buffer_rsrc_t;
@@ -85,6 +86,9 @@ __global__ void f16_rows_to_panels_kernel(const uint16_t *__restrict__ rows, int
 constexpr int KS = 8;       // k-steps of 16 per LDS stage (128 k)
 #ifndef D16_RING
 #define D16_RING 4
+#endif
+#ifndef D16_AF_AHEAD
+#define D16_AF_AHEAD 2
 #endif
 constexpr int RING = D16_RING;   // weight fragments in flight, in k-steps (A/B: -DD16_RING=n)
 
@@ -164,27 +168,47 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
             bq[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(voffW + 512u * i), (int)((uint32_t)gstep * 2 * w_pan), 0);
     };
 
+    // The stage's A fragments (activations, LDS) run AF_AHEAD n-tile steps ahead of the MFMAs that use them: a ds_read_b128 issued
+    // right in front of its MFMAs exposes the whole LDS latency 32 times per stage (what hipcc makes of the plain loop).
+    constexpr int AF_AHEAD = D16_AF_AHEAD, NSTEP = KS * WNT;
     auto compute = [&](int s, int buf) {
         const uint8_t *sA = gsm + (buf & 1) * C::STAGE + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
+        f16x8 afr[AF_AHEAD + 1];
+        auto fetch_af = [&](auto gc) {
+            constexpr int g = decltype(gc)::value, ks = g / WNT, j = g % WNT;
+            afr[g % (AF_AHEAD + 1)] = *(const f16x8 *)(sA + (ks * 2 * C::TN + 32 * j) * 16);
+        };
+        static_for<AF_AHEAD>([&](auto gc) { fetch_af(gc); });
         static_for<KS>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
             static_for<WNT>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
+                constexpr int j = decltype(jc)::value, g = ks * WNT + j;
                 static_for<C::PP>([&](auto uc) {
                     constexpr int pc = C::PP * (ks * WNT + j) + decltype(uc)::value;
                     if constexpr (pc < C::ROUNDS) dma_piece(s + KSP, buf + 1, std::integral_constant<int, pc>{});
                 });
-                const f16x8 af = *(const f16x8 *)(sA + (ks * 2 * C::TN + 32 * j) * 16);
+                if constexpr (g + AF_AHEAD < NSTEP) fetch_af(std::integral_constant<int, g + AF_AHEAD>{});
+                const f16x8 af = afr[g % (AF_AHEAD + 1)];
 #pragma unroll
                 for (int i = 0; i < WMT; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, bq[ks % RING][i]), acc[i][j], 0, 0, 0);
+                // hipcc's scheduler otherwise sinks the look-ahead reads (LDS fragments, weight ring) down to their uses
+                __builtin_amdgcn_sched_barrier(0);
             });
-            // the DMA pieces of the next stage must have landed before the barrier: drain where nothing is young
+            // The DMA pieces of the next stage must have landed before the barrier.  They are all issued by k-step KS_DMA; vector-memory
+            // operations complete in issue order, so waiting until only the weight loads issued SINCE then are outstanding is enough --
+            // vmcnt(0) here (and again at the barrier) made every wave sit out the L2 latency of its youngest weight loads once per stage.
 #ifndef D16_NODRAIN   /* timing ablation only: without the drain the kernel races */
-            if constexpr (ks == KS - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (ks == KS - 2) {
+                constexpr int KS_DMA = ((C::ROUNDS - 1) / C::PP) / WNT;               // k-step of the last DMA piece
+                constexpr int YOUNGER = (KS - 2 - KS_DMA) * WMT;                        // weight loads issued behind it (end of k-steps KS_DMA .. KS - 3)
+                static_assert(KS_DMA <= KS - 3 && YOUNGER >= 0 && YOUNGER < 64, "drain point");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            }
 #endif
             // this group's next k-steps: the rest of the stage, then its next stage s + KSP
             load_b(ks + RING < KS ? s * KS + ks + RING : (s + KSP) * KS + (ks + RING - KS), std::integral_constant<int, ks % RING>{});
+            __builtin_amdgcn_sched_barrier(0);
         });
     };
 
@@ -198,7 +222,9 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
     for (int it = 0; it < niter; ++it) {
         const int s = it * KSP + grp;
         if (KSP == 1 || s < nstages) compute(s, it);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the drain inside compute, again for a skipped stage)
+        // (KSP > 1: a group may skip its last stage, and with it the drain inside compute; KSP == 1: the weight loads in flight stay in flight)
+        if constexpr (KSP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
@@ -253,6 +279,172 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
         }
 }
 
+// ---- the same product on v_mfma_f32_16x16x32_f16 (K10c): the forms that do not split K (more than 512 src1 rows) ----
+// Same panels, same stage image, same DMA, same wave tile (64 x 128 or 64 x 64 outputs); the tile is cut into 16 x 16 MFMA tiles and a
+// k-step is 32: lane (row l & 15, k-group g = l >> 4) takes the 16-byte entry of panel 4 ks + g -- a 16-lane group reads 256
+// contiguous bytes of LDS.  Flops per cycle are those of the 32 x 32 x 16 shape; what differs is the clock the chip holds under this
+// load (MI355X_MICROARCH.md, DVFS give-back item 7: bare loops on random data ran 1.12-1.15 x the FLOP/s on this shape at equal
+// cycles).  The sum of an output element: k in groups of 32 inside the MFMA, groups in order -- fixed by N and K like every form here.
+template <int WMT, int WNT, int WGM, int WGN>
+struct CfgS {
+    static constexpr int TM = WGM * WMT * 16, TN = WGN * WNT * 16, NT = WGM * WGN * 64;
+    static constexpr int KS32 = KS / 2;                       // k-steps of 32 per stage
+    static constexpr int STAGE = KS * 2 * TN * 16, TOTAL = 2 * STAGE;
+    static constexpr int P = NT / TN;
+    static_assert(NT % TN == 0 && (KS * 2) % P == 0, "chunk decomposition");
+    static constexpr int ROUNDS = KS * 2 * TN / NT;          // DMA pieces per stage, one per n-tile step from the top of the stage
+    static constexpr int NSTEP = KS32 * WNT;
+    static_assert(ROUNDS <= (KS32 - 1) * WNT, "all DMA pieces are issued before the stage's last k-step");
+};
+
+template <int WMT, int WNT, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64, 2)
+void dense16s_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict__ apan, float *__restrict__ dst, int M, int N, int Mpad,
+                     int Npad, int nstages, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes) {
+    using C = CfgS<WMT, WNT, WGM, WGN>;
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    constexpr int KS32 = C::KS32, RING32 = 2;                 // weight fragments in flight, in k-steps of 32
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wn = wave / WGM, wm_ = wave % WGM;
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    int tm_i, tn_i;
+    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {           // 2 x 4 blocks of the tile grid per XCD, as dense16_kernel
+        const int hm = tiles_m >> 1, l = bid >> 3;
+        tm_i = (xcd & 1) * hm + l % hm;
+        tn_i = (xcd >> 1) * (tiles_n >> 2) + l / hm;
+    } else {
+        const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        tm_i = t_lin % tiles_m;
+        tn_i = t_lin / tiles_m;
+    }
+    const int m0 = tm_i * C::TM, n0 = tn_i * C::TN;
+
+    f32x4 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    const uint32_t a_pan = (uint32_t)(Npad * 16);
+    const uint32_t voffA = (uint32_t)(((tid / C::TN) * Npad + n0 + tid % C::TN) * 16);
+    const rsrc_t rA = make_rsrc(apan, a_bytes);
+    auto dma_piece = [&](int s, int buf, auto pc) {
+        constexpr int i = decltype(pc)::value;
+        uint8_t *sp = smem + (buf & 1) * C::STAGE;
+        blds16(rA, sp + (size_t)(wave * 64 + C::NT * i) * 16, voffA, ((uint32_t)s * KS * 2 + C::P * i) * a_pan);
+    };
+
+    const uint32_t w_pan = (uint32_t)(Mpad * 16);
+    const uint32_t voffW = (uint32_t)((g4 * Mpad + m0 + wm_ * WMT * 16 + l15) * 16);
+    const rsrc_t rW = make_rsrc(wpan, w_bytes);
+    u32x4 bq[RING32][WMT];
+    auto load_b = [&](int gstep, auto rc) {                 // global k-step of 32 -> ring slot
+        constexpr int slot = decltype(rc)::value;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+            bq[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(voffW + 256u * i), (int)((uint32_t)gstep * 4 * w_pan), 0);
+    };
+
+    constexpr int AF_AHEAD = D16_AF_AHEAD;
+    auto compute = [&](int s, int buf) {
+        const uint8_t *sA = smem + (buf & 1) * C::STAGE + ((size_t)(g4 * C::TN + wn * WNT * 16 + l15)) * 16;
+        f16x8 afr[AF_AHEAD + 1];
+        auto fetch_af = [&](auto gc) {
+            constexpr int g = decltype(gc)::value, ks = g / WNT, j = g % WNT;
+            afr[g % (AF_AHEAD + 1)] = *(const f16x8 *)(sA + (ks * 4 * C::TN + 16 * j) * 16);
+        };
+        static_for<AF_AHEAD>([&](auto gc) { fetch_af(gc); });
+        static_for<KS32>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            static_for<WNT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, g = ks * WNT + j;
+                if constexpr (g < C::ROUNDS) dma_piece(s + 1, buf + 1, std::integral_constant<int, g>{});
+                if constexpr (g + AF_AHEAD < C::NSTEP) fetch_af(std::integral_constant<int, g + AF_AHEAD>{});
+                const f16x8 af = afr[g % (AF_AHEAD + 1)];
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, __builtin_bit_cast(f16x8, bq[ks % RING32][i]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // next stage's DMA pieces landed before the barrier: all but the weight loads issued since the last piece (see dense16_kernel)
+            if constexpr (ks == KS32 - 2) {
+                constexpr int KS_DMA = (C::ROUNDS - 1) / WNT;
+                constexpr int YOUNGER = (KS32 - 2 - KS_DMA) * WMT;
+                static_assert(KS_DMA <= KS32 - 2 && YOUNGER >= 0, "drain point");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            }
+            load_b(ks + RING32 < KS32 ? s * KS32 + ks + RING32 : (s + 1) * KS32 + (ks + RING32 - KS32), std::integral_constant<int, ks % RING32>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    static_for<C::ROUNDS>([&](auto pc) { dma_piece(0, 0, pc); });
+    static_for<RING32>([&](auto rc) { load_b(decltype(rc)::value, rc); });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int it = 0; it < nstages; ++it) {
+        compute(it, it);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // dst[n][m]: the MFMA leaves D[row = 4 * (lane >> 4) + r][col = lane & 15] of a 16 x 16 tile -- a store of one accumulator register
+    // would write four 64-byte pieces of four rows.  The wave's four m-tiles of one n-tile are 64 consecutive m: transpose (m-tile
+    // index) x (lane group) with two rounds of lane swaps, and a store writes ONE row of dst, 256 contiguous bytes.
+    static_assert(WMT == 4, "the store transpose pairs four m-tiles with the four 16-lane groups");
+    const rsrc_t rD = make_rsrc(dst + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
+    const bool full = n0 + C::TN <= N && m0 + C::TM <= M;
+    const int mw = wm_ * WMT * 16;                            // the wave's first m inside the workgroup tile
+    const bool mok = full || m0 + mw + lane < M;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+        const int nb = (wn * WNT + j) * 16;
+        if (!full && n0 + nb >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint32_t v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float f = acc[i][j][r]; v[i] = __builtin_bit_cast(uint32_t, f); }
+            // (a, b) -> ({a.lo, b.lo}, {a.hi, b.hi}) on halves, then ({a.r0, b.r0, a.r2, b.r2}, {a.r1, b.r1, a.r3, b.r3}) on rows of 16
+            const u32x2 p02 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false), p13 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+            const u32x2 q01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false), q23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+            const uint32_t t[4] = {q01[0], q01[1], q23[0], q23[1]};       // t[g]: row nb + 4 g + r, m = mw + lane
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nr = nb + 4 * g + r;
+                if (full || (mok && n0 + nr < N))
+                    __builtin_amdgcn_raw_buffer_store_b32(t[g], rD, (int)(lane * 4), (int)((uint32_t)(nr * ldd + mw) * 4u), 0);
+            }
+        }
+    }
+}
+
+template <int WMT, int WNT, int WGM, int WGN>
+hipError_t launch_cfg_s(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
+    using C = CfgS<WMT, WNT, WGM, WGN>;
+    auto kern = dense16s_kernel<WMT, WNT, WGM, WGN>;
+    static PerDeviceOnce once;
+    const hipError_t attr = once.max_dynamic_lds((const void *)kern, C::TOTAL);
+    if (attr != hipSuccess) return attr;
+    if (w->Mpad % C::TM != 0 || Npad % C::TN != 0) return hipErrorInvalidValue;
+    const int64_t Kpad = dense16_kpad(w->K);
+    const int tiles_m = (int)((w->M + C::TM - 1) / C::TM), tiles_n = (int)((N + C::TN - 1) / C::TN);
+    const uint64_t w_bytes = (uint64_t)(Kpad / 8 + DENSE16_SPARE_PANELS) * w->Mpad * 16, a_bytes = (uint64_t)(Kpad / 8) * Npad * 16;
+    if (w_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull || (uint64_t)C::TN * ldd * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
+    kern<<<dim3((unsigned)(tiles_m * tiles_n)), C::NT, C::TOTAL, st>>>(w->p16, apan, dst, (int)w->M, (int)N, (int)w->Mpad, (int)Npad,
+                                                                       (int)(Kpad / (16 * KS)), (int)ldd, tiles_m, tiles_n, (uint32_t)w_bytes,
+                                                                       (uint32_t)a_bytes);
+    return hipGetLastError();
+}
+
 template <int WMT, int WNT, int WGM, int WGN, int KSP = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<WMT, WNT, WGM, WGN>;
@@ -300,6 +492,11 @@ hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1
 
 hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     const int64_t Npad = pad_act(N);
+    static const int shape = dev_env_int("GGML_HIP_D16_SHAPE", 0);   // developer A/B switch: 1 = the 32 x 32 x 16 forms everywhere
+    if (N > 512 && shape != 1) {   // (by N alone: the two tile sizes below sum alike)
+        if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg_s<4, 8, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+        return launch_cfg_s<4, 4, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    }
     if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     // batches up to 128 rows: K split four ways inside the workgroup (fixed by N and K: same summation tree for a row shard), on
     // 32-row tiles, or on 128-row tiles of 16 waves where those cover the chip

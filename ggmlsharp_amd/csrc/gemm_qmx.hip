@@ -75,6 +75,9 @@ __device__ unsigned long long k3m_clock_buf[8192 * 2];
 #endif
 
 // WMT x WNT 32x32 tiles per wave, WGM x WGN waves per workgroup, KB k-blocks per LDS stage
+#ifndef GGML_MX_FULLDRAIN    // developer A/B: 1 = vmcnt(0) at the drain point and at the barrier, as through round 2
+#define GGML_MX_FULLDRAIN 0
+#endif
 template <int TYPE, int WMT, int WNT, int WGM, int WGN, int KB>
 struct Cfg {
     static constexpr int TM = WGM * WMT * 32, TN = WGN * WNT * 32, NT = WGM * WGN * 64;
@@ -302,7 +305,16 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
             // for them HERE, in the middle of the stage's last k-block, costs nothing (every vector-memory operation
             // issued so far is at least half a k-block old) and leaves the weight loads issued after this point in
             // flight across the barrier.
-            if constexpr (t == DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (Vector-memory operations complete in issue order: where no wave group skips a stage, waiting until only the weight
+            // loads issued BEHIND the last DMA piece are outstanding is enough -- fragment of tile u, the last n-tile of its block,
+            // is requested in step u - 1; the last piece in step LASTP.)
+            if constexpr (t == DRAIN) {
+                constexpr int LASTP = (C::NPIECE - 1) / C::PP;
+                constexpr int FRAG_LOADS = NF * 2 + 1 + (TYPE == GGML_TYPE_Q4_1 ? 1 : 0);
+                constexpr int YOUNGER = [] { int n = 0; for (int u = LASTP + 1; u <= DRAIN; ++u) n += ((u % NTILE) / WMT == WNT - 1); return n; }() * FRAG_LOADS;
+                if constexpr (KSP == 1 && VS == 1 && YOUNGER < 64 && !GGML_MX_FULLDRAIN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if constexpr (t < LAST) issue(std::integral_constant<int, t + 1>{});
             f32x16 &ac = acc[i][j];
             static_for<4>([&](auto gc) {
@@ -366,7 +378,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         int sn = sc + KV, pn = pass;
         if (VS > 1 && sn >= nstages) { pn = pass + 1; sn = pn < VS ? grp * VS + pn : nstages; }
         if ((KSP == 1 && VS == 1) || sc < nstages) compute(sc, sn, it);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the drain inside compute, again for a skipped stage)
+        // (the drain inside compute, again for a skipped stage; without K split every stage runs and the weight loads in flight stay in flight)
+        if constexpr (KSP == 1 && VS == 1 && !GGML_MX_FULLDRAIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (!(GGML_MX_DBG & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (VS > 1) {

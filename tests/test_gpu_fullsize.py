@@ -247,10 +247,11 @@ def test_batched_decode_form_follows_M_only_in_its_geometry(dev, N):
         W.free()
 
 
-@pytest.mark.parametrize("N", [100, 300])
+@pytest.mark.parametrize("N", [100, 300, 1536 + 5])
 def test_dense_f16_tile_forms_agree_bitwise(dev, N):
-    """F16 weights: the K split of a batch (four ways up to 128 rows, two ways up to 512) is fixed by N and K, the tile shape by
-    the number of tiles -- a 2048-row shard and the 16384-row matrix run different tiles and must agree bit for bit."""
+    """F16 weights: the K split of a batch (four ways up to 128 rows, two ways up to 512) and the MFMA shape (16 x 16 x 32 above
+    512 rows) are fixed by N and K, the tile shape by the number of tiles -- a 2048-row shard and the 16384-row matrix run
+    different tiles (above 512 rows: 256 x 128 against 128 x 128 workgroup tiles) and must agree bit for bit."""
     M, K = 16384, 2048
     g = torch.Generator(device="cuda")
     g.manual_seed(3 + N)
