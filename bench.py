@@ -408,20 +408,32 @@ def self_launch(args):
 PREHEAT_S = float(os.environ.get("GGML_BENCH_PREHEAT_S", "0.6"))
 
 
-def preheat(fn, seconds=None):
-    """Untimed: run `fn` back to back for `seconds` so that the timed region that follows starts on a chip that is already busy.
+def preheat(fn, seconds=None, world=1):
+    """Untimed: run `fn` back to back for about `seconds` so that the timed region that follows starts on a chip that is already busy.
     The clock of an MI355X that was idle (or busy for milliseconds only) is not the clock it holds in service: the same
     4096^3 kernel on the same data measured 177 us per launch over 20 launches after 3 warm-up launches, 152 us over 200,
     144 us over 5000 (docs/experiments/README.md).  A handful of warm-up steps is over in a millisecond; this is the part
-    of the warm-up that is measured in time rather than in steps.  Returns the number of calls made."""
+    of the warm-up that is measured in time rather than in steps.  With several ranks `fn` holds collectives, so every rank must
+    make the SAME number of calls: rank 0 times one chunk, the chunk count is broadcast.  Returns the number of calls made."""
     seconds = PREHEAT_S if seconds is None else seconds
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(16):
+    if seconds <= 0:
+        return 0
+    chunk = 16
+    t0 = time.perf_counter()
+    for _ in range(chunk):
+        fn()
+    torch.cuda.synchronize()
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n_chunks = max(0, min(int(seconds / dt), 100000))
+    if world > 1:
+        t = torch.tensor([n_chunks], dtype=torch.int64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.broadcast(t, src=0)
+        n_chunks = int(t.item())
+    for _ in range(n_chunks):
+        for _ in range(chunk):
             fn()
         torch.cuda.synchronize()
-        n += 16
-    return n
+    return chunk * (1 + n_chunks)
 
 
 def timed_steps(fn, warmup, steps, world):
@@ -620,7 +632,7 @@ def main():
     # the round-2 protocol first (W warm-up steps on a chip that was busy for milliseconds), reported as "cold"; then the same
     # W + K steps behind PREHEAT_S seconds of the same step: the steady-state figure, which is `value`
     cold_ms_per_step = timed_steps(lambda: runner.step(x), args.warmup, args.steps, world)
-    n_pre = preheat(lambda: runner.step(x))
+    n_pre = preheat(lambda: runner.step(x), world=world)
     ms_per_step = timed_steps(lambda: runner.step(x), args.warmup, args.steps, world)
     flops_step = 2.0 * M * K * N
     value = flops_step / (ms_per_step * 1e-3) / 1e9
