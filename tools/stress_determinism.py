@@ -51,7 +51,8 @@ for (M, K, N) in SHAPES:
             del wd, xs, first
 lib().ggml_hip_debug_force_gemm(0)
 # dense weights: F16 (dense16.hip on full grids, dense.hip otherwise) and F32 (dense.hip)
-for (M, K, N) in ((4096, 4096, 4096), (2048, 1000, 300), (512, 4096, 7), (4096, 4096, 64), (16384, 2048, 100), (4096, 2048, 300), (3000, 4096, 3)):
+for (M, K, N) in ((4096, 4096, 4096), (2048, 1000, 300), (512, 4096, 7), (4096, 4096, 64), (16384, 2048, 100), (4096, 2048, 300), (3000, 4096, 3),
+                  (1000, 4104, 700), (9000, 1032, 1537), (300, 11008, 513)):      # the 16 x 16 x 32 forms (N > 512): 128 x 128 and 256 x 128 tiles, ragged edges
     for t, dt in ((1, torch.float16), (0, torch.float32)):
         g = torch.Generator(device="cuda"); g.manual_seed(M + N + t)
         w = torch.randn((M, K), generator=g, device="cuda").to(dt)
