@@ -36,6 +36,7 @@ for f in newest(f"gpurun_out/pmc_{tag}_stats.log"):
     lines.append("## kbench's own HIP-event timings in the same (profiled) run")
     lines += [ln.rstrip() for ln in open(f) if re.match(r"^(q\d|f16|f32)", ln)]
     lines.append("")
+hbm = collections.defaultdict(dict)          # kernel -> {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "dur_us": ...}
 for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_p*/")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
@@ -58,8 +59,17 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_p*/")):
             a = sum(v) / len(v)
             if name in ("FETCH_SIZE", "WRITE_SIZE"):
                 lines.append(f"    {name:28s} {a:14.1f} KB")
+                hbm[k][name] = a
+                hbm[k]["dur_us"] = sum(du) / len(du) / 1e3
             else:
                 lines.append(f"    {name:28s} {a / 1e6:14.4f} M")
     lines.append("")
+lines.append("## HBM-side traffic against the 8 TB/s roofline (per launch: 2 * FETCH_SIZE + WRITE_SIZE, over the kernel's duration in the FETCH_SIZE pass)")
+for k, v in sorted(hbm.items()):
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v and v.get("dur_us", 0) > 0:
+        b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        lines.append(f"{k}: {b / 1e6:8.1f} MB per launch / {v['dur_us']:.1f} us = {b / v['dur_us'] / 1e3:7.1f} GB/s = {b / v['dur_us'] / 1e3 / 8000:.3f} of 8 TB/s")
+lines.append("")
+out = out[:-4] if out.endswith(".txt") else out
 open(f"profiles/{out}.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
