@@ -463,6 +463,9 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (type == GGML_TYPE_F16) {   // k-panel copy for the f16 MFMA kernel (dense16.hip)
             off_p16 = total;
             total += (size_t)(dense16_kpad(K) / 8 + DENSE16_SPARE_PANELS) * w->Mpad * 16;
+        } else {                       // the rows as three bf16 pieces per element (dense16.hip K10d)
+            off_p16 = total;
+            total += (size_t)(dense16_kpad(K) / 8 * 3 + DENSE32_SPARE_PANELS) * w->Mpad * 16;
         }
     } else {
         w->nbk = K / QK;
@@ -492,6 +495,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
         w->dense = base;
         if (type == GGML_TYPE_F16) w->p16 = (uint8_t *)base + off_p16;
+        else w->p32 = (uint8_t *)base + off_p16;
     } else {
         w->qs = (uint8_t *)base + off_qs;
         w->d = (float *)((uint8_t *)base + off_d);
@@ -580,6 +584,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
     if (e == hipSuccess) e = launch_q5_to_i8(w, st);
     if (e == hipSuccess) e = launch_gemv_side_image(w, st);
     if (e == hipSuccess) e = launch_f16_rows_to_panels(w, st);
+    if (e == hipSuccess) e = launch_f32_rows_to_split_panels(w, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (staging) (void)hipFree(staging);
     if (e != hipSuccess) {
@@ -710,6 +715,7 @@ size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
     if (K <= 0 || N <= 0) return 0;
     if (type == GGML_HIP_TYPE_Q5_K) type = GGML_TYPE_Q5_1;      // same operand images
     if (type == GGML_TYPE_F16) return (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 2;   // src1 as Half (Ggml.cs:3356-3357), padded
+    if (type == GGML_TYPE_F32) return N > 256 ? (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 6 : 0;   // src1 as three bf16 pieces (dense16.hip K10d; the reference needs none)
     if (!is_q(type)) return 0;
     return act_bytes(K, pad_act(N));
 }
@@ -805,6 +811,12 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
             ((uintptr_t)d_src1 & 15) == 0) {      // (the INIT kernel reads src1 rows in 16-byte pieces)
             HIP_TRY(launch_dense16_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));       // INIT: src1 -> Half (Ggml.cs:6362-6379)
             HIP_TRY(launch_dense16(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
+            return GGML_HIP_OK;
+        }
+        if (dense32_serves(w, N) && d_work && work_bytes >= ggml_hip_mul_mat_work_size(w->type, w->K, N) && ld1 % 4 == 0 &&
+            ((uintptr_t)d_src1 & 15) == 0) {
+            HIP_TRY(launch_dense32_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));
+            HIP_TRY(launch_dense32(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
             return GGML_HIP_OK;
         }
         HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));

@@ -66,6 +66,7 @@ struct ggml_hip_weight {
                       //   beside the 0.69 B / weight of the format, for prompt-sized batches (gemm_qmp.hip)
     void    *dense;
     uint8_t *p16;     // F16 only: k-panel-major copy [Kpad/8 + spare][Mpad][16 B] for dense16.hip
+    uint8_t *p32;     // F32 only: the rows split exactly into three bf16 pieces, [Kpad/8 * 3 + spare][Mpad][16 B] (dense16.hip K10d): 6 B / weight
     uint32_t *gs;     // mat-vec side image (gemv.hip): the per-block words a 16-row tile needs beside its nibbles, tile-major
                       //   [Mpad/16][nbk][NP][16 rows] 4-byte words, planes in the order d, m, qh (NP = 1..3 by type).  A copy of
                       //   d / m / qh: in their [k-block][row] planes a tile's share of a k-block is one 64-byte piece per plane
@@ -263,6 +264,12 @@ hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st);
 bool dense16_serves(const ggml_hip_weight *w, int64_t N);
 hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st);
 hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+// K10d (dense16.hip): F32 x F32 on the bf16 matrix cores, operands split into three bf16 pieces
+#define DENSE32_SPARE_PANELS 24          // (one stage of look-ahead past the padded end: zero)
+hipError_t launch_f32_rows_to_split_panels(ggml_hip_weight *w, hipStream_t st);
+bool dense32_serves(const ggml_hip_weight *w, int64_t N);
+hipError_t launch_dense32_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st);
+hipError_t launch_dense32(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 // eltwise.hip (op: 0 add, 1 mul; contiguous f32)
 hipError_t launch_binary_f32(int op, const float *x, const float *y, float *z, int64_t n, hipStream_t st);
 hipError_t launch_scale_f32(float *z, int64_t n, float v, hipStream_t st);

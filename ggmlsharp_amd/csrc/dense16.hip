@@ -463,6 +463,213 @@ hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, 
     return hipGetLastError();
 }
 
+
+// ---- K10d: dense F32 x F32 on the bf16 matrix cores, every f32 operand split EXACTLY into three bf16 pieces -------------------------
+// ggml_compute_forward_mul_mat_f32 (Ggml.cs:5969-6178; ggml_vec_dot_f32 2631-2640: f32 products, f64 running sum).  The f32 matrix
+// instruction (v_mfma_f32_32x32x2_f32, dense.hip) runs at 1/16 of the bf16 rate.  a = a0 + a1 + a2 with bf16 pieces (truncation: the
+// three pieces hold the 24 significand bits exactly), likewise b, and
+//     a * b = a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0) + [a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b|, dropped]
+// Every kept product of two bf16 values is exact in f32; the six partial products go through six v_mfma_f32_16x16x32_bf16 per tile and
+// k-step into ONE f32 accumulator.  Error against the exact product: 2^-23 relative -- that of rounding the product to f32, which the
+// reference does -- and the sum is f32 as in dense.hip (the reference: f64): same class as the kernel it replaces, 2.2 x its speed.
+// Images: panel-plane q = 3 * (k / 8) + piece, [Kpad/8 * 3][rows][16 B] for both operands (weights at upload, src1 by the INIT kernel).
+// Workgroup 128 x 128, four waves of 64 x 64 (4 x 4 MFMA tiles); a stage is ONE k-step of 32 (4 panels x 3 pieces x 128 rows = 24 KB of
+// LDS, double-buffered), 96 MFMAs per wave and stage; the weights of the next stage travel into a second register set meanwhile.
+__device__ __forceinline__ void split3(float a, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+    const uint32_t b0 = __float_as_uint(a) & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(b0);                       // exact
+    const uint32_t b1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b1);                      // exact, at most 8 significant bits
+    p0 = b0 >> 16; p1 = b1 >> 16; p2 = __float_as_uint(r2) >> 16;
+}
+
+// INIT: src1 f32 rows -> split image; a thread owns 8 consecutive k of one row = one 16-byte entry of each of the three planes
+__global__ __launch_bounds__(256) void convert_act_split_kernel(const float *__restrict__ x, int64_t N, int64_t K, int64_t Kpad, int64_t ld1,
+                                                               uint8_t *__restrict__ img, int64_t Npad) {
+    const int64_t n = (int64_t)blockIdx.y * 32 + (threadIdx.x >> 3);
+    const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x & 7);             // panel (8 k)
+    if (n >= N || p * 8 >= Kpad) return;
+    const float *row = x + n * ld1 + p * 8;
+    float v[8];
+    if (p * 8 + 7 < K) {
+        const float4 a = *(const float4 *)row, b = *(const float4 *)(row + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p * 8 + e < K ? row[e] : 0.0f;
+    }
+    uint32_t w[3][4] = {};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        uint32_t q0, q1, q2;
+        split3(v[e], q0, q1, q2);
+        w[0][e >> 1] |= q0 << (16 * (e & 1)); w[1][e >> 1] |= q1 << (16 * (e & 1)); w[2][e >> 1] |= q2 << (16 * (e & 1));
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *(uint4 *)(img + ((p * 3 + pl) * Npad + n) * 16) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+// weights: f32 rows -> split panels [Kpad/8 * 3 + spare][Mpad][16 B] (zero past K and past M: the buffer is pre-zeroed)
+__global__ void f32_rows_to_split_panels_kernel(const float *__restrict__ rows, int64_t M, int64_t K, int64_t Mpad, uint8_t *__restrict__ pan) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    if (m >= M) return;
+    uint32_t w[3][4] = {};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t k = p * 8 + e;
+        uint32_t q0 = 0, q1 = 0, q2 = 0;
+        if (k < K) split3(rows[m * K + k], q0, q1, q2);
+        w[0][e >> 1] |= q0 << (16 * (e & 1)); w[1][e >> 1] |= q1 << (16 * (e & 1)); w[2][e >> 1] |= q2 << (16 * (e & 1));
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *(uint4 *)(pan + ((p * 3 + pl) * Mpad + m) * 16) = make_uint4(w[pl][0], w[pl][1], w[pl][2], w[pl][3]);
+}
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__global__ __launch_bounds__(256, 2)
+void dense32s_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict__ apan, float *__restrict__ dst, int M, int N, int Mpad,
+                     int Npad, int nstages, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    constexpr int WMT = 4, WNT = 4, TM = 128, TN = 128, NT = 256;
+    constexpr int STAGE = 12 * TN * 16;                       // 4 panels x 3 pieces
+    constexpr int ROUNDS = 12 * TN / NT;                      // DMA pieces per stage (6)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wn = wave >> 1, wm_ = wave & 1;
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    int tm_i, tn_i;
+    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {           // 2 x 4 blocks of the tile grid per XCD, as dense16_kernel
+        const int hm = tiles_m >> 1, l = bid >> 3;
+        tm_i = (xcd & 1) * hm + l % hm;
+        tn_i = (xcd >> 1) * (tiles_n >> 2) + l / hm;
+    } else {
+        const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+        tm_i = t_lin % tiles_m;
+        tn_i = t_lin / tiles_m;
+    }
+    const int m0 = tm_i * TM, n0 = tn_i * TN;
+
+    f32x4 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    // activations: DMA, chunk c = tid + NT * i of a stage = [12 panel-planes][TN rows] x 16 B (two panel-planes per round)
+    const uint32_t a_pan = (uint32_t)(Npad * 16);
+    const uint32_t voffA = (uint32_t)(((tid / TN) * Npad + n0 + tid % TN) * 16);
+    const rsrc_t rA = make_rsrc(apan, a_bytes);
+    auto dma_piece = [&](int s, int buf, auto pc) {
+        constexpr int i = decltype(pc)::value;
+        uint8_t *sp = smem + (buf & 1) * STAGE;
+        blds16(rA, sp + (size_t)(wave * 64 + NT * i) * 16, voffA, ((uint32_t)s * 12 + 2 * i) * a_pan);
+    };
+    // weights: registers, one stage ahead; lane (row l15, k-group g4) takes panel-plane 3 * (4 s + g4) + piece
+    const uint32_t w_pan = (uint32_t)(Mpad * 16);
+    const uint32_t voffW = (uint32_t)((3 * g4 * Mpad + m0 + wm_ * 64 + l15) * 16);
+    const rsrc_t rW = make_rsrc(wpan, w_bytes);
+    u32x4 bq[2][3][WMT];
+    auto load_b = [&](int s, auto sc) {
+        constexpr int slot = decltype(sc)::value;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+                bq[slot][pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(voffW + (uint32_t)pl * w_pan + 256u * i), (int)((uint32_t)s * 12 * w_pan), 0);
+    };
+
+    // piece pairs (src1, weight), smallest products first
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    auto compute = [&](int s, auto sc) {
+        constexpr int slot = decltype(sc)::value;
+        const uint8_t *sA = smem + (s & 1) * STAGE + ((size_t)(3 * g4 * TN + wn * 64 + l15)) * 16;
+        u32x4 af[2][3];
+        auto fetch_af = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[j & 1][pl] = *(const u32x4 *)(sA + (pl * TN + 16 * j) * 16);
+        };
+        fetch_af(std::integral_constant<int, 0>{});
+        // the next stage: its DMA pieces first (they must have landed at this stage's barrier), its weights behind them
+        static_for<ROUNDS>([&](auto pc) { dma_piece(s + 1, s + 1, pc); });
+        load_b(s + 1, std::integral_constant<int, 1 - slot>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // The six products of an n-tile and k-step go into a FRESH accumulator t (the matrix pipe truncates when it aligns its partial sums
+        // with the accumulator: harmless against a block's own small sum, a bias of up to 768 half-ulps against the running sum -- measured
+        // 1.6e-5 of the rms at K = 4096 with everything in one accumulator); t joins the running sum by a rounded VALU add, issued behind the
+        // MFMAs of the NEXT n-tile so that the pipe never waits for it.
+        f32x4 t[2][WMT];
+        static_for<WNT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 1 < WNT) fetch_af(std::integral_constant<int, j + 1>{});
+            // (everything requested at the top of the stage is three n-tile steps = 72 MFMAs old here)
+            if constexpr (j == WNT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+                    t[j & 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j & 1][PA[c]]), __builtin_bit_cast(bf16x8, bq[slot][PB[c]][i]),
+                                                                          c == 0 ? (f32x4){0.0f, 0.0f, 0.0f, 0.0f} : t[j & 1][i], 0, 0, 0);
+            if constexpr (j > 0) {
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) acc[i][j - 1] += t[(j - 1) & 1][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) acc[i][WNT - 1] += t[(WNT - 1) & 1][i];
+    };
+
+    static_for<ROUNDS>([&](auto pc) { dma_piece(0, 0, pc); });
+    load_b(0, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < nstages; s += 2) {                    // (nstages is even: K is padded to whole groups of 128)
+        compute(s, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        compute(s + 1, std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // dst[n][m]: the store transpose of dense16s_kernel (one 256-byte row of dst per store)
+    const rsrc_t rD = make_rsrc(dst + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
+    const bool full = n0 + TN <= N && m0 + TM <= M;
+    const int mw = wm_ * 64;
+    const bool mok = full || m0 + mw + lane < M;
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+        const int nb = (wn * WNT + j) * 16;
+        if (!full && n0 + nb >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint32_t v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float f = acc[i][j][r]; v[i] = __builtin_bit_cast(uint32_t, f); }
+            const u32x2 p02 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false), p13 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+            const u32x2 q01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false), q23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+            const uint32_t t[4] = {q01[0], q01[1], q23[0], q23[1]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nr = nb + 4 * g + r;
+                if (full || (mok && n0 + nr < N))
+                    __builtin_amdgcn_raw_buffer_store_b32(t[g], rD, (int)(lane * 4), (int)((uint32_t)(nr * ldd + mw) * 4u), 0);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st) {
@@ -513,4 +720,47 @@ hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N,
         return launch_cfg<1, 2, 4, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     }
     return launch_cfg<2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+}
+
+// ---- K10d host side ----
+hipError_t launch_f32_rows_to_split_panels(ggml_hip_weight *w, hipStream_t st) {
+    if (!w->p32 || w->M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)(dense16_kpad(w->K) / 8));
+    f32_rows_to_split_panels_kernel<<<grid, 256, 0, st>>>((const float *)w->dense, w->M, w->K, w->Mpad, w->p32);
+    return hipGetLastError();
+}
+
+// true when the split-bf16 kernel serves this shape (by N alone: a row shard runs the arithmetic of the unsplit matrix); else dense.hip
+bool dense32_serves(const ggml_hip_weight *w, int64_t N) {
+    if (w->type != GGML_TYPE_F32 || !w->p32) return false;
+    static const int old = dev_env_int("GGML_HIP_D32_OLD", 0);   // developer A/B switch: 1 = dense.hip (f32 matrix instruction) everywhere
+    if (old == 1) return false;
+    const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
+    if ((Kpad / 8 * 3 + DENSE32_SPARE_PANELS) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (Kpad / 8 * 3) * Npad * 16 > 0xFFFFFFFFull) return false;
+    // By N alone.  A workgroup's K loop is one latency chain (K = 4096: ~165 us whatever the grid), so the form pays once the 128 x 128
+    // tiles cover the chip: 4096 x 4096 x N, this kernel | dense.hip in us -- N = 128 167 | 120, 256 168 | 122, 512 171 | 173, 1024 186 | 287,
+    // 4096 623 | 1200 (11008 x 4096 x 256: 175 | 229; 32000 x 4096 x 128: 222 | 344).
+    return N > 256;
+}
+
+hipError_t launch_dense32_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st) {
+    const int64_t Kpad = dense16_kpad(K), Npad = pad_act(N);
+    dim3 grid((unsigned)((Kpad / 8 + 7) / 8), (unsigned)((N + 31) / 32));
+    convert_act_split_kernel<<<grid, 256, 0, st>>>(x, N, K, Kpad, ld1, (uint8_t *)work, Npad);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense32(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    const int64_t Npad = pad_act(N), Kpad = dense16_kpad(w->K);
+    constexpr int LDS = 2 * 12 * 128 * 16;
+    static PerDeviceOnce once;
+    const hipError_t attr = once.max_dynamic_lds((const void *)dense32s_kernel, LDS);
+    if (attr != hipSuccess) return attr;
+    if (w->Mpad % 128 != 0 || Npad % 128 != 0) return hipErrorInvalidValue;
+    const int tiles_m = (int)((w->M + 127) / 128), tiles_n = (int)((N + 127) / 128);
+    const uint64_t w_bytes = (uint64_t)(Kpad / 8 * 3 + DENSE32_SPARE_PANELS) * w->Mpad * 16, a_bytes = (uint64_t)(Kpad / 8 * 3) * Npad * 16;
+    if (w_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull || (uint64_t)128 * ldd * 4 > 0xFFFFFFFFull) return hipErrorNotSupported;
+    dense32s_kernel<<<dim3((unsigned)(tiles_m * tiles_n)), 256, LDS, st>>>(w->p32, (const uint8_t *)work, dst, (int)w->M, (int)N, (int)w->Mpad, (int)Npad,
+                                                                           (int)(Kpad / 32), (int)ldd, tiles_m, tiles_n, (uint32_t)w_bytes, (uint32_t)a_bytes);
+    return hipGetLastError();
 }

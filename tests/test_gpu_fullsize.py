@@ -270,6 +270,29 @@ def test_dense_f16_tile_forms_agree_bitwise(dev, N):
     W.free()
 
 
+def test_dense_f32_split_form_is_tight_and_shards_are_bitwise_slices(dev):
+    """F32 weights above 256 src1 rows: every operand as three bf16 pieces, six bf16 MFMAs per product, a fresh accumulator per k-step
+    joined by a rounded add (dense16.hip K10d).  Tighter than the f32 fma chain it replaces (max 1.5e-5 of the rms at K = 4096), and a row
+    shard is the bitwise slice of the unsplit product (one tile form, chosen by N alone)."""
+    M, K, N = 3000, 4096 + 24, 700
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 3
+    rows = w.view(torch.uint8).view(M, -1)
+    W = dev.Weight.from_device(0, rows, K)
+    full = dev.mul_mat(W, x)
+    ref = x.double() @ w.double().T
+    err = (full.double() - ref).abs()
+    assert (err.max() / ref.pow(2).mean().sqrt()).item() < 8e-6
+    for (r0, r1) in ((0, 1000), (1111, 1300), (2990, 3000)):
+        Ws = dev.Weight.from_device(0, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1])
+        Ws.free()
+    assert np.array_equal(W.download(), w.cpu().numpy().view(np.uint8).reshape(-1))      # the row-major copy still round-trips
+    W.free()
+
+
 def test_fullsize_byte_roundtrips(dev):
     M, K = 4096, 4096
     for t in (Q4_0, Q5_0, Q8_0):

@@ -29,28 +29,30 @@ def ev_ms(fn, iters):
     return s.elapsed_time(e) / iters
 
 
-def run_f16(M, K, N, iters):
-    """dense f16 x f32 (ggml_compute_forward_mul_mat_f16_f32): the f16 MFMA kernel incl. its INIT (src1 -> Half)"""
+def run_f16(M, K, N, iters, f32=False):
+    """dense f16 x f32 (ggml_compute_forward_mul_mat_f16_f32): the f16 MFMA kernel incl. its INIT (src1 -> Half); f32: the F32 x F32 product"""
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
-    w = torch.randn((M, K), generator=g, device="cuda").half()
+    w = torch.randn((M, K), generator=g, device="cuda")
+    if not f32:
+        w = w.half()
     x = torch.randn((N, K), generator=g, device="cuda")
-    W = device.Weight.from_device(1, w.contiguous().view(torch.uint8), K)
+    W = device.Weight.from_device(0 if f32 else 1, w.contiguous().view(torch.uint8), K)
     out = torch.empty((N, M), device="cuda")
-    work = device.alloc_work(1, K, N)
+    work = device.alloc_work(0 if f32 else 1, K, N)
     device.mul_mat(W, x, out=out, work=work)
-    ref = x.half().double() @ w.double().T
+    ref = (x.double() if f32 else x.half().double()) @ w.double().T
     err = (out.double() - ref).abs()
     rms = ref.pow(2).mean().sqrt()
     t = ev_ms(lambda: device.mul_mat(W, x, out=out, work=work), iters)
-    print(f"f16 M{M} K{K} N{N}: init+compute {t * 1e3:8.1f} us  {2.0 * M * K * N / t / 1e9:9.1f} TFLOP/s  "
+    print(f"{'f32' if f32 else 'f16'} M{M} K{K} N{N}: init+compute {t * 1e3:8.1f} us  {2.0 * M * K * N / t / 1e9:9.1f} TFLOP/s  "
           f"max_err/rms {err.max().item() / rms.item():.2e}", flush=True)
     W.free()
 
 
 def run(tname, M, K, N, iters, check=True, copies=1):
-    if tname == "f16":
-        return run_f16(M, K, N, iters)
+    if tname in ("f16", "f32"):
+        return run_f16(M, K, N, iters, f32=tname == "f32")
     t = TYPES[tname]
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
