@@ -206,7 +206,9 @@ int     ggml_hip_weight_type(const ggml_hip_weight *w);
  * For F32 / F16 weights it is ggml_compute_forward_mul_mat_f32 / _f16_f32 (Ggml.cs:5969-6178, 6180-6438).
  * d_src1: device f32 [N rows][K], row stride ld1 ELEMENTS; d_dst: device f32 [N][M], row stride ldd ELEMENTS
  * (the reference's dst layout: element (i01, ic) at ic*ne0 + i01, Ggml.cs:6692-6697).
- * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378).
+ * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378; F32 weights: none in the
+ *         reference, here 6 B per src1 element above 256 src1 rows -- src1 as three bf16 pieces for the matrix cores; without it, or
+ *         with src1 not 16-byte aligned, the f32 matrix-instruction kernel runs instead: same contract, half the speed).
  * Alignment: for quantized weights d_src1 must be 16-byte aligned and ld1 a multiple of 4 (the INIT kernels read rows in
  * 16-byte pieces); GGML_HIP_ERR_SHAPE otherwise.  The device the weight lives on is made current for the launch. */
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);

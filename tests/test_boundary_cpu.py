@@ -209,7 +209,8 @@ def test_argument_validation_without_touching_a_device():
     assert L.ggml_hip_weight_upload(G.Q4_0, p, 64, 1, 20, 0, 1, None, C.byref(h)) == _lib.ERR_SHAPE     # nb01 < row
     assert L.ggml_hip_weight_upload(G.Q4_0, None, 64, 1, 40, 0, 1, None, C.byref(h)) == _lib.ERR_ARG
     assert L.ggml_hip_mul_mat_work_size(G.Q4_0, 4096, 500) == 128 * 4 * 512 * 16 + 2 * 128 * 512 * 4   # rows padded to 256
-    assert L.ggml_hip_mul_mat_work_size(G.F32, 4096, 512) == 0                                          # Ggml.cs:3360-3364
+    assert L.ggml_hip_mul_mat_work_size(G.F32, 4096, 256) == 0                                          # Ggml.cs:3360-3364
+    assert L.ggml_hip_mul_mat_work_size(G.F32, 4096, 300) == 4096 * 512 * 6                             # (above 256 rows: src1 as three bf16 pieces)
 
 
 def test_reference_style_c_program_compiles_links_and_fails_loudly_without_gpu(tmp_path):
