@@ -1043,8 +1043,9 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // in the multi-tile forms -- a different f32 addition order (measured: last-bit differences against the unsplit matrix).
     // 512 x 4096 x 4096: 45.1 -> 40.6 us (the form is stage-latency bound: four tile-blocks of work per wave and barrier).
     if constexpr (TYPE == GGML_TYPE_Q4_0) {
-        const int64_t wg64 = ((w->M + 63) / 64) * ((N + 63) / 64);
-        if (var == 32 || (var != 31 && tm128 * ((N + 63) / 64) <= 256 && wg64 >= 384))
+        // (r3: wherever the 128 x 64 grid leaves CUs idle, not only from 384 of the smaller tiles on -- 1024 x 4096 x 768 37.0 -> 26.3 us,
+        // 512 x 4096 x 1024 36.8 -> 24.1, 256 x 4096 x 2048 36.7 -> 27.3, 1536 x 4096 x 900 37.7 -> 33.6, 512 x 11008 x 2048 94.5 -> 71.8)
+        if (var == 32 || (var != 31 && tm128 * ((N + 63) / 64) <= 256))
             return launch_cfg<TYPE, 1, 1, 2, 2, 4, 2>(w, p, N, dst, ldd, st);                      // 64 x 64, 1 tile per wave
     }
     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
