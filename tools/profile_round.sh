@@ -13,6 +13,8 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY
 done
 # dense f16 path: MFMA utilisation of dense16_kernel (SQ_VALU_MFMA_BUSY_CYCLES / 4 SIMD-cycles vs SQ_BUSY...)
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmc_${T}_dense16 -- python3 $R/tools/kbench.py --cfg f16:4096:4096:4096 --iters 5 > $R/gpurun_out/pmc_${T}_dense16.log 2>&1 || exit 4
+# dense f32 path (operands as three bf16 pieces each, six bf16 MFMAs per product): the same counters for dense32s_kernel
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/pmc_${T}_dense32 -- python3 $R/tools/kbench.py --cfg f32:4096:4096:4096 --iters 5 > $R/gpurun_out/pmc_${T}_dense32.log 2>&1 || exit 4
 echo ok
 # round 3: the other BASELINE configs, one set of passes each (summaries: tools/summarize_cfgs.py <tag> <name> <kernel regex>)
 bash $R/tools/pmc_cfgs.sh ${T}c3 q4_0:4096:4096:512 || exit 5

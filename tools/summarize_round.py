@@ -10,7 +10,7 @@ import json
 import re
 import shutil
 
-PAT = re.compile("gemm_q|gemv_q|gemv_fused|quantize_act|dense16|convert_act")
+PAT = re.compile("gemm_q|gemv_q|gemv_fused|quantize_act|dense16|dense32|convert_act")
 
 
 def short(n):
