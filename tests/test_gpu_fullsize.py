@@ -70,6 +70,27 @@ def _check_oracle_sample(t, rows, w, x, got, K, seed, nm=64, nn=64):
     assert np.linalg.norm(g - ref) / np.linalg.norm(ref) <= 1e-3
 
 
+def _check_dense_oracle_sample(t, w_raw, x, got, K, seed, nm=48, nn=48):
+    """nm x nn outputs of a full-size DENSE product against the CPU oracle's mul_mat on the sampled weight rows and src1 rows
+    (ggml_compute_forward_mul_mat_f32 / _f16_f32, Ggml.cs:5969-6178 / 6180-6438: f32 or Half products, f64 running sum).
+    SURVEY 8(c)'s metric with the floor of the quantized samples: the kernels sum in f32, not f64."""
+    M, N = w_raw.shape[0], x.shape[0]
+    rs = np.random.default_rng(seed)
+    ms = np.sort(rs.choice(M, size=min(nm, M), replace=False))
+    ns = np.sort(rs.choice(N, size=min(nn, N), replace=False))
+    ws = w_raw[torch.from_numpy(ms).cuda()].cpu().numpy()
+    xs = x[torch.from_numpy(ns).cuda()].cpu().numpy()
+    wo = ws if t == O.F32 else ws.view(np.uint16)
+    ref = O.mul_mat(t, np.ascontiguousarray(wo), np.ascontiguousarray(xs), len(ms), K, len(ns), nth=4)[0, 0].astype(np.float64)
+    g = got[torch.from_numpy(ns).cuda()][:, torch.from_numpy(ms).cuda()].double().cpu().numpy()
+    rms = float(np.sqrt(np.mean(ref * ref)))
+    err = np.abs(g - ref)
+    floor = max(1e-6, 8 * 2.0 ** -24 * np.sqrt(K / 32)) * rms
+    bad = err > np.maximum(1e-3 * np.abs(ref), floor)
+    assert not bad.any(), f"{bad.sum()} of {bad.size} sampled outputs beyond SURVEY 8(c); max err {err.max():.3e}, rms {rms:.3e}"
+    assert np.linalg.norm(g - ref) / np.linalg.norm(ref) <= 1e-3
+
+
 def _check_fp64(dev, t, rows, x, got, K):
     wd = dev.dequantize_rows(t, rows, K).double()
     xq = dev.dequantize_rows(Q8_0, dev.quantize_rows(Q8_0, x.contiguous()), K).double()
@@ -129,13 +150,15 @@ def test_dense_f16_fullsize_matches_fp64(dev, M, K, N):
     rms = ref.pow(2).mean().sqrt()
     assert (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item() == 0, f"max err / rms = {(err.max() / rms).item():.3e}"
     assert np.array_equal(W.download(), w.cpu().numpy().view(np.uint8).reshape(-1))      # the row-major copy still round-trips
+    _check_dense_oracle_sample(O.F16, w, x, got, K, seed=M + N)
     W.free()
 
 
-@pytest.mark.parametrize("M,K,N", [(2048, 1056, 2048 + 17), (4096, 512, 4096), (2000, 1024, 64)])
+@pytest.mark.parametrize("M,K,N", [(2048, 1056, 2048 + 17), (4096, 512, 4096), (2000, 1024, 64), (4096, 4096, 4096)])
 def test_dense_f32_fullsize_matches_fp64(dev, M, K, N):
     """ggml_compute_forward_mul_mat_f32 (Ggml.cs:5969-6178; dot 2631-2640: f32 products, f64 sum) at sizes served by the
-    128 x 128-tile kernel of dense.hip (the first two) and by its 64 x 64 one: f32 fma chain in k order, ~1e-6 relative."""
+    split-bf16 kernel of dense16.hip (more than 256 src1 rows: six bf16 MFMAs per product, K10d) and by dense.hip's 64 x 64 tiles (the
+    third: f32 fma chain in k order); sampled outputs also against the CPU oracle."""
     g = torch.Generator(device="cuda")
     g.manual_seed(M + N)
     w = torch.randn((M, K), generator=g, device="cuda")
@@ -150,6 +173,7 @@ def test_dense_f32_fullsize_matches_fp64(dev, M, K, N):
     Ws = dev.Weight.from_device(0, w.contiguous().view(torch.uint8), K, row_begin=128, row_end=640)
     assert torch.equal(dev.mul_mat(Ws, x), got[:, 128:640])
     Ws.free()
+    _check_dense_oracle_sample(O.F32, w, x, got, K, seed=M + N)
     W.free()
 
 
