@@ -716,7 +716,9 @@ hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N,
     // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (as gemm_qmx.hip)
     if (N <= 512 && nst >= 4 && var != 9 && var != 8) {
         // the same two-way split on 128 x 128 tiles where those cover the chip
-        if (var == 7 || (var != 6 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 128)) return launch_cfg<2, 2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+        // (from 160 such tiles on: with 128 of them half the chip idles -- 4096 x 4096 x 512 44.1 -> 37.5 us, 4096 x 11008 x 512 98.6 -> 79.6 on
+        // the 128 x 64 form; 8192 x 4096 x 384, 192 tiles: 44.9 against 66.7, 11008 x 4096 x 512, 344 tiles: 85.4 against 108.2)
+        if (var == 7 || (var != 6 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 160)) return launch_cfg<2, 2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
         return launch_cfg<1, 2, 4, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     }
     return launch_cfg<2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
