@@ -107,7 +107,10 @@ struct Cfg {
 
 // KSP = 1 | 2 | 4: K split inside the workgroup as in gemm_qmx.hip -- KSP wave groups take alternate stages (own stage buffers)
 // and add their tiles through LDS in group order at the end; for batches that leave most of the chip idle otherwise.
-template <int WMT, int WNT, int WGM, int WGN, int KSP>
+// VS = 2: the two-way tree WITHOUT the second wave group ("virtual" split, as gemm_qmx.hip): one group runs the stage sets of both groups one
+// after the other, banks the first sum and adds the second to it -- group 0 + group 1, the addition the split form makes, bit for bit -- on
+// the 4-wave geometry that keeps two workgroups per CU.  For grids of many tiles, where the 8-wave form's one workgroup per CU costs rounds.
+template <int WMT, int WNT, int WGM, int WGN, int KSP, int VS = 1>
 __global__ __launch_bounds__(WGM * WGN * 64 * KSP, 2)
 void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict__ apan, float *__restrict__ dst, int M, int N, int Mpad,
                     int Npad, int nstages, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes) {
@@ -171,7 +174,8 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
     // The stage's A fragments (activations, LDS) run AF_AHEAD n-tile steps ahead of the MFMAs that use them: a ds_read_b128 issued
     // right in front of its MFMAs exposes the whole LDS latency 32 times per stage (what hipcc makes of the plain loop).
     constexpr int AF_AHEAD = D16_AF_AHEAD, NSTEP = KS * WNT;
-    auto compute = [&](int s, int buf) {
+    static_assert(VS == 1 || KSP == 1, "virtual split: one wave group");
+    auto compute = [&](int s, int sn, int buf) {              // stage s; sn = the stage this group runs next (prefetch target)
         const uint8_t *sA = gsm + (buf & 1) * C::STAGE + ((size_t)(hh * C::TN + wn * WNT * 32 + l31)) * 16;
         f16x8 afr[AF_AHEAD + 1];
         auto fetch_af = [&](auto gc) {
@@ -185,7 +189,7 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
                 constexpr int j = decltype(jc)::value, g = ks * WNT + j;
                 static_for<C::PP>([&](auto uc) {
                     constexpr int pc = C::PP * (ks * WNT + j) + decltype(uc)::value;
-                    if constexpr (pc < C::ROUNDS) dma_piece(s + KSP, buf + 1, std::integral_constant<int, pc>{});
+                    if constexpr (pc < C::ROUNDS) dma_piece(sn, buf + 1, std::integral_constant<int, pc>{});
                 });
                 if constexpr (g + AF_AHEAD < NSTEP) fetch_af(std::integral_constant<int, g + AF_AHEAD>{});
                 const f16x8 af = afr[g % (AF_AHEAD + 1)];
@@ -206,8 +210,8 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
             }
 #endif
-            // this group's next k-steps: the rest of the stage, then its next stage s + KSP
-            load_b(ks + RING < KS ? s * KS + ks + RING : (s + KSP) * KS + (ks + RING - KS), std::integral_constant<int, ks % RING>{});
+            // this group's next k-steps: the rest of the stage, then its next stage
+            load_b(ks + RING < KS ? s * KS + ks + RING : sn * KS + (ks + RING - KS), std::integral_constant<int, ks % RING>{});
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -218,15 +222,47 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const int niter = (nstages + KSP - 1) / KSP;              // every wave passes the same number of barriers
-    for (int it = 0; it < niter; ++it) {
-        const int s = it * KSP + grp;
-        if (KSP == 1 || s < nstages) compute(s, it);
-        // (KSP > 1: a group may skip its last stage, and with it the drain inside compute; KSP == 1: the weight loads in flight stay in flight)
-        if constexpr (KSP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    if constexpr (VS == 1) {
+        const int niter = (nstages + KSP - 1) / KSP;          // every wave passes the same number of barriers
+        for (int it = 0; it < niter; ++it) {
+            const int s = it * KSP + grp;
+            if (KSP == 1 || s < nstages) compute(s, s + KSP, it);
+            // (KSP > 1: a group may skip its last stage, and with it the drain inside compute; KSP == 1: the weight loads in flight stay in flight)
+            if constexpr (KSP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    } else {
+        // passes 0 .. VS-1 over stages p, p + VS, ...; the launcher guarantees nstages >= VS (no pass is empty)
+        f32x16 sav[WMT][WNT];
+        int s = 0, pass = 0;
+        for (int it = 0; it < nstages; ++it) {
+            int sn = s + VS, pn = pass;
+            if (sn >= nstages) { pn = pass + 1; sn = pn < VS ? pn : nstages; }
+            compute(s, sn, it);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (pn != pass && pn < VS) {                      // (uniform) pass boundary: bank this pass's sum in group order, start the next from zero
+#pragma unroll
+                for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            sav[i][j][r] = pass == 0 ? acc[i][j][r] : sav[i][j][r] + acc[i][j][r];
+                            acc[i][j][r] = 0.0f;
+                        }
+            }
+            s = sn; pass = pn;
+        }
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = sav[i][j][r] + acc[i][j][r];
     }
 
     // ---- K split: groups 1 .. KSP-1 hand their tiles to group 0 through LDS; group 0 adds them in group order ----
@@ -445,10 +481,10 @@ hipError_t launch_cfg_s(const ggml_hip_weight *w, const uint8_t *apan, int64_t N
     return hipGetLastError();
 }
 
-template <int WMT, int WNT, int WGM, int WGN, int KSP = 1>
+template <int WMT, int WNT, int WGM, int WGN, int KSP = 1, int VS = 1>
 hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, int64_t Npad, float *dst, int64_t ldd, hipStream_t st) {
     using C = Cfg<WMT, WNT, WGM, WGN>;
-    auto kern = dense16_kernel<WMT, WNT, WGM, WGN, KSP>;
+    auto kern = dense16_kernel<WMT, WNT, WGM, WGN, KSP, VS>;
         static PerDeviceOnce once;   // per kernel instantiation; the attribute is set once per device
     const hipError_t attr = once.max_dynamic_lds((const void *)kern, C::TOTAL * KSP);
     if (attr != hipSuccess) return attr;
@@ -704,7 +740,10 @@ hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N,
         if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg_s<4, 8, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
         return launch_cfg_s<4, 4, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     }
-    if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    // (the unsplit 256 x 128 form used to take every grid of 384 tiles and more -- also at N <= 512, where M >= 24576 reaches that while
+    // its row shards run the K-split forms below: different summation trees, a shard was not the bitwise slice of the product.  r3: up to
+    // 512 rows the tree is the split one whatever M; the form remains for the developer switch above.)
+    if (N > 512 && ((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     // batches up to 128 rows: K split four ways inside the workgroup (fixed by N and K: same summation tree for a row shard), on
     // 32-row tiles, or on 128-row tiles of 16 waves where those cover the chip
     static const int var = dev_env_int("GGML_HIP_D16_TILE", 0);   // developer A/B switch
@@ -718,6 +757,9 @@ hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N,
         // the same two-way split on 128 x 128 tiles where those cover the chip
         // (from 160 such tiles on: with 128 of them half the chip idles -- 4096 x 4096 x 512 44.1 -> 37.5 us, 4096 x 11008 x 512 98.6 -> 79.6 on
         // the 128 x 64 form; 8192 x 4096 x 384, 192 tiles: 44.9 against 66.7, 11008 x 4096 x 512, 344 tiles: 85.4 against 108.2)
+        // many tiles (a vocabulary-sized matrix): the same two-way tree as a virtual split on 4-wave workgroups, two per CU
+        // (32000 x 4096 x 512: 1000 tiles, 229 us on the 8-wave form = 3.9 rounds of one workgroup per CU)
+        if (var == 5 || (var == 0 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 512)) return launch_cfg<2, 2, 2, 2, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
         if (var == 7 || (var != 6 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 160)) return launch_cfg<2, 2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
         return launch_cfg<1, 2, 4, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
     }

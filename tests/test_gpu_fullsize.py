@@ -294,6 +294,25 @@ def test_dense_f16_tile_forms_agree_bitwise(dev, N):
     W.free()
 
 
+@pytest.mark.parametrize("N", [128, 512])
+def test_dense_f16_vocabulary_sized_matrix_and_its_shards_share_one_tree(dev, N):
+    """F16, up to 512 src1 rows: a 32000-row matrix used to reach the unsplit 256 x 128 form (384 tiles and more) while its 4000-row
+    shards ran the K-split forms -- found in round 3, the F16 twin of the Q4_0 case config 5's eight-slot test caught."""
+    M, K = 32000, 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5 + N)
+    w = torch.randn((M, K), generator=g, device="cuda").half()
+    x = torch.randn((N, K), generator=g, device="cuda")
+    rows = w.view(torch.uint8).view(M, -1)
+    W = dev.Weight.from_device(1, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((4000, 8000), (31000, 32000)):
+        Ws = dev.Weight.from_device(1, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (N, r0, r1)
+        Ws.free()
+    W.free()
+
+
 def test_dense_f32_split_form_is_tight_and_shards_are_bitwise_slices(dev):
     """F32 weights above 256 src1 rows: every operand as three bf16 pieces, six bf16 MFMAs per product, a fresh accumulator per k-step
     joined by a rounded add (dense16.hip K10d).  Tighter than the f32 fma chain it replaces (max 1.5e-5 of the rms at K = 4096), and a row
