@@ -87,6 +87,9 @@ constexpr int KS = 8;       // k-steps of 16 per LDS stage (128 k)
 #ifndef D16_RING
 #define D16_RING 4
 #endif
+#ifndef D16_FLATMAP       // developer A/B: 1 = the one-round tile order for every grid
+#define D16_FLATMAP 0
+#endif
 #ifndef D16_AF_AHEAD
 #define D16_AF_AHEAD 2
 #endif
@@ -315,6 +318,26 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
         }
 }
 
+// Workgroup -> tile for grids of SEVERAL rounds (dense16s / dense32s): the hardware deals workgroups to the eight XCDs in turn
+// (bid & 7) and an XCD keeps about 64 of them resident, so an XCD's run of the tile list is ordered in 8 x 8 blocks of tiles (m fastest
+// inside a block, blocks down a block-column, block-columns across n): the 64 resident tiles share 8 weight panels and 8 activation
+// panels.  With the list ordered m-fastest over ALL rows (the one-round order of the kernels above) an XCD streams every weight panel
+// once per tile column: 11008 x 4096 x 4096 F16 pulled ~2.9 GB through the L2s for 210 MB of operands and ran at the HBM rate.
+__device__ __forceinline__ void tile_of_blocked(int bid, int tiles_m, int tiles_n, int &tm_i, int &tn_i) {
+    const int nwg = tiles_m * tiles_n, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);       // position in the blocked list
+    const int colsz = tiles_m * 8, nbn = (tiles_n + 7) >> 3;
+    int bj = t / colsz;
+    if (bj > nbn - 1) bj = nbn - 1;
+    const int u = t - bj * colsz, wd = tiles_n - bj * 8 < 8 ? tiles_n - bj * 8 : 8;               // inside block-column bj, wd tiles wide
+    const int nbm = (tiles_m + 7) >> 3;
+    int bi = u / (8 * wd);
+    if (bi > nbm - 1) bi = nbm - 1;
+    const int r = u - bi * 8 * wd, h = tiles_m - bi * 8 < 8 ? tiles_m - bi * 8 : 8;
+    tm_i = bi * 8 + r % h;
+    tn_i = bj * 8 + r / h;
+}
+
 // ---- the same product on v_mfma_f32_16x16x32_f16 (K10c): the forms that do not split K (more than 512 src1 rows) ----
 // Same panels, same stage image, same DMA, same wave tile (64 x 128 or 64 x 64 outputs); the tile is cut into 16 x 16 MFMA tiles and a
 // k-step is 32: lane (row l & 15, k-group g = l >> 4) takes the 16-byte entry of panel 4 ks + g -- a 16-lane group reads 256
@@ -350,7 +373,9 @@ void dense16s_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     int tm_i, tn_i;
-    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {           // 2 x 4 blocks of the tile grid per XCD, as dense16_kernel
+    if (nwg > 512 && !D16_FLATMAP) {                          // more than one round of the chip: 8 x 8 blocks of tiles per XCD
+        tile_of_blocked(bid, tiles_m, tiles_n, tm_i, tn_i);
+    } else if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {    // 2 x 4 blocks of the tile grid per XCD, as dense16_kernel
         const int hm = tiles_m >> 1, l = bid >> 3;
         tm_i = (xcd & 1) * hm + l % hm;
         tn_i = (xcd >> 1) * (tiles_n >> 2) + l / hm;
@@ -581,7 +606,9 @@ void dense32s_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     int tm_i, tn_i;
-    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {           // 2 x 4 blocks of the tile grid per XCD, as dense16_kernel
+    if (nwg > 512 && !D16_FLATMAP) {                          // more than one round of the chip: 8 x 8 blocks of tiles per XCD
+        tile_of_blocked(bid, tiles_m, tiles_n, tm_i, tn_i);
+    } else if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {    // 2 x 4 blocks of the tile grid per XCD, as dense16_kernel
         const int hm = tiles_m >> 1, l = bid >> 3;
         tm_i = (xcd & 1) * hm + l % hm;
         tn_i = (xcd >> 1) * (tiles_n >> 2) + l / hm;
