@@ -83,6 +83,26 @@ __global__ void f16_rows_to_panels_kernel(const uint16_t *__restrict__ rows, int
     *(uint4 *)(pan + (p * Mpad + m) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Workgroup -> tile for grids of SEVERAL rounds (dense16s / dense32s): the hardware deals workgroups to the eight XCDs in turn
+// (bid & 7) and an XCD keeps about 64 of them resident, so an XCD's run of the tile list is ordered in 8 x 8 blocks of tiles (m fastest
+// inside a block, blocks down a block-column, block-columns across n): the 64 resident tiles share 8 weight panels and 8 activation
+// panels.  With the list ordered m-fastest over ALL rows (the one-round order of the kernels above) an XCD streams every weight panel
+// once per tile column: 11008 x 4096 x 4096 F16 pulled ~2.9 GB through the L2s for 210 MB of operands and ran at the HBM rate.
+__device__ __forceinline__ void tile_of_blocked(int bid, int tiles_m, int tiles_n, int &tm_i, int &tn_i) {
+    const int nwg = tiles_m * tiles_n, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);       // position in the blocked list
+    const int colsz = tiles_m * 8, nbn = (tiles_n + 7) >> 3;
+    int bj = t / colsz;
+    if (bj > nbn - 1) bj = nbn - 1;
+    const int u = t - bj * colsz, wd = tiles_n - bj * 8 < 8 ? tiles_n - bj * 8 : 8;               // inside block-column bj, wd tiles wide
+    const int nbm = (tiles_m + 7) >> 3;
+    int bi = u / (8 * wd);
+    if (bi > nbm - 1) bi = nbm - 1;
+    const int r = u - bi * 8 * wd, h = tiles_m - bi * 8 < 8 ? tiles_m - bi * 8 : 8;
+    tm_i = bi * 8 + r % h;
+    tn_i = bj * 8 + r / h;
+}
+
 constexpr int KS = 8;       // k-steps of 16 per LDS stage (128 k)
 #ifndef D16_RING
 #define D16_RING 4
@@ -130,7 +150,9 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     int tm_i, tn_i;
-    if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {
+    if (nwg > 512 && !D16_FLATMAP) {                          // several rounds: 8 x 8 blocks of tiles per XCD (tile_of_blocked above)
+        tile_of_blocked(bid, tiles_m, tiles_n, tm_i, tn_i);
+    } else if ((tiles_m & 1) == 0 && (tiles_n & 3) == 0) {
         // 2 x 4 blocks of the tile grid per XCD (gemm_qmx.hip): its resident workgroups share half of the weight panels and a
         // quarter of the activation panels
         const int hm = tiles_m >> 1, l = bid >> 3;
@@ -316,26 +338,6 @@ void dense16_kernel(const uint8_t *__restrict__ wpan, const uint8_t *__restrict_
                                                           (int)((uint32_t)(nr * ldd + mb) * 4u), 0);
             }
         }
-}
-
-// Workgroup -> tile for grids of SEVERAL rounds (dense16s / dense32s): the hardware deals workgroups to the eight XCDs in turn
-// (bid & 7) and an XCD keeps about 64 of them resident, so an XCD's run of the tile list is ordered in 8 x 8 blocks of tiles (m fastest
-// inside a block, blocks down a block-column, block-columns across n): the 64 resident tiles share 8 weight panels and 8 activation
-// panels.  With the list ordered m-fastest over ALL rows (the one-round order of the kernels above) an XCD streams every weight panel
-// once per tile column: 11008 x 4096 x 4096 F16 pulled ~2.9 GB through the L2s for 210 MB of operands and ran at the HBM rate.
-__device__ __forceinline__ void tile_of_blocked(int bid, int tiles_m, int tiles_n, int &tm_i, int &tn_i) {
-    const int nwg = tiles_m * tiles_n, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);       // position in the blocked list
-    const int colsz = tiles_m * 8, nbn = (tiles_n + 7) >> 3;
-    int bj = t / colsz;
-    if (bj > nbn - 1) bj = nbn - 1;
-    const int u = t - bj * colsz, wd = tiles_n - bj * 8 < 8 ? tiles_n - bj * 8 : 8;               // inside block-column bj, wd tiles wide
-    const int nbm = (tiles_m + 7) >> 3;
-    int bi = u / (8 * wd);
-    if (bi > nbm - 1) bi = nbm - 1;
-    const int r = u - bi * 8 * wd, h = tiles_m - bi * 8 < 8 ? tiles_m - bi * 8 : 8;
-    tm_i = bi * 8 + r % h;
-    tn_i = bj * 8 + r / h;
 }
 
 // ---- the same product on v_mfma_f32_16x16x32_f16 (K10c): the forms that do not split K (more than 512 src1 rows) ----
