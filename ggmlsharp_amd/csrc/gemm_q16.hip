@@ -292,7 +292,11 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
         const float *sDa = (const float *)(sp + C::A_BYTES) + wn * WNT * 32 + 4 * hh;
         // Min term: on the VALU (16 v_fmac per tile and block) for the 8-tile waves, whose registers are full; otherwise as a K = 2
         // f32 MFMA per pair of k-blocks (issue_b) -- d1 * sum(a) is then read as its A operand, lane half hh = the odd block of the pair
-        constexpr bool MIN_MFMA = WT<TYPE>::MIN && NTILE < 8, MIN_VALU = WT<TYPE>::MIN && !MIN_MFMA;
+        // (r3: by the SPLIT, not by the tile count -- the two forms add the same terms in a different order, and above 512 src1 rows the
+        // 8-tile form and the 2-tile form serve the same N: a 26000-row Q5_1 matrix and its 4000-row shard differed in the last bits
+        // (tools/sweep_parity.py with row shards).  Unsplit forms: VALU; forms that split K (up to 512 rows): MFMA.)
+        static_assert(KSP == 1 || NTILE < 8, "the split forms have room for the min-term MFMA");
+        constexpr bool MIN_MFMA = WT<TYPE>::MIN && KSP > 1, MIN_VALU = WT<TYPE>::MIN && !MIN_MFMA;
         const float *sSa = sDa + C::SC_BYTES / 4;                        // d1 * sum(a) (Q5_1: d1 * (s0 + s1))
         const float *sSp = (const float *)(sp + C::A_BYTES + C::SC_BYTES) + hh * C::TN + wn * WNT * 32 + l31;
         const int kb0 = s * KB;

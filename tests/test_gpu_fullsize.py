@@ -294,6 +294,31 @@ def test_dense_f16_tile_forms_agree_bitwise(dev, N):
     W.free()
 
 
+@pytest.mark.parametrize("t,kernel", [(7, 0), (3, 2)])
+def test_min_term_types_tall_matrix_and_its_shards_add_in_one_order(dev, t, kernel):
+    """Q5_1 (and Q4_1 when forced onto the f16 kernel) above 512 src1 rows: the 8-tile form added the min term per block on the VALU, the
+    2-tile form per pair of blocks on the matrix pipe -- the same terms in another order -- and which form runs follows M.  A 26000-row
+    matrix and its shard differed in the last bits (tools/sweep_parity.py with row shards, r3); the order now follows the K split, i.e. N."""
+    from ggmlsharp_amd._lib import lib
+    M, K, N = 26000, 1024, 600
+    g = torch.Generator(device="cuda")
+    g.manual_seed(t)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    rows = dev.quantize_rows(t, w)
+    lib().ggml_hip_debug_force_gemm(kernel)
+    try:
+        W = dev.Weight.from_device(t, rows, K)
+        full = dev.mul_mat(W, x)
+        for (r0, r1) in ((0, 4000), (25000, 26000)):
+            Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+            assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, r0, r1)
+            Ws.free()
+        W.free()
+    finally:
+        lib().ggml_hip_debug_force_gemm(0)
+
+
 @pytest.mark.parametrize("N", [128, 512])
 def test_dense_f16_vocabulary_sized_matrix_and_its_shards_share_one_tree(dev, N):
     """F16, up to 512 src1 rows: a 32000-row matrix used to reach the unsplit 256 x 128 form (384 tiles and more) while its 4000-row
