@@ -551,6 +551,13 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     }
     if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
     if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
+    // short or narrow products (row shards of a multi-GPU split): 64 x 64 tiles of four 1-tile waves wherever the 128 x 64 grid leaves CUs
+    // idle -- the same unsplit K loop per element, the same bits (gemm_qmx.hip has the same rule for Q4_0).  Q8_0 / Q5_0, COMPUTE in us:
+    // 256 x 4096 x 2048 48.7 -> 36.3, 1024 x 4096 x 1024 50.2 -> 39.5, 512 x 11008 x 2048 125.9 -> 93.2, 512 x 4096 x 4096 51.2 -> 46.1
+    static const int tile64 = dev_env_int("GGML_HIP_Q16_T64", 0);   // developer A/B switch: 1 = never, 2 = always
+    // (not the min-term types: with one tile per wave the per-block min-term accumulate is not wired for this geometry -- wrong results when tried)
+    if constexpr (!WT<TYPE>::MIN)
+        if (tile64 == 2 || (tile64 != 1 && ((w->M + 127) / 128) * ((N + 63) / 64) <= 256)) return launch_cfg<TYPE, 1, 1, 2, 2, 4>(w, p, N, dst, ldd, st);
     // otherwise 128 x 64 tiles of 4 waves (2 tiles per wave).  f16 compute us at N = 1024, this | 128 x 128 of 4 waves | 128 x 64 of 2 waves:
     // Q8_0 4096 x 4096 69 | 84 | 104, 4096 x 11008 172 | 206 | 262, 11008 x 4096 175 | 181 | 213; Q5_1 4096 x 4096 89 | 114 | 144
     return launch_cfg<TYPE, 1, 2, 4, 1, 4>(w, p, N, dst, ldd, st);
