@@ -68,16 +68,16 @@ def _program(G, t, wraw, x, K, M, N, graph_chain=False, w2raw=None, M2=0):
         G.ggml_free(ctx)
 
 
-@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q5_1, O.F16])
+@pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q5_1, O.F16, O.F32])
 def test_seam1_row_split_over_slots_is_bitwise_the_single_slot_result(slots, t):
     from ggmlsharp_amd import ggml as G
-    for (M, K, N) in ((515, 256, 40), (96, 512, 1), (992, 1024, 300)):
+    for (M, K, N) in ((515, 256, 40), (96, 512, 1), (992, 1024, 300)):      # (300 src1 rows: F32 runs the split-bf16 matrix-core kernel)
         w = _rand((M, K))
         x = _rand((N, K))
-        wraw = w.astype(np.float16).view(np.uint16) if t == O.F16 else O.quantize_row(t, w)
+        wraw = w.astype(np.float16).view(np.uint16) if t == O.F16 else w if t == O.F32 else O.quantize_row(t, w)
         w2 = _rand((64, M))
         w2raw = w2.astype(np.float16).view(np.uint16) if t == O.F16 else None
-        chain = t != O.F16 and M % 32 == 0
+        chain = t not in (O.F16, O.F32) and M % 32 == 0
         if chain:
             w2raw = O.quantize_row(t, w2)
         slots([0])
