@@ -369,6 +369,10 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
             if constexpr (t == DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (t < LAST) issue_a(std::integral_constant<int, t + 1>{});
             const float dw = frag[bb & 1].d[i];
+            // (read here, like dw: with one tile per k-block the unpack behind the next tile's second MFMA -- issued from inside this tile's
+            // scale-accumulate groups -- refills this very fragment buffer)
+            float mw_blk = 0.0f;
+            if constexpr (MIN_VALU) mw_blk = frag[bb & 1].mn[i];
             f32x16 &ac = acc[i][j];
             static_for<4>([&](auto gc) {
                 constexpr int q = decltype(gc)::value;
@@ -400,7 +404,7 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
                                    "v"(tacc[t & 1][4 * q + 3]), "v"(da[q][0]), "v"(da[q][1]), "v"(da[q][2]), "v"(da[q][3]), "v"(dw));
                 }
                 if constexpr (MIN_VALU) {
-                    const float mw = frag[bb & 1].mn[i];
+                    const float mw = mw_blk;
                     asm volatile("v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %8\n\tv_fmac_f32 %2, %6, %8\n\tv_fmac_f32 %3, %7, %8"
                                  : "+v"(ac[4 * q + 0]), "+v"(ac[4 * q + 1]), "+v"(ac[4 * q + 2]), "+v"(ac[4 * q + 3])
                                  : "v"(sa[q][0]), "v"(sa[q][1]), "v"(sa[q][2]), "v"(sa[q][3]), "v"(mw));
@@ -555,9 +559,9 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // idle -- the same unsplit K loop per element, the same bits (gemm_qmx.hip has the same rule for Q4_0).  Q8_0 / Q5_0, COMPUTE in us:
     // 256 x 4096 x 2048 48.7 -> 36.3, 1024 x 4096 x 1024 50.2 -> 39.5, 512 x 11008 x 2048 125.9 -> 93.2, 512 x 4096 x 4096 51.2 -> 46.1
     static const int tile64 = dev_env_int("GGML_HIP_Q16_T64", 0);   // developer A/B switch: 1 = never, 2 = always
-    // (not the min-term types: with one tile per wave the per-block min-term accumulate is not wired for this geometry -- wrong results when tried)
-    if constexpr (!WT<TYPE>::MIN)
-        if (tile64 == 2 || (tile64 != 1 && ((w->M + 127) / 128) * ((N + 63) / 64) <= 256)) return launch_cfg<TYPE, 1, 1, 2, 2, 4>(w, p, N, dst, ldd, st);
+    // (not the min-term types: their 48 VALU instructions per tile make the one-tile wave slower -- Q5_1 512 x 4096 x 4096 61.0 -> 66.0 us;
+    // GGML_HIP_Q16_T64=2 forces the form for them, too)
+    if (tile64 == 2 || (!WT<TYPE>::MIN && tile64 != 1 && ((w->M + 127) / 128) * ((N + 63) / 64) <= 256)) return launch_cfg<TYPE, 1, 1, 2, 2, 4>(w, p, N, dst, ldd, st);
     // otherwise 128 x 64 tiles of 4 waves (2 tiles per wave).  f16 compute us at N = 1024, this | 128 x 128 of 4 waves | 128 x 64 of 2 waves:
     // Q8_0 4096 x 4096 69 | 84 | 104, 4096 x 11008 172 | 206 | 262, 11008 x 4096 175 | 181 | 213; Q5_1 4096 x 4096 89 | 114 | 144
     return launch_cfg<TYPE, 1, 2, 4, 1, 4>(w, p, N, dst, ldd, st);
