@@ -956,7 +956,7 @@ hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float
     // 32000-row matrix at N = 512 used to land here while its 4000-row shards took the split forms: different summation trees,
     // found by the eight-slot test of config 5's partition, tests/test_multi_slot.py)
     if constexpr (TYPE == GGML_TYPE_Q4_0) {
-        if (tm256 * tn128 >= 384 && N > 512) {
+        if ((tm256 * tn128 >= 384 || var == 30) && N > 512) {
             // 256 x 128 with waves of 128 x 64 (half the LDS reads, weights single-buffered) measured 10 % slower: A/B only
             if (var == 2) return launch_cfg<TYPE, 4, 2, 2, 2, 4, 1>(w, p, N, dst, ldd, st);
             return launch_cfg<TYPE, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                 // 256 x 128, waves 64 x 128

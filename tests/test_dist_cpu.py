@@ -132,8 +132,11 @@ def _gpu_worker(rank, world, port, M, K, N, chunks, exchange, out_q):
         Wfull = device.Weight.from_device(O.Q4_0, rows_dev, K)
         full = torch.cat([device.mul_mat(Wfull, xd[a:b]) for (a, b) in runner._chunk_bounds()], dim=0)
         ref = O.mul_mat(O.Q4_0, wq, x, M, K, N)[0, 0]
-        rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
-        close = bool(np.all(np.abs(got.cpu().numpy() - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms))
+        try:                                    # THE mul_mat tolerance (tests/oracle_lib.py)
+            O.assert_mul_mat_close(got.cpu().numpy(), ref, K, f"rank {rank}")
+            close = True
+        except AssertionError:
+            close = False
         out_q.put((rank, bool(torch.equal(got, full)) and bool(torch.equal(got2, full)) and bool(torch.equal(got3, full)), close, tuple(got.shape)))
         torch.cuda.synchronize()
         dist.barrier()

@@ -132,13 +132,11 @@ def test_fused_graph_equals_the_node_by_node_seams_bitwise(dev, N):
     assert np.allclose(norm, O.eltwise("rms_norm", x), rtol=2e-7, atol=0)
     assert np.array_equal(mul, O.eltwise("mul", norm, g))
     ref_mm = O.mul_mat(t, w1q, np.ascontiguousarray(mul), M1, K, N)[0, 0]
-    rms = np.sqrt(np.mean(ref_mm.astype(np.float64) ** 2))
-    assert np.all(np.abs(mm - ref_mm) <= 1e-3 * np.abs(ref_mm) + 1e-5 * rms)
+    O.assert_mul_mat_close(mm, ref_mm, K, "mul_mat behind the fused prologue")
     assert np.array_equal(add, O.eltwise("add", mm, r))
     assert np.array_equal(mm2, sc)                                              # the scale node is a view: both hold product * s
     ref_mm2 = O.mul_mat(t, w1q, x, M1, K, N)[0, 0]
-    rms2 = np.sqrt(np.mean(ref_mm2.astype(np.float64) ** 2))
-    assert np.all(np.abs(sc - 0.125 * ref_mm2) <= 1e-3 * np.abs(0.125 * ref_mm2) + 1e-5 * 0.125 * rms2)
+    O.assert_mul_mat_close(sc, 0.125 * ref_mm2.astype(np.float64), K, "mul_mat with the scale epilogue")
     assert np.array_equal(silu, O.eltwise("silu", add))
     assert np.array_equal(gate, O.eltwise("mul", silu, r))
     assert np.array_equal(fin, O.eltwise("add", gate, sc))

@@ -40,10 +40,9 @@ def test_hip_path_reproduces_golden():
         W = device.Weight.from_host(t, O.quantize_row(t, G["w"]), K)
         got = device.mul_mat(W, torch.from_numpy(G["a"]).cuda()).cpu().numpy()
         ref = G[f"mulmat_{name}"].astype(np.float64)
-        rms = np.sqrt(np.mean(ref ** 2))
-        assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms), name
+        O.assert_mul_mat_close(got, ref, K, name)
     for name, t, wraw in (("f32", O.F32, G["w"].view(np.uint8)), ("f16", O.F16, G["w"].astype(np.float16).view(np.uint8))):
         W = device.Weight.from_host(t, wraw, K)
         got = device.mul_mat(W, torch.from_numpy(G["a"]).cuda()).cpu().numpy()
         ref = G[f"mulmat_{name}"].astype(np.float64)
-        assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-5 * np.sqrt(np.mean(ref ** 2))), name
+        O.assert_mul_mat_close(got, ref, K, name)

@@ -366,8 +366,7 @@ def test_an_error_inside_a_named_scope_is_reported_every_time(dev):
             assert rc2 != 0, f"compute {it}: the rejected node reported success"
             ref = O.mul_mat(O.Q4_0, np.array(G.tensor_bytes(W)), np.array(G.tensor_f32(X)).reshape(N, K), M, K, N)[0, 0]
             got = np.array(G.tensor_f32(y1)).reshape(N, M)
-            rms = np.sqrt(np.mean(ref.astype(np.float64) ** 2))
-            assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-5 * rms), it
+            O.assert_mul_mat_close(got, ref, K, f"compute {it}")
         c1 = _counters()
         assert c1[1] == c0[1] and c1[2] == c0[2], f"a scope with a failing node was captured / replayed: {c0} -> {c1}"
     finally:

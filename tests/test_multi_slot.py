@@ -21,10 +21,9 @@ def _rand(shape, scale=1.0):
     return (RNG.standard_normal(shape) * scale).astype(np.float32)
 
 
-def assert_close(got, ref, what=""):
-    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    rms = np.sqrt(np.mean(ref * ref))
-    assert not (np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-5 * rms).any(), what
+def assert_close(got, ref, what, K):
+    """THE mul_mat tolerance (tests/oracle_lib.py: SURVEY 8(c) with its one stated floor); K = the product's inner dimension"""
+    O.assert_mul_mat_close(got, ref, K, what)
 
 
 @pytest.fixture()
@@ -83,7 +82,7 @@ def test_seam1_row_split_over_slots_is_bitwise_the_single_slot_result(slots, t):
         slots([0])
         one = _program(G, t, wraw, x, K, M, N, chain, w2raw, 64)
         ref = O.mul_mat(t, wraw, x, M, K, N, nth=3)[0, 0]
-        assert_close(one[0], ref, f"single slot type {t}")
+        assert_close(one[0], ref, f"single slot type {t}", K=K)
         for ids in ([0, 0], [0, 0, 0]):
             slots(ids)
             many = _program(G, t, wraw, x, K, M, N, chain, w2raw, 64)
@@ -172,7 +171,7 @@ def test_bound_threads_run_on_their_own_slot_concurrently(slots):
         t.join()
     assert not errs, errs
     for i in range(2):
-        assert_close(got[i], refs[i], f"thread {i}")
+        assert_close(got[i], refs[i], f"thread {i}", K=K)
     assert lib().ggml_hip_bind_thread(5) == -4
 
 
@@ -192,7 +191,7 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
     got = _program(G, O.Q4_0, wq, x, K, M, N)[0]
     lib().ggml_hip_debug_transfer_counters(*[C.byref(c) for c in c1])
     ref = O.mul_mat(O.Q4_0, wq, x, M, K, N, nth=8)[0, 0]
-    assert_close(got, ref, "pinned pipeline")
+    assert_close(got, ref, "pinned pipeline", K=K)
     assert c1[0].value - c0[0].value == N * K * 4 and c1[1].value - c0[1].value == N * M * 4
     # the same pipeline again and again on the same tensors -- same bits
     ctx = G.ggml_init(64 * 1024 * 1024)
@@ -214,13 +213,13 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
         x2 = _rand((N, K))
         G.tensor_f32(X)[:] = x2.reshape(1, 1, N, K)
         G.ggml_graph_compute(ctx, gf)
-        assert_close(G.tensor_f32(Y)[0, 0], O.mul_mat(O.Q4_0, wq, x2, M, K, N, nth=8)[0, 0], "replay with new activations")
+        assert_close(G.tensor_f32(Y)[0, 0], O.mul_mat(O.Q4_0, wq, x2, M, K, N, nth=8)[0, 0], "replay with new activations", K=K)
         # rewritten weights (host mirror invalidates on its own writers; a direct store needs the explicit call)
         wq2 = O.quantize_row(O.Q4_0, _rand((M, K)))
         G.tensor_bytes(W)[:] = wq2.reshape(-1)
         lib().ggml_hip_invalidate(W.contents.data)
         G.ggml_graph_compute(ctx, gf)
-        assert_close(G.tensor_f32(Y)[0, 0], O.mul_mat(O.Q4_0, wq2, x2, M, K, N, nth=8)[0, 0], "after invalidate")
+        assert_close(G.tensor_f32(Y)[0, 0], O.mul_mat(O.Q4_0, wq2, x2, M, K, N, nth=8)[0, 0], "after invalidate", K=K)
     finally:
         G.ggml_free(ctx)
     # pageable memory (a caller-provided, unregistered buffer): same values, no chunking
@@ -234,7 +233,7 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
         G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
         Y = G.ggml_mul_mat(ctx, W, X)
         G.ggml_graph_compute(ctx, G.ggml_build_forward(Y))
-        assert_close(G.tensor_f32(Y)[0, 0], ref, "pageable")
+        assert_close(G.tensor_f32(Y)[0, 0], ref, "pageable", K=K)
     finally:
         G.ggml_free(ctx)
 
@@ -255,10 +254,10 @@ def test_weight_cache_is_invalidated_by_writers_and_not_used_for_computed_src0(s
         Y = G.ggml_mul_mat(ctx, W, X)
         gf = G.ggml_build_forward(Y)
         G.ggml_graph_compute(ctx, gf)
-        assert_close(G.tensor_f32(Y)[0, 0], np.repeat(0.5 * x.astype(np.float64).sum(1, keepdims=True), M, 1), "first")
+        assert_close(G.tensor_f32(Y)[0, 0], np.repeat(0.5 * x.astype(np.float64).sum(1, keepdims=True), M, 1), "first", K=K)
         G.ggml_set_f32(W, -2.0)                                  # rewritten leaf, same pointer and shape
         G.ggml_graph_compute(ctx, gf)
-        assert_close(G.tensor_f32(Y)[0, 0], np.repeat(-2.0 * x.astype(np.float64).sum(1, keepdims=True), M, 1), "after set_f32")
+        assert_close(G.tensor_f32(Y)[0, 0], np.repeat(-2.0 * x.astype(np.float64).sum(1, keepdims=True), M, 1), "after set_f32", K=K)
         # (2) src0 = a computed tensor: A = add(P, Q) [K x M], Y2 = mul_mat(A, X); change P and recompute
         P = G.ggml_new_tensor_2d(ctx, G.F32, K, M)
         Q = G.ggml_new_tensor_2d(ctx, G.F32, K, M)
@@ -272,7 +271,7 @@ def test_weight_cache_is_invalidated_by_writers_and_not_used_for_computed_src0(s
             G.ggml_graph_compute(ctx, g2)
             a = (p + q).astype(np.float32)
             ref = O.mul_mat(O.F32, a, x, M, K, N)[0, 0]
-            assert_close(G.tensor_f32(Y2)[0, 0], ref, f"computed src0, trial {trial}")
+            assert_close(G.tensor_f32(Y2)[0, 0], ref, f"computed src0, trial {trial}", K=K)
             p = _rand((M, K))
             G.tensor_f32(P)[:] = p.reshape(1, 1, M, K)           # direct store through the data pointer: P is not cached (src1-side operand)
     finally:
