@@ -100,7 +100,7 @@ static bool q8_small_serves(int type, int64_t K, int64_t N) {
 // Q8_0 / Q5_0, 257..512 rows, K >= 2048: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type, N and K alone
 // (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against 58).
 static bool q8_mid_serves(int type, int64_t K, int64_t N) {
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N > 256 && N <= 512 && K / QK >= 64 && gemm_force() == 0;
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= 512 && K / QK >= 64 && gemm_force() == 0;
 }
 
 // The K1 image -- hence the kernel family -- for (type, K, N).  NOT a function of the number of weight rows: a row shard runs the
@@ -479,7 +479,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         off_gs = total; total += (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (gemm_force() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
-        if (type == GGML_TYPE_Q5_0) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
+        if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
         if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
@@ -504,7 +504,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         w->gs = (uint32_t *)((uint8_t *)base + off_gs);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
         if (q5k) w->khdr = (uint8_t *)base + off_kh;
-        if (type == GGML_TYPE_Q5_0) w->i8p = (uint8_t *)base + off_i8;
+        if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) w->i8p = (uint8_t *)base + off_i8;
     }
     *out = w;
     return GGML_HIP_OK;
@@ -542,6 +542,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
         } else if (e == hipSuccess) {
             e = launch_q5k_to_planar((const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
         }
+        if (e == hipSuccess) e = launch_q5_to_i8(w, st);      // (the planar Q5_1 form's int8 operand planes: gemm_qmp.hip serves prompt-sized batches)
         if (e == hipSuccess) e = launch_gemv_side_image(w, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (staging) (void)hipFree(staging);
@@ -781,7 +782,7 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
         if (e == hipSuccess) return GGML_HIP_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported = planes beyond the 32-bit offsets: the staged int8 kernel below)
     }
-    if (w->ext_type == 0 && q8_mid_serves(w->type, w->K, N)) {
+    if (q8_mid_serves(w->type, w->K, N)) {                  // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)
         const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
         const hipError_t e = launch_gemm_q8_mid(w, p, N, d_dst, ldd, (hipStream_t)stream, none);
         if (e == hipSuccess) return GGML_HIP_OK;

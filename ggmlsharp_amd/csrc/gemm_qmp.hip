@@ -302,15 +302,29 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 // Per block, Q8_0: acc = fma((float)sumi, d1 * d0, acc) (gemm_q8s.hip, the batched-decode form of the same arithmetic); Q5_0:
 // acc = fma(d0 * (float)sumi, d1, acc) -- the reference's a = d * sxy, t = a * y.d (Ggml.cs:1296-1298).  Structure as above; the weights of block b + 1 are requested at the start of block b into a second
 // register set (the sets take turns: two k-blocks per trip, nloc even).
+//
+// r4 -- Q5_1 and Q4_1 (and through Q5_1 the Q5_K extension, whose super-blocks live as eight k-blocks of the planar Q5_1 form): the same loop on
+// int8 planes of the UNSIGNED values (nib | bit << 4) in 0..31, per block acc = fma(d0 * (float)sxy, d1, acc) -- the reference's
+// (d * sxy) * y.d (Ggml.cs:1344) -- and the min term m * (s0 + s1) as a matrix product: over a PAIR of k-blocks it is a K = 2 outer
+// product, one v_mfma_f32_32x32x2_f32 per tile and pair straight into the tile's accumulators (A = d1 * sum(a) of the column tile's
+// rows, B = m of the m-tile's rows, the two k-blocks of the pair in the two lane halves).  It is issued in the MIDDLE of the next
+// tile's scale-accumulates of the pair's second block (the int8 MFMA of that step has left the pipe by then, the next one is half a
+// step away), so its 16 passes hide under VALU work.  Order of an element's additions: block b, block b + 1, the pair's two min
+// terms (k-block order inside the instruction), next pair -- fixed by K, N and the type like everything else in this form.
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 struct WI8 { i32x4 q[WMT]; float d[WMT]; };
 
 template <int TYPE>
 __global__ __launch_bounds__(KS * 64, 2)
-void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
-                        float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int ldd, int tiles_m, int tiles_n,
-                        uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep) {
+void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const float *__restrict__ wmn, const int8_t *__restrict__ a8,
+                        const float *__restrict__ ad, const int32_t *__restrict__ asum, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
+                        int nbk, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep) {
+    constexpr bool MIN = TYPE == GGML_TYPE_Q5_1;           // (Q4_1 runs this instantiation: its int8 planes hold 0..15)
+#ifndef K3P_DA_INPLACE
+#define K3P_DA_INPLACE MIN
+#endif
+    constexpr bool DA_INPLACE = K3P_DA_INPLACE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -323,9 +337,11 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const int kb0 = wave * nloc;
 
     const rsrc_t rW = make_rsrc(qs, w_bytes), rD = make_rsrc(wd, w_bytes / 8), rA = make_rsrc(a8, a_bytes);
-    uint32_t offW, offD, offA;
+    const rsrc_t rM = make_rsrc(MIN ? wmn : wd, w_bytes / 8), rS = make_rsrc(MIN ? (const void *)asum : (const void *)ad, a_bytes / 8);
+    uint32_t offW, offD, offA, offS;
     auto set_offsets = [&](int m0_, int n0_) {
         offW = (uint32_t)((hh * Mpad + m0_ + l31) * 16); offD = (uint32_t)((m0_ + l31) * 4); offA = (uint32_t)((hh * Npad + n0_ + l31) * 16);
+        offS = (uint32_t)((n0_ + l31) * 4);
     };
     set_offsets(m0, n0);
     const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
@@ -339,6 +355,20 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
     WI8 w0, w1;
     i32x4 af[WNT];
+    // min term of the pair of k-blocks (b, b + 1), b even: lane half hh holds block b + hh -- the B operand (m of m-tile i's rows) and the
+    // integer block sums of column tile j's rows, requested at the start of the pair's first block
+    float mnp[MIN ? WMT : 1];
+    int sump[MIN ? WNT : 1];
+    auto load_pair = [&](int b) {
+        if constexpr (MIN) {
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+                mnp[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, (int)(offD + (uint32_t)hh * d_blk + 128u * i), (int)((uint32_t)(kb0 + b) * d_blk), 0));
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+                sump[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(rS, (int)(offS + (uint32_t)hh * (uint32_t)(Npad * 4) + 128u * j), (int)((uint32_t)(kb0 + b) * (uint32_t)(Npad * 4)), 0);
+        }
+    };
     auto load_first = [&]() {
         load_w(w0, kb0);                                    // (requested first: the weights come from HBM, the table from L2)
 #pragma unroll
@@ -367,9 +397,29 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     f32x4 da[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) da[q] = *(const f32x4 *)(tabD + 4 * hh + 8 * q);
-    auto block = [&](int b, WI8 &w, WI8 &wn) {
+    // (Q5_1) the pair's A operands, d1 * (float)sum(a) = the Q8_1 s0 + s1 of Ggml.cs:820-821 (intent D3; the value the f16 / bf6 images
+    // carry in their `as` plane), computed at the start of the pair's second block; a k-block past the end of K has d1 = 0 in the table
+    float sap[MIN ? WNT : 1];
+    auto min_term = [&](auto tc) {
+        constexpr int t = decltype(tc)::value, j = t / WMT, i = t % WMT;
+        if constexpr (MIN) {
+            asm volatile("" : "+v"(acc[i][j]));             // (order pins: the MFMA stays where it is written, between two scale-accumulate groups)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sap[j], mnp[i], acc[i][j], 0, 0, 0);
+            asm volatile("" : "+v"(acc[i][j]));
+        }
+    };
+    auto block = [&](int b, WI8 &w, WI8 &wn, auto oddc) {
+        constexpr bool ODD = decltype(oddc)::value;
         if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }   // (see the MX kernel)
         load_w(wn, kb0 + b + 1);
+        if constexpr (MIN) {
+            if constexpr (!ODD) {
+                load_pair(b);
+            } else {
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) sap[j] = tabD[(b - 1 + hh) * (32 * WNT) + 32 * j + l31] * (float)sump[j];
+            }
+        }
         const float *dp = tabD + b * (32 * WNT) + 4 * hh;
         i32x16 x[2];
         x[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], w.q[0], zero, 0, 0, 0);
@@ -388,21 +438,27 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
                 if constexpr (i1 == WMT - 1)
                     af[j1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j1), (int)((uint32_t)(kb0 + b + 1) * a_blk), 0));
             }
-            f32x4 dn[4];
-            if constexpr (i == WMT - 1) {                   // the next column tile's scales (j + 1, or tile 0 of the next k-block: 64 floats on)
+            f32x4 dn[DA_INPLACE ? 1 : 4];
+            if constexpr (i == WMT - 1 && !DA_INPLACE) {    // the next column tile's scales (j + 1, or tile 0 of the next k-block: 64 floats on)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dn[q] = *(const f32x4 *)(dp + 32 * (j + 1) + 8 * q);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                // the min-term MFMA of the PREVIOUS tile of the pair's second block, between this tile's scale-accumulate groups
+                if constexpr (MIN && ODD && q == 2 && t >= 1) min_term(std::integral_constant<int, (t >= 1 ? t - 1 : 0)>{});
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if constexpr (TYPE == GGML_TYPE_Q8_0)
                         acc[i][j][4 * q + e] = __builtin_fmaf((float)x[t & 1][4 * q + e], da[q][e] * w.d[i], acc[i][j][4 * q + e]);   // Ggml.cs:1377-1378
                     else
-                        acc[i][j][4 * q + e] = __builtin_fmaf(w.d[i] * (float)x[t & 1][4 * q + e], da[q][e], acc[i][j][4 * q + e]);   // Ggml.cs:1296-1298
-            }
-            if constexpr (i == WMT - 1) {
+                        acc[i][j][4 * q + e] = __builtin_fmaf(w.d[i] * (float)x[t & 1][4 * q + e], da[q][e], acc[i][j][4 * q + e]);   // Ggml.cs:1296-1298, 1344
+                // (Q5_1: no second register set for the next column tile's scales -- group q's are dead after its last m-tile and are
+                // refetched into place, a whole tile step ahead of their next use)
+                if constexpr (DA_INPLACE && i == WMT - 1) da[q] = *(const f32x4 *)(dp + 32 * (j + 1) + 8 * q);
+            });
+            if constexpr (MIN && ODD && t == WMT * WNT - 1) min_term(tc);      // (the pair's last tile: behind its own scale-accumulates)
+            if constexpr (i == WMT - 1 && !DA_INPLACE) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) da[q] = dn[q];
             }
@@ -413,8 +469,8 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
     for (int b = 0; b < nloc; b += 2) {                     // (the look-ahead of the last trip reads past the wave's range: never used)
-        block(b, w0, w1);
-        block(b + 1, w1, w0);
+        block(b, w0, w1, std::false_type{});
+        block(b + 1, w1, w0, std::true_type{});
     }
 #ifdef K3P_TRACE
     asm volatile("" : "+v"(acc[0][0]));
@@ -457,8 +513,9 @@ static unsigned persistent_grid(int tiles) {
 }
 
 hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
-    const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : w->type == GGML_TYPE_Q5_0 ? w->i8p : nullptr;
-    if (!planes || !w->d) return hipErrorNotSupported;
+    const bool with_min = w->type == GGML_TYPE_Q5_1 || w->type == GGML_TYPE_Q4_1;
+    const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : (w->type == GGML_TYPE_Q5_0 || with_min) ? w->i8p : nullptr;
+    if (!planes || !w->d || (with_min && !w->m)) return hipErrorNotSupported;
     const int nbkp = (int)pad_kblocks(w->nbk);
     int nloc = (nbkp + KS - 1) / KS;
     nloc += nloc & 1;                                       // two k-blocks per trip
@@ -476,9 +533,10 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N,
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
-        kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, \
-                                                                        (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep); } while (0)
-    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else Q8MID_GO(GGML_TYPE_Q5_0);
+        kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, w->m, p.a8, p.ad, p.as, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
+                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep); } while (0)
+    // (Q4_1: the kernel of Q5_1 -- unsigned values 0..15 on the int8 planes, the same min term)
+    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else if (w->type == GGML_TYPE_Q5_0) Q8MID_GO(GGML_TYPE_Q5_0); else Q8MID_GO(GGML_TYPE_Q5_1);
 #undef Q8MID_GO
     return hipGetLastError();
 }

@@ -262,8 +262,10 @@ __global__ void quants_to_bf6_kernel(const uint8_t *__restrict__ qs, const uint3
     }
 }
 
-// Q5_0: nibble plane + fifth-bit plane -> int8 operand planes [nbk][2][Mpad][16 B] (the layout of Q8_0's qs: plane h byte j =
-// element 2j + h), value (nib | bit << 4) - 16 as in ggml_vec_dot_q5_0_q8_0 (Ggml.cs:1285-1289).  One thread per (row, k-block).
+// Q5_0 / Q5_1 / Q4_1: nibble plane (+ fifth-bit plane) -> int8 operand planes [nbk][2][Mpad][16 B] (the layout of Q8_0's qs: plane h
+// byte j = element 2j + h), value (nib | bit << 4) - OFF: OFF = 16 as in ggml_vec_dot_q5_0_q8_0 (Ggml.cs:1285-1289), OFF = 0 for Q5_1
+// and Q4_1, whose values stay unsigned (Ggml.cs:1330-1334, 1190-1191) and carry a min term instead.  One thread per (row, k-block).
+template <int OFF, bool QH>
 __global__ void q5_to_i8_kernel(const uint8_t *__restrict__ qs, const uint32_t *__restrict__ qh, int64_t rows, int64_t Mpad, uint8_t *__restrict__ i8p) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t b = blockIdx.y;
@@ -271,13 +273,13 @@ __global__ void q5_to_i8_kernel(const uint8_t *__restrict__ qs, const uint32_t *
     const int64_t pi = b * Mpad + m;
     const uint4 q = *(const uint4 *)(qs + pi * 16);
     const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
-    const uint32_t hb = qh[pi];
+    const uint32_t hb = QH ? qh[pi] : 0u;
     uint32_t ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {                          // byte j of the block: element 2j = low nibble, 2j + 1 = high nibble
         const uint32_t byte = (qq[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        const int x0 = (int)((byte & 0xFu) | (((hb >> (2 * j)) & 1u) << 4)) - 16;
-        const int x1 = (int)((byte >> 4) | (((hb >> (2 * j + 1)) & 1u) << 4)) - 16;
+        const int x0 = (int)((byte & 0xFu) | (((hb >> (2 * j)) & 1u) << 4)) - OFF;
+        const int x1 = (int)((byte >> 4) | (((hb >> (2 * j + 1)) & 1u) << 4)) - OFF;
         ev[j >> 2] |= (uint32_t)(uint8_t)(int8_t)x0 << (8 * (j & 3));
         od[j >> 2] |= (uint32_t)(uint8_t)(int8_t)x1 << (8 * (j & 3));
     }
@@ -344,7 +346,9 @@ hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st) {
 hipError_t launch_q5_to_i8(ggml_hip_weight *w, hipStream_t st) {
     if (!w->i8p || w->M <= 0 || w->nbk <= 0) return hipSuccess;
     dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)w->nbk);
-    q5_to_i8_kernel<<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
+    if (w->type == GGML_TYPE_Q5_0) q5_to_i8_kernel<16, true><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
+    else if (w->type == GGML_TYPE_Q5_1) q5_to_i8_kernel<0, true><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
+    else q5_to_i8_kernel<0, false><<<grid, 256, 0, st>>>(w->qs, nullptr, w->M, w->Mpad, w->i8p);
     return hipGetLastError();
 }
 

@@ -61,13 +61,7 @@ def _check_oracle_sample(t, rows, w, x, got, K, seed, nm=64, nn=64):
         for b in range(len(ms)):
             ref[a, b] = O.vec_dot(t, K, wq[b], xq[a])
     g = got[torch.from_numpy(ns).cuda()][:, torch.from_numpy(ms).cuda()].double().cpu().numpy()
-    rms = float(np.sqrt(np.mean(ref * ref)))
-    err = np.abs(g - ref)
-    floor = max(1e-6, 8 * 2.0 ** -24 * np.sqrt(K / 32)) * rms
-    bound = np.maximum(1e-3 * np.abs(ref), floor)
-    bad = err > bound
-    assert not bad.any(), f"{bad.sum()} of {bad.size} sampled outputs beyond SURVEY 8(c); max err {err.max():.3e}, rms {rms:.3e}"
-    assert np.linalg.norm(g - ref) / np.linalg.norm(ref) <= 1e-3
+    O.assert_mul_mat_close(g, ref, K, "sampled outputs of a full-size product")
 
 
 def _check_dense_oracle_sample(t, w_raw, x, got, K, seed, nm=48, nn=48):
@@ -83,23 +77,27 @@ def _check_dense_oracle_sample(t, w_raw, x, got, K, seed, nm=48, nn=48):
     wo = ws if t == O.F32 else ws.view(np.uint16)
     ref = O.mul_mat(t, np.ascontiguousarray(wo), np.ascontiguousarray(xs), len(ms), K, len(ns), nth=4)[0, 0].astype(np.float64)
     g = got[torch.from_numpy(ns).cuda()][:, torch.from_numpy(ms).cuda()].double().cpu().numpy()
-    rms = float(np.sqrt(np.mean(ref * ref)))
-    err = np.abs(g - ref)
-    floor = max(1e-6, 8 * 2.0 ** -24 * np.sqrt(K / 32)) * rms
-    bad = err > np.maximum(1e-3 * np.abs(ref), floor)
-    assert not bad.any(), f"{bad.sum()} of {bad.size} sampled outputs beyond SURVEY 8(c); max err {err.max():.3e}, rms {rms:.3e}"
-    assert np.linalg.norm(g - ref) / np.linalg.norm(ref) <= 1e-3
+    O.assert_mul_mat_close(g, ref, K, "sampled outputs of a full-size dense product")
+
+
+def _assert_close_dev(got, ref, K, what=""):
+    """tests/oracle_lib.assert_mul_mat_close (THE mul_mat tolerance: SURVEY 8(c) with its one stated floor), evaluated on the device
+    for whole full-size results; ref fp64 [N][M]"""
+    err = (got.double() - ref).abs()
+    rms = ref.pow(2).mean().sqrt().item()
+    floor = max(1e-6, 8 * 2.0 ** -24 * float(np.sqrt(K / 32))) * rms
+    bound = (1e-3 * ref.abs()).clamp_min(floor)
+    bad = (~(err <= bound)).sum().item()
+    assert bad == 0, f"{what}: {bad} elements beyond SURVEY 8(c); max err / rms = {err.max().item() / rms:.3e}"
+    assert (torch.linalg.norm(got.double() - ref) / torch.linalg.norm(ref)).item() <= 1e-3
 
 
 def _check_fp64(dev, t, rows, x, got, K):
     wd = dev.dequantize_rows(t, rows, K).double()
     xq = dev.dequantize_rows(Q8_0, dev.quantize_rows(Q8_0, x.contiguous()), K).double()
     ref = xq @ wd.T
-    err = (got.double() - ref).abs()
-    rms = ref.pow(2).mean().sqrt()
-    bad = (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item()
-    assert bad == 0, f"{bad} elements beyond 1e-3 relative; max err / rms = {(err.max() / rms).item():.3e}"
-    assert (err.max() / rms).item() < 1e-4
+    _assert_close_dev(got, ref, K, "fp64 evaluation of the block arithmetic")
+    assert ((got.double() - ref).abs().max() / ref.pow(2).mean().sqrt()).item() < 1e-4
 
 
 CONFIGS = [  # BASELINE.json configs (M, K, N), Q5_0 standing in for the absent Q5_K (SURVEY.md 0.2)
@@ -146,9 +144,7 @@ def test_dense_f16_fullsize_matches_fp64(dev, M, K, N):
     W = dev.Weight.from_device(1, w.contiguous().view(torch.uint8), K)
     got = dev.mul_mat(W, x)
     ref = x.half().double() @ w.double().T
-    err = (got.double() - ref).abs()
-    rms = ref.pow(2).mean().sqrt()
-    assert (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item() == 0, f"max err / rms = {(err.max() / rms).item():.3e}"
+    _assert_close_dev(got, ref, K)
     assert np.array_equal(W.download(), w.cpu().numpy().view(np.uint8).reshape(-1))      # the row-major copy still round-trips
     _check_dense_oracle_sample(O.F16, w, x, got, K, seed=M + N)
     W.free()
@@ -166,9 +162,7 @@ def test_dense_f32_fullsize_matches_fp64(dev, M, K, N):
     W = dev.Weight.from_device(0, w.contiguous().view(torch.uint8), K)
     got = dev.mul_mat(W, x)
     ref = x.double() @ w.double().T
-    err = (got.double() - ref).abs()
-    rms = ref.pow(2).mean().sqrt()
-    assert (err > 1e-3 * ref.abs() + 1e-5 * rms).sum().item() == 0, f"max err / rms = {(err.max() / rms).item():.3e}"
+    _assert_close_dev(got, ref, K)
     # a row shard goes through the other tile size (fewer tiles): same k order, same bits
     Ws = dev.Weight.from_device(0, w.contiguous().view(torch.uint8), K, row_begin=128, row_end=640)
     assert torch.equal(dev.mul_mat(Ws, x), got[:, 128:640])
@@ -317,6 +311,28 @@ def test_min_term_types_tall_matrix_and_its_shards_add_in_one_order(dev, t, kern
         W.free()
     finally:
         lib().ggml_hip_debug_force_gemm(0)
+
+
+@pytest.mark.parametrize("t", [Q4_0, 3, Q5_0, 7, Q8_0])
+@pytest.mark.parametrize("N", [300, 512])
+def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
+    """257..512 src1 rows, K >= 2048 (gemm_qmp.hip): eight K ranges per workgroup whatever M -- a vocabulary-sized matrix (persistent
+    workgroups: more than four rounds of tiles), a 4000-row shard (one dispatch round) and a ragged shard compute the same bits.
+    r4: Q5_1 (min term per pair of k-blocks on the matrix pipe) and Q4_1 run the form too."""
+    M, K = 26000, 2048
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 * t + N)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    rows = dev.quantize_rows(t, w)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    _check_fp64(dev, t, rows, x, full, K)
+    for (r0, r1) in ((0, 4000), (25000, 26000), (12345, 12345 + 777)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, N, r0, r1)
+        Ws.free()
+    W.free()
 
 
 @pytest.mark.parametrize("N", [128, 512])

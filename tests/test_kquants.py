@@ -163,7 +163,8 @@ def test_mul_mat_q5_K_matches_the_restatement(dev):
     and unsplit, int8 MFMA; ragged M and N; raw random super-blocks as well as quantized normal data"""
     import torch
     for (M, K, N) in ((96, 256, 1), (300, 1024, 3), (128, 512, 8), (515, 768, 40), (256, 2048, 130), (640, 1024, 300),
-                      (130, 512, 600), (257, 768, 1100)):
+                      (130, 512, 600), (257, 768, 1100),
+                      (200, 2048, 300), (130, 4352, 512)):      # r4: K3p on the int8 planes of the planar Q5_1 form (257..512 rows, K >= 2048)
         for raw in (False, True):
             rows = _random_blocks(M * K // 256).reshape(M, -1) if raw else KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
             x = _rand((N, K))
