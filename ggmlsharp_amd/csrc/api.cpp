@@ -159,17 +159,25 @@ void DeviceCtx::scope_dirty() {
         e.seen = 0;
         if (++e.strikes >= 3) { e.refused = true; ++n_refused; }
     }
+    // (the capture is begun in relaxed mode, so the thread that ends it need not be the one that began it: a foreign thread's seam
+    // on this slot lands here too, seams.cpp Call::begin)
     hipGraph_t g = nullptr;
-    if (hipStreamEndCapture(stream, &g) == hipSuccess && g) {
-        hipGraphExec_t ex = nullptr;
-        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
-            (void)hipGraphLaunch(ex, stream);
-            (void)hipStreamSynchronize(stream);
-            (void)hipGraphExecDestroy(ex);
-        }
-        (void)hipGraphDestroy(g);
-    } else {
+    hipError_t e = hipStreamEndCapture(stream, &g);
+    hipGraphExec_t ex = nullptr;
+    if (e == hipSuccess && !g) e = hipErrorStreamCaptureInvalidated;
+    if (e == hipSuccess) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e == hipSuccess) e = hipGraphLaunch(ex, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (ex) (void)hipGraphExecDestroy(ex);
+    if (g) (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        // what the scope had issued so far did not run and cannot be issued again from here: its owner is told at the scope's end
+        // (ggml_hip_graph_end returns the error), the key is never captured again
         (void)hipGetLastError();
+        scope_lost = true;
+        Captured &c = captured[scope_key];
+        if (!c.refused) { c.refused = true; ++n_refused; }
+        fail(GGML_HIP_ERR_RUNTIME, "a graph scope's capture could not be ended and issued live (%s): its nodes so far did not run", hipGetErrorString(e));
     }
 }
 void DeviceCtx::drop_captured() {

@@ -127,6 +127,7 @@ struct DeviceCtx {
     std::thread::id scope_owner;                   // the thread that opened the named scope: only ITS seam calls are the scope's
     bool dead = false;                             // ggml_hip_shutdown released this slot while the caller was waiting for its lock
     int scope_mode = 0;                            // 0 plain, 1 observing, 2 capturing, 3 replaying
+    bool scope_lost = false;                       // a capture of the open scope could not be ended: ggml_hip_graph_end reports it
     bool scope_clean = true;
     std::vector<std::pair<const void *, size_t>> scope_leaves;   // (observing) whole host tensors uploaded so far in this scope
     void note_leaf(const void *host, size_t bytes) { if (scope_mode == 1) scope_leaves.emplace_back(host, bytes); }

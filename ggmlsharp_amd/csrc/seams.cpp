@@ -383,6 +383,7 @@ static int graph_begin(uint64_t key) {
     c->scope_key = key;
     c->scope_owner = std::this_thread::get_id();
     c->scope_clean = true;
+    c->scope_lost = false;
     c->scope_leaves.clear();
     c->scope_mode = 1;
     auto it = c->captured.find(key);
@@ -401,8 +402,10 @@ static int graph_begin(uint64_t key) {
         c->captured.erase(it);
         return GGML_HIP_OK;
     }
-    // observed clean before: capture this run (thread-local mode: other threads' HIP calls are none of its business)
-    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) c->scope_mode = 2;
+    // observed clean before: capture this run.  Relaxed mode: other threads' HIP calls are none of the capture's business, and a
+    // foreign thread whose seam arrives on this slot (Call::begin) must be able to END the capture -- in the other modes only the
+    // thread that began a capture may end it (hipErrorStreamCaptureWrongThread), and the stream would stay capturing.
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) c->scope_mode = 2;
     else { (void)hipGetLastError(); e.refused = true; c->scope_mode = 0; return GGML_HIP_OK; }
     // the leaves the scope uploaded one by one when it was observed come down TOGETHER, as the first node of the captured
     // graph (one launch through the device mapping of the pool instead of a copy node each); the seams then find them resident
@@ -495,6 +498,10 @@ int ggml_hip_graph_end(void) {
                 DeviceCtx::Captured &e = c->captured[c->scope_key];
                 if (clean && !r) { e.seen = 1; e.leaves = c->scope_leaves; ++c->n_observed; }     // (a scope that was not clean is simply observed again next time)
             }
+        }
+        if (outer && c->scope_lost) {                    // (DeviceCtx::scope_dirty could not end a capture of this scope)
+            c->scope_lost = false;
+            if (!r) r = fail(GGML_HIP_ERR_RUNTIME, "a capture of this graph scope could not be ended: nodes issued before that point did not run");
         }
         if (outer) { c->scope_mode = 0; c->outputs_only = false; c->outputs.clear(); }
         if (r && !rc) rc = r;

@@ -371,3 +371,53 @@ def test_an_error_inside_a_named_scope_is_reported_every_time(dev):
         assert c1[1] == c0[1] and c1[2] == c0[2], f"a scope with a failing node was captured / replayed: {c0} -> {c1}"
     finally:
         G.ggml_free(ctx)
+
+
+def test_a_foreign_threads_seam_during_a_capture_ends_it_and_both_results_are_right(dev):
+    """thread B's seam arrives on a slot between two seams of thread A's CAPTURING scope.  The capture is ended by B (begun
+    in relaxed mode: the ending thread need not be the beginning one) and issued live, B's product runs, A carries on live: every
+    result is right every time, nothing of such a run is kept as a captured graph, and the stream is left usable."""
+    import threading
+    L = _lib.lib()
+    rng = np.random.default_rng(99)
+    ctx = G.ggml_init(16 * 1024 * 1024)
+    try:
+        K, M, N = 256, 96, 4
+        X, Xb = G.ggml_new_tensor_2d(ctx, G.F32, K, N), G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        Ws = [G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M) for _ in range(3)]
+        for w in Ws:
+            G.tensor_bytes(w)[:] = O.quantize_row(G.Q4_0, rng.standard_normal((M, K)).astype(np.float32)).reshape(-1)
+        y1, y2, yb = G.ggml_mul_mat(ctx, Ws[0], X), G.ggml_mul_mat(ctx, Ws[1], X), G.ggml_mul_mat(ctx, Ws[2], Xb)
+        p = _lib.ggml_compute_params(_lib.GGML_TASK_COMPUTE, 0, 1, 0, None)
+        c0 = _counters()
+        for it in range(6):
+            for t in (X, Xb):
+                G.tensor_f32(t)[:] = rng.standard_normal((N, K)).astype(np.float32).reshape(1, 1, N, K)
+                L.ggml_hip_invalidate_range(t.contents.data, N * K * 4)
+            for y in (y1, y2, yb):
+                G.tensor_f32(y)[:] = -7.0
+            rcb = []
+
+            def foreign():
+                rcb.append(L.ggml_hip_compute_forward_mul_mat(C.byref(p), yb.contents.src0, yb.contents.src1, yb))
+
+            _lib.check(L.ggml_hip_graph_begin_keyed(0xF0E1), "begin")
+            rc1 = L.ggml_hip_compute_forward_mul_mat(C.byref(p), y1.contents.src0, y1.contents.src1, y1)
+            th = threading.Thread(target=foreign)
+            th.start()
+            th.join()
+            rc2 = L.ggml_hip_compute_forward_mul_mat(C.byref(p), y2.contents.src0, y2.contents.src1, y2)
+            _lib.check(L.ggml_hip_graph_end(), f"end (compute {it})")
+            assert rc1 == 0 and rc2 == 0 and rcb == [0], (it, rc1, rc2, rcb)
+            xs = np.array(G.tensor_f32(X)).reshape(N, K)
+            for y, w, xin, name in ((y1, Ws[0], xs, "A first"), (y2, Ws[1], xs, "A second"), (yb, Ws[2], np.array(G.tensor_f32(Xb)).reshape(N, K), "B")):
+                ref = O.mul_mat(O.Q4_0, np.array(G.tensor_bytes(w)), xin, M, K, N)[0, 0]
+                O.assert_mul_mat_close(np.array(G.tensor_f32(y)).reshape(N, M), ref, K, f"compute {it}, {name}")
+        c1 = _counters()
+        assert c1[1] == c0[1] and c1[2] == c0[2], f"a scope that a foreign seam cut into was kept as a graph: {c0} -> {c1}"
+        # the slot is healthy afterwards: the same scope without the intruder still computes
+        _lib.check(L.ggml_hip_graph_begin_keyed(0xF0E2), "begin")
+        assert L.ggml_hip_compute_forward_mul_mat(C.byref(p), y1.contents.src0, y1.contents.src1, y1) == 0
+        _lib.check(L.ggml_hip_graph_end(), "end")
+    finally:
+        G.ggml_free(ctx)
