@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x BF16 per clock, ~5 PF dense.  The MX kernel issues bf6 MFMAs
                             # (4x BF16 per clock, ~10 PF) over twice the algorithmic K (two digits per Q8 activation): the same
                             # 5 PF ceiling in algorithmic FLOPs.
-PROFILE_TRAFFIC = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
+PROFILE_TRAFFIC = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
 def algorithmic_bytes(M, K, N, blk=20):
@@ -153,7 +153,10 @@ def compute_kernel_name(qtype, K, N):
     """which COMPUTE kernel serves (type, K, N): the selection is by type, N and K alone (csrc/api.cpp act_image_kind, gemm_qmx.hip launch_typed)"""
     if N <= 8:
         return "gemv_fused_kernel (gemv.hip)"
-    if K >= 2048 and 256 < N <= 512 and qtype in (Q4_0, Q8_0, Q5_0):
+    if K >= 2048 and 256 < N <= 512 and qtype in (Q4_0, Q8_0, Q5_0, Q5_K):
+        if qtype == Q5_K:
+            return ("gemm_q8_mid_kernel<Q5_1>: K3p on the int8 planes of the planar Q5_1 form a Q5_K weight lives in, min term as one "
+                    "v_mfma_f32_32x32x2_f32 per tile and pair of k-blocks (gemm_qmp.hip, r4)")
         return ("gemm_qmx_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, MX bf6 MFMA (gemm_qmp.hip)" if qtype == Q4_0 else
                 "gemm_q8_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, v_mfma_i32_32x32x32_i8 off resident int8 planes (gemm_qmp.hip)")
     if qtype == Q4_0:
@@ -646,7 +649,12 @@ def main():
     out = {
         "metric": "effective GFLOP/s, Q4_0 mul_mat 4096x4096x4096 (2*M*K*N / step time)",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 5),
+        # the SAME W + K steps WITHOUT the untimed preheat (the protocol of rounds 1-2): compare rounds on this pair, not on `value` alone
+        "cold_ms_per_step": round(cold_ms_per_step, 5), "cold_value": round(flops_step / (cold_ms_per_step * 1e-3) / 1e9, 1),
+        "timing_protocol": f"value / ms_per_step: {PREHEAT_S} s of untimed steps of the same workload, then W warm-up steps, then exactly K timed steps between "
+                           "barrier + synchronize; cold_*: W warm-up steps then K timed steps on a chip that was idle (no preheat)",
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
         "dtype": "i8", "data": "synthetic",
         "config": {"workload": f"Q4_0 mul_mat M={M} K={K} N={N} f32 src1, weights resident",
                    "per_gpu": f"rows [{gdist.shard_rows(M, world, 0)[0]}, {gdist.shard_rows(M, world, 0)[1]}) of W on rank 0, all of src1, whole dst [N][M] on every rank",
@@ -701,10 +709,27 @@ def main():
         torch.cuda.synchronize()
         init_ts = [e0.elapsed_time(e1) for e0, e1, _ in ev]
         comp_ts = [e1.elapsed_time(e2) for _, e1, e2 in ev]
-        t_init, t_comp = float(np.mean(init_ts)), float(np.mean(comp_ts))     # mean: what rocprofv3 --stats reports as average
+        t_init_ev, t_comp_ev = float(np.mean(init_ts)), float(np.mean(comp_ts))
+        # an event pair around EVERY launch exposes ~10 us between a kernel's dispatch and its first tiles (r3: kernel_ms
+        # came out larger than ms_per_step).  The dominant kernel's duration AS THE STEP RUNS IT: ONE event pair around `blk` back-to-back
+        # INIT + COMPUTE pairs, minus INIT's own duration measured the same way (one pair around `blk` back-to-back INIT launches) --
+        # so init_kernel_ms + kernel_ms is the step the headline times, and the rocprofv3 --kernel-trace average of the same command
+        # (profiles/r04_bench_kernel_stats.csv) is the cross-check.  The per-launch event figures stay as *_per_launch_events.
+        blk, nblk = 25, 8
+
+        def pairs():
+            device.mul_mat_init(W, x, runner.work)
+            device.mul_mat_compute(W, N, runner.shard, runner.work)
+
+        def inits():
+            device.mul_mat_init(W, x, runner.work)
+        t_pairs = [event_time_ms(pairs, blk, stream) for _ in range(nblk)]
+        t_inits = [event_time_ms(inits, blk, stream) for _ in range(nblk)]
+        t_init = float(np.median(t_inits))
+        t_comp = float(np.median(t_pairs)) - t_init
         achieved = 2.0 * M * K * N / (t_comp * 1e-3) / 1e12
         ab = algorithmic_bytes(M, K, N)
-        traffic = None
+        traffic, traffic_src = None, None
         kernels = {0: ("gemm_q_kernel<Q4_0,2,2>", "v_mfma_i32_32x32x32_i8 + f32 block-scale epilogue on the VALU"),
                    1: ("gemm_q16_kernel<Q4_0,2,4,4,1>", "2 x v_mfma_f32_32x32x16_f16 per tile and block + f32 block-scale epilogue on the VALU"),
                    3: ("gemm_qmx_kernel<Q4_0,2,4,4,1>", "1 x v_mfma_scale_f32_32x32x64_f8f6f4 (bf6 digits, exact) per tile and block + f32 block-scale epilogue on the VALU")}
@@ -714,13 +739,21 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     traffic = json.load(f)[f"{kname} M=4096 K=4096 N=4096"]["traffic_bytes"]
+                traffic_src = f"profiles/{fn}"
                 break
             except Exception:
                 pass
         out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
+                           # NOT measured by this run: HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+                           # (tools/profile_round.sh -> tools/summarize_round.py, the guide's FETCH/WRITE_SIZE recipe and gfx950 corrections)
+                           "traffic_from_profile": traffic_src,
                            "kernel": f"{kname} ({kdesc})",
-                           "kernel_ms": round(t_comp, 5), "kernel_ms_stats": stats(comp_ts), "init_kernel_ms": round(t_init, 5),
+                           "kernel_ms": round(t_comp, 5), "init_kernel_ms": round(t_init, 5),
+                           "kernel_ms_method": f"median over {nblk} blocks of (one HIP event pair around {blk} back-to-back INIT + COMPUTE pairs) - (the same around {blk} INIT launches)",
+                           "step_from_kernels_ms": round(t_comp + t_init, 5),
+                           "kernel_ms_per_launch_events": round(t_comp_ev, 5), "kernel_ms_per_launch_events_stats": stats(comp_ts),
+                           "init_kernel_ms_per_launch_events": round(t_init_ev, 5),
                            "algorithmic_bytes": ab,
                            "note": "the binding unit is the VALU, not the matrix pipe: the reference applies two f32 scales per 32-element "
                                    "block (Ggml.cs:1158) = 32 VALU instructions per 32x32 tile and block, floor ~55 us for this shape",
@@ -743,6 +776,7 @@ def main():
                 # ... and Q5_K itself as an UNPINNED EXTRA (upstream format, no oracle in the reference; ggml_hip.h GGML_HIP_TYPE_Q5_K)
                 "q5_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_K),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
+                "vocab512_shard_of_8": side_config(device, 4000, 4096, 512, copies=24, iters=100),      # what each rank of config 5's 8-GPU split computes
                 # the dense case of the path (north_star: MFMA utilisation for the dense f16 / f32 mul_mat)
                 "dense_f16": dense_config(device, 1, 4096, 4096, 4096, iters=20),
                 "dense_f32": dense_config(device, 0, 4096, 4096, 4096, iters=5),
@@ -750,6 +784,20 @@ def main():
             for k in ("batch1", "batch1_M32000"):
                 out["other_configs"][k]["roofline"] = {"bound": "hbm", "achieved": out["other_configs"][k]["algorithmic_GBs"],
                                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["other_configs"][k]["hbm_frac"]}
+            out["other_configs"]["vocab512"]["note"] = ("config 5's TOTAL on one GPU runs the kernel form of its 4000-row shards (K split eight ways, 7.8 rounds of "
+                                                        "persistent workgroups) so that the 8-GPU result is bit for bit the 1-GPU result; each of the 8 ranks runs "
+                                                        "the 4000 x 4096 x 512 shard")
+            # the BASELINE configs' rooflines where the driver's record shows them: top level, one line each
+            oc = out["other_configs"]
+            out["baseline_config_rooflines"] = {
+                "config2_batch1_Q4_0_4096x4096": dict(oc["batch1"]["roofline"], ms_per_step=oc["batch1"]["ms_per_step"]),
+                "config3_prompt512_Q4_0_4096x4096x512": dict(oc["prompt512"]["roofline"], ms_per_step=oc["prompt512"]["ms_per_step"]),
+                "config4_Q8_0_4096x11008x512": dict(oc["q8_0_ffn512"]["roofline"], ms_per_step=oc["q8_0_ffn512"]["ms_per_step"]),
+                "config4_Q5_K_4096x11008x512_unpinned_extra": dict(oc["q5_k_ffn512_unpinned_extra"]["roofline"], ms_per_step=oc["q5_k_ffn512_unpinned_extra"]["ms_per_step"]),
+                "config4_Q5_0_standin_4096x11008x512": dict(oc["q5_0_ffn512"]["roofline"], ms_per_step=oc["q5_0_ffn512"]["ms_per_step"]),
+                "config5_total_on_one_gpu_Q4_0_32000x4096x512": dict(oc["vocab512"]["roofline"], ms_per_step=oc["vocab512"]["ms_per_step"]),
+                "config5_shard_of_8_Q4_0_4000x4096x512": dict(oc["vocab512_shard_of_8"]["roofline"], ms_per_step=oc["vocab512_shard_of_8"]["ms_per_step"]),
+            }
             # the drop-in path with HOST tensors (PCIe-inclusive; never `value`)
             try:
                 pc = pcie_probe()
