@@ -72,6 +72,14 @@ class ggml_cgraph(C.Structure):
 
 assert C.sizeof(ggml_cgraph) == 98360
 
+class ggml_hip_mm_plan_t(C.Structure):
+    """include/ggml_hip_ext.h: the plan of one product (csrc/plan.cpp)"""
+    _fields_ = [("family", C.c_int32), ("image_kind", C.c_int32), ("form", C.c_int32), ("tree_id", C.c_uint32),
+                ("arith", C.c_int32), ("ksplit", C.c_int32), ("kstyle", C.c_int32), ("kunit", C.c_int32),
+                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("waves", C.c_int32), ("tiles_per_wave", C.c_int32),
+                ("workgroups", C.c_int64), ("flags", C.c_int32)]
+
+
 # every symbol include/ggml_hip.h declares (HIP_SYMBOLS, exported by libggml_hip.so) and include/ggml.h declares
 # (MIRROR_SYMBOLS, exported by libggml_hostmirror.so): name -> (restype, argtypes)
 _P = C.c_void_p
@@ -134,6 +142,7 @@ HIP_SYMBOLS = {
     "ggml_hip_graph_end": (C.c_int, []),
     "ggml_hip_debug_transfer_counters": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ggml_hip_act_image_kind": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
+    "ggml_hip_mm_plan": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
     "ggml_hip_debug_force_gemm": (None, [C.c_int]),
     "ggml_hip_quantize_act_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "ggml_hip_mul_mat_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),

@@ -2,6 +2,7 @@
 // device-resident data, the row functions (Seam 2).  seams.cpp holds the host-pointer seams, multi.cpp the row split
 // over several devices.  No CPU fallback anywhere: without a device every compute entry returns GGML_HIP_ERR_NO_DEVICE.
 #include "ctx.h"
+#include "plan.h"
 #include <algorithm>
 
 namespace ghip {
@@ -65,76 +66,19 @@ bool contiguous_f32(const ggml_tensor *t) {
 }
 
 namespace {
-// src1 rows up to which the mat-vec kernel serves a type (two-step form above GEMV_MAX_N): the types with small-batch MFMA
-// configurations leave it at 8; Q4_2, which only has the int8 kernel's 64 x 64 tiles behind it, stays on it up to 16
-int64_t gemv_rows_max(int t) { return t == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N : GEMV_MAX_N; }
 bool has_min_plane(int t) { return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1 || t == GGML_TYPE_Q4_2; }   // Q4_2: its second scale
 bool has_qh_plane(int t) { return t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q5_1; }
-
-// Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat (measured on MI355X):
-//   gemm_qmx.hip (MX matrix path, bf6 digits, one exact MFMA per tile and block) -- Q4_0 / Q4_1,
-//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q5_1 / Q8_0 on prompt-sized batches (N <= 512, K split in the
-//                workgroup) and from 1024 rows up,
-//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q4_2, and Q5_0 / Q5_1 / Q8_0 in between.
-// ggml_hip_debug_force_gemm forces one (test / developer switch; the product library reads no environment variable: the
-// GGML_HIP_GEMM variable is honoured by -DGGML_HIP_DEV builds only).  The MX kernel also has a two-digit form for Q5_0 / Q8_0
-// (two MFMAs per tile and block); it measured no faster than the kernels above, so its digit planes
-// (1.5 B / weight) are only built for weights uploaded while "mx" is forced.
-// Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images of gemm_q16.hip, 3 = the bf6 image of gemm_qmx.hip.
-thread_local int t_force_gemm = -1;   // -1: not set yet; 0 auto, 1 int8, 2 f16, 3 MX.  Per calling thread: a test hook never reaches another thread's calls
-
-int gemm_force() {
-    if (t_force_gemm < 0) {
-        const char *e = dev_env_str("GGML_HIP_GEMM");
-        t_force_gemm = !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'm' ? 3 : 0)));
-    }
-    return t_force_gemm;
-}
 }  // namespace
 
-// Q8_0, 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
-static bool q8_small_serves(int type, int64_t K, int64_t N) {
-    return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && gemm_force() == 0;
-}
-
-// Q8_0 / Q5_0, 257..512 rows, K >= 2048: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type, N and K alone
-// (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against 58).
-static bool q8_mid_serves(int type, int64_t K, int64_t N) {
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= 512 && K / QK >= 64 && gemm_force() == 0;
-}
-
-// The K1 image -- hence the kernel family -- for (type, K, N).  NOT a function of the number of weight rows: a row shard runs the
-// kernel form of the unsplit matrix (the signature has no M to consult).
-int act_image_kind(int type, int64_t K, int64_t N) {
-    const int force = gemm_force();
-    if (q8_small_serves(type, K, N) || q8_mid_serves(type, K, N)) return 0;
-    if (N <= 4 || force == 1) return 0;
-    // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
-    // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them (a 7B
-    // decoder layer through ggml_graph_compute: batch 9 192 us against batch 8 232 us on the mat-vec)
-    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= 64)) return 0;
-    if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
-    // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
-    const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
-    if (nba * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull) return 0;
-    if (force == 2) return gemm_q16_image_kind(type);
-    if (type == GGML_TYPE_Q5_1 && force == 3) return 0;                 // no MX form: the forced choice falls back to the int8 kernel
-    if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
-    // Q5_0 / Q5_1 / Q8_0: the f16 kernel's K-split form wins on prompt-sized batches (4096 x 11008 x 512: 92 / 110 us against 108 /
-    // 130 us for the int8 kernel) and its unsplit forms from 1024 rows up (Q8_0 4096^3 199 against 220 us, 32000 x 4096 x 1024 405
-    // against 450, 4096 x 11008 x 1024 172 against 194; Q5_1 4096 x 4096 x 1024 89 against 115 -- 4096 x 4096 x 2048 is the
-    // one shape measured the other way, 124 against 116); in between (4096 x 4096 x 640: 67 against 57 us) the int8 kernel's
-    // 64 x 64 tiles balance the chip better.  Decided from N and K only, like the K split itself: never from M, so a row shard
-    // runs the kernel form of the unsplit matrix.
-    return ((N <= 512 || N >= 1024) && K / QK >= 8) ? gemm_q16_image_kind(type) : 0;
-}
-
-// ... for ONE weight: the stated exception -- planes that do not fit 32-bit buffer offsets (> 4 GiB per plane) are served by the
-// int8 kernel and its image, whatever the type.  INIT and COMPUTE both come through here, so they agree.
+// Kernel selection lives in plan.cpp (plan.h): ONE decision per product -- family, form, summation tree -- that every launcher consumes.
+// The K1 image for (type, K, N): NOT a function of the number of weight rows (a row shard runs the kernel form of the unsplit matrix).
+int act_image_kind(int type, int64_t K, int64_t N) { return plan_image_kind(type, K, N); }
+mm_plan weight_plan(const ggml_hip_weight *w, int64_t N, bool one_call) { return plan_mul_mat(w->type, w->ext_type, w->M, w->K, N, one_call); }
+// ... for ONE weight, as the two-phase entries see it (INIT writes it, COMPUTE reads it): the stated exception included -- planes beyond
+// 32-bit buffer offsets are served by the int8 family and its image
 int weight_image_kind(const ggml_hip_weight *w, int64_t N) {
-    const uint64_t nba = (uint64_t)pad_kblocks(w->K / QK);
-    if ((nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 32 > 0xFFFFFFFFull) return 0;
-    return act_image_kind(w->type, w->K, N);
+    const mm_plan pl = weight_plan(w, N, false);
+    return pl.image >= 0 && pl.image <= 3 ? pl.image : 0;
 }
 
 // ---------------- DeviceCtx ----------------
@@ -486,7 +430,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (has_qh_plane(type)) { off_qh = total; total += plane; }
         off_gs = total; total += (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
-        with6 = q4 || (gemm_force() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
+        with6 = q4 || (plan_force_gemm() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
         if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
@@ -755,7 +699,22 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
 }
 
 int ggml_hip_act_image_kind(int type, int64_t K, int64_t N) { return act_image_kind(type == GGML_HIP_TYPE_Q5_K ? GGML_TYPE_Q5_1 : type, K, N); }
-void ggml_hip_debug_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 : which; }
+void ggml_hip_debug_force_gemm(int which) { plan_set_force_gemm(which); }
+
+// the plan of mul_mat(type, M, K, N) as ggml_hip_mul_mat_dev will run it; no device is needed (tests/test_plan_cpu.py)
+int ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_plan_t *out) {
+    if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
+    const bool q5k = type == GGML_HIP_TYPE_Q5_K;
+    const int t = q5k ? GGML_TYPE_Q5_1 : type;
+    if (t < 0 || t >= GGML_TYPE_COUNT || !weight_type_ok(t)) return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type", type);
+    if (M <= 0 || K <= 0 || N <= 0 || K % BLCK[t] != 0 || (is_q(t) && K % QK != 0) || (q5k && K % 256 != 0)) return fail(GGML_HIP_ERR_SHAPE, "bad shape");
+    const mm_plan p = plan_mul_mat(t, q5k ? GGML_HIP_TYPE_Q5_K : 0, M, K, N, true);
+    out->family = p.family; out->image_kind = p.image; out->form = p.form; out->tree_id = plan_tree_id(p);
+    out->ksplit = p.ksplit; out->kstyle = p.kstyle; out->kunit = p.kunit; out->arith = p.arith;
+    out->tile_m = p.tile_m; out->tile_n = p.tile_n; out->waves = p.waves; out->tiles_per_wave = p.tiles_per_wave;
+    out->workgroups = p.wgs; out->flags = p.flags;
+    return GGML_HIP_OK;
+}
 
 int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
                               int image_kind, void *stream) {
@@ -785,25 +744,18 @@ int ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *d_d
     int rc = weight_device_current(w);
     if (rc) return rc;
     act_planes p = act_carve((void *)d_work, w->K, pad_act(N));
-    if (w->ext_type == 0 && q8_small_serves(w->type, w->K, N)) {
-        const hipError_t e = launch_gemm_q8_small(w, p, N, d_dst, ldd, (hipStream_t)stream, nullptr);
-        if (e == hipSuccess) return GGML_HIP_OK;
-        if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported = planes beyond the 32-bit offsets: the staged int8 kernel below)
+    const mm_plan pl = weight_plan(w, N, false);            // (the COMPUTE-only entry: INIT wrote this plan's image)
+    const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
+    switch (pl.family) {
+    case MMF_K3S_I8:    HIP_TRY(launch_gemm_q8_small(w, pl, p, N, d_dst, ldd, (hipStream_t)stream, nullptr)); break;
+    case MMF_K3P_I8:    HIP_TRY(launch_gemm_q8_mid(w, pl, p, N, d_dst, ldd, (hipStream_t)stream, none)); break;
+    case MMF_GEMV_ROWS: HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream)); break;
+    case MMF_K3S_MX: case MMF_K3P_MX: case MMF_MX:
+                        HIP_TRY(launch_gemm_qmx(w, pl, p, N, d_dst, ldd, (hipStream_t)stream)); break;
+    case MMF_F16:       HIP_TRY(launch_gemm_q16(w, pl, p, N, d_dst, ldd, (hipStream_t)stream)); break;
+    case MMF_I8:        HIP_TRY(launch_gemm_q(w, pl, p, N, d_dst, ldd, (hipStream_t)stream)); break;
+    default:            return fail(GGML_HIP_ERR_RUNTIME, "no kernel family for this product (plan family %d)", pl.family);
     }
-    if (q8_mid_serves(w->type, w->K, N)) {                  // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)
-        const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
-        const hipError_t e = launch_gemm_q8_mid(w, p, N, d_dst, ldd, (hipStream_t)stream, none);
-        if (e == hipSuccess) return GGML_HIP_OK;
-        if (e != hipErrorNotSupported) HIP_TRY(e);          // (not supported: the staged int8 kernel below reads the same image)
-    }
-    if (N <= gemv_rows_max(w->type) && weight_image_kind(w, N) == 0)
-        HIP_TRY(launch_gemv_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (weight_image_kind(w, N) == 3)
-        HIP_TRY(launch_gemm_qmx(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else if (weight_image_kind(w, N) != 0)
-        HIP_TRY(launch_gemm_q16(w, p, N, d_dst, ldd, (hipStream_t)stream));
-    else
-        HIP_TRY(launch_gemm_q(w, p, N, d_dst, ldd, (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 
@@ -815,23 +767,28 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
     int rc = weight_device_current(w);
     if (rc) return rc;
+    const mm_plan pl = weight_plan(w, N, true);
     if (!is_q(w->type)) {
-        if (dense16_serves(w, N) && d_work && work_bytes >= ggml_hip_mul_mat_work_size(w->type, w->K, N) && ld1 % 4 == 0 &&
-            ((uintptr_t)d_src1 & 15) == 0) {      // (the INIT kernel reads src1 rows in 16-byte pieces)
-            HIP_TRY(launch_dense16_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));       // INIT: src1 -> Half (Ggml.cs:6362-6379)
-            HIP_TRY(launch_dense16(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
+        if (pl.family == MMF_DENSE16 || pl.family == MMF_DENSE32) {
+            // The matrix-core forms need INIT scratch (the reference's own wdata for F16, Ggml.cs:6362-6379; three bf16 pieces per element for
+            // F32 above 256 rows) and read src1 rows in 16-byte pieces.  r4: a missing buffer or a misaligned src1 is an ERROR -- it
+            // used to select dense.hip silently, whose arithmetic differs in the last bits, so the same product could differ between callers.
+            if (!d_work || work_bytes < ggml_hip_mul_mat_work_size(w->type, w->K, N))
+                return fail(GGML_HIP_ERR_ARG, "work buffer too small: this shape needs %zu bytes (ggml_hip_mul_mat_work_size)", ggml_hip_mul_mat_work_size(w->type, w->K, N));
+            if (ld1 % 4 != 0 || ((uintptr_t)d_src1 & 15) != 0) return fail(GGML_HIP_ERR_SHAPE, "src1 rows must be 16-byte aligned (base and row stride) for this shape");
+            if (pl.family == MMF_DENSE16) {
+                HIP_TRY(launch_dense16_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));       // INIT: src1 -> Half (Ggml.cs:6362-6379)
+                HIP_TRY(launch_dense16(w, pl, d_work, N, d_dst, ldd, (hipStream_t)stream));
+            } else {
+                HIP_TRY(launch_dense32_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));
+                HIP_TRY(launch_dense32(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
+            }
             return GGML_HIP_OK;
         }
-        if (dense32_serves(w, N) && d_work && work_bytes >= ggml_hip_mul_mat_work_size(w->type, w->K, N) && ld1 % 4 == 0 &&
-            ((uintptr_t)d_src1 & 15) == 0) {
-            HIP_TRY(launch_dense32_init(d_src1, N, w->K, ld1, d_work, (hipStream_t)stream));
-            HIP_TRY(launch_dense32(w, d_work, N, d_dst, ldd, (hipStream_t)stream));
-            return GGML_HIP_OK;
-        }
-        HIP_TRY(launch_dense(w, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
+        HIP_TRY(launch_dense(w, pl, d_src1, N, ld1, d_dst, ldd, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
-    if (N <= GEMV_MAX_N && w->ext_type == 0 && weight_image_kind(w, N) == 0 && !q8_small_serves(w->type, w->K, N)) {  // small N: INIT and COMPUTE fused in one launch, no scratch needed
+    if (pl.family == MMF_GEMV_FUSED) {                      // small N: INIT and COMPUTE fused in one launch, no scratch needed
         rc = check_src1_alignment(d_src1, ld1);     // (float4 loads of the activation rows)
         if (rc) return rc;
         HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream));
@@ -842,14 +799,11 @@ int ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t 
     return ggml_hip_mul_mat_compute_dev(w, N, d_dst, ldd, d_work, work_bytes, stream);
 }
 
-// does a kernel form with a fused store-phase epilogue serve this (weight, N)?  The fused mat-vec (N <= 4), the MX mat-mat (Q4_0 / Q4_1:
-// N > 8, and from 5 rows where K >= 2048) and Q8_0's batched-decode form; every other form runs the epilogue as its own launch behind the mat-mul.
+// does a kernel form with a fused store-phase epilogue serve this (weight, N)?  The fused mat-vec (N <= 4), the MX mat-mat (Q4_0 / Q4_1),
+// K3p and Q8_0's batched-decode form; every other form runs the epilogue as its own launch behind the mat-mul.  (The plan's flag: selection,
+// this report and the launch agree by construction -- ADVICE r3.)
 static bool epilogue_is_fused(const ggml_hip_weight *w, int64_t N) {
-    if (!is_q(w->type) || w->ext_type != 0) return false;
-    if (q8_small_serves(w->type, w->K, N) || q8_mid_serves(w->type, w->K, N)) return true;
-    const int kind = weight_image_kind(w, N);
-    if (N <= GEMV_MAX_N && kind == 0) return gemv_fused_has_epilogue(N);
-    return kind == 3;
+    return is_q(w->type) && w->ext_type == 0 && (weight_plan(w, N, true).flags & MM_FLAG_EPILOGUE_FUSED) != 0;
 }
 
 int ggml_hip_mul_mat_epilogue_fused(const ggml_hip_weight *w, int64_t N) { return w && epilogue_is_fused(w, N) ? 1 : 0; }
@@ -868,7 +822,8 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         if (ld1 < w->K || ldd < w->M) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K or ldd < M");
         int rc = weight_device_current(w);
         if (rc) return rc;
-        if (N <= GEMV_MAX_N && weight_image_kind(w, N) == 0 && !q8_small_serves(w->type, w->K, N)) {
+        const mm_plan plan = weight_plan(w, N, true);
+        if (plan.family == MMF_GEMV_FUSED) {
             rc = check_src1_alignment(d_src1, ld1);
             if (rc) return rc;
             HIP_TRY(launch_gemv_q_fused(w, d_src1, ld1, N, d_dst, ldd, (hipStream_t)stream, &ep));
@@ -877,12 +832,12 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
         rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
         if (rc) return rc;
         const act_planes pl = act_carve(d_work, w->K, pad_act(N));
-        const hipError_t e = q8_small_serves(w->type, w->K, N) ? launch_gemm_q8_small(w, pl, N, d_dst, ldd, (hipStream_t)stream, &ep)
-                             : q8_mid_serves(w->type, w->K, N) ? launch_gemm_q8_mid(w, pl, N, d_dst, ldd, (hipStream_t)stream, ep)
-                                                               : launch_gemm_qmx(w, pl, N, d_dst, ldd, (hipStream_t)stream, &ep);
+        const hipError_t e = plan.family == MMF_K3S_I8 ? launch_gemm_q8_small(w, plan, pl, N, d_dst, ldd, (hipStream_t)stream, &ep)
+                             : plan.family == MMF_K3P_I8 ? launch_gemm_q8_mid(w, plan, pl, N, d_dst, ldd, (hipStream_t)stream, ep)
+                                                         : launch_gemm_qmx(w, plan, pl, N, d_dst, ldd, (hipStream_t)stream, &ep);
         if (e == hipSuccess) return GGML_HIP_OK;
-        // not supported = operands beyond the 32-bit offsets of these kernels (planes, or ld_add / ld2 past 4 GiB): the same product
-        // succeeds without an epilogue (ggml_hip_mul_mat_compute_dev falls back), so it does with one -- the unfused path below
+        // not supported = operands of the EPILOGUE beyond the 32-bit offsets of these kernels (ld_add / ld2 past 4 GiB): the product itself
+        // succeeds, so it does with an epilogue -- the unfused path below
         if (e != hipErrorNotSupported) HIP_TRY(e);
         (void)hipGetLastError();
     }
@@ -980,8 +935,9 @@ int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, co
     }
     if (n_w >= 2 && multi_ok(w, n_w, N)) return ggml_hip_mul_mat_multi_dev(w, n_w, d_src1, ld1, N, d_dst, ldd, nullptr, 0, nullptr, nullptr, stream);
     // one image for all of them?  (the image kind of a type follows N and K; M enters for shapes beyond the 32-bit offsets only)
+    const mm_plan pl0 = weight_plan(w[0], N, false);
     const int kind = weight_image_kind(w[0], N);
-    bool shared = (!(N <= gemv_rows_max(w[0]->type) && kind == 0) || q8_small_serves(w[0]->type, w[0]->K, N)) && w[0]->ext_type == 0;
+    bool shared = pl0.family != MMF_GEMV_ROWS && w[0]->ext_type == 0;
     for (int i = 1; i < n_w && shared; ++i) shared = weight_image_kind(w[i], N) == kind;
     if (!shared) {
         for (int i = 0; i < n_w; ++i) {
@@ -998,7 +954,7 @@ int ggml_hip_mul_mat_multi_work_dev(const ggml_hip_weight *const *w, int n_w, co
         if (e == hipSuccess) return GGML_HIP_OK;
         if (e != hipErrorNotSupported) { (void)hipGetLastError(); return fail(GGML_HIP_ERR_RUNTIME, "multi mul_mat: %s", hipGetErrorString(e)); }
     }
-    if (kind == 0 && n_w >= 2 && q8_small_serves(w[0]->type, w[0]->K, N)) {
+    if (kind == 0 && n_w >= 2 && pl0.family == MMF_K3S_I8) {
         for (int i = 1; i < n_w; ++i) { rc = weight_device_current(w[i]); if (rc) return rc; }
         const hipError_t e = launch_gemm_q8_small_multi(w, n_w, act_carve(d_work, w[0]->K, pad_act(N)), N, d_dst, ldd, (hipStream_t)stream);
         if (e == hipSuccess) return GGML_HIP_OK;

@@ -250,7 +250,6 @@ hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1
 hipError_t launch_q5k_to_planar(const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_q5k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_dequantize_q5k(const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
-int gemm_q16_image_kind(int type);   // which f16 image (1 nibble order, 2 byte-plane order) gemm_q16.hip wants for a weight type
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
 hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,
                                 hipStream_t st);
@@ -260,14 +259,13 @@ hipError_t launch_dequantize_rows(int type, const void *blocks, int64_t nrows, i
 // dense16.hip: K padded to whole stages of 128, plus spare (zero) panels for the register look-ahead
 #define DENSE16_SPARE_PANELS 8
 static inline int64_t dense16_kpad(int64_t K) { return (K + 127) / 128 * 128; }
+struct mm_plan;                      // plan.h: the one decision per product every launcher below consumes
 hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st);
-bool dense16_serves(const ggml_hip_weight *w, int64_t N);
 hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st);
-hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_dense16(const ggml_hip_weight *w, const mm_plan &pl, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 // K10d (dense16.hip): F32 x F32 on the bf16 matrix cores, operands split into three bf16 pieces
 #define DENSE32_SPARE_PANELS 24          // (one stage of look-ahead past the padded end: zero)
 hipError_t launch_f32_rows_to_split_panels(ggml_hip_weight *w, hipStream_t st);
-bool dense32_serves(const ggml_hip_weight *w, int64_t N);
 hipError_t launch_dense32_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st);
 hipError_t launch_dense32(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 // eltwise.hip (op: 0 add, 1 mul; contiguous f32)
@@ -299,21 +297,21 @@ bool gemv_fused_has_epilogue(int64_t N);       // the kernel form that serves N 
 // the same launch with the rms_norm -> mul prologue (N <= 4 only: gemv_fused_has_epilogue)
 hipError_t launch_gemv_q_fused_pro(const ggml_hip_weight *w, const float *x, int64_t ld1, const mm_prologue &pro, int64_t N, float *dst,
                                    int64_t ldd, hipStream_t st, const mm_epilogue *ep = nullptr);
-hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemm_q(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 // Q8_0, 5 <= N <= 64, K >= 2048: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip; image 0 of K1); ep: add / scale in the store phase
-hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue *ep);
+hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue *ep);
 hipError_t launch_gemm_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st);
-hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
+hipError_t launch_gemm_q16(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st);
 // 2..4 matrices of one type and K behind one activation image in ONE launch (5 <= N <= 64, Q4_0 / Q4_1, K >= 2048: gemm_qmx.hip K3s);
 // hipErrorNotSupported otherwise -- the caller computes them one after the other
 hipError_t launch_gemm_qmx_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st);
-hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
+hipError_t launch_gemm_qmx(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
                            const mm_epilogue *ep = nullptr);
 // Q4_0, prompt-sized batches, K >= 2048 (gemm_qmp.hip K3p); hipErrorNotSupported where the form does not apply
-hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep);
+hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep);
 // the same form on the int8 matrix cores: Q8_0, image 0 (gemm_qmp.hip)
-hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep);
-hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
+hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep);
+hipError_t launch_dense(const ggml_hip_weight *w, const mm_plan &pl, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st);
 
 // N at or below this goes to the wave-reduction mat-vec kernel, above it to the MFMA kernel.

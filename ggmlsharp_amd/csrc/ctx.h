@@ -7,6 +7,7 @@
 // rehearsed -- and tested bit for bit -- on a one-GPU box.
 #pragma once
 #include "common.h"
+#include "plan.h"
 
 #include <cstdarg>
 #include <cstdio>
@@ -38,8 +39,9 @@ int vec_dot_type(int t);                           // Ggml.cs:219-290
 inline size_t row_bytes_of(int t, int64_t k) { return TSIZE[t] * (size_t)(k / BLCK[t]); }
 inline int64_t nelem(const ggml_tensor *t) { return t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
 bool contiguous_f32(const ggml_tensor *t);
-int act_image_kind(int type, int64_t K, int64_t N);              // by type, K and N alone
+int act_image_kind(int type, int64_t K, int64_t N);              // by type, K and N alone (plan.cpp)
 int weight_image_kind(const ggml_hip_weight *w, int64_t N);         // ... for one weight (kind 0 when its planes exceed 32-bit offsets)
+mm_plan weight_plan(const ggml_hip_weight *w, int64_t N, bool one_call);   // plan.h: the one decision per product
 
 struct Scratch {
     void *p = nullptr;

@@ -7,6 +7,7 @@
 // gfx950), i.e. the reference's sum with f32 instead of f64 accumulation: ~1e-6 relative at these K, inside the
 // 1e-3 budget.  Same orientation as the quantized kernel: MFMA rows = src1 rows n, MFMA cols = weight rows m.
 #include "common.h"
+#include "plan.h"
 #include <cstdlib>
 #include <hip/hip_fp16.h>
 
@@ -254,14 +255,15 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const void *__restrict_
 
 }  // namespace
 
-hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
+hipError_t launch_dense(const ggml_hip_weight *w, const mm_plan &pl, const float *x, int64_t N, int64_t ld1, float *dst, int64_t ldd,
                         hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
+    if (pl.family != MMF_DENSE && pl.family != MMF_DENSE_GEMV) return hipErrorInvalidValue;
     // mat-vec form: rows of the resident copy are K elements apart, so 16-byte pieces need K % 8 (f16) / K % 4 (f32) == 0
     const bool f16 = w->type == GGML_TYPE_F16;
-    // up to 16 rows: passes of 8 columns over the weights (4096 x 4096 x 16: two passes 53 us, the tile kernel below 121 us;
-    // at 32 rows and M = 11008 the tile kernel is ahead, 121 against 243 us)
-    if (N <= 16 && w->K % (f16 ? 8 : 4) == 0 && w->K >= 512) {
+    // up to 16 rows (plan.cpp plan_dense): passes of 8 columns over the weights (4096 x 4096 x 16: two passes 53 us, the tile kernel
+    // below 121 us; at 32 rows and M = 11008 the tile kernel is ahead, 121 against 243 us)
+    if (pl.family == MMF_DENSE_GEMV) {
         for (int64_t c0 = 0; c0 < N; c0 += 8) {
             const int n = (int)(N - c0 < 8 ? N - c0 : 8);
             const float *xc = x + c0 * ld1;
@@ -276,10 +278,10 @@ hipError_t launch_dense(const ggml_hip_weight *w, const float *x, int64_t N, int
     dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
     // K % 32 == 0 keeps every 8-element piece of a stage inside the row
     const bool vec = w->K % DK == 0 && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0;
-    {   // F32 weights, enough 128 x 128 tiles to fill the chip: the big-tile kernel (bitwise the same result)
-        static const bool old = dev_env_set("GGML_HIP_DENSE_OLD");   // developer A/B switch
+    {   // F32 weights, enough 128 x 128 tiles to fill the chip (plan.cpp): the big-tile kernel (bitwise the same result; it reads src1 in
+        // 16-byte pieces -- a strided or misaligned src1 takes the 64 x 64 kernel, whose fma chain is the same)
         const int64_t tm = (w->M + 127) / 128, tn = (N + 127) / 128;
-        if (!f16 && vec && !old && tm * tn >= 256 && tm * tn < (1 << 30) && w->Mpad % 128 == 0) {
+        if (pl.form == DNF_BIG && vec) {
             dense_f32_big_kernel<<<dim3((unsigned)(tm * tn)), 256, 0, st>>>((const float *)w->dense, x, dst, w->M, N, w->K, ld1, ldd, (int)tm, (int)tn);
             return hipGetLastError();
         }

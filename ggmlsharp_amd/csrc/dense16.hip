@@ -15,6 +15,7 @@
 // Structure as gemm_qmx.hip: 4 waves, wave tile 64 (m) x 128 (n) = 2 x 4 MFMA tiles, workgroup tile 256 x 128, two
 // workgroups per CU, activations by buffer_load ... lds DMA in double-buffered stages of 8 k-steps, one barrier per stage.
 #include "common.h"
+#include "plan.h"
 #include <hip/hip_fp16.h>
 #include <cstdlib>
 #include <utility>
@@ -744,17 +745,6 @@ hipError_t launch_f16_rows_to_panels(ggml_hip_weight *w, hipStream_t st) {
     return hipGetLastError();
 }
 
-// true when the f16 MFMA kernel serves this shape; else dense.hip does
-bool dense16_serves(const ggml_hip_weight *w, int64_t N) {
-    if (w->type != GGML_TYPE_F16 || !w->p16) return false;
-    const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
-    if ((Kpad / 8 + DENSE16_SPARE_PANELS) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (Kpad / 8) * Npad * 16 > 0xFFFFFFFFull) return false;
-    // Every F16 shape with more than 4 src1 rows (chosen from N alone, so that a row shard of any height runs the arithmetic of
-    // the unsplit matrix): the tile kernel of dense.hip took 588 us for 4096 x 4096 x 512.  Up to 4 rows: the mat-vec form of
-    // dense.hip (5 .. 8 rows: 22 us here against 25 us there at 4096 x 4096, 46 against 108 us at 32000 x 4096).
-    return N > 4;
-}
-
 hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st) {
     const int64_t Kpad = dense16_kpad(K), Npad = pad_act(N);
     dim3 grid((unsigned)((Kpad / 32 + CV_CH - 1) / CV_CH), (unsigned)((N + 31) / 32));
@@ -762,37 +752,28 @@ hipError_t launch_dense16_init(const float *x, int64_t N, int64_t K, int64_t ld1
     return hipGetLastError();
 }
 
-hipError_t launch_dense16(const ggml_hip_weight *w, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+// The form was chosen by plan.cpp (plan_dense: the shape of the matrix instruction and the K split by N and K, the tile by the tile count):
+//   * above 512 src1 rows v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on it), 256 x 128 tiles from 384 tiles on, else 128 x 128;
+//   * up to 128 rows K split four ways inside the workgroup, on 32-row tiles, or on 128-row tiles of 16 waves where those cover the chip;
+//   * prompt-sized batches: two wave groups splitting K -- on 128 x 128 tiles from 160 such tiles on (4096 x 4096 x 512 44.1 -> 37.5 us), as a
+//     VIRTUAL split on 4-wave workgroups for vocabulary-sized matrices (32000 x 4096 x 512: 229 us on the 8-wave form -> 203), else 128 x 64.
+hipError_t launch_dense16(const ggml_hip_weight *w, const mm_plan &pl, const void *work, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     const int64_t Npad = pad_act(N);
-    static const int shape = dev_env_int("GGML_HIP_D16_SHAPE", 0);   // developer A/B switch: 1 = the 32 x 32 x 16 forms everywhere
-    if (N > 512 && shape != 1) {   // (by N alone: the two tile sizes below sum alike)
-        if (((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg_s<4, 8, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-        return launch_cfg_s<4, 4, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    const uint8_t *a = (const uint8_t *)work;
+    if (pl.family != MMF_DENSE16 || !w->p16) return hipErrorInvalidValue;
+    switch (pl.form) {
+    case D16F_S_256x128:  return launch_cfg_s<4, 8, 4, 1>(w, a, N, Npad, dst, ldd, st);
+    case D16F_S_128x128:  return launch_cfg_s<4, 4, 2, 2>(w, a, N, Npad, dst, ldd, st);
+    case D16F_256x128:    return launch_cfg<2, 4, 4, 1>(w, a, N, Npad, dst, ldd, st);
+    case D16F_S4_H128:    return launch_cfg<1, 2, 4, 1, 4>(w, a, N, Npad, dst, ldd, st);
+    case D16F_S4_H32:     return launch_cfg<1, 2, 1, 1, 4>(w, a, N, Npad, dst, ldd, st);
+    case D16F_V2_128x128: return launch_cfg<2, 2, 2, 2, 1, 2>(w, a, N, Npad, dst, ldd, st);
+    case D16F_S2_128x128: return launch_cfg<2, 2, 2, 2, 2>(w, a, N, Npad, dst, ldd, st);
+    case D16F_S2_128x64:  return launch_cfg<1, 2, 4, 1, 2>(w, a, N, Npad, dst, ldd, st);
+    case D16F_128x128:    return launch_cfg<2, 2, 2, 2>(w, a, N, Npad, dst, ldd, st);
+    default: break;
     }
-    // (the unsplit 256 x 128 form used to take every grid of 384 tiles and more -- also at N <= 512, where M >= 24576 reaches that while
-    // its row shards run the K-split forms below: different summation trees, a shard was not the bitwise slice of the product.  r3: up to
-    // 512 rows the tree is the split one whatever M; the form remains for the developer switch above.)
-    if (N > 512 && ((w->M + 255) / 256) * ((N + 127) / 128) >= 384) return launch_cfg<2, 4, 4, 1>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-    // batches up to 128 rows: K split four ways inside the workgroup (fixed by N and K: same summation tree for a row shard), on
-    // 32-row tiles, or on 128-row tiles of 16 waves where those cover the chip
-    static const int var = dev_env_int("GGML_HIP_D16_TILE", 0);   // developer A/B switch
-    const int64_t nst = dense16_kpad(w->K) / (16 * KS);
-    if (N <= 128 && nst >= 8 && var != 9) {
-        if (var == 1 || (var != 2 && ((w->M + 127) / 128) * ((N + 63) / 64) >= 80)) return launch_cfg<1, 2, 4, 1, 4>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-        return launch_cfg<1, 2, 1, 1, 4>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-    }
-    // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (as gemm_qmx.hip)
-    if (N <= 512 && nst >= 4 && var != 9 && var != 8) {
-        // the same two-way split on 128 x 128 tiles where those cover the chip
-        // (from 160 such tiles on: with 128 of them half the chip idles -- 4096 x 4096 x 512 44.1 -> 37.5 us, 4096 x 11008 x 512 98.6 -> 79.6 on
-        // the 128 x 64 form; 8192 x 4096 x 384, 192 tiles: 44.9 against 66.7, 11008 x 4096 x 512, 344 tiles: 85.4 against 108.2)
-        // many tiles (a vocabulary-sized matrix): the same two-way tree as a virtual split on 4-wave workgroups, two per CU
-        // (32000 x 4096 x 512: 1000 tiles, 229 us on the 8-wave form = 3.9 rounds of one workgroup per CU)
-        if (var == 5 || (var == 0 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 512)) return launch_cfg<2, 2, 2, 2, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-        if (var == 7 || (var != 6 && ((w->M + 127) / 128) * ((N + 127) / 128) >= 160)) return launch_cfg<2, 2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-        return launch_cfg<1, 2, 4, 1, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
-    }
-    return launch_cfg<2, 2, 2, 2>(w, (const uint8_t *)work, N, Npad, dst, ldd, st);
+    return hipErrorInvalidValue;
 }
 
 // ---- K10d host side ----
@@ -803,19 +784,9 @@ hipError_t launch_f32_rows_to_split_panels(ggml_hip_weight *w, hipStream_t st) {
     return hipGetLastError();
 }
 
-// true when the split-bf16 kernel serves this shape (by N alone: a row shard runs the arithmetic of the unsplit matrix); else dense.hip
-bool dense32_serves(const ggml_hip_weight *w, int64_t N) {
-    if (w->type != GGML_TYPE_F32 || !w->p32) return false;
-    static const int old = dev_env_int("GGML_HIP_D32_OLD", 0);   // developer A/B switch: 1 = dense.hip (f32 matrix instruction) everywhere
-    if (old == 1) return false;
-    const uint64_t Kpad = (uint64_t)dense16_kpad(w->K), Npad = (uint64_t)pad_act(N);
-    if ((Kpad / 8 * 3 + DENSE32_SPARE_PANELS) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (Kpad / 8 * 3) * Npad * 16 > 0xFFFFFFFFull) return false;
-    // By N alone.  A workgroup's K loop is one latency chain (K = 4096: ~165 us whatever the grid), so the form pays once the 128 x 128
-    // tiles cover the chip: 4096 x 4096 x N, this kernel | dense.hip in us -- N = 128 167 | 120, 256 168 | 122, 512 171 | 173, 1024 186 | 287,
-    // 4096 623 | 1200 (11008 x 4096 x 256: 175 | 229; 32000 x 4096 x 128: 222 | 344).
-    return N > 256;
-}
-
+// (whether this form serves a shape -- more than 256 src1 rows, by N alone -- is plan.cpp's decision: plan_dense.  A workgroup's K loop is one
+// latency chain (K = 4096: ~165 us whatever the grid), so the form pays once the 128 x 128 tiles cover the chip: 4096 x 4096 x N, this kernel |
+// dense.hip in us -- N = 128 167 | 120, 256 168 | 122, 512 171 | 173, 1024 186 | 287, 4096 623 | 1200.)
 hipError_t launch_dense32_init(const float *x, int64_t N, int64_t K, int64_t ld1, void *work, hipStream_t st) {
     const int64_t Kpad = dense16_kpad(K), Npad = pad_act(N);
     dim3 grid((unsigned)((Kpad / 8 + 7) / 8), (unsigned)((N + 31) / 32));

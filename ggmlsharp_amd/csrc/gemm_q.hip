@@ -25,6 +25,7 @@
 // VALU epilogue issues at full rate).  K is streamed in stages of BKB k-blocks through a double-buffered LDS ring:
 // activations by global_load_lds (16 B/lane, image is lane-linear), weights through registers (nibble -> int8).
 #include "common.h"
+#include "plan.h"
 #include <cstdlib>
 #include <utility>
 
@@ -445,28 +446,25 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     return hipGetLastError();
 }
 
+// 128 x 128 tiles when they already give >= 2 workgroups per CU, else 64 x 64 to fill the chip (plan.cpp plan_i8; one chain over K either way)
 template <int TYPE>
-hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
-    // 128x128 tiles when they already give >= 2 workgroups per CU, else 64x64 to fill the chip
-    const int64_t big = ((w->M + 127) / 128) * ((N + 127) / 128);
-    static const char *force = dev_env_str("GGML_HIP_GEMM_TILE");  // developer override: "1" = 64x64, "2" = 128x128
-    if (force && force[0] == '1') return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
-    if (force && force[0] == '2') return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
-    if (big >= 512) return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
+hipError_t launch_typed(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    if (pl.family != MMF_I8) return hipErrorInvalidValue;
+    if (pl.form == I8F_128x128) return launch_cfg<TYPE, 2, 2>(w, p, N, dst, ldd, st);
     return launch_cfg<TYPE, 1, 1>(w, p, N, dst, ldd, st);
 }
 
 }  // namespace
 
-hipError_t launch_gemm_q(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+hipError_t launch_gemm_q(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
     switch (w->type) {
-    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, pl, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }
 }

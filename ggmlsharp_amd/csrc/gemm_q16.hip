@@ -29,6 +29,7 @@
 // divided by 16 (exact in f16), so the products are unchanged.  "Panel" p = 2*kk + h of the activation image holds
 // those 8 f16 for every row: image [k-block][panel][row][16 B].
 #include "common.h"
+#include "plan.h"
 #include <cstdlib>
 #include <utility>
 
@@ -526,59 +527,44 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     return hipGetLastError();
 }
 
+// The form was chosen by plan.cpp (plan_f16: the K split by N and K, the tile height by the tile count).  The measurements behind it:
+//   * batches up to 256 rows: 32-row weight tiles, K split four ways inside the workgroup (129 .. 256 rows, four-way | two-way us: Q8_0
+//     4096 x 4096 x 256 27 | 37, 4096 x 11008 x 256 58 | 81, Q5_0 4096 x 4096 x 256 25 | 39; 11008 x 4096 x 256 63 | 58); the same split on
+//     64-row tiles of 8 waves / 128-row tiles of 16 waves where those cover the chip (the 16-wave form not for the min-term types: registers);
+//   * prompt-sized batches: 128 x 64 tiles, two wave groups splitting K;
+//   * the big tile (256 x 128, 8 tiles per wave) when it still fills the chip with >= 2 workgroups per CU;
+//   * short or narrow products (row shards): 64 x 64 tiles of four 1-tile waves wherever the 128 x 64 grid leaves CUs idle -- the same
+//     unsplit K loop per element, the same bits (Q8_0 / Q5_0: 256 x 4096 x 2048 48.7 -> 36.3 us, 512 x 11008 x 2048 125.9 -> 93.2; not the
+//     min-term types: their 48 VALU instructions per tile make the one-tile wave slower -- Q5_1 512 x 4096 x 4096 61.0 -> 66.0 us);
+//   * otherwise 128 x 64 tiles of 4 waves (N = 1024, this | 128 x 128 of 4 waves | 128 x 64 of 2 waves: Q8_0 4096 x 4096 69 | 84 | 104 us).
 template <int TYPE>
-hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
-    // big tile (256 x 128, 8 tiles per wave) when it still fills the chip with >= 2 workgroups per CU; else 128 x 64
-    const int64_t big = ((w->M + 255) / 256) * ((N + 127) / 128);
-    // prompt-sized batches: 128 x 64 tiles, two wave groups splitting K (chosen from N and K only, see gemm_qmx.hip)
-    // batches up to 256 rows: 32-row weight tiles, K split four ways inside the workgroup (see gemm_qmx.hip).  129 .. 256 rows, four-way |
-    // two-way us: Q8_0 4096 x 4096 x 256 27 | 37, 4096 x 11008 x 256 58 | 81, Q5_0 4096 x 4096 x 256 25 | 39; 11008 x 4096 x 256 63 | 58,
-    // 32000 x 4096 x 256 141 | 128
-    static const bool old128 = dev_env_set("GGML_HIP_Q16_OLD128");   // developer A/B switch
-    static const int n4 = dev_env_int("GGML_HIP_Q16_N4", 256);   // developer A/B switch (128 = the former bound)
-    if (N <= n4 && w->nbk >= 16 && !old128) {
-        // same split on 64-row tiles of 8 waves / 128-row tiles of 16 waves where those cover the chip (see gemm_qmx.hip; the
-        // 16-wave form not for the min-term types: registers)
-        static const int tile = dev_env_int("GGML_HIP_Q16_TILE", 0);   // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
-        const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
-        // up to 32 rows: 32-column tiles (gemm_qmx.hip: half of the 64-column tile's work is on padding columns there); same tree
-        if (N <= 32 && tile != 4) {
-            const int h32 = tile == 2 ? 32 : tile == 1 || tile == 3 ? 64 : (t64 < 160 ? 32 : 64);
-            if (h32 >= 64) return launch_cfg<TYPE, 1, 1, 2, 1, 4, 4>(w, p, N, dst, ldd, st);
-            return launch_cfg<TYPE, 1, 1, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
-        }
-        const int h = tile == 1 ? 128 : tile == 3 ? 64 : tile == 2 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || WT<TYPE>::MIN) ? 64 : 128);
-        if constexpr (!WT<TYPE>::MIN)
-            if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st);
-        if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 4>(w, p, N, dst, ldd, st);
-        return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
+hipError_t launch_typed(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    if (pl.family != MMF_F16) return hipErrorInvalidValue;
+    switch (pl.form) {
+    case F16F_N32_H64:  return launch_cfg<TYPE, 1, 1, 2, 1, 4, 4>(w, p, N, dst, ldd, st);
+    case F16F_N32_H32:  return launch_cfg<TYPE, 1, 1, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
+    case F16F_S4_H128:  if constexpr (!WT<TYPE>::MIN) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 4>(w, p, N, dst, ldd, st); break;
+    case F16F_S4_H64:   return launch_cfg<TYPE, 1, 2, 2, 1, 4, 4>(w, p, N, dst, ldd, st);
+    case F16F_S4_H32:   return launch_cfg<TYPE, 1, 2, 1, 1, 4, 4>(w, p, N, dst, ldd, st);
+    case F16F_S2_H128:  return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
+    case F16F_256x128:  return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
+    case F16F_64x64:    return launch_cfg<TYPE, 1, 1, 2, 2, 4>(w, p, N, dst, ldd, st);
+    case F16F_128x64:   return launch_cfg<TYPE, 1, 2, 4, 1, 4>(w, p, N, dst, ldd, st);
+    default: break;
     }
-    if (N <= 512 && w->nbk >= 8) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
-    if (big >= 384) return launch_cfg<TYPE, 2, 4, 4, 1, 4>(w, p, N, dst, ldd, st);
-    // short or narrow products (row shards of a multi-GPU split): 64 x 64 tiles of four 1-tile waves wherever the 128 x 64 grid leaves CUs
-    // idle -- the same unsplit K loop per element, the same bits (gemm_qmx.hip has the same rule for Q4_0).  Q8_0 / Q5_0, COMPUTE in us:
-    // 256 x 4096 x 2048 48.7 -> 36.3, 1024 x 4096 x 1024 50.2 -> 39.5, 512 x 11008 x 2048 125.9 -> 93.2, 512 x 4096 x 4096 51.2 -> 46.1
-    static const int tile64 = dev_env_int("GGML_HIP_Q16_T64", 0);   // developer A/B switch: 1 = never, 2 = always
-    // (not the min-term types: their 48 VALU instructions per tile make the one-tile wave slower -- Q5_1 512 x 4096 x 4096 61.0 -> 66.0 us;
-    // GGML_HIP_Q16_T64=2 forces the form for them, too)
-    if (tile64 == 2 || (!WT<TYPE>::MIN && tile64 != 1 && ((w->M + 127) / 128) * ((N + 63) / 64) <= 256)) return launch_cfg<TYPE, 1, 1, 2, 2, 4>(w, p, N, dst, ldd, st);
-    // otherwise 128 x 64 tiles of 4 waves (2 tiles per wave).  f16 compute us at N = 1024, this | 128 x 128 of 4 waves | 128 x 64 of 2 waves:
-    // Q8_0 4096 x 4096 69 | 84 | 104, 4096 x 11008 172 | 206 | 262, 11008 x 4096 175 | 181 | 213; Q5_1 4096 x 4096 89 | 114 | 144
-    return launch_cfg<TYPE, 1, 2, 4, 1, 4>(w, p, N, dst, ldd, st);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-int gemm_q16_image_kind(int type) { return type == GGML_TYPE_Q8_0 ? 2 : 1; }
-
-hipError_t launch_gemm_q16(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+hipError_t launch_gemm_q16(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
     switch (w->type) {
-    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, pl, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }
 }

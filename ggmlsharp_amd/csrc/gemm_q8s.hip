@@ -3,6 +3,7 @@
 // aligned register tuples across the loop over K and the looped kernels spill -- 256 registers + 0.1 .. 1.4 KB of scratch against
 // 119 registers without it; Makefile FLAGS_gemm_q8s.hip.)
 #include "common.h"
+#include "plan.h"
 #include <utility>
 
 namespace {
@@ -220,18 +221,16 @@ hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_p
     return hipGetLastError();
 }
 
-hipError_t launch_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
+hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     constexpr int KS = 8;
+    // k-blocks per wave and tiles per workgroup (one up to 256 tile groups, two beyond: same bits) from plan.cpp (plan_k3s_i8)
     const int nbkp = (int)pad_kblocks(w->nbk);
-    const int nloc = (nbkp + KS - 1) / KS;
+    const int nloc = pl.nloc, wmt = pl.wmt;
     const int ncol = (int)((N + 31) / 32);
-    if (w->type != GGML_TYPE_Q8_0 || !w->qs || !w->d || nloc > 64 || p.Npad < 32 * ncol) return hipErrorNotSupported;
-    const int64_t t32 = (w->M + 31) / 32 * ncol;
-    static const int geo = dev_env_int("GGML_HIP_Q8S_TILES", 0);   // developer A/B switch: 1 / 2 tiles per workgroup whatever M
-    const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : t32 <= 256 ? 1 : 2;
-    if (w->Mpad % (32 * wmt) != 0) return hipErrorNotSupported;
+    if (pl.family != MMF_K3S_I8 || w->type != GGML_TYPE_Q8_0 || !w->qs || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
+    if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
-    if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+    if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
     const int ntw = (int)((w->M + 32 * wmt - 1) / (32 * wmt));
     const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;   // (table rows: whole rounds of the form's slots)
     const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
@@ -257,10 +256,10 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, fl
 
 }  // namespace
 
-hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue *ep) {
+hipError_t launch_gemm_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue *ep) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
     const mm_epilogue none{0, nullptr, 0, nullptr, 0, 1.0f};
-    return launch_q8_small(w, p, N, dst, ldd, st, ep ? *ep : none);
+    return launch_q8_small(w, pl, p, N, dst, ldd, st, ep ? *ep : none);
 }
 
 hipError_t launch_gemm_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {

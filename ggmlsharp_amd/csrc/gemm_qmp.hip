@@ -19,6 +19,7 @@
 //   * the eight partial tiles are added in wave order through LDS (two rounds of four tiles), every wave storing its share of
 //     the rows: an eight-way tree fixed by K alone, so a row shard computes the bits of the unsplit matrix.
 #include "common.h"
+#include "plan.h"
 #include <utility>
 
 namespace {
@@ -493,7 +494,6 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
 
 }  // namespace
 
-// Q8_0 / Q5_0, at least 8 k-blocks per wave: hipErrorNotSupported otherwise (the caller falls back to the staged int8 kernel, same image)
 // workgroups of a launch: every tile its own up to four rounds of the chip, beyond that one persistent workgroup per CU (a multiple of 8: XCD order)
 static unsigned persistent_grid(int tiles) {
     static std::atomic<int> cus[64];
@@ -512,21 +512,22 @@ static unsigned persistent_grid(int tiles) {
     return (unsigned)(tiles < 4 * n ? tiles : n);
 }
 
-hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
+hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     const bool with_min = w->type == GGML_TYPE_Q5_1 || w->type == GGML_TYPE_Q4_1;
     const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : (w->type == GGML_TYPE_Q5_0 || with_min) ? w->i8p : nullptr;
-    if (!planes || !w->d || (with_min && !w->m)) return hipErrorNotSupported;
+    if (pl.family != MMF_K3P_I8 || !planes || !w->d || (with_min && !w->m)) return hipErrorInvalidValue;
+    // applicability (at least 8 k-blocks per wave, the eight scale tables within 160 KB of LDS, every offset within 32 bits) and the
+    // k-blocks per wave were decided by plan.cpp (plan_k3p_i8); the checks below only guard the kernel's assumptions
     const int nbkp = (int)pad_kblocks(w->nbk);
-    int nloc = (nbkp + KS - 1) / KS;
-    nloc += nloc & 1;                                       // two k-blocks per trip
-    if (nloc < 8) return hipErrorNotSupported;
+    const int nloc = pl.nloc;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
-    if ((uint64_t)(KS * nloc + 2) * 2 * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 2 * (uint64_t)p.Npad * 16 > 0xFFFFFFFFull) return hipErrorNotSupported;
-    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorNotSupported;
+    if (nloc < 8 || (nloc & 1) || KS * nloc < nbkp) return hipErrorInvalidValue;
+    if ((uint64_t)(KS * nloc + 2) * 2 * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 2 * (uint64_t)p.Npad * 16 > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
     const size_t tab = (size_t)KS * nloc * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
     const size_t lds = tab > xch ? tab : xch;
-    if (lds > 160 * 1024) return hipErrorNotSupported;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     (void)hipGetLastError();
 #define Q8MID_GO(T) do { \
         auto kern = gemm_q8_mid_kernel<T>; \
@@ -541,22 +542,22 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, act_planes p, int64_t N,
     return hipGetLastError();
 }
 
-// Serves Q4_0 with at least 8 k-blocks per wave; hipErrorNotSupported otherwise (the caller falls back to the staged forms).
-hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
-    if (w->type != GGML_TYPE_Q4_0 || !w->q6a || !w->q6b) return hipErrorNotSupported;
+// Q4_0 (plan.cpp plan_k3p_mx: at least 8 k-blocks per wave, tables within LDS, offsets within 32 bits)
+hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
+    if (pl.family != MMF_K3P_MX || w->type != GGML_TYPE_Q4_0 || !w->q6a || !w->q6b) return hipErrorInvalidValue;
     const int nbkp = (int)pad_kblocks(w->nbk);
-    int nloc = (nbkp + KS - 1) / KS;
-    if (nloc < 8) return hipErrorNotSupported;
+    const int nloc = pl.nloc;
+    if (nloc < 8 || KS * nloc < nbkp) return hipErrorInvalidValue;
     const uint64_t nba = (uint64_t)nbkp;
     const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4;
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad;
     // (32-bit buffer offsets, the look-ahead past a wave's range included)
-    if ((uint64_t)(KS * nloc + 2) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 48 * (uint64_t)p.Npad > 0xFFFFFFFFull) return hipErrorNotSupported;
-    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorNotSupported;
+    if ((uint64_t)(KS * nloc + 2) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 48 * (uint64_t)p.Npad > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
     const size_t tab = (size_t)KS * nloc * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
     const size_t lds = tab > xch ? tab : xch;
-    if (lds > 160 * 1024) return hipErrorNotSupported;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     static PerDeviceOnce once;
     const hipError_t attr = once.max_dynamic_lds((const void *)gemm_qmx_mid_kernel, 160 * 1024);
     if (attr != hipSuccess) return attr;

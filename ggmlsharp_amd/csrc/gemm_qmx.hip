@@ -27,6 +27,7 @@
 // segments along m); activations reach LDS by DMA (K1 writes the bf6 image), row scales by broadcast ds_read_b128;
 // raw buffer addressing; inline-asm scale-accumulate; K zero-padded to whole stages by the host side.
 #include "common.h"
+#include "plan.h"
 #include <cstdlib>
 #include <utility>
 
@@ -846,28 +847,21 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
 // K3s launch: KS = 8 waves per 32-row tile, each a contiguous eighth of K in pairs of blocks; the slots hold a wave's whole range
 // for K <= 4096 (8 pairs) and K <= 2048 (4 pairs), longer K refills them in turn.  Chosen by N and K alone.
 template <int TYPE>
-hipError_t launch_small(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+hipError_t launch_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
     constexpr int KS = 8;
     if (!w->q6a || !w->q6b) return hipErrorInvalidValue;
+    // geometry and applicability were decided by plan.cpp (plan_k3s_mx): k-blocks per wave, 32-row tiles per workgroup (more tiles than CUs:
+    // two of them per workgroup, four beyond 512 tiles -- every workgroup pulls the whole activation image through its CU's vector
+    // memory path, and that path is what bounds the form; same blocks in the same order per element: the same bits)
     const int nbkp = (int)pad_kblocks(w->nbk);
-    int nloc = (nbkp + KS - 1) / KS;
-    nloc += nloc & 1;                                       // pairs of blocks stay inside one wave
-    if (nloc > 64) return hipErrorNotSupported;             // (the table pieces a lane holds: K <= 16384)
+    const int nloc = pl.nloc, wmt = pl.wmt;
     const uint64_t nba = (uint64_t)nbkp;
     const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4;
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
-    if (wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+    if (nloc > 64 || wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;    // (the plan never sends such a shape here)
     const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
-    // More 32-row tiles than CUs: two of them per workgroup, four beyond 512 tiles.  Every workgroup pulls the whole activation
-    // image through its CU's vector memory path (196 KB for K = 4096, against 115 KB of weights per tile), and that path is what
-    // bounds the form: two / four times the weights behind the same activation fragments (32000 x 4096 x 32: 41.5 | 36.1 | 30.1 us
-    // with one | two | four tiles).  Same blocks in the same order per element: the same bits (only the geometry follows M).
-    static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 / 2 / 4 = that many tiles per workgroup whatever M
     const int ncol = (int)((N + 31) / 32);                  // 32-column slices of src1: one workgroup per tile group and slice
     if (p.Npad < 32 * ncol) return hipErrorInvalidValue;
-    const int64_t t32 = (w->M + 31) / 32 * ncol;
-    // (four tiles: Q4_0 only -- Q4_1's min-term registers do not fit beside four accumulator tiles)
-    const int wmt = geo == 1 ? 1 : geo == 2 || TYPE == GGML_TYPE_Q4_1 ? (geo == 2 || geo == 4 || t32 > 256 ? 2 : 1) : geo == 4 ? 4 : (t32 <= 256 ? 1 : t32 <= 512 ? 2 : 4);
     const bool two = wmt == 2;
     const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
     const int lds = tab > xch ? tab : xch;
@@ -946,109 +940,45 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
 #define MX_SMALL_FB 2                  // weight fragment look-ahead of the small-batch forms (A/B 4: 4096 x 4096 x {16, 64} 13.2 us either way,
                                        // 32000 x 4096 x 32 32 -> 66 us: these forms are bound by their latency chain, not by the prefetch depth)
 #endif
+// The form was chosen by plan.cpp (plan_mx: by type, N and K -- the tile height by the tile count); the measurements behind the choice:
+//   * 256 x 128 (8 tiles per wave) only where the registers allow it (Q4_0) and only above 512 rows; 256 x 128 with waves of 128 x 64
+//     (half the LDS reads, weights single-buffered) measured 10 % slower: A/B only;
+//   * prompt-sized batches (N <= 512) rarely fill the chip with one wave group per tile: two groups per 128 x 64 tile split K between them
+//     (4096 x 4096 x 512: 45.8 -> 31.9 us; 4096 x 11008 x 512: 107 -> 75 us; N = 1024 is 10 % slower that way);
+//   * batches up to 128 rows: 32-row weight tiles with K split four ways -- M / 32 x N / 64 workgroups of 4 waves instead of M / 128 x N / 64
+//     of 8 (4096 x 4096 x 64 covered 32 CUs); the same tree on taller tiles where those cover the chip (compute us, 32-row x 4 waves | 64-row
+//     x 8 | 128-row x 16, N = 64: M = 4096 13 | 14 | 23, M = 11008 29 | 17 | 27, M = 32000 57 | 34 | 32); the 16-wave form only for Q4_0;
+//   * up to 64 rows, K >= 2048: the stage-free form K3s (weights cold, staged | K3s: 4096 x 4096 x 32 16.8 | 12.3 us, 4096 x 11008 36.7 | 24.8);
+//   * 129 .. 256 rows (Q4_0): the four-way tree really split while the tiles are few (4096 x 4096 x 256 28.5 -> 21 us), else two wave groups
+//     running two stage sets each (11008 x 4096 x 256 44 us, 32000 x 4096 x 256 112 against 107 us: the banked sums cost registers);
+//   * a short, wide product (a row shard): 64 x 64 tiles of four 1-tile waves wherever the 128 x 64 grid leaves CUs idle
+//     (1024 x 4096 x 768 37.0 -> 26.3 us, 512 x 4096 x 1024 36.8 -> 24.1, 512 x 11008 x 2048 94.5 -> 71.8).
 template <int TYPE>
-hipError_t launch_typed(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
-    // the largest tile that still gives the chip ~2 workgroups per CU; small problems get more, smaller workgroups
-    static const int var = dev_env_int("GGML_HIP_MX_TILE", 0);   // developer A/B switch
-    const int64_t tm256 = (w->M + 255) / 256, tm128 = (w->M + 127) / 128, tn128 = (N + 127) / 128;
-    // 8 tiles per wave only where the registers allow it: one weight digit and one scale plane (Q4_0)
-    // (only above 512 rows: up to 512 rows every form splits K -- two, four or eight ways by N and K -- and this one does not; a
-    // 32000-row matrix at N = 512 used to land here while its 4000-row shards took the split forms: different summation trees,
-    // found by the eight-slot test of config 5's partition, tests/test_multi_slot.py)
-    if constexpr (TYPE == GGML_TYPE_Q4_0) {
-        if ((tm256 * tn128 >= 384 || var == 30) && N > 512) {
-            // 256 x 128 with waves of 128 x 64 (half the LDS reads, weights single-buffered) measured 10 % slower: A/B only
-            if (var == 2) return launch_cfg<TYPE, 4, 2, 2, 2, 4, 1>(w, p, N, dst, ldd, st);
-            return launch_cfg<TYPE, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                 // 256 x 128, waves 64 x 128
-        }
+hipError_t launch_typed(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st) {
+    constexpr bool Q40 = TYPE == GGML_TYPE_Q4_0, Q4 = Q40 || TYPE == GGML_TYPE_Q4_1;
+    if (pl.family == MMF_K3S_MX) {
+        if constexpr (Q4) return launch_small<TYPE>(w, pl, p, N, dst, ldd, st);
+        return hipErrorInvalidValue;
     }
-    // Prompt-sized batches (N <= 512) rarely fill the chip with one wave group per tile: two groups per 128 x 64 tile split K
-    // between them (4096 x 4096 x 512: 45.8 -> 31.9 us; 4096 x 11008 x 512: 107 -> 75 us; N = 1024 is 10 % slower that
-    // way, M = 32000 x N = 512 6 % slower).  The choice depends on N and K only -- never on M -- so a row shard still
-    // computes bit for bit what the unsplit matrix does (the summation tree of an element is a function of the kernel form).
-    // Batches up to 128 rows: 32-row weight tiles with K split four ways inside the workgroup -- M / 32 x N / 64 workgroups of
-    // 4 waves instead of M / 128 x N / 64 of 8 (4096 x 4096 x 64 covered 32 CUs).
-    // (Q4_1: up to 256 rows this way -- 4096 x 4096 x 256 29 -> 23 us, 11008 x 4096 x 256 level at 58 us; Q4_0 has its own form for 129 .. 256 below)
-    if (N <= (TYPE == GGML_TYPE_Q4_0 || var == 20 ? 128 : 256) && w->nbk >= 16 && var != 3 && var != 9) {
-        // The same four-way split -- hence the same summation tree, bit for bit -- on taller tiles where those cover the chip
-        // (one workgroup per CU either way).  Compute times in us, 32-row x 4 waves | 64-row x 8 | 128-row x 16, N = 64:
-        // M = 4096 13 | 14 | 23, M = 11008 29 | 17 | 27, M = 16384 30 | 18 | 27, M = 32000 57 | 34 | 32 (N = 128: 109 | 66 | 62).
-        // The 16-wave form only for Q4_0: Q4_1 spills in the 128 registers of a 1024-thread workgroup and measures no faster
-        // (32000 x 4096 x 64: 43.5 against 42 us on 64-row tiles).
-        const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
-        // up to 32 rows: 32-column tiles (the 64-column tile spends half of its MFMAs and scale-accumulates on padding columns
-        // there); same four-way tree, same bits; 32- or 64-row tiles by tile count
-        if constexpr (TYPE == GGML_TYPE_Q4_0 || TYPE == GGML_TYPE_Q4_1) {
-            // up to 32 rows (64: below), K >= 2048: the stage-free form (K3s above).  Weights cold in HBM, compute kernel in us, staged form | K3s:
-            // 4096 x 4096 x 32 16.8 | 12.3, 8192 x 4096 17.6 | 13.2, 11008 x 4096 20.1 | 18.5-19.3, 16384 x 4096 21.3 | 20.3, 32000 x 4096
-            // 31.1 | 30.1 (four tiles per workgroup; two: 36.1), 4096 x 11008 36.7 | 24.8, 4096 x 2048 10.4 | 8.2; K = 1024 7.2 | 7.7:
-            // shorter K stays on the staged form.  The choice is by N and K alone (GGML_HIP_MX_TILE=26: the staged form, A/B).
-            // 33..64 rows: two workgroups per tile group, one per 32-column slice of src1 (the weights come twice, the second time mostly
-            // from L2): COMPUTE in us, staged 64-column form | K3s -- 4096 x 4096 x 64 19.8 | 12.2, 8192 x 4096 20.4 | 17.9, 11008 x 4096 23.0 |
-            // 23.0, 4096 x 11008 42.8 | 24.2, 4096 x 2048 12.1 | 8.4; 32000 x 4096 42.0 | 51.2 (the one loss: a vocabulary projection)
-            static const int ncmax = dev_env_int("GGML_HIP_K3S_COLS", 2);   // developer A/B switch: 1 = K3s up to 32 rows only
-            if (N <= 32 * ncmax && w->nbk >= 64 && var != 25 && var != 26) {
-                const hipError_t e = launch_small<TYPE>(w, p, N, dst, ldd, st);
-                if (e != hipErrorNotSupported) return e;
-            }
-        }
-        if (N <= 32 && var != 25) {
-            const int h32 = var == 13 ? 32 : var == 15 || var == 12 ? 64 : (t64 < 160 ? 32 : 64);
-            if (h32 >= 64) return launch_cfg<TYPE, 1, 1, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
-            return launch_cfg<TYPE, 1, 1, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
-        }
-        const int h = var == 12 ? 128 : var == 15 ? 64 : var == 13 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || TYPE != GGML_TYPE_Q4_0) ? 64 : 128);
-        if constexpr (TYPE == GGML_TYPE_Q4_0)
-            if (h == 128) return launch_cfg<TYPE, 1, 2, 4, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
-        if (h >= 64) return launch_cfg<TYPE, 1, 2, 2, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
-        return launch_cfg<TYPE, 1, 2, 1, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
+    if (pl.family == MMF_K3P_MX) return launch_gemm_qmx_mid(w, pl, p, N, dst, ldd, st, t_epilogue);
+    if (pl.family != MMF_MX) return hipErrorInvalidValue;
+    switch (pl.form) {
+    case MXF_256x128:     if constexpr (Q40) return launch_cfg<TYPE, 2, 4, 4, 1, 4, 2>(w, p, N, dst, ldd, st); break;
+    case MXF_256x128_ALT: if constexpr (Q40) return launch_cfg<TYPE, 4, 2, 2, 2, 4, 1>(w, p, N, dst, ldd, st); break;
+    case MXF_N32_H64:     return launch_cfg<TYPE, 1, 1, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+    case MXF_N32_H32:     return launch_cfg<TYPE, 1, 1, 1, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
+    case MXF_S4_H128:     if constexpr (Q40) return launch_cfg<TYPE, 1, 2, 4, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st); break;
+    case MXF_S4_H64:      return launch_cfg<TYPE, 1, 2, 2, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
+    case MXF_S4_H32:      return launch_cfg<TYPE, 1, 2, 1, 1, 4, MX_SMALL_FB, 4>(w, p, N, dst, ldd, st);
+    case MXF_S2V2_H64:    if constexpr (Q40) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2, 2>(w, p, N, dst, ldd, st); break;
+    case MXF_S2_H128:     return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
+    case MXF_S2_H64:      return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
+    case MXF_128x128:     return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);
+    case MXF_64x64:       if constexpr (Q40) return launch_cfg<TYPE, 1, 1, 2, 2, 4, 2>(w, p, N, dst, ldd, st); break;
+    case MXF_128x64:      return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);
+    default: break;
     }
-    // 129 .. 256 rows: the four-way tree as well.  Really split (8 waves per 64-row tile) while the tiles are few -- 4096 x 4096 x 256
-    // 28.5 -> 21 us, 4096 x 11008 x 256 62 -> 42 us -- and for larger M, where the split costs (11008 x 4096 x 256: 41.5 -> 52 us), two wave
-    // groups that each run two of the four stage sets one after the other: same tree, same bits, the geometry of the two-way form
-    // (11008 x 4096 x 256 44 us, 32000 x 4096 x 256 112 against 107 us: the banked sums cost registers).
-    // (Q4_0 only: Q4_1's second form spills at three workgroups per CU and runs 14 % behind its two-way form.)
-    if constexpr (TYPE == GGML_TYPE_Q4_0) {
-        if (N <= 256 && w->nbk >= 16 && var != 3 && var != 9 && var != 20) {
-            const int64_t t64 = ((w->M + 63) / 64) * ((N + 63) / 64);
-            if (var == 23 || (var != 24 && t64 <= 256)) return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 4>(w, p, N, dst, ldd, st);
-            return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2, 2>(w, p, N, dst, ldd, st);
-        }
-    }
-    // (64-row tiles of 4 waves, three per CU: grids that are not a multiple of 256 workgroups lose less in their last round --
-    // 11008 x 4096 x 256: 53 -> 38 us, 32000 x 4096 x 256: 119 -> 107 us; 4096 x 4096 x 512 unchanged; var 17 = the 128-row form)
-    // the largest grids keep the 128-row form (32000 x 4096 x 512: 171 us against 179 us)
-    if (N <= 512 && w->nbk >= 8 && var != 3) {
-        // 257 .. 512 rows, K >= 2048, Q4_0: K3p (gemm_qmp.hip) -- 128 x 64 tiles per WAVE, K split eight ways over the waves of a workgroup,
-        // no stages: half the bytes per tile and k-block through the CU's memory path.  By N and K alone (GGML_HIP_K3P=1: the staged form, A/B).
-        if constexpr (TYPE == GGML_TYPE_Q4_0) {
-            static const int k3p = dev_env_int("GGML_HIP_K3P", 0);
-            if (k3p != 1) {
-                const hipError_t e = launch_gemm_qmx_mid(w, p, N, dst, ldd, st, t_epilogue);
-                if (e != hipErrorNotSupported) return e;
-            }
-        }
-        // (the same two-way tree run by ONE wave group on unsplit 128 x 64 tiles measured level: 32000 x 4096 x 512 161 | 161 us,
-        // 11008 x 4096 x 512 74 | 79, 16384 x 4096 x 512 114 | 110)
-        // (weight fragments a whole stage ahead, FB = 4, with weights cold in HBM: 4096 x 4096 x 512 35.7 -> 34.9 us, the others level)
-        if (var == 17 || (var != 16 && tm128 * ((N + 63) / 64) >= 1536)) return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
-        return launch_cfg<TYPE, 1, 2, 2, 1, 4, 2, 2>(w, p, N, dst, ldd, st);
-    }
-    if (tm128 * tn128 >= 384) return launch_cfg<TYPE, 2, 2, 2, 2, 4, 2>(w, p, N, dst, ldd, st);   // 128 x 128, 4 tiles per wave
-    // A short, wide product (a row shard of a multi-GPU split: 512 x 4096 x 4096) gives the 128 x 64 form one wave per SIMD,
-    // and a lone wave issues its scale-accumulates at half the rate of two (45 us where the work is 20).  64 x 64 tiles of four
-    // 1-tile waves put two waves on every SIMD with the same unsplit K loop per element: the same bits, only the geometry
-    // follows M (var 31 / 32 force either form).
-    // Q4_0 only: with one tile per wave Q4_1's min-term MFMA would land between other scale-accumulates of its own tile than
-    // in the multi-tile forms -- a different f32 addition order (measured: last-bit differences against the unsplit matrix).
-    // 512 x 4096 x 4096: 45.1 -> 40.6 us (the form is stage-latency bound: four tile-blocks of work per wave and barrier).
-    if constexpr (TYPE == GGML_TYPE_Q4_0) {
-        // (r3: wherever the 128 x 64 grid leaves CUs idle, not only from 384 of the smaller tiles on -- 1024 x 4096 x 768 37.0 -> 26.3 us,
-        // 512 x 4096 x 1024 36.8 -> 24.1, 256 x 4096 x 2048 36.7 -> 27.3, 1536 x 4096 x 900 37.7 -> 33.6, 512 x 11008 x 2048 94.5 -> 71.8)
-        if (var == 32 || (var != 31 && tm128 * ((N + 63) / 64) <= 256))
-            return launch_cfg<TYPE, 1, 1, 2, 2, 4, 2>(w, p, N, dst, ldd, st);                      // 64 x 64, 1 tile per wave
-    }
-    return launch_cfg<TYPE, 1, 2, 4, 1, 4, 2>(w, p, N, dst, ldd, st);                              // 128 x 64, 2 tiles per wave
+    return hipErrorInvalidValue;                            // (a form the plan never gives this type)
 }
 
 }  // namespace
@@ -1064,7 +994,7 @@ hipError_t launch_gemm_qmx_multi(const ggml_hip_weight *const *w, int n_w, act_p
     }
 }
 
-hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
+hipError_t launch_gemm_qmx(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st,
                            const mm_epilogue *ep) {
     if (N <= 0 || w->M <= 0) return hipSuccess;
     struct Scope {                                          // the epilogue lives for this launch only
@@ -1074,10 +1004,10 @@ hipError_t launch_gemm_qmx(const ggml_hip_weight *w, act_planes p, int64_t N, fl
     if (ep && ep->mode == 1 && ((uint64_t)64 * (uint64_t)ep->ld_add * 4 > 0xFFFFFFFFull || (uint64_t)256 * (uint64_t)ep->ld2 * 4 > 0xFFFFFFFFull))
         return hipErrorNotSupported;                        // (32-bit offsets inside a tile, as for dst)
     switch (w->type) {
-    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, p, N, dst, ldd, st);
-    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, pl, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,388 @@
+// plan.cpp -- the ONE place where a product's kernel family, form and summation tree are decided (plan.h).  Host code only: no
+// device is touched, so the whole decision surface is testable in a container without a GPU (tests/test_plan_cpu.py sweeps
+// type x K x N x M through ggml_hip_mm_plan and asserts that tree_id never depends on M).
+//
+// The numbers behind every threshold are measurements on MI355X; they sit next to the launchers that consume the forms (gemm_qmx.hip,
+// gemm_q16.hip, gemm_q.hip, gemm_qmp.hip, gemm_q8s.hip, gemv.hip, dense.hip, dense16.hip) and in DESIGN.md section 5.
+#include "common.h"
+#include "plan.h"
+
+namespace {
+
+thread_local int t_force_gemm = -1;   // -1: not set yet; 0 auto, 1 int8, 2 f16, 3 MX.  Per calling thread: a test hook never reaches another thread's calls
+
+inline bool is_quant(int t) { return t >= GGML_TYPE_Q4_0 && t <= GGML_TYPE_Q8_1; }
+inline bool min_type(int t) { return t == GGML_TYPE_Q4_1 || t == GGML_TYPE_Q5_1; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+constexpr uint64_t LIM32 = 0xFFFFFFFFull;                  // 32-bit buffer offsets
+
+// src1 rows up to which the mat-vec kernel serves a type (two-step form above GEMV_MAX_N): the types with small-batch MFMA
+// configurations leave it at 8; Q4_2, which only has the int8 kernel's 64 x 64 tiles behind it, stays on it up to 16
+int64_t gemv_rows_max(int t) { return t == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N : GEMV_MAX_N; }
+
+// ---- K3p / K3s / q8s geometry of K: contiguous ranges of k-blocks, one per wave (KS = 8 waves) ----
+constexpr int KS8 = 8;
+int k3p_mx_nloc(int64_t K) { return (int)cdiv(pad_kblocks(K / QK), KS8); }
+int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return n + (n & 1); }      // two k-blocks per trip (and the min term goes by pairs)
+constexpr int K3P_LDS = 160 * 1024;
+bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LDS; }               // the waves' row-scale tables
+
+// Q8_0, 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
+bool q8_small_serves(int type, int64_t K, int64_t N) {
+    return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
+}
+// Q8_0 / Q5_0 / Q5_1 / Q4_1, 257..512 rows, 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type, N and K alone
+// (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against 58; beyond
+// K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
+bool q8_mid_serves(int type, int64_t K, int64_t N) {
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= 512 &&
+           K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
+}
+
+int f16_image_kind(int type) { return type == GGML_TYPE_Q8_0 ? 2 : 1; }
+
+}  // namespace
+
+int plan_force_gemm() {
+    if (t_force_gemm < 0) {
+        const char *e = dev_env_str("GGML_HIP_GEMM");
+        t_force_gemm = !e ? 0 : (e[0] == 'i' ? 1 : (e[0] == 'f' ? 2 : (e[0] == 'm' ? 3 : 0)));
+    }
+    return t_force_gemm;
+}
+void plan_set_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 : which; }
+
+// Which MFMA kernel (and so which activation image K1 writes) serves a quantized mat-mat (measured on MI355X):
+//   gemm_qmx.hip (MX matrix path, bf6 digits, one exact MFMA per tile and block) -- Q4_0 / Q4_1,
+//   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q5_1 / Q8_0 on prompt-sized batches (N <= 512, K split in the
+//                workgroup) and from 1024 rows up,
+//   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q4_2, and Q5_0 / Q5_1 / Q8_0 in between,
+//   gemm_qmp.hip / gemm_q8s.hip -- the stage-free forms (257..512 rows; Q8_0 5..64 rows).
+// ggml_hip_debug_force_gemm forces one (test / developer switch; the product library reads no environment variable: GGML_HIP_GEMM is
+// honoured by -DGGML_HIP_DEV builds only).  Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images, 3 = the bf6 image.
+// NOT a function of the number of weight rows: the signature has no M to consult.
+int plan_image_kind(int type, int64_t K, int64_t N) {
+    const int force = plan_force_gemm();
+    if (q8_small_serves(type, K, N) || q8_mid_serves(type, K, N)) return 0;
+    if (N <= 4 || force == 1) return 0;
+    // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
+    // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them
+    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= 64)) return 0;
+    if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
+    // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
+    const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
+    if (nba * 64 * (uint64_t)pad_act(N) > LIM32) return 0;
+    if (force == 2) return f16_image_kind(type);
+    if (type == GGML_TYPE_Q5_1 && force == 3) return 0;                 // no MX form: the forced choice falls back to the int8 kernel
+    if (force == 3 || type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) return 3;
+    // Q5_0 / Q5_1 / Q8_0: the f16 kernel's K-split form wins on prompt-sized batches and its unsplit forms from 1024 rows up; in between
+    // the int8 kernel's 64 x 64 tiles balance the chip better.  Decided from N and K only, like the K split itself.
+    return ((N <= 512 || N >= 1024) && K / QK >= 8) ? f16_image_kind(type) : 0;
+}
+
+namespace {
+
+// ---- family plans: the decisions that used to sit in each launcher, verbatim ----
+
+void plan_gemv(mm_plan &p, int type, int64_t M, int64_t K, int64_t N, bool fused) {
+    p.family = fused ? MMF_GEMV_FUSED : MMF_GEMV_ROWS;
+    p.image = fused ? -1 : 0;
+    // 16 rows per workgroup for every M (gemv.hip launch_typed: a choice by M would change the tree); 8 waves x 4 k-lanes = 32 k-workers,
+    // worker u takes k-blocks u, u + 32, ...; two xor-shuffles + one LDS pass join them in a fixed order
+    p.form = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : 16;                    // columns per pass (NC)
+    p.arith = 100 + (fused && N <= 4 ? 1 : 0);                                           // the wave-private fused form (N <= 4) is its own kernel
+    p.ksplit = 32; p.kstyle = MMK_WORKERS; p.kunit = 1;
+    p.tile_m = 16; p.tile_n = p.form; p.waves = 8; p.tiles_per_wave = 1;
+    const int64_t ntiles = cdiv(M, 16);
+    p.wgs = ntiles < 512 ? ntiles : 512;
+    if (fused && (N <= 1 || N >= 3) && K / QK <= 128 && ntiles > 256) p.wgs = 256;       // the look-ahead form: one workgroup per CU
+    p.flags |= MM_FLAG_PERSISTENT;
+    if (fused && N >= 1 && N <= 4) p.flags |= MM_FLAG_EPILOGUE_FUSED;
+}
+
+bool plan_k3s_i8(mm_plan &p, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+    const int nbkp = (int)pad_kblocks(K / QK);
+    const int nloc = (int)cdiv(nbkp, KS8);
+    const int ncol = (int)cdiv(N, 32);
+    if (nloc > 64) return false;
+    if ((uint64_t)nbkp * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)nbkp * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
+    static const int geo = dev_env_int("GGML_HIP_Q8S_TILES", 0);   // developer A/B switch: 1 / 2 tiles per workgroup whatever M
+    const int64_t t32 = cdiv(M, 32) * ncol;
+    const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : t32 <= 256 ? 1 : 2;
+    p.family = MMF_K3S_I8; p.image = 0;
+    p.form = wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
+    p.arith = 200; p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;
+    p.nloc = nloc; p.wmt = wmt;
+    p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
+    p.wgs = cdiv(M, 32 * wmt) * ncol;
+    p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    return true;
+}
+
+bool plan_k3p_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+    const int nloc = k3p_i8_nloc(K);
+    if (nloc < 8 || !k3p_lds_ok(nloc)) return false;
+    // (32-bit buffer offsets, the look-ahead past a wave's range included -- the SAME bound the exception test of plan_mul_mat uses)
+    if ((uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
+    p.family = MMF_K3P_I8; p.image = 0; p.form = 0;
+    p.arith = 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0);        // Q8_0: fma(sumi, d1 * d0); others: fma(d0 * sumi, d1); min types: + MFMA per pair
+    p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
+    p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
+    p.wgs = cdiv(M, 128) * cdiv(N, 64);
+    p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    return true;
+}
+
+bool plan_k3p_mx(mm_plan &p, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+    const int nloc = k3p_mx_nloc(K);
+    if (nloc < 8 || !k3p_lds_ok(nloc)) return false;
+    if ((uint64_t)(KS8 * nloc + 2) * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)(KS8 * nloc + 2) * 48 * (uint64_t)pad_act(N) > LIM32) return false;
+    p.family = MMF_K3P_MX; p.image = 3; p.form = 0;
+    p.arith = 310; p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
+    p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
+    p.wgs = cdiv(M, 128) * cdiv(N, 64);
+    p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    return true;
+}
+
+// K3s (gemm_qmx.hip launch_small): KS = 8 waves per 32-row tile, each a contiguous eighth of K in pairs of blocks
+bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+    const int nbkp = (int)pad_kblocks(K / QK);
+    int nloc = (int)cdiv(nbkp, KS8);
+    nloc += nloc & 1;                                       // pairs of blocks stay inside one wave
+    if (nloc > 64) return false;                            // (the table pieces a lane holds: K <= 16384)
+    if (((uint64_t)nbkp + K_LOOKAHEAD) * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)nbkp * 48 * (uint64_t)pad_act(N) > LIM32) return false;
+    static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 / 2 / 4 = that many tiles per workgroup whatever M
+    const int ncol = (int)cdiv(N, 32);
+    const int64_t t32 = cdiv(M, 32) * ncol;
+    // (four tiles: Q4_0 only -- Q4_1's min-term registers do not fit beside four accumulator tiles)
+    const int wmt = geo == 1 ? 1 : geo == 2 || type == GGML_TYPE_Q4_1 ? (geo == 2 || geo == 4 || t32 > 256 ? 2 : 1) : geo == 4 ? 4 : (t32 <= 256 ? 1 : t32 <= 512 ? 2 : 4);
+    p.family = MMF_K3S_MX; p.image = 3; p.form = 0;
+    p.arith = 210 + (type == GGML_TYPE_Q4_1 ? 1 : 0);
+    p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = wmt;
+    p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
+    p.wgs = cdiv(M, 32 * wmt) * ncol;
+    p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    return true;
+}
+
+struct FormGeo { int wmt, wnt, wgm, wgn, ksp, vs; };
+void set_staged_geo(mm_plan &p, const FormGeo &g, int64_t M, int64_t N) {
+    p.tile_m = g.wgm * g.wmt * 32; p.tile_n = g.wgn * g.wnt * 32;
+    p.waves = g.wgm * g.wgn * g.ksp; p.tiles_per_wave = g.wmt * g.wnt;
+    p.ksplit = g.ksp * g.vs; p.kstyle = p.ksplit > 1 ? MMK_STAGE_SETS : MMK_CHAIN; p.kunit = 4;
+    p.wgs = cdiv(M, p.tile_m) * cdiv(N, p.tile_n);
+}
+
+// the staged MX family (gemm_qmx.hip launch_typed), TYPE in {Q4_0, Q4_1} (+ Q5_0 / Q8_0 with two weight digits when MX is forced)
+void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+    static const int var = dev_env_int("GGML_HIP_MX_TILE", 0);   // developer A/B switch
+    const int64_t nbk = K / QK;
+    const int64_t tm256 = cdiv(M, 256), tm128 = cdiv(M, 128), tn128 = cdiv(N, 128);
+    const bool q40 = type == GGML_TYPE_Q4_0, q4 = q40 || type == GGML_TYPE_Q4_1;
+    static const FormGeo geo[] = {{2, 4, 4, 1, 1, 1}, {4, 2, 2, 2, 1, 1}, {1, 1, 2, 1, 4, 1}, {1, 1, 1, 1, 4, 1}, {1, 2, 4, 1, 4, 1}, {1, 2, 2, 1, 4, 1},
+                                  {1, 2, 1, 1, 4, 1}, {1, 2, 2, 1, 2, 2}, {1, 2, 4, 1, 2, 1}, {1, 2, 2, 1, 2, 1}, {2, 2, 2, 2, 1, 1}, {1, 1, 2, 2, 1, 1}, {1, 2, 4, 1, 1, 1}};
+    auto take = [&](int f) {
+        p.family = MMF_MX; p.image = 3; p.form = f;
+        set_staged_geo(p, geo[f], M, N);
+        // Q4_1: with ONE tile per wave the min-term MFMA lands between other scale-accumulates of its tile than in the multi-tile forms
+        // (a different f32 addition order): the one-tile forms are chosen by N alone (up to 32 rows), the 64 x 64 form is Q4_0's only
+        p.arith = 400 + (type == GGML_TYPE_Q4_1 ? 1 + (p.tiles_per_wave == 1 ? 1 : 0) : type == GGML_TYPE_Q4_0 ? 0 : 10 + type);
+        p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    };
+    // 8 tiles per wave only where the registers allow it: one weight digit and one scale plane (Q4_0); only above 512 rows: up to 512
+    // rows every form splits K (two, four or eight ways by N and K) and this one does not
+    if (q40 && (tm256 * tn128 >= 384 || var == 30) && N > 512) return take(var == 2 ? MXF_256x128_ALT : MXF_256x128);
+    // Batches up to 128 rows (Q4_1: 256): 32-row weight tiles with K split four ways inside the workgroup; the same four-way tree on
+    // taller tiles where those cover the chip.  The choice of the SPLIT depends on N and K only; the tile height follows the tile count.
+    if (N <= (q40 || var == 20 ? 128 : 256) && nbk >= 16 && var != 3 && var != 9) {
+        const int64_t t64 = cdiv(M, 64) * cdiv(N, 64);
+        if (q4) {
+            // up to 64 rows, K >= 2048: the stage-free form K3s (by N and K alone; GGML_HIP_MX_TILE=26: the staged form, A/B)
+            static const int ncmax = dev_env_int("GGML_HIP_K3S_COLS", 2);   // developer A/B switch: 1 = K3s up to 32 rows only
+            if (N <= 32 * ncmax && nbk >= 64 && var != 25 && var != 26 && plan_k3s_mx(p, type, M, Mpad, K, N)) return;
+        }
+        if (N <= 32 && var != 25) {
+            const int h32 = var == 13 ? 32 : var == 15 || var == 12 ? 64 : (t64 < 160 ? 32 : 64);
+            return take(h32 >= 64 ? MXF_N32_H64 : MXF_N32_H32);
+        }
+        const int h = var == 12 ? 128 : var == 15 ? 64 : var == 13 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || !q40) ? 64 : 128);
+        if (q40 && h == 128) return take(MXF_S4_H128);
+        return take(h >= 64 ? MXF_S4_H64 : MXF_S4_H32);
+    }
+    // 129 .. 256 rows (Q4_0): the four-way tree as well -- really split while the tiles are few, else two wave groups that each run two
+    // of the four stage sets one after the other (same tree, same bits)
+    if (q40 && N <= 256 && nbk >= 16 && var != 3 && var != 9 && var != 20) {
+        const int64_t t64 = cdiv(M, 64) * cdiv(N, 64);
+        return take(var == 23 || (var != 24 && t64 <= 256) ? MXF_S4_H64 : MXF_S2V2_H64);
+    }
+    if (N <= 512 && nbk >= 8 && var != 3) {
+        // 257 .. 512 rows, K >= 2048, Q4_0: K3p (gemm_qmp.hip).  By N and K alone (GGML_HIP_K3P=1: the staged form, A/B).
+        if (q40) {
+            static const int k3p = dev_env_int("GGML_HIP_K3P", 0);
+            if (k3p != 1 && plan_k3p_mx(p, M, Mpad, K, N)) return;
+        }
+        return take(var == 17 || (var != 16 && tm128 * cdiv(N, 64) >= 1536) ? MXF_S2_H128 : MXF_S2_H64);
+    }
+    if (tm128 * tn128 >= 384) return take(MXF_128x128);
+    // a short, wide product (a row shard of a multi-GPU split): 64 x 64 tiles of four 1-tile waves wherever the 128 x 64 grid leaves
+    // CUs idle -- the same unsplit K loop per element, the same bits, only the geometry follows M (Q4_0 only: see `arith` above)
+    if (q40 && (var == 32 || (var != 31 && tm128 * cdiv(N, 64) <= 256))) return take(MXF_64x64);
+    return take(MXF_128x64);
+}
+
+// the staged f16 family (gemm_q16.hip launch_typed)
+void plan_f16(mm_plan &p, int type, int64_t M, int64_t K, int64_t N) {
+    const int64_t nbk = K / QK;
+    const bool mn = min_type(type);
+    static const FormGeo geo[] = {{1, 1, 2, 1, 4, 1}, {1, 1, 1, 1, 4, 1}, {1, 2, 4, 1, 4, 1}, {1, 2, 2, 1, 4, 1}, {1, 2, 1, 1, 4, 1},
+                                  {1, 2, 4, 1, 2, 1}, {2, 4, 4, 1, 1, 1}, {1, 1, 2, 2, 1, 1}, {1, 2, 4, 1, 1, 1}};
+    auto take = [&](int f) {
+        p.family = MMF_F16; p.image = f16_image_kind(type); p.form = f;
+        set_staged_geo(p, geo[f], M, N);
+        // the min term: on the matrix pipe per pair of k-blocks in the forms that split K, on the VALU per block in the unsplit ones --
+        // by the SPLIT (i.e. by N and K), not by the tile count (r3)
+        p.arith = 500 + type * 4 + (mn ? (p.ksplit > 1 ? 1 : 2) : 0);
+    };
+    const int64_t big = cdiv(M, 256) * cdiv(N, 128);
+    static const bool old128 = dev_env_set("GGML_HIP_Q16_OLD128");   // developer A/B switch
+    static const int n4 = dev_env_int("GGML_HIP_Q16_N4", 256);       // developer A/B switch (128 = the former bound)
+    if (N <= n4 && nbk >= 16 && !old128) {
+        static const int tile = dev_env_int("GGML_HIP_Q16_TILE", 0); // A/B: 1 = 128-row, 2 = 32-row, 3 = 64-row
+        const int64_t t64 = cdiv(M, 64) * cdiv(N, 64);
+        if (N <= 32 && tile != 4) {
+            const int h32 = tile == 2 ? 32 : tile == 1 || tile == 3 ? 64 : (t64 < 160 ? 32 : 64);
+            return take(h32 >= 64 ? F16F_N32_H64 : F16F_N32_H32);
+        }
+        const int h = tile == 1 ? 128 : tile == 3 ? 64 : tile == 2 ? 32 : (t64 < 160 ? 32 : (t64 <= 320 || mn) ? 64 : 128);
+        if (!mn && h == 128) return take(F16F_S4_H128);
+        return take(h >= 64 ? F16F_S4_H64 : F16F_S4_H32);
+    }
+    if (N <= 512 && nbk >= 8) return take(F16F_S2_H128);
+    if (big >= 384) return take(F16F_256x128);
+    static const int tile64 = dev_env_int("GGML_HIP_Q16_T64", 0);   // developer A/B switch: 1 = never, 2 = always
+    if (tile64 == 2 || (!mn && tile64 != 1 && cdiv(M, 128) * cdiv(N, 64) <= 256)) return take(F16F_64x64);
+    return take(F16F_128x64);
+}
+
+// the staged int8 family (gemm_q.hip): 128 x 128 tiles when they already give >= 2 workgroups per CU, else 64 x 64; one chain over K either way
+void plan_i8(mm_plan &p, int type, int64_t M, int64_t N) {
+    static const char *force = dev_env_str("GGML_HIP_GEMM_TILE");  // developer override: "1" = 64x64, "2" = 128x128
+    const int64_t big = cdiv(M, 128) * cdiv(N, 128);
+    const bool b = force && force[0] == '1' ? false : force && force[0] == '2' ? true : big >= 512;
+    p.family = MMF_I8; p.image = 0; p.form = b ? I8F_128x128 : I8F_64x64;
+    p.arith = 600 + type; p.ksplit = 1; p.kstyle = MMK_CHAIN; p.kunit = 4;
+    p.tile_m = p.tile_n = b ? 128 : 64; p.waves = 4; p.tiles_per_wave = b ? 4 : 1;
+    p.wgs = cdiv(M, p.tile_m) * cdiv(N, p.tile_n);
+}
+
+void plan_dense(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+    const bool f16 = type == GGML_TYPE_F16;
+    const uint64_t Kpad = (uint64_t)dense16_kpad(K), Npad = (uint64_t)pad_act(N);
+    p.image = -1;
+    // F16, more than 4 src1 rows: the f16 matrix cores (by N alone; K % 4: the INIT kernel reads src1 rows in 16-byte pieces, and a
+    // contiguous row is K floats -- r4: the choice no longer depends on whether the CALLER brought a work buffer or an aligned src1:
+    // ggml_hip_mul_mat_dev reports those as errors)
+    if (f16 && N > 4 && K % 4 == 0) {
+        if ((Kpad / 8 + DENSE16_SPARE_PANELS) * (uint64_t)Mpad * 16 > LIM32 || (Kpad / 8) * Npad * 16 > LIM32) {
+            p.flags |= MM_FLAG_WIDE;
+        } else {
+            static const int shape = dev_env_int("GGML_HIP_D16_SHAPE", 0);   // developer A/B switch: 1 = the 32 x 32 x 16 forms everywhere
+            static const int var = dev_env_int("GGML_HIP_D16_TILE", 0);      // developer A/B switch
+            const int64_t nst = (int64_t)Kpad / (16 * 8);
+            const int64_t tm128 = cdiv(M, 128), tn128 = cdiv(N, 128);
+            p.family = MMF_DENSE16; p.image = 32; p.flags |= MM_FLAG_NEEDS_WORK;
+            p.kunit = 8;
+            auto take = [&](int f, int tm, int tn, int waves, int ks, int shape16) {
+                p.form = f; p.tile_m = tm; p.tile_n = tn; p.waves = waves; p.ksplit = ks; p.kstyle = ks > 1 ? MMK_STAGE_SETS : MMK_CHAIN;
+                p.arith = 700 + shape16; p.wgs = cdiv(M, tm) * cdiv(N, tn);
+                p.tiles_per_wave = tm * tn / 1024 * ks / waves > 0 ? tm * tn / 1024 * ks / waves : 1;
+            };
+            if (N > 512 && shape != 1)   // (v_mfma_f32_16x16x32_f16, by N alone: the two tile sizes sum alike)
+                return cdiv(M, 256) * tn128 >= 384 ? take(D16F_S_256x128, 256, 128, 4, 1, 1) : take(D16F_S_128x128, 128, 128, 4, 1, 1);
+            if (N > 512 && cdiv(M, 256) * tn128 >= 384) return take(D16F_256x128, 256, 128, 4, 1, 0);
+            if (N <= 128 && nst >= 8 && var != 9)
+                return var == 1 || (var != 2 && tm128 * cdiv(N, 64) >= 80) ? take(D16F_S4_H128, 128, 64, 16, 4, 0) : take(D16F_S4_H32, 32, 64, 4, 4, 0);
+            if (N <= 512 && nst >= 4 && var != 9 && var != 8) {
+                if (var == 5 || (var == 0 && tm128 * tn128 >= 512)) return take(D16F_V2_128x128, 128, 128, 4, 2, 0);
+                if (var == 7 || (var != 6 && tm128 * tn128 >= 160)) return take(D16F_S2_128x128, 128, 128, 8, 2, 0);
+                return take(D16F_S2_128x64, 128, 64, 8, 2, 0);
+            }
+            return take(D16F_128x128, 128, 128, 4, 1, 0);
+        }
+    }
+    // F32 above 256 src1 rows: the bf16 cores, every operand split exactly into three bf16 pieces (K10d).  By N alone.
+    if (!f16 && N > 256 && K % 4 == 0) {
+        static const int old = dev_env_int("GGML_HIP_D32_OLD", 0);   // developer A/B switch: 1 = dense.hip (f32 matrix instruction) everywhere
+        if ((Kpad / 8 * 3 + DENSE32_SPARE_PANELS) * (uint64_t)Mpad * 16 > LIM32 || (Kpad / 8 * 3) * Npad * 16 > LIM32) {
+            p.flags |= MM_FLAG_WIDE;
+        } else if (old != 1) {
+            p.family = MMF_DENSE32; p.image = 33; p.form = 0; p.flags |= MM_FLAG_NEEDS_WORK;
+            p.arith = 710; p.ksplit = 1; p.kstyle = MMK_CHAIN; p.kunit = 1;
+            p.tile_m = p.tile_n = 128; p.waves = 4; p.tiles_per_wave = 16; p.wgs = cdiv(M, 128) * cdiv(N, 128);
+            return;
+        }
+    }
+    // dense.hip.  Mat-vec form up to 16 rows (passes of 8 columns; rows of the resident copy are K elements apart: 16-byte pieces need
+    // K % 8 (f16) / K % 4 (f32)); else the 64 x 64 tile kernel (F32: 128 x 128 tiles where they fill the chip -- bitwise the same result)
+    if (N <= 16 && K % (f16 ? 8 : 4) == 0 && K >= 512) {
+        p.family = MMF_DENSE_GEMV; p.form = 8;
+        p.arith = 720 + (f16 ? 1 : 0); p.ksplit = 64; p.kstyle = MMK_WORKERS; p.kunit = 1;
+        p.tile_m = 4; p.tile_n = 8; p.waves = 4; p.tiles_per_wave = 1; p.wgs = cdiv(M, 16);
+        return;
+    }
+    const int64_t tm = cdiv(M, 128), tn = cdiv(N, 128);
+    static const bool oldd = dev_env_set("GGML_HIP_DENSE_OLD");   // developer A/B switch
+    const bool bigt = !f16 && K % 32 == 0 && !oldd && tm * tn >= 256 && tm * tn < (1 << 30) && Mpad % 128 == 0;
+    p.family = MMF_DENSE; p.form = bigt ? DNF_BIG : DNF_TILE;
+    p.arith = 730 + (f16 ? 1 : 0); p.ksplit = 1; p.kstyle = MMK_CHAIN; p.kunit = 32;
+    p.tile_m = p.tile_n = bigt ? 128 : 64; p.waves = 4; p.tiles_per_wave = 1; p.wgs = cdiv(M, p.tile_m) * cdiv(N, p.tile_n);
+}
+
+}  // namespace
+
+mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bool one_call) {
+    mm_plan p = {};
+    p.ksplit = 1;
+    const int64_t Mpad = pad_rows(M > 0 ? M : 1);
+    if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) { plan_dense(p, type, M, Mpad, K, N); return p; }
+    if (!is_quant(type) || K <= 0 || K % QK != 0) return p;
+    if (ext_type != 0) p.flags |= MM_FLAG_Q8K;
+    // the stated exception: planes that do not fit 32-bit buffer offsets (> 4 GiB per plane) are served by the int8 family and its image,
+    // whatever the type.  INIT and COMPUTE both come through here, so they agree.  (For the K3p-int8 types the bound is the form's own:
+    // its waves' ranges reach up to 15 k-blocks past the padded end -- with the generic bound a matrix just under the limit fell to the
+    // staged int8 kernel while its row shards ran K3p)
+    const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
+    bool wide = (nba + K_LOOKAHEAD) * (uint64_t)Mpad * 32 > LIM32;
+    int kind = wide ? 0 : plan_image_kind(type, K, N);
+    bool no_fused = false;
+    if (q8_small_serves(type, K, N) && ext_type == 0) {
+        if (plan_k3s_i8(p, M, Mpad, K, N)) { p.flags |= MM_FLAG_NEEDS_WORK; return p; }
+        wide = true; kind = 0; no_fused = true;             // (its planes are beyond the form's offsets: the two-step forms below)
+    }
+    if (q8_mid_serves(type, K, N)) {                        // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)
+        if (plan_k3p_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
+        wide = true; kind = 0;
+    }
+    if (wide) p.flags |= MM_FLAG_WIDE;
+    if (kind == 0) {
+        if (one_call && N <= GEMV_MAX_N && ext_type == 0 && !no_fused) { plan_gemv(p, type, M, K, N, true); return p; }
+        p.flags |= MM_FLAG_NEEDS_WORK;
+        if (N <= gemv_rows_max(type)) { plan_gemv(p, type, M, K, N, false); return p; }
+        plan_i8(p, type, M, N);
+        return p;
+    }
+    if (kind == 3) plan_mx(p, type, M, Mpad, K, N);
+    else plan_f16(p, type, M, K, N);
+    p.flags |= MM_FLAG_NEEDS_WORK;
+    if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED;  // (the fused seams are for the reference's own types)
+    return p;
+}
+
+uint32_t plan_tree_id(const mm_plan &p) {
+    // what fixes an element's bits, and nothing of the geometry
+    uint32_t h = 2166136261u;
+    const int parts[] = {p.arith, p.ksplit, p.kstyle, p.kunit, p.flags & MM_FLAG_Q8K};
+    for (int v : parts) { h ^= (uint32_t)v; h *= 16777619u; }
+    return h;
+}

@@ -60,6 +60,33 @@ void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, 
  * unsplit matrix (what makes a shard's result bit for bit the matching columns).  The one exception is stated, not hidden: a
  * weight whose planes do not fit 32-bit buffer offsets (more than 4 GiB per plane) takes kind 0 whatever this says. */
 int    ggml_hip_act_image_kind(int type, int64_t K, int64_t N);
+/* THE PLAN of mul_mat(type, M, K, N) as ggml_hip_mul_mat_dev will run it (csrc/plan.cpp: the one place where a product's kernel is decided;
+ * every launcher consumes the same structure).  No device is needed to ask.  What the row split over several GPUs stands on
+ * (Ggml.cs:6665-6672: contiguous row ranges, each computed independently) is visible here and tested without a GPU:
+ *     tree_id -- the ORDER OF AN ELEMENT'S ADDITIONS (arithmetic form of a block term and of the min term, number of partial sums, how K is
+ *     divided among them) -- is a function of (type, K, N) and never of M,
+ * so a row shard computes, bit for bit, the matching columns of the unsplit product; family / form / tiles may follow M.  The one
+ * exception carries GGML_HIP_PLAN_WIDE: planes beyond 32-bit buffer offsets (> 4 GiB per plane) are served by the int8 family. */
+enum {  /* ggml_hip_mm_plan_t.family */
+    GGML_HIP_MMF_GEMV_FUSED = 1, GGML_HIP_MMF_GEMV_ROWS = 2, GGML_HIP_MMF_K3S_MX = 3, GGML_HIP_MMF_K3S_I8 = 4, GGML_HIP_MMF_K3P_MX = 5,
+    GGML_HIP_MMF_K3P_I8 = 6, GGML_HIP_MMF_MX = 7, GGML_HIP_MMF_F16 = 8, GGML_HIP_MMF_I8 = 9, GGML_HIP_MMF_DENSE = 10,
+    GGML_HIP_MMF_DENSE_GEMV = 11, GGML_HIP_MMF_DENSE16 = 12, GGML_HIP_MMF_DENSE32 = 13
+};
+enum {  /* ggml_hip_mm_plan_t.flags */
+    GGML_HIP_PLAN_WIDE = 1,            /* the 32-bit-offset exception applied */
+    GGML_HIP_PLAN_EPILOGUE_FUSED = 2,  /* an add / scale node behind the product runs in the kernel's store phase */
+    GGML_HIP_PLAN_PERSISTENT = 4, GGML_HIP_PLAN_Q8K = 8,
+    GGML_HIP_PLAN_NEEDS_WORK = 16      /* the product needs a work buffer of ggml_hip_mul_mat_work_size bytes */
+};
+typedef struct ggml_hip_mm_plan_t {
+    int32_t  family, image_kind, form;       /* which kernel, what INIT writes (-1 nothing, 0..3 K1's images, 32 / 33 dense panels), which instantiation */
+    uint32_t tree_id;                        /* hash of (arith, ksplit, kstyle, kunit): what fixes an element's bits */
+    int32_t  arith, ksplit, kstyle, kunit;   /* kstyle: 0 one chain over K, 1 stage sets taken in turn, 2 contiguous ranges, 3 interleaved workers */
+    int32_t  tile_m, tile_n, waves, tiles_per_wave;
+    int64_t  workgroups;
+    int32_t  flags;
+} ggml_hip_mm_plan_t;
+int    ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_plan_t *out);
 /* TEST HOOK, per calling thread (a host thread that never calls it is never affected): which matrix-core kernel serves
  * N > 8 on THIS thread's calls -- 0 automatic (by type, N and K), 1 int8 MFMA
  * (gemm_q.hip), 2 f16 MFMA (gemm_q16.hip), 3 MX (gemm_qmx.hip; for Q5_0 / Q8_0 its two-digit form, which needs the

@@ -1,0 +1,99 @@
+"""The kernel plan (csrc/plan.cpp, ggml_hip_mm_plan) without a GPU: ONE decision per product, and the invariant the multi-GPU row split
+stands on -- the order of an element's additions (tree_id) is a function of (type, K, N), never of the number of weight rows M -- checked
+over a sweep of type x K x N x M that includes vocabulary-sized matrices and the stated 32-bit-offset exception (the
+three shard-identity violations of round 3 were found by GPU sweeps only; each of them fails this test in the build container)."""
+import ctypes as C
+
+import pytest
+
+from ggmlsharp_amd import _lib
+
+F32, F16, Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0, Q5_K = 0, 1, 2, 3, 4, 6, 7, 8, 113
+QUANT = (Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0)
+WIDE, EPI, PERSIST, Q8K, NEEDS_WORK = 1, 2, 4, 8, 16
+FAM = {"gemv_fused": 1, "gemv_rows": 2, "k3s_mx": 3, "k3s_i8": 4, "k3p_mx": 5, "k3p_i8": 6, "mx": 7, "f16": 8, "i8": 9, "dense": 10,
+       "dense_gemv": 11, "dense16": 12, "dense32": 13}
+KS = (32, 64, 256, 512, 1024, 2048, 2304, 4096, 4352, 11008, 16384, 20480, 22016, 32768)
+NS = (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 256, 257, 300, 384, 512, 513, 640, 768, 1023, 1024, 2048, 4096)
+MS = (1, 31, 32, 100, 256, 512, 1000, 2048, 4000, 4096, 8192, 11008, 16384, 24576, 26000, 32000, 33000, 65536, 262144)
+
+
+def plan(t, M, K, N):
+    out = _lib.ggml_hip_mm_plan_t()
+    rc = _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(out))
+    assert rc == 0, (t, M, K, N, rc)
+    return out
+
+
+@pytest.mark.parametrize("t", QUANT + (F16, F32, Q5_K))
+def test_summation_tree_is_a_function_of_type_K_and_N_only(t):
+    checked = wide_seen = 0
+    for K in KS:
+        if t == Q5_K and K % 256:
+            continue
+        for N in NS:
+            trees = {}
+            for M in MS:
+                p = plan(t, M, K, N)
+                assert p.family in FAM.values(), (t, M, K, N, p.family)
+                assert p.ksplit >= 1 and p.tile_m > 0 and p.tile_n > 0 and p.workgroups > 0
+                if p.flags & WIDE:
+                    # the stated exception: only where a plane of the weight really is beyond 32-bit offsets (> 4 GiB), and then a family
+                    # that addresses with 64 bits: the int8 staged kernel / the mat-vec (quantized), dense.hip (dense)
+                    wide_seen += 1
+                    rows = (M + 255) // 256 * 256
+                    plane = rows * (K + 1024) * (6 if t == F32 else 2) if t in (F16, F32) else rows * (K // 32 + 18) * 32   # (F32: three bf16 pieces)
+                    assert plane > 0xFFFFFFFF, (t, M, K, N)
+                    assert p.family in (FAM["i8"], FAM["gemv_rows"], FAM["gemv_fused"], FAM["dense"], FAM["dense_gemv"]), (t, M, K, N, p.family)
+                    continue
+                trees.setdefault(p.tree_id, []).append((M, p.family, p.form, p.ksplit, p.kstyle, p.kunit, p.arith))
+                checked += 1
+            assert len(trees) <= 1, f"type {t} K {K} N {N}: the summation tree follows M: {trees}"
+    assert checked > 1000
+    if t in QUANT:
+        assert wide_seen > 0            # (262144 rows x K = 32768: 4 GiB of nibbles -- the sweep does reach the exception)
+
+
+def test_the_image_of_a_plan_is_the_image_of_its_type_K_and_N():
+    L = _lib.lib()
+    for t in QUANT:
+        for K in KS:
+            for N in NS:
+                for M in (100, 4096, 32000):
+                    p = plan(t, M, K, N)
+                    if p.flags & WIDE:
+                        continue
+                    if p.family == FAM["gemv_fused"]:
+                        assert p.image_kind == -1 and not (p.flags & NEEDS_WORK)
+                    else:
+                        assert p.image_kind == L.ggml_hip_act_image_kind(t, K, N), (t, M, K, N)
+                        assert p.flags & NEEDS_WORK
+
+
+def test_baseline_configs_get_the_kernels_design_md_names():
+    p = plan(Q4_0, 4096, 4096, 4096)                                # the headline: K3m 256 x 128, one chain over K
+    assert (p.family, p.form, p.tile_m, p.tile_n, p.ksplit, p.image_kind) == (FAM["mx"], 0, 256, 128, 1, 3) and p.workgroups == 512
+    assert plan(Q4_0, 4096, 4096, 1).family == FAM["gemv_fused"]    # config 2
+    for M in (4096, 4000, 32000):                                   # configs 3 and 5 (total and the 4000-row shard): K3p, eight K ranges of 16 k-blocks
+        p = plan(Q4_0, M, 4096, 512)
+        assert (p.family, p.ksplit, p.kstyle, p.kunit, p.tile_m, p.tile_n) == (FAM["k3p_mx"], 8, 2, 16, 128, 64)
+    for t in (Q8_0, Q5_0, Q5_1, Q4_1, Q5_K):                        # config 4 and its min-term relatives: K3p on the int8 cores
+        p = plan(t, 4096, 11008, 512)
+        assert (p.family, p.ksplit, p.kunit) == (FAM["k3p_i8"], 8, 44), t
+        assert bool(p.flags & Q8K) == (t == Q5_K)
+        assert bool(p.flags & EPI) == (t != Q5_K)
+    assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
+    assert plan(Q8_0, 4096, 22016, 512).family == FAM["f16"]        # K > 20480: the eight scale tables do not fit LDS (decided in the plan)
+    assert plan(F16, 4096, 4096, 4096).family == FAM["dense16"] and plan(F32, 4096, 4096, 4096).family == FAM["dense32"]
+    assert plan(F32, 64, 128, 256).family == FAM["dense"]           # config 1 (Test1-style f32 64 x 128 x 256)
+    assert plan(F32, 4096, 4096, 257).family == FAM["dense32"] and plan(F32, 4096, 4096, 256).family == FAM["dense"]
+
+
+def test_bad_arguments_are_reported():
+    out = _lib.ggml_hip_mm_plan_t()
+    L = _lib.lib()
+    assert L.ggml_hip_mm_plan(Q4_0, 4096, 4096, 16, None) == -4
+    assert L.ggml_hip_mm_plan(9, 4096, 4096, 16, C.byref(out)) == -2      # Q8_1 is not a weight type (Ggml.cs:278-282)
+    assert L.ggml_hip_mm_plan(Q4_0, 4096, 4100, 16, C.byref(out)) == -3    # K % 32
+    assert L.ggml_hip_mm_plan(Q5_K, 4096, 4128, 16, C.byref(out)) == -3    # K % 256
+    assert L.ggml_hip_mm_plan(Q4_0, 0, 4096, 16, C.byref(out)) == -3
