@@ -546,6 +546,7 @@ def pick_exchange(device, gdist, world, rank, requested, K):
         return "rccl", "requested"
     ok = 1.0
     why = "verified against the all-gather form"
+    want = "push" if requested == "push" else "push_fused"
     N, M = 96, 64 * world + 8
     g = torch.Generator(device="cuda")
     g.manual_seed(5)
@@ -554,7 +555,7 @@ def pick_exchange(device, gdist, world, rank, requested, K):
     a = ra.step(x).clone()
     try:
         # (the set-up keeps every rank in step with its peers whatever fails locally and raises on ALL ranks or on none)
-        rb, wb = make_runner(device, gdist, M, K, N, world, rank, "push", 2, 4242)
+        rb, wb = make_runner(device, gdist, M, K, N, world, rank, want, 2, 4242)
     except Exception as e:  # noqa: BLE001 -- the IPC set-up is unavailable: the RCCL form runs
         return "rccl", f"push set-up failed: {type(e).__name__}: {e}"[:200]
     b1 = rb.step(x).clone()
@@ -567,7 +568,7 @@ def pick_exchange(device, gdist, world, rank, requested, K):
     t = torch.tensor([ok], dtype=torch.float32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if float(t.item()) >= 1.0:
-        return "push", why
+        return want, why
     return "rccl", why if ok == 0.0 else "another rank could not use push"
 
 
@@ -600,8 +601,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N > 1 flow on one GPU)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push"],
-                    help="dst shard exchange for --gpus > 1: RCCL all-gather + re-layout, or direct peer stores (auto: push when verified, else rccl)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push", "push_fused"],
+                    help="dst shard exchange for --gpus > 1: RCCL all-gather + re-layout, direct peer stores by a kernel behind the product (push), or "
+                         "peer stores from the GEMM's own store phase (push_fused); auto: push_fused when verified bit for bit against the all-gather, else rccl")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -690,8 +692,10 @@ def main():
             oc["weak_4096_rows_per_gpu"] = multi_config(device, gdist, "weak scaling", 4096 * world, K, N, world, rank, exchange, 4, small, 3)
             # BASELINE.json configs[4]: Q4_0 32000 x 4096 x 512 row-split (Ms = 4000 at 8 GPUs)
             oc["config5_vocab512"] = multi_config(device, gdist, "BASELINE config 5", 32000, K, 512, world, rank, exchange, 2, small, 3)
-            if exchange == "push":   # the RCCL form beside it, same problem
+            if exchange in ("push", "push_fused"):   # the other forms beside it, same problem: what fusing the exchange into the store phase buys
                 oc["headline_rccl_allgather"] = multi_config(device, gdist, "strong scaling, RCCL all-gather + re-layout", M, K, N, world, rank, "rccl", chunks, small, 3)
+                other = "push" if exchange == "push_fused" else "push_fused"
+                oc[f"headline_{other}"] = multi_config(device, gdist, f"strong scaling, exchange '{other}'", M, K, N, world, rank, other, chunks, small, 3)
             out["other_configs"] = oc
 
     if world == 1 and rank == 0:

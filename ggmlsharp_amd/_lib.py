@@ -109,6 +109,8 @@ HIP_SYMBOLS = {
     "ggml_hip_ipc_close": (C.c_int, [_P]),
     "ggml_hip_ipc_free": (C.c_int, [_P]),
     "ggml_hip_push_columns_dev": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _PP, C.c_int, C.c_int64, C.c_int64, _P]),
+    "ggml_hip_mul_mat_push_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _PP, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.c_size_t, _P]),
+    "ggml_hip_mul_mat_push_fused": (C.c_int, [_P, C.c_int64, C.c_int]),
     "ggml_hip_slot_malloc": (_P, [C.c_int, C.c_size_t]),
     "ggml_hip_slot_free": (None, [C.c_int, _P]),
     "ggml_hip_slot_upload": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),

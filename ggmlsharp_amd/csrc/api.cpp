@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "plan.h"
 #include <algorithm>
+#include <vector>
 
 namespace ghip {
 
@@ -851,6 +852,48 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
     }
     if (ldd == w->M && ld_add == w->M && ldd2 == w->M) HIP_TRY(launch_binary_f32(0, d_dst, d_addend, d_dst2, N * w->M, (hipStream_t)stream));
     else for (int64_t n = 0; n < N; ++n) HIP_TRY(launch_binary_f32(0, d_dst + n * ldd, d_addend + n * ld_add, d_dst2 + n * ldd2, w->M, (hipStream_t)stream));
+    return GGML_HIP_OK;
+}
+
+/* ---- the row split's product + exchange ---- */
+// Which kernel forms store to the peers themselves: the staged MX forms and K3p (plan.h).  The others compute into this rank's own buffer
+// and hand their columns to the peers with the column-push kernel (layout.hip) behind the product: the same bytes, one more launch.
+static bool push_is_fused(const ggml_hip_weight *w, int64_t N, int n_peers) {
+    if (!is_q(w->type) || n_peers - 1 > MM_PUSH_MAX) return false;
+    const int f = weight_plan(w, N, true).family;
+    return f == MMF_MX || f == MMF_K3P_MX || f == MMF_K3P_I8;
+}
+int ggml_hip_mul_mat_push_fused(const ggml_hip_weight *w, int64_t N, int n_peers) { return w && push_is_fused(w, N, n_peers) ? 1 : 0; }
+
+int ggml_hip_mul_mat_push_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *const *d_peers, int n_peers, int own,
+                              int64_t ld_total, int64_t col0, void *d_work, size_t work_bytes, void *stream) {
+    if (!w || !d_peers) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (n_peers < 1 || n_peers > 16 || own < 0 || own >= n_peers || !d_peers[own]) return fail(GGML_HIP_ERR_ARG, "1..16 destination buffers, this rank's own among them");
+    if (N <= 0 || w->M <= 0) return GGML_HIP_OK;
+    if (col0 < 0 || ld_total < col0 + w->M) return fail(GGML_HIP_ERR_SHAPE, "ld_total < col0 + M");
+    float *mine = d_peers[own] + col0;
+    if (push_is_fused(w, N, n_peers)) {
+        if (!d_src1) return fail(GGML_HIP_ERR_ARG, "null argument");
+        if (ld1 < w->K) return fail(GGML_HIP_ERR_SHAPE, "ld1 < K");
+        mm_epilogue ep = {3, nullptr, 0, nullptr, 0, 1.0f, 0, {}};
+        for (int g = 0; g < n_peers; ++g)
+            if (g != own && d_peers[g]) ep.push[ep.npush++] = d_peers[g] + col0;
+        int rc = weight_device_current(w);
+        if (rc) return rc;
+        rc = ggml_hip_mul_mat_init_dev(w, d_src1, N, ld1, d_work, work_bytes, stream);
+        if (rc) return rc;
+        const mm_plan plan = weight_plan(w, N, true);
+        const act_planes pl = act_carve(d_work, w->K, pad_act(N));
+        const hipError_t e = plan.family == MMF_K3P_I8 ? launch_gemm_q8_mid(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, ep)
+                                                       : launch_gemm_qmx(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, &ep);
+        HIP_TRY(e);
+        return GGML_HIP_OK;
+    }
+    int rc = ggml_hip_mul_mat_dev(w, d_src1, N, ld1, mine, ld_total, d_work, work_bytes, stream);
+    if (rc) return rc;
+    std::vector<float *> others((size_t)n_peers);
+    for (int g = 0; g < n_peers; ++g) others[(size_t)g] = g == own ? nullptr : d_peers[g];
+    HIP_TRY(launch_push_columns(mine, ld_total, N, w->M, others.data(), n_peers, ld_total, col0, (hipStream_t)stream));
     return GGML_HIP_OK;
 }
 

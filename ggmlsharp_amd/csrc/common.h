@@ -163,11 +163,18 @@ struct PerDeviceOnce {
 // that follows a mul_mat node, fused into its store phase).  mode 0: none.  mode 1 (add, Ggml.cs:4622-4682): dst keeps the
 // product, dst2[n][m] = product + addend[n][m] -- both nodes' data are materialised, one f32 add, bit for bit the separate
 // kernel.  mode 2 (scale, Ggml.cs:6746-6778, in place: the scale node is a view of the product): dst[n][m] = product * scale.
+// mode 3 (r4, the exchange of a row split fused into the store phase -- SURVEY 8(e): "epilogue peer-writes straight into each peer's final
+// [N][M] buffer"): dst is this rank's own [N][M] buffer at its column offset, push[0 .. npush) are the SAME position in every peer's buffer
+// (IPC-mapped, or other slots' buffers of one process); every element is stored to all of them with dst's row stride (Ggml.cs:6692-6697
+// is the layout every rank must end with).  Kernels that apply it: the staged MX forms, K3p (MX and int8).
+#define MM_PUSH_MAX 7
 struct mm_epilogue {
     int mode;
     const float *addend; int64_t ld_add;
     float *dst2; int64_t ld2;
     float scale;
+    int npush;
+    float *push[MM_PUSH_MAX];
 };
 
 // ---- prologue of the fused mat-vec (prologue side): the activation row the kernel quantizes is not read

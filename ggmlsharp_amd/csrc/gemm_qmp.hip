@@ -122,7 +122,10 @@ __device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[WMT][WNT], uint8_
             for (int e = 0; e < 4; ++e) {
                 const int n = n0 + 32 * j + e + 8 * q + 4 * hh;
                 if (n < N && m < M) {
-                    if (ep.mode == 2) {
+                    if (ep.mode == 3) {                      // the row split's exchange: the same position in this rank's and every peer's [N][M] buffer
+                        dst[(size_t)n * ldd + m] = v[e];
+                        for (int k = 0; k < ep.npush; ++k) ep.push[k][(size_t)n * ldd + m] = v[e];
+                    } else if (ep.mode == 2) {
                         dst[(size_t)n * ldd + m] = v[e] * ep.scale;
                     } else {
                         dst[(size_t)n * ldd + m] = v[e];

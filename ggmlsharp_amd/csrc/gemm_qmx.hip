@@ -452,6 +452,33 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     const rsrc_t rD = make_rsrc(dst + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
     const bool full = n0 + C::TN <= N && m0 + C::TM <= M;                    // uniform
     const uint32_t lane_off = (uint32_t)((4 * hh * ldd + l31) * 4);
+    if (ep.mode == 3) {
+        // the exchange of a row split, fused into the store phase (common.h mm_epilogue mode 3): every element goes to the same position of
+        // this rank's own [N][M] buffer (dst) and of every peer's -- one descriptor per destination, the tile's offsets shared
+        rsrc_t rP[MM_PUSH_MAX];
+#pragma unroll
+        for (int k = 0; k < MM_PUSH_MAX; ++k) rP[k] = make_rsrc((k < ep.npush ? ep.push[k] : dst) + (size_t)n0 * ldd + m0, 0xFFFFFFFFu);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                const int mb = (wm_ * WMT + i) * 32, nb = (wn * WNT + j) * 32;        // relative to (n0, m0)
+                if (m0 + mb >= M || n0 + nb >= N) continue;                    // uniform
+                const bool mok = m0 + mb + l31 < M;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nr = nb + (r & 3) + 8 * (r >> 2);
+                    const float v = acc[i][j][r];
+                    if (!(mok && n0 + nr + 4 * hh < N)) continue;
+                    const uint32_t so = (uint32_t)(nr * ldd + mb) * 4u, vb = __builtin_bit_cast(uint32_t, v);
+                    __builtin_amdgcn_raw_buffer_store_b32(vb, rD, (int)lane_off, (int)so, 0);
+#pragma unroll
+                    for (int k = 0; k < MM_PUSH_MAX; ++k)
+                        if (k < ep.npush) __builtin_amdgcn_raw_buffer_store_b32(vb, rP[k], (int)lane_off, (int)so, 0);
+                }
+            }
+        return;
+    }
     if (ep.mode != 0) {
         // the add / scale node that follows this mul_mat, applied as the accumulators are stored (common.h mm_epilogue): uniform
         // branch, taken only by the fused seams; one f32 operation per element, the separate kernel's result bit for bit

@@ -13,6 +13,10 @@ reference's dst layout [N][M] (Ggml.cs:6692-6697).  Two exchange forms, identica
           columns and one kernel stores them into every peer's buffer (compute units over xGMI: one hop, all links of the
           sender at once, final layout -- no [G][N][Ms] intermediate, no re-layout pass); one tiny all-reduce per step is
           the barrier.  Two result buffers alternate, so a step's stores never race the previous step's consumers.
+  "push_fused" (r4)  the same buffers, but the stores to the peers are the GEMM's OWN store phase (ggml_hip_mul_mat_push_dev:
+          mm_epilogue mode 3, up to eight destination bases) where the kernel form has it -- the staged MX forms and K3p --
+          so a step is INIT + one COMPUTE launch whose tiles go out over xGMI as they finish; forms without it fall back to
+          "push" for that call.  SURVEY 8(e): "epilogue peer-writes straight into each peer's final [N][M] buffer".
 """
 import ctypes as C
 
@@ -56,7 +60,11 @@ class RowSplitMulMat:
         else:
             self.M_total = weight.M
         self.chunks = max(1, min(chunks, N)) if world > 1 else 1
+        self.fused_store = exchange == "push_fused"
+        if exchange == "push_fused":
+            exchange = "push"
         self.exchange = exchange if world > 1 else "none"
+        self._default_compute = compute_shard is None
         dev = device if device is not None else "cuda"
         self.dev = dev
         self.work = None
@@ -188,6 +196,14 @@ class RowSplitMulMat:
         side = self._side                                               # the stores of chunk i overlap the kernels of chunk i + 1
         peers = (C.c_void_p * self.world)(*[None if r == self.rank else p for r, p in enumerate(self._peers[b])])
         for (a, e) in self._chunk_bounds():
+            if Mw > 0 and self.fused_store and self._default_compute and self._L.ggml_hip_mul_mat_push_fused(self.W.handle, e - a, self.world):
+                # the exchange IS the GEMM's store phase: every destination's base at this chunk's first row, this rank's own among them
+                xa = x[a:e]
+                allp = (C.c_void_p * self.world)(*[p + a * self.M_total * 4 for p in self._peers[b]])
+                check(self._L.ggml_hip_mul_mat_push_dev(self.W.handle, C.c_void_p(xa.data_ptr()), e - a, xa.stride(0), allp, self.world, self.rank,
+                                                        self.M_total, r0, C.c_void_p(self.work.data_ptr()), self.work.numel(),
+                                                        C.c_void_p(main.cuda_stream)), "ggml_hip_mul_mat_push_dev")
+                continue
             if Mw > 0:
                 own = out[a:e, r0:r1]                                   # this rank's rows as columns of its own dst
                 self.compute_shard(x[a:e], own)

@@ -243,6 +243,16 @@ int ggml_hip_ipc_close(void *d_ptr);
 int ggml_hip_ipc_free(void *d_ptr);
 int ggml_hip_push_columns_dev(const float *d_shard, int64_t lds, int64_t N, int64_t Ms, float *const *d_peers, int n_peers,
                               int64_t ldd, int64_t col0, void *stream);
+/* The product AND the exchange in one call (r4; SURVEY 8(e): "epilogue peer-writes straight into each peer's final [N][M] buffer"):
+ * this rank's rows of W (Ggml.cs:6665-6672) against all of src1, every element stored as column col0 + m of EVERY rank's reference-layout
+ * dst [N][ld_total] (Ggml.cs:6692-6697).  d_peers: HOST array of n_peers <= 16 device pointers to the buffers' BASES, this rank's own at
+ * index `own`, NULL entries skipped.  Where the kernel form that serves (type, K, N) has the store-phase exchange -- the staged MX forms
+ * and K3p, up to 8 destinations: ggml_hip_mul_mat_push_fused says so -- the GEMM's store phase writes to all of them (no shard pass, no
+ * second launch); otherwise the product lands in this rank's buffer and ggml_hip_push_columns_dev's kernel follows.  Same bytes either
+ * way.  The caller orders consumers behind a barrier of its own. */
+int ggml_hip_mul_mat_push_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *const *d_peers, int n_peers,
+                              int own, int64_t ld_total, int64_t col0, void *d_work, size_t work_bytes, void *stream);
+int ggml_hip_mul_mat_push_fused(const ggml_hip_weight *w, int64_t N, int n_peers);
 /* One process PER device (torch.distributed / RCCL ranks, ggmlsharp_amd/dist.py): after an all-gather of per-rank dst
  * shards ([G][N][Ms], rank-major) produce the reference layout [N][G*Ms -> M] (SURVEY.md 8(e) "layout catch"); rows of
  * the last rank beyond M are dropped. */

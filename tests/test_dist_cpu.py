@@ -146,8 +146,8 @@ def _gpu_worker(rank, world, port, M, K, N, chunks, exchange, out_q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["rccl", "push"])
-@pytest.mark.parametrize("M,K,N,chunks", [(300, 256, 70, 1), (515, 512, 130, 4), (1000, 128, 1, 1)])
+@pytest.mark.parametrize("exchange", ["rccl", "push", "push_fused"])
+@pytest.mark.parametrize("M,K,N,chunks", [(300, 256, 70, 1), (515, 512, 130, 4), (1000, 128, 1, 1), (700, 2048, 300, 2)])
 def test_row_split_world2_on_one_gpu_is_bitwise_the_unsplit_result(M, K, N, chunks, exchange):
     """exchange "rccl": all-gather (gloo standing in for RCCL) + the re-layout kernel; "push": IPC-shared dst buffers across
     the two PROCESSES and the peer-store kernel (ggml_hip_ipc_*, ggml_hip_push_columns_dev)."""

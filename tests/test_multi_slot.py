@@ -377,3 +377,52 @@ def test_both_exchange_forms_move_eight_ranks_shards_into_the_unsplit_result(nam
     torch.cuda.synchronize()
     for r, p in enumerate(peers):
         assert torch.equal(p, full), f"{name}: rank {r}'s pushed dst differs from the unsplit result"
+
+
+FUSED_PUSH_CASES = [("config 5 (K3p-MX shards)", O.Q4_0, 32000, 4096, 512, True), ("headline 4096^3 (64 x 64 MX shards)", O.Q4_0, 4096, 4096, 4096, True),
+                    ("weak scaling (256 x 128 MX shards)", O.Q4_0, 32768, 2048, 1024, True), ("config 4's type (K3p-int8 shards)", O.Q8_0, 8192, 4096, 512, True),
+                    ("Q5_1, ragged last shard (K3p-int8 + min term)", 7, 4000, 2048, 300, True), ("Q4_1 above 512 rows (staged MX with the min-term MFMA)", 3, 4096, 1024, 640, True),
+                    ("Q8_0, 640 rows: a family without the store-phase exchange", O.Q8_0, 4096, 1024, 640, False),
+                    ("decode batch: the mat-vec", O.Q4_0, 4096, 4096, 2, False)]
+
+
+@pytest.mark.parametrize("name,t,M,K,N,fused", FUSED_PUSH_CASES)
+def test_exchange_fused_into_the_store_phase_fills_eight_ranks_buffers_with_the_unsplit_result(name, t, M, K, N, fused):
+    """r4 (SURVEY 8(e) "epilogue peer-writes"): ggml_hip_mul_mat_push_dev computes a rank's rows and stores every
+    element into EVERY rank's reference-layout dst [N][M] from the GEMM's store phase (mm_epilogue mode 3: up to eight destination
+    bases).  Eight ranks' shards, one after the other on the one GPU, the eight destination buffers standing in for the peers' IPC
+    mappings: each buffer must end as the unsplit product, bit for bit (the checker: the column-push kernel's path, tested above)."""
+    from ggmlsharp_amd import device
+    from ggmlsharp_amd import dist as gdist
+    from ggmlsharp_amd._lib import lib, check
+    device.init(0)
+    L = lib()
+    G = 8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + N + t)
+    rows = device.quantize_rows(t, torch.randn((M, K), generator=g, device="cuda"))
+    x = torch.randn((N, K), generator=g, device="cuda")
+    W = device.Weight.from_device(t, rows, K)
+    full = device.mul_mat(W, x).clone()
+    W.free()
+    peers = [torch.full((N, M), -3.0, device="cuda") for _ in range(G)]
+    pp = (C.c_void_p * G)(*[p.data_ptr() for p in peers])
+    work = device.alloc_work(t, K, N)
+    for r in range(G):
+        r0, r1 = gdist.shard_rows(M, G, r)
+        if r1 <= r0:
+            continue
+        Wr = device.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert bool(L.ggml_hip_mul_mat_push_fused(Wr.handle, N, G)) == fused, f"{name}: rank {r}"
+        check(L.ggml_hip_mul_mat_push_dev(Wr.handle, C.c_void_p(x.data_ptr()), N, K, pp, G, r, M, r0, C.c_void_p(work.data_ptr()), work.numel(), None),
+              "ggml_hip_mul_mat_push_dev")
+        torch.cuda.synchronize()
+        Wr.free()
+    for r, p in enumerate(peers):
+        assert torch.equal(p, full), f"{name}: rank {r}'s dst differs from the unsplit result"
+    # argument checks: this rank's own buffer must be among the destinations; the row must hold the columns
+    Wr = device.Weight.from_device(t, rows, K, row_begin=0, row_end=min(64, M))
+    none = (C.c_void_p * G)(*[None] * G)
+    assert L.ggml_hip_mul_mat_push_dev(Wr.handle, C.c_void_p(x.data_ptr()), N, K, none, G, 0, M, 0, C.c_void_p(work.data_ptr()), work.numel(), None) == -4
+    assert L.ggml_hip_mul_mat_push_dev(Wr.handle, C.c_void_p(x.data_ptr()), N, K, pp, G, 0, M, M - 8, C.c_void_p(work.data_ptr()), work.numel(), None) == -3
+    Wr.free()
