@@ -1,7 +1,7 @@
 """ctypes binding of libggml_hip.so (the product: the C-ABI declared in include/ggml_hip.h) and of
-libggml_hostmirror.so (test support: the C++ stand-in for the reference's C# host, include/ggml.h).
+libggml_hostmirror.so (TEST SUPPORT: the C++ stand-in for the reference's C# host, tests/support/ggml.h + ggml_host.cpp).
 
-Both are built in-tree (ggmlsharp_amd/lib/) by `make -C ggmlsharp_amd/csrc`.
+The product is built in-tree (ggmlsharp_amd/lib/) by `make -C ggmlsharp_amd/csrc`, the mirror by `make -C tests/support`.
 Nothing here falls back to a CPU implementation: if the library is missing, loading raises.
 """
 import ctypes as C
@@ -11,7 +11,8 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GGML_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libggml_hip.so")   # env: developer ablation builds
-MIRROR_PATH = os.path.join(PKG_DIR, "lib", "libggml_hostmirror.so")
+SUPPORT_DIR = os.path.join(os.path.dirname(PKG_DIR), "tests", "support")
+MIRROR_PATH = os.path.join(SUPPORT_DIR, "libggml_hostmirror.so")
 
 GGML_MAX_DIMS = 4
 GGML_MAX_OPT = 4
@@ -222,6 +223,7 @@ def build(force=False):
     if force:
         subprocess.check_call(["make", "-C", CSRC_DIR, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", CSRC_DIR, "-j4"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", SUPPORT_DIR], stdout=subprocess.DEVNULL)      # the host mirror (test support) links the product
     return LIB_PATH
 
 

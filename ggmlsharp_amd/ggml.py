@@ -1,4 +1,4 @@
-"""Python face of the host mirror (include/ggml.h): the same ggml_* names and argument meaning as
+"""Python face of the host mirror (TEST SUPPORT: tests/support/ggml.h): the same ggml_* names and argument meaning as
 GGMLSharp's public static API (Ggml.cs:1447, 2347-2395, 7137, 7648-7673, 3209), so a test program reads
 like the reference's Test0..Test3.  All work is done by libggml_hip.so; this file only converts arguments.
 """

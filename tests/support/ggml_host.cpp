@@ -6,7 +6,7 @@
 // built into its own library, libggml_hostmirror.so, which links libggml_hip.so exactly as the C# host would bind it --
 // through the exported ggml_hip_* C-ABI only.  The real host never loads it, and libggml_hip.so exports no ggml_* name
 // that could collide with a native ggml in the same process.
-#include "../../include/ggml.h"
+#include "ggml.h"
 
 #include <cstdio>
 #include <cstdlib>

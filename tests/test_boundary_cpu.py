@@ -19,7 +19,10 @@ def _has_gpu():
 
 
 def _declared(header):
-    src = open(os.path.join(ROOT, "include", header)).read()
+    path = os.path.join(ROOT, "include", header)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "tests", "support", header)       # the host mirror's ggml.h (test support)
+    src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b(ggml_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
@@ -34,7 +37,7 @@ def _exported(path):
 def test_library_exports_every_declared_symbol():
     """libggml_hip.so (the product) exports exactly the ggml_hip_* names of include/ggml_hip.h -- no ggml_* name that
     could collide with a native ggml in the host process, no C++ symbol; the host mirror (test support, its own
-    library) exports exactly what include/ggml.h declares."""
+    library, tests/support/) exports exactly what its ggml.h declares."""
     L = _lib.lib()
     core_decl, ext_decl = set(_declared("ggml_hip.h")), set(_declared("ggml_hip_ext.h"))
     # the drop-in core (SURVEY 8(b): lifecycle, pool, Seam 1 + invalidation + scope, Seam 2, resident weights, the two-phase
@@ -221,10 +224,10 @@ def test_reference_style_c_program_compiles_links_and_fails_loudly_without_gpu(t
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    libdir = os.path.join(root, "ggmlsharp_amd", "lib")
+    libdir, supdir = os.path.join(root, "ggmlsharp_amd", "lib"), os.path.join(root, "tests", "support")
     exe = str(tmp_path / "refprog")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
-                           os.path.join(root, "tests", "c", "reference_style_program.c"), "-L" + libdir, "-lggml_hostmirror", "-lggml_hip",
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), "-I" + supdir,
+                           os.path.join(root, "tests", "c", "reference_style_program.c"), "-L" + supdir, "-L" + libdir, "-lggml_hostmirror", "-lggml_hip", "-Wl,-rpath," + supdir,
                            "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -377,6 +377,39 @@ def test_dense_f32_split_form_is_tight_and_shards_are_bitwise_slices(dev):
     W.free()
 
 
+def test_dense_f32_split_form_keeps_infinities_nans_and_tiny_values(dev):
+    """the three-piece split of K10d used to turn an infinite operand into NaN (inf - inf in the remainder pieces) where the
+    reference's f32 product gives +-inf.  An infinite weight, an infinite activation, a NaN (payload in the low mantissa bits) and
+    operands at the bottom of the normal range, at more than 256 src1 rows (the split form), against torch's f32 product."""
+    M, K, N = 256, 512, 300
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda")
+    w[3, 7] = float("inf")                                     # column 3 of dst: +-inf by the sign of x[:, 7]
+    x[5, 9] = float("-inf")                                    # row 5 of dst: -+inf by the sign of w[:, 9]
+    x[11, 0] = torch.tensor([0x7F800001], dtype=torch.int32, device="cuda").view(torch.float32)[0]   # a NaN whose payload is in the low bits
+    w[20] = w[20] * 1e-38
+    x[21] = x[21] * 1e-30
+    W = dev.Weight.from_device(0, w.view(torch.uint8).view(M, -1), K)
+    got = dev.mul_mat(W, x)
+    W.free()
+    ref = x.double() @ w.double().T
+    assert torch.isnan(got[11]).all()
+    inf_ref = torch.isinf(ref)
+    fin = torch.isfinite(ref)
+    assert inf_ref[:, 3].sum() > 200 and inf_ref[5].sum() > 200
+    ok_inf = inf_ref & torch.isinf(got) & (torch.sign(got.double()) == torch.sign(ref))
+    assert torch.equal(ok_inf, inf_ref), "an infinite product did not come out as the same infinity"
+    mask = fin.clone()
+    mask[11] = False
+    # finite outputs: the usual bound; rows / columns scaled down to the denormal border: nothing blows up (flush-to-zero of the pieces is allowed)
+    err = (got.double() - ref).abs()[mask]
+    rms = ref[mask & (ref.abs() > 1e-20)].pow(2).mean().sqrt()
+    assert (err.max() / rms).item() < 1e-5
+    assert torch.isfinite(got[21][fin[21]]).all() and torch.isfinite(got[:, 20][fin[:, 20]]).all()
+
+
 def test_fullsize_byte_roundtrips(dev):
     M, K = 4096, 4096
     for t in (Q4_0, Q5_0, Q8_0):

@@ -469,9 +469,9 @@ def test_reference_style_c_program_on_gpu(dev, tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    libdir = os.path.join(root, "ggmlsharp_amd", "lib")
+    libdir, supdir = os.path.join(root, "ggmlsharp_amd", "lib"), os.path.join(root, "tests", "support")
     exe = str(tmp_path / "refprog")
-    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "c", "reference_style_program.c"),
-                           "-L" + libdir, "-lggml_hostmirror", "-lggml_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), "-I" + supdir, os.path.join(root, "tests", "c", "reference_style_program.c"),
+                           "-L" + supdir, "-L" + libdir, "-lggml_hostmirror", "-lggml_hip", "-Wl,-rpath," + supdir, "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr

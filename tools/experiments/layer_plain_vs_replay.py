@@ -7,7 +7,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ggmlsharp_amd import _lib
 if len(sys.argv) > 1 and sys.argv[1] == "plain":
-    _lib.MIRROR_PATH = os.path.join(_lib.PKG_DIR, "lib", "dbg", "libggml_hostmirror_plain.so")
+    _lib.MIRROR_PATH = os.path.join(_lib.PKG_DIR, "lib", "dbg", "libggml_hostmirror_plain.so")   # (a variant of tests/support/ggml_host.cpp built by hand)
 import bench
 from ggmlsharp_amd import device
 device.init(0)
