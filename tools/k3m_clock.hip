@@ -6,6 +6,9 @@
 //   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DK3M_CLOCK -I ggmlsharp_amd/csrc -o tools/bin/k3m_clock tools/k3m_clock.hip -lpthread
 //   run:   tools/bin/k3m_clock [seconds] [M K N]
 #include "../ggmlsharp_amd/csrc/gemm_qmx.hip"
+#include "../ggmlsharp_amd/csrc/plan.cpp"      // (r4: the launchers consume the plan of the product)
+// (K3p lives in gemm_qmp.hip, which this tool does not build: the shapes it clocks are served by the staged forms)
+hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *, const mm_plan &, act_planes, int64_t, float *, int64_t, hipStream_t, const mm_epilogue &) { return hipErrorNotSupported; }
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -89,7 +92,7 @@ int main(int argc, char **argv) {
         int launches = 0; float last_ms = 0;
         while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
             CK(hipEventRecord(e0));
-            for (int i = 0; i < 50; ++i) CK(launch_gemm_qmx(&w, p, N, dst, M, 0, nullptr));
+            for (int i = 0; i < 50; ++i) CK(launch_gemm_qmx(&w, plan_mul_mat(w.type, 0, w.M, w.K, N, false), p, N, dst, M, 0, nullptr));
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             CK(hipEventElapsedTime(&last_ms, e0, e1)); launches += 50;
         }

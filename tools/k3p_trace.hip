@@ -5,6 +5,7 @@
 //   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -DK3P_TRACE -I ggmlsharp_amd/csrc -o tools/bin/k3p_trace tools/k3p_trace.hip
 //   run:   tools/bin/k3p_trace [M K N]
 #include "../ggmlsharp_amd/csrc/gemm_qmp.hip"
+#include "../ggmlsharp_amd/csrc/plan.cpp"      // (r4: the launchers consume the plan of the product)
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -36,12 +37,14 @@ int main(int argc, char **argv) {
     fill(a6, ab); fillf(ad, adb);
     act_planes p; p.a8 = (int8_t *)a6; p.ad = ad; p.as = (int32_t *)ad; p.Npad = Npad;
     const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
+    const mm_plan pl = plan_mul_mat(i8 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_0, 0, M, K, N, false);
+    if (pl.family != (i8 ? MMF_K3P_I8 : MMF_K3P_MX)) { printf("this shape is not served by K3p (plan family %d)\n", pl.family); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int it = 0; it < 200; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], p, N, dst, M, 0, ep));
+    for (int it = 0; it < 200; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], pl, p, N, dst, M, 0, ep));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     const int iters = 2000;
-    for (int it = 0; it < iters; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], p, N, dst, M, 0, ep));
+    for (int it = 0; it < iters; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], pl, p, N, dst, M, 0, ep));
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const int nwg = ((M + 127) / 128) * ((N + 63) / 64);
