@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun): bash tools/profile_round.sh r02  -- bench line + rocprofv3 kernel stats + PMC passes
-T=${1:-r03}
+T=${1:-r04}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -21,4 +21,6 @@ bash $R/tools/pmc_cfgs.sh ${T}c3 q4_0:4096:4096:512 || exit 5
 bash $R/tools/pmc_cfgs.sh ${T}c4q8 q8_0:4096:11008:512 || exit 6
 bash $R/tools/pmc_cfgs.sh ${T}c4q5 q5_0:4096:11008:512 || exit 7
 bash $R/tools/pmc_cfgs.sh ${T}c5 q4_0:32000:4096:512 || exit 8
+# round 4: the min-term form of K3p (Q5_1 = the planar form a Q5_K weight lives in)
+bash $R/tools/pmc_cfgs.sh ${T}c4q51 q5_1:4096:11008:512 || exit 9
 echo ok-configs
