@@ -117,12 +117,6 @@ struct DeviceCtx {
         uint64_t scratch_sig = 0;                  // the scratch pointers baked into the captured launches
         std::vector<std::pair<const void *, size_t>> leaves;   // host tensors the scope uploaded when it was observed: prefetched together
         int seen = 0, strikes = 0; bool refused = false;   // refused: a capture failed outright, or was cut short three times
-        // The captured graph as a LAUNCH LIST: when every node is a kernel and the nodes form one chain (a scope issues everything on
-        // one stream), replaying = launching the kernels again, in order, with the argument blocks the graph holds.  A replay
-        // through hipGraphLaunch has a fixed cost of its own (10-16 us, MI355X_MICROARCH.md "graph-replay-floor"; measured here:
-        // 24.6 us per graph compute with nothing in it, tools/experiments/node_cost.py) that a decode-sized scope of eight nodes does
-        // not amortise; direct launches stay ahead of the GPU from the first one on.
-        std::vector<hipKernelNodeParams> launches;
     };
     std::map<uint64_t, Captured> captured;
     uint64_t scope_key = 0;
