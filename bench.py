@@ -149,19 +149,27 @@ def cpu_baseline(M, K, N):
                               "sample": f"first {n1} of {N} src1 rows, median of 3 repetitions ({fmt(dts1)} s wall)"}}
 
 
-def compute_kernel_name(qtype, K, N):
-    """which COMPUTE kernel serves (type, K, N): the selection is by type, N and K alone (csrc/api.cpp act_image_kind, gemm_qmx.hip launch_typed)"""
-    if N <= 8:
-        return "gemv_fused_kernel (gemv.hip)"
-    if K >= 2048 and 256 < N <= 512 and qtype in (Q4_0, Q8_0, Q5_0, Q5_K):
-        if qtype == Q5_K:
-            return ("gemm_q8_mid_kernel<Q5_1>: K3p on the int8 planes of the planar Q5_1 form a Q5_K weight lives in, min term as one "
-                    "v_mfma_f32_32x32x2_f32 per tile and pair of k-blocks (gemm_qmp.hip, r4)")
-        return ("gemm_qmx_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, MX bf6 MFMA (gemm_qmp.hip)" if qtype == Q4_0 else
-                "gemm_q8_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, v_mfma_i32_32x32x32_i8 off resident int8 planes (gemm_qmp.hip)")
-    if qtype == Q4_0:
-        return "gemm_qmx_small_kernel: K3s (gemm_qmx.hip)" if (N <= 64 and K >= 2048) else "gemm_qmx_kernel: K3m staged MX form (gemm_qmx.hip)"
-    return "gemm_q16_kernel / gemm_q_kernel (f16 / int8 staged forms)"
+FAMILY_NAME = {1: "gemv_fused_kernel: fused mat-vec, INIT + COMPUTE in one launch (gemv.hip)", 2: "gemv_q_kernel: two-step mat-vec (gemv.hip)",
+               3: "gemm_qmx_small_kernel: K3s, stage-free batched decode, MX bf6 MFMA (gemm_qmx.hip)",
+               4: "gemm_q8_small_kernel: K3s on the int8 cores (gemm_q8s.hip)",
+               5: "gemm_qmx_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, MX bf6 MFMA (gemm_qmp.hip)",
+               6: "gemm_q8_mid_kernel: K3p, 128x64 tiles per wave, K split over 8 waves, v_mfma_i32_32x32x32_i8 off resident int8 planes (gemm_qmp.hip)",
+               7: "gemm_qmx_kernel: K3m staged MX form (gemm_qmx.hip)", 8: "gemm_q16_kernel: staged f16 form (gemm_q16.hip)",
+               9: "gemm_q_kernel: staged int8 form (gemm_q.hip)", 10: "dense_kernel (dense.hip)", 11: "dense_gemv_kernel (dense.hip)",
+               12: "dense16_kernel: F16 on the f16 cores (dense16.hip)", 13: "dense32s_kernel: F32 as split bf16 (dense16.hip)"}
+
+
+def compute_kernel_name(qtype, M, K, N):
+    """which COMPUTE kernel serves the product: asked of the library's own plan (csrc/plan.cpp through ggml_hip_mm_plan), not restated here"""
+    import ctypes as C
+    from ggmlsharp_amd import _lib
+    pl = _lib.ggml_hip_mm_plan_t()
+    if _lib.lib().ggml_hip_mm_plan(qtype, M, K, N, C.byref(pl)) != 0:
+        return "?"
+    name = FAMILY_NAME.get(pl.family, f"family {pl.family}")
+    if pl.family == 6 and qtype in (Q5_K, 7, 3):
+        name += " + min term as one v_mfma_f32_32x32x2_f32 per tile and pair of k-blocks (r4)"
+    return f"{name}; plan: form {pl.form}, tile {pl.tile_m}x{pl.tile_n}, {pl.waves} waves, K in {pl.ksplit} partial sum(s), {pl.workgroups} workgroups"
 
 
 def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
@@ -220,7 +228,7 @@ def side_config(device, M, K, N, copies, iters, qtype=Q4_0):
         # the binding roof of the mat-mat shapes is the matrix unit: the COMPUTE kernel alone against the dense int8-class peak
         tops = flops / (t_comp * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": round(tops, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(tops / I8_MFMA_PEAK_TOPS, 4),
-                           "kernel_ms": round(t_comp, 5), "kernel": compute_kernel_name(qtype, K, N)}
+                           "kernel_ms": round(t_comp, 5), "kernel": compute_kernel_name(qtype, M, K, N)}
     for w in ws:
         w.free()
     return res
@@ -752,7 +760,7 @@ def main():
                            # NOT measured by this run: HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
                            # (tools/profile_round.sh -> tools/summarize_round.py, the guide's FETCH/WRITE_SIZE recipe and gfx950 corrections)
                            "traffic_from_profile": traffic_src,
-                           "kernel": f"{kname} ({kdesc})",
+                           "kernel": f"{kname} ({kdesc})", "kernel_plan": compute_kernel_name(Q4_0, M, K, N),
                            "kernel_ms": round(t_comp, 5), "init_kernel_ms": round(t_init, 5),
                            "kernel_ms_method": f"median over {nblk} blocks of (one HIP event pair around {blk} back-to-back INIT + COMPUTE pairs) - (the same around {blk} INIT launches)",
                            "step_from_kernels_ms": round(t_comp + t_init, 5),
