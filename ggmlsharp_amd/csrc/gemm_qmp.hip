@@ -226,8 +226,10 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     for (int b = 0; b < nloc; ++b) {
         // Two waves share a SIMD and the older one wins every arbitration: left alone, waves 0..3 finish their K range a quarter
         // early and waves 4..7 run the rest at one wave per SIMD (tools/k3p_trace.hip: 15.8 against 21.5 us).  The younger half
-        // takes priority on every other k-block, so both halves finish together.
-        if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        // takes priority on most k-blocks, so both halves finish together.
+        // r4: two blocks of three (it was every other one: the older half still finished 2.3 us early -- K loop done at 18.2 | 20.5 us after
+        // the launch's first stamp, now 19.4 | 19.7; 4096 x 4096 x 512 27.6 -> 27.0 us per launch, tools/k3p_trace.hip)
+        if (wave >= KS / 2) { if (b % 3 != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         i32x8 B[WMT];
         float dw[WMT];
 #pragma unroll
