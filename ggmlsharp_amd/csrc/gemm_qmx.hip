@@ -375,7 +375,26 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
 #ifdef K3M_CLOCK
     const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
 #endif
+    // r4: two 4-wave workgroups share a CU, one wave of each per SIMD, and the arbiter serves the OLDER wave first: on real data the older
+    // workgroup's waves finished their K loops at ~123 us and the younger one's at ~147 us (tools/k3m_clock.hip: per-wave loop times
+    // bimodal), i.e. for the last 24 us every SIMD ran a lone wave at half the issue rate.  As in K3p (gemm_qmp.hip), the younger wave of
+    // a SIMD -- the one in the odd wave slot -- takes priority on two stages of three, so both finish together.  Speed only: real data,
+    // back to back, 4096^3 146.7 -> 144.8 us, 4096 x 11008 x 2048 211.8 -> 208.0, Q4_1 4096^3 208.0 -> 202.9 (same bits).  Only for grids
+    // of one round (at most two workgroups per CU): with more rounds the early finisher's place is taken by the next workgroup at once,
+    // and its store tail overlaps that workgroup's start (32000 x 4096 x 2048: 586 us without, 589 with).
+#ifndef GGML_MX_PRIO
+#define GGML_MX_PRIO 3
+#endif
+    bool younger = false;
+    if constexpr (WGM * WGN * KSP == 4 && GGML_MX_PRIO != 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        younger = (hwid & 1u) != 0 && nwg <= 512;            // WAVE_ID: the slot inside the SIMD
+    }
     for (int it = 0; it < niter; ++it) {
+        if constexpr (WGM * WGN * KSP == 4 && GGML_MX_PRIO != 0) {
+            if (younger) { if (it % GGML_MX_PRIO != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        }
         int sn = sc + KV, pn = pass;
         if (VS > 1 && sn >= nstages) { pn = pass + 1; sn = pn < VS ? grp * VS + pn : nstages; }
         if ((KSP == 1 && VS == 1) || sc < nstages) compute(sc, sn, it);

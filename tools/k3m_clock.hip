@@ -110,6 +110,9 @@ int main(int argc, char **argv) {
                "K loop %.1f us; board power median %.0f W (min %.0f, max %.0f; %zu samples), hwmon sclk median %.0f MHz\n",
                mode, M, K, N, launches, seconds, last_ms * 1e3 / 50, ghz.size(), med(ghz), ghz.empty() ? -1 : ghz[ghz.size() / 10], ghz.empty() ? -1 : ghz[ghz.size() * 9 / 10],
                med(loop_us), med(P2), P2.empty() ? -1 : P2.front(), P2.empty() ? -1 : P2.back(), P2.size(), med(F2));
+        if (!loop_us.empty())          // (r4) how far apart the waves finish their K loops: two workgroups share a CU, one wave of each per SIMD
+            printf("       K loop per wave: min %.1f  p10 %.1f  p25 %.1f  median %.1f  p75 %.1f  p90 %.1f  max %.1f us\n", loop_us.front(), loop_us[loop_us.size() / 10],
+                   loop_us[loop_us.size() / 4], med(loop_us), loop_us[loop_us.size() * 3 / 4], loop_us[loop_us.size() * 9 / 10], loop_us.back());
     }
     for (auto &f : find((base + "/pp_dpm_sclk").c_str())) printf("pp_dpm_sclk (%s) after the run:\n%s", f.c_str(), read_txt(f).c_str());
     return 0;
