@@ -403,7 +403,18 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
     store_scales(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA of stage 0 landed (this wave's part)
     __syncthreads();
+    // r4 (see gemm_qmx.hip): on one-round grids the younger wave of a SIMD (the second workgroup on the CU) takes priority on two stages of three
+#ifndef GQ_PRIO
+#define GQ_PRIO 3
+#endif
+    bool younger = false;
+    if constexpr (GQ_PRIO != 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        younger = (hwid & 1u) != 0 && (int64_t)tiles_m * tiles_n <= 512;
+    }
     for (int s = 0; s < nstages; ++s) {
+        if constexpr (GQ_PRIO != 0) { if (younger) { if (s % GQ_PRIO != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
         const bool more = (s + 1) < nstages;
         if (more) {
             issue_loads(s + 1);

@@ -431,7 +431,20 @@ void gemm_q16_kernel(const uint8_t *__restrict__ wqs, const uint32_t *__restrict
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                          // no LDS read may move above the barrier
     const int niter = (nstages + KSP - 1) / KSP;            // group grp takes stages grp, grp + KSP, ...; same barrier count for all
+    // r4 (see gemm_qmx.hip): on one-round grids of 4-wave workgroups the younger wave of a SIMD takes priority on two stages of three
+#ifndef Q16_PRIO
+#define Q16_PRIO 3
+#endif
+    bool younger = false;
+    if constexpr (WGM * WGN * KSP == 4 && Q16_PRIO != 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        younger = (hwid & 1u) != 0 && tiles_m * tiles_n <= 512;
+    }
     for (int it = 0; it < niter; ++it) {
+        if constexpr (WGM * WGN * KSP == 4 && Q16_PRIO != 0) {
+            if (younger) { if (it % Q16_PRIO != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        }
         const int s = it * KSP + grp;
         if (KSP == 1 || s < nstages) compute(s, it);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the drain inside compute, again for a skipped stage)
