@@ -6,8 +6,10 @@
 // [G][N][Ms] intermediate exists); the exchange then completes every slot's copy.  Two exchange forms:
 //   0 (default) peer DMA: each slot pushes its column range into every peer's dst with one strided 2-D copy per peer --
 //       xGMI is point-to-point, so the G-1 pushes of a slot run on different links; no re-layout pass, no staging buffer;
-//   1 RCCL: ncclAllGather (librccl, loaded at run time) of contiguous [N][Ms] shards + the re-layout kernel.
-// Same bits either way: the exchange only moves data.
+//   1 RCCL: ncclAllGather (librccl, loaded at run time) of contiguous [N][Ms] shards + the re-layout kernel;
+//   2 (r4) no exchange pass: every slot's GEMM stores its rows into EVERY slot's dst from its own store phase (mm_epilogue mode 3,
+//       ggml_hip_mul_mat_push_dev) -- ggml_hip_mul_mat_split_dev; the graph-scope row split of seams.cpp keeps form 0 behind its products.
+// Same bits whichever runs: the exchange only moves data.
 #include "ctx.h"
 
 #include <dlfcn.h>
@@ -140,6 +142,21 @@ int exchange_rccl(int G, DeviceCtx *const *ctxs, float *const *bufs, int64_t N, 
 
 }  // namespace
 
+// can a kernel on any slot's device store into any other slot's memory?  (same device, or peer access that is or can be enabled)
+bool slots_reach_each_other(int G, DeviceCtx *const *ctxs) {
+    for (int a = 0; a < G; ++a)
+        for (int b = 0; b < G; ++b) {
+            if (ctxs[a]->device == ctxs[b]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ctxs[a]->device, ctxs[b]->device) != hipSuccess || !can) { (void)hipGetLastError(); return false; }
+            if (hipSetDevice(ctxs[a]->device) != hipSuccess) { (void)hipGetLastError(); return false; }
+            const hipError_t e = hipDeviceEnablePeerAccess(ctxs[b]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return false; }
+            (void)hipGetLastError();
+        }
+    return true;
+}
+
 int exchange_columns(int G, DeviceCtx *const *ctxs, float *const *bufs, int64_t N, int64_t ldd, const int64_t *r0, const int64_t *r1) {
     if (G <= 1 || N <= 0) return GGML_HIP_OK;
     if (g_exchange_mode.load() == 1) return exchange_rccl(G, ctxs, bufs, N, ldd, r0, r1);
@@ -167,7 +184,7 @@ struct ggml_hip_split_weight {
 extern "C" {
 
 int ggml_hip_set_exchange(int mode) {
-    if (mode != 0 && mode != 1) return fail(GGML_HIP_ERR_ARG, "exchange mode %d (0 = peer DMA, 1 = RCCL all-gather)", mode);
+    if (mode < 0 || mode > 2) return fail(GGML_HIP_ERR_ARG, "exchange mode %d (0 = peer DMA, 1 = RCCL all-gather, 2 = the GEMM's store phase)", mode);
     g_exchange_mode.store(mode);
     return GGML_HIP_OK;
 }
@@ -254,6 +271,36 @@ int ggml_hip_mul_mat_split_dev(const ggml_hip_split_weight *w, const float *cons
         locks.emplace_back(ctxs[(size_t)g]->mu);
     }
     const size_t wb = ggml_hip_mul_mat_work_size(w->type, w->K, N);
+    // r4, exchange mode 2: every slot's GEMM stores its rows, as they leave the accumulators, into EVERY slot's dst (mm_epilogue mode 3
+    // through ggml_hip_mul_mat_push_dev: up to eight destinations; kernel forms without the store phase push their columns with the
+    // column kernel behind the product) -- no exchange pass at all.  Needs every slot's device to reach every other's memory.
+    if (g_exchange_mode.load() == 2 && G > 1 && G <= 16 && slots_reach_each_other(G, ctxs.data())) {
+        for (int g = 0; g < G; ++g) {                        // "everything issued so far on my stream is done": peers may write into my dst
+            int rc = ctxs[(size_t)g]->make_current();
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ctxs[(size_t)g]->ev_ready, ctxs[(size_t)g]->stream));
+        }
+        for (int g = 0; g < G; ++g) {
+            DeviceCtx *c = ctxs[(size_t)g];
+            int rc = c->make_current();
+            if (rc) return rc;
+            if (w->r1[(size_t)g] > w->r0[(size_t)g]) {
+                if (c->work.ensure(wb ? wb : 16)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
+                for (int p = 0; p < G; ++p)
+                    if (p != g) HIP_TRY(hipStreamWaitEvent(c->stream, ctxs[(size_t)p]->ev_ready, 0));
+                rc = ggml_hip_mul_mat_push_dev(w->shard[(size_t)g], d_src1[g], N, ld1, d_dst, G, g, ldd, w->r0[(size_t)g], c->work.p, c->work.cap, c->stream);
+                if (rc) return rc;
+            }
+            HIP_TRY(hipEventRecord(c->ev_xchg, c->stream));
+        }
+        for (int p = 0; p < G; ++p) {                        // a slot's stream continues only when every slot's stores into its dst have landed
+            int rc = ctxs[(size_t)p]->make_current();
+            if (rc) return rc;
+            for (int g = 0; g < G; ++g)
+                if (g != p) HIP_TRY(hipStreamWaitEvent(ctxs[(size_t)p]->stream, ctxs[(size_t)g]->ev_xchg, 0));
+        }
+        return GGML_HIP_OK;
+    }
     for (int g = 0; g < G; ++g) {
         DeviceCtx *c = ctxs[(size_t)g];
         int rc = c->make_current();

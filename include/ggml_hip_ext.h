@@ -215,8 +215,10 @@ int ggml_hip_add_q_f32_rows_dev(int type, const void *d_blocks_in, const float *
  * exchange then completes every slot's dst.  Stream-ordered on the slots' streams: ggml_hip_sync_slots() waits.
  * Exchange forms (ggml_hip_set_exchange): 0 = peer DMA over xGMI, one strided 2-D copy per (slot, peer) -- the default;
  * 1 = RCCL ncclAllGather of contiguous shards + the re-layout kernel below (librccl is loaded at run time; needs distinct
- * devices).  Both only move data: identical bits.  Every element equals the single-device result bit for bit (the kernel
- * form is a function of N, K and the type, never of M). */
+ * devices); 2 (r4) = no exchange pass: every slot's GEMM stores its rows into EVERY slot's dst from its own store phase
+ * (ggml_hip_mul_mat_push_dev below; needs every device to reach every other's memory, else the call runs form 0).  All three only
+ * move data: identical bits.  Every element equals the single-device result bit for bit (the kernel form is a function of N, K and
+ * the type, never of M). */
 typedef struct ggml_hip_split_weight ggml_hip_split_weight;
 int  ggml_hip_split_weight_upload(int type, const void *host_rows, int64_t ne00, int64_t ne01, uint64_t nb01,
                                   ggml_hip_split_weight **out);

@@ -114,13 +114,17 @@ def test_split_dev_entry_matches_single_device_bitwise(slots):
             torch.cuda.synchronize()
             xs = (C.c_void_p * G)(*[x.data_ptr()] * G)
             ds = (C.c_void_p * G)(*[o.data_ptr() for o in outs])
-            for mode in (0,):
+            for mode in (0, 2):                                          # peer copies behind the products; the GEMMs' own store phase (r4)
+                for o in outs:
+                    o.fill_(-5.0)
+                torch.cuda.synchronize()
                 check(L.ggml_hip_set_exchange(mode), "set_exchange")
                 check(L.ggml_hip_mul_mat_split_dev(h, xs, N, K, ds, M + 16), "split mul_mat")
                 check(L.ggml_hip_sync_slots(), "sync")
                 for o in outs:
                     assert np.array_equal(o[:, :M].cpu().numpy(), single), f"type {t} G {G}"
                     assert torch.all(o[:, M:] == -5.0)
+            L.ggml_hip_set_exchange(0)
             L.ggml_hip_split_weight_free(h)
         # the RCCL form refuses slots that share a device instead of hanging
         slots([0, 0])
@@ -332,12 +336,21 @@ def test_eight_slots_on_one_device_exact_partition_is_bitwise_the_unsplit_result
     torch.cuda.synchronize()
     xs = (C.c_void_p * G)(*[x.data_ptr()] * G)
     ds = (C.c_void_p * G)(*[o.data_ptr() for o in outs])
-    check(L.ggml_hip_set_exchange(0), "set_exchange")           # peer copies (the in-process RCCL form refuses slots that share a device)
-    check(L.ggml_hip_mul_mat_split_dev(h, xs, N, K, ds, M), "split mul_mat")
-    check(L.ggml_hip_sync_slots(), "sync")
-    for g, o in enumerate(outs):
-        assert torch.equal(o, single), f"{name}: slot {g}'s copy of dst differs from the unsplit result"
-    L.ggml_hip_split_weight_free(h)
+    # exchange form 0: peer copies behind the products (the in-process RCCL form refuses slots that share a device);
+    # form 2 (r4): no exchange pass -- every slot's GEMM stores its rows into every slot's dst from its own store phase
+    try:
+        for mode in (0, 2):
+            for o in outs:
+                o.fill_(-5.0)
+            torch.cuda.synchronize()
+            check(L.ggml_hip_set_exchange(mode), "set_exchange")
+            check(L.ggml_hip_mul_mat_split_dev(h, xs, N, K, ds, M), "split mul_mat")
+            check(L.ggml_hip_sync_slots(), "sync")
+            for g, o in enumerate(outs):
+                assert torch.equal(o, single), f"{name}, exchange form {mode}: slot {g}'s copy of dst differs from the unsplit result"
+    finally:
+        L.ggml_hip_set_exchange(0)
+        L.ggml_hip_split_weight_free(h)
 
 
 @pytest.mark.parametrize("name,M,K,N", G8_CASES)
