@@ -89,6 +89,21 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(F32, 4096, 4096, 257).family == FAM["dense32"] and plan(F32, 4096, 4096, 256).family == FAM["dense"]
 
 
+def test_geometry_may_follow_M_and_the_sweep_can_see_it():
+    """Not vacuous: the plan DOES change with M -- in the fields that are allowed to (tile height, tiles per workgroup, form, family
+    between forms of one tree) -- while tree_id stays put; so an M-dependent tree would be seen just as well."""
+    a, b = plan(Q4_0, 4096, 4096, 100), plan(Q4_0, 32000, 4096, 100)          # four-way tree on 32-row / 128-row tiles
+    assert (a.tile_m, b.tile_m) == (32, 128) and a.tree_id == b.tree_id and a.ksplit == b.ksplit == 4
+    a, b = plan(Q4_0, 512, 4096, 4096), plan(Q4_0, 4096, 4096, 4096)          # a row shard of the headline: 64 x 64 tiles, the whole: 256 x 128
+    assert (a.tile_m, a.tile_n, b.tile_m, b.tile_n) == (64, 64, 256, 128) and a.tree_id == b.tree_id
+    a, b = plan(Q8_0, 4096, 4096, 32), plan(Q8_0, 32000, 4096, 32)            # K3s on the int8 cores: one / two tiles per workgroup
+    assert (a.tile_m, b.tile_m) == (32, 64) and a.tree_id == b.tree_id
+    # and trees DO differ where they should: across N classes and across types
+    assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_0, 4096, 4096, 513).tree_id
+    assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_1, 4096, 4096, 512).tree_id
+    assert plan(Q5_1, 4096, 4096, 512).tree_id != plan(Q5_0, 4096, 4096, 512).tree_id     # the min term is part of the tree
+
+
 def test_bad_arguments_are_reported():
     out = _lib.ggml_hip_mm_plan_t()
     L = _lib.lib()
