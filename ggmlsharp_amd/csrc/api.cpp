@@ -79,7 +79,7 @@ mm_plan weight_plan(const ggml_hip_weight *w, int64_t N, bool one_call) { return
 // 32-bit buffer offsets are served by the int8 family and its image
 int weight_image_kind(const ggml_hip_weight *w, int64_t N) {
     const mm_plan pl = weight_plan(w, N, false);
-    return pl.image >= 0 && pl.image <= 3 ? pl.image : 0;
+    return (pl.image >= 0 && pl.image <= 3 ? pl.image : 0) | ((pl.flags & MM_FLAG_MIN_PIECES) ? ACT_IMAGE_MIN_PIECES : 0);
 }
 
 // ---------------- DeviceCtx ----------------
@@ -408,7 +408,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
     w->ext_type = q5k ? GGML_HIP_TYPE_Q5_K : 0;
     static std::atomic<uint64_t> next_uid{1};
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
-    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, off_gs = 0, off_i8 = 0, total = 0;
+    size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, off_gs = 0, off_i8 = 0, off_mp = 0, total = 0;
     bool with6 = false;
     size_t off_p16 = 0;
     if (type == GGML_TYPE_F32 || type == GGML_TYPE_F16) {
@@ -433,6 +433,8 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (plan_force_gemm() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
+        // the min plane as three bf16 pieces (K3p-int8's min-term product): whole pairs of k-groups, zero past the end of K
+        if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_mp = total; total += (size_t)((w->nbk + 15) / 16 * 2 * 3) * w->Mpad * 16; }
         if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
@@ -458,6 +460,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
         if (q5k) w->khdr = (uint8_t *)base + off_kh;
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) w->i8p = (uint8_t *)base + off_i8;
+        if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) w->mp3 = (uint8_t *)base + off_mp;
     }
     *out = w;
     return GGML_HIP_OK;
@@ -496,6 +499,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
             e = launch_q5k_to_planar((const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
         }
         if (e == hipSuccess) e = launch_q5_to_i8(w, st);      // (the planar Q5_1 form's int8 operand planes: gemm_qmp.hip serves prompt-sized batches)
+        if (e == hipSuccess) e = launch_min_pieces(w, st);
         if (e == hipSuccess) e = launch_gemv_side_image(w, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (staging) (void)hipFree(staging);
@@ -536,6 +540,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
     }
     if (e == hipSuccess) e = launch_nibbles_to_bf6(w, st);
     if (e == hipSuccess) e = launch_q5_to_i8(w, st);
+    if (e == hipSuccess) e = launch_min_pieces(w, st);
     if (e == hipSuccess) e = launch_gemv_side_image(w, st);
     if (e == hipSuccess) e = launch_f16_rows_to_panels(w, st);
     if (e == hipSuccess) e = launch_f32_rows_to_split_panels(w, st);
@@ -710,7 +715,7 @@ int ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_plan
     if (t < 0 || t >= GGML_TYPE_COUNT || !weight_type_ok(t)) return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type", type);
     if (M <= 0 || K <= 0 || N <= 0 || K % BLCK[t] != 0 || (is_q(t) && K % QK != 0) || (q5k && K % 256 != 0)) return fail(GGML_HIP_ERR_SHAPE, "bad shape");
     const mm_plan p = plan_mul_mat(t, q5k ? GGML_HIP_TYPE_Q5_K : 0, M, K, N, true);
-    out->family = p.family; out->image_kind = p.image; out->form = p.form; out->tree_id = plan_tree_id(p);
+    out->family = p.family; out->image_kind = p.image | ((p.flags & MM_FLAG_MIN_PIECES) ? ACT_IMAGE_MIN_PIECES : 0); out->form = p.form; out->tree_id = plan_tree_id(p);
     out->ksplit = p.ksplit; out->kstyle = p.kstyle; out->kunit = p.kunit; out->arith = p.arith;
     out->tile_m = p.tile_m; out->tile_n = p.tile_n; out->waves = p.waves; out->tiles_per_wave = p.tiles_per_wave;
     out->workgroups = p.wgs; out->flags = p.flags;
@@ -724,14 +729,17 @@ int ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t
     if (K <= 0 || K % QK != 0 || ld1 < K) return fail(GGML_HIP_ERR_SHAPE, "K %% 32 != 0 or ld1 < K");
     int rc = check_src1_alignment(d_src1, ld1);
     if (rc) return rc;
+    const bool pieces = image_kind >= 0 && (image_kind & ACT_IMAGE_MIN_PIECES) != 0;   // + 64 (kind 0 only): the min-term piece planes as well
+    if (pieces) image_kind &= ~ACT_IMAGE_MIN_PIECES;
     const bool q8k = image_kind >= 16;                         // + 16: the Q8_K rule of the k-quants (K % 256 == 0; kinds 0..2)
     if (q8k) image_kind -= 16;
-    if (image_kind < 0 || image_kind > 3 || (q8k && (image_kind == 3 || K % 256 != 0))) return fail(GGML_HIP_ERR_ARG, "image kind %d", image_kind);
+    if (image_kind < 0 || image_kind > 3 || (q8k && (image_kind == 3 || K % 256 != 0)) || (pieces && (image_kind != 0 || K / QK < 8)))
+        return fail(GGML_HIP_ERR_ARG, "image kind %d", image_kind);
     if (work_bytes < act_bytes(K, pad_act(N))) return fail(GGML_HIP_ERR_ARG, "work buffer too small: need %zu", act_bytes(K, pad_act(N)));
     // the MFMA images are written (and read) through 32-bit buffer offsets: 64 image bytes per row and k-block
     if (image_kind != 0 && (uint64_t)pad_kblocks(K / QK) * 64 * (uint64_t)pad_act(N) > 0xFFFFFFFFull)
         return fail(GGML_HIP_ERR_SHAPE, "image kind %d needs K/32 * 64 * Npad < 4 GiB (ggml_hip_act_image_kind never selects it beyond that)", image_kind);
-    HIP_TRY(launch_quantize_act(d_src1, N, K, ld1, act_carve(d_work, K, pad_act(N)), image_kind, (hipStream_t)stream, q8k));
+    HIP_TRY(launch_quantize_act(d_src1, N, K, ld1, act_carve(d_work, K, pad_act(N)), image_kind | (pieces ? ACT_IMAGE_MIN_PIECES : 0), (hipStream_t)stream, q8k));
     return GGML_HIP_OK;
 }
 

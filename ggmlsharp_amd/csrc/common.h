@@ -71,6 +71,9 @@ struct ggml_hip_weight {
                       //   [Mpad/16][nbk][NP][16 rows] 4-byte words, planes in the order d, m, qh (NP = 1..3 by type).  A copy of
                       //   d / m / qh: in their [k-block][row] planes a tile's share of a k-block is one 64-byte piece per plane
                       //   (a fifth of the bytes cost a third of the mat-vec's time, tools/stream_floor.hip)
+    uint8_t *mp3;     // Q5_1 / Q4_1 (and the Q5_K extension living in the Q5_1 form): the min plane split EXACTLY into three bf16 pieces,
+                      //   [ceil(nbk / 8) * 3 (+ pad to whole pairs of k-groups)][Mpad][16 B]: plane 3 * (b / 8) + piece holds 8 consecutive k-blocks of a row --
+                      //   the B operand of v_mfma_f32_32x32x16_bf16 for K3p's min-term product (gemm_qmp.hip); 0.19 B / weight
     uint8_t *khdr;    // Q5_K only: the 16 header bytes (d, dmin, scales[12]) of every super-block, [K/256][Mpad][16 B]
     int      ext_type; // 0, or GGML_HIP_TYPE_Q5_K: the weight was uploaded as k-quant super-blocks and lives in the planar Q5_1 form (type == Q5_1)
     size_t   bytes;
@@ -84,12 +87,16 @@ struct ggml_hip_weight {
 //   bf6 image  (gemm_qmx.hip)  :  per k-block [2][Npad][16 B] then [2][Npad][8 B]: half 0 = digits ah, half 1 = digits al
 //                                 of a = 16*ah + al, 32 bf6 codes per 24-byte fragment
 //   ad [nbk][Npad] f32 block scales, as [nbk][Npad] i32 block sums of the quants (MFMA images: the float d * sum)
+//   sp3 (int8 image + ACT_IMAGE_MIN_PIECES only): d * sum split exactly into three bf16 pieces, [ceil(nbk / 8) * 3][Npad][16 B] like
+//       ggml_hip_weight::mp3 -- in the upper half of the a8 region, which the int8 image leaves unused
 struct act_planes {
     int8_t  *a8;
     float   *ad;
     int32_t *as;
     int64_t  Npad;
+    uint8_t *sp3;
 };
+#define ACT_IMAGE_MIN_PIECES 64      /* flag on image kind 0: K1 also writes sp3 (K3p-int8 with a min-term weight type; needs K / 32 >= 8) */
 static inline size_t act_bytes(int64_t K, int64_t Npad) {
     const int64_t nbk = pad_kblocks(K / QK);
     return (size_t)nbk * 4 * Npad * 16 + (size_t)nbk * Npad * 4 * 2;
@@ -101,6 +108,7 @@ static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
     p.ad = (float *)((uint8_t *)base + (size_t)nbk * 4 * Npad * 16);
     p.as = (int32_t *)((uint8_t *)p.ad + (size_t)nbk * Npad * 4);
     p.Npad = Npad;
+    p.sp3 = (uint8_t *)base + (size_t)nbk * 2 * Npad * 16;   // ((nbk / 8 rounded up) * 3 planes <= 2 nbk planes from two k-blocks on)
     return p;
 }
 
@@ -124,6 +132,22 @@ __device__ __forceinline__ int group8_sum(int v) {
     v += dpp_i<DPP_XOR1>(v);
     v += dpp_i<DPP_XOR2>(v);
     return v + dpp_i<DPP_HALF_MIRROR>(v);
+}
+// ---- an f32 value as three bf16 pieces that sum to it exactly (truncation: 8 + 8 + 8 significand bits); dense16.hip K10d, gemm_qmp.hip ----
+__device__ __forceinline__ void split3(float a, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+    const uint32_t u = __float_as_uint(a);
+    const uint32_t b0 = u & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(b0);                       // exact
+    const uint32_t b1 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b1);                      // exact, at most 8 significant bits
+    p0 = b0 >> 16; p1 = b1 >> 16; p2 = __float_as_uint(r2) >> 16;
+    // r4: an infinity or a NaN.  As written above, inf - inf put a NaN into the remainder pieces and every output that touched an
+    // infinite operand came out NaN where the reference's f32 product gives +-inf.  The value goes into the THIRD piece alone: of the six
+    // kept piece products only a2 * b0 (b0 * a2) then sees it -- against the other operand's LEADING piece, which is zero only if that operand
+    // is (inf * 0 is NaN in the reference too) -- while in the first piece it would meet remainder pieces that are zero for one operand in
+    // 256 (inf * 0).  A NaN whose payload sits in the low 16 bits keeps a set quiet bit, so truncation cannot turn it into an infinity.
+    // (Two infinities at the same k meet in no kept product: that one case gives NaN where the reference gives inf.)
+    if ((u & 0x7F800000u) == 0x7F800000u) { p0 = 0; p1 = 0; p2 = (u >> 16) | ((u & 0x007FFFFFu) ? 0x0040u : 0u); }
 }
 #endif
 
@@ -241,6 +265,7 @@ hipError_t launch_repack_to_planar(int type, const uint8_t *aos, uint64_t nb01, 
 hipError_t launch_planar_to_aos(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_nibbles_to_bf6(ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_q5_to_i8(ggml_hip_weight *w, hipStream_t st);     // Q5_0 / Q5_1 / Q4_1 nibble (+ fifth-bit) planes -> w->i8p
+hipError_t launch_min_pieces(ggml_hip_weight *w, hipStream_t st);   // Q5_1 / Q4_1 min plane -> w->mp3 (three bf16 pieces, K3p's min-term product)
 // up to 32 device buffers -> device-visible (mapped host) destinations in one launch; sizes and addresses multiples of 4
 hipError_t launch_scatter_copy(const void *const *src, void *const *dst, const size_t *bytes, int n, hipStream_t st);
 hipError_t launch_gemv_side_image(ggml_hip_weight *w, hipStream_t st);   // d / m / qh planes -> w->gs (after every write of the planes)

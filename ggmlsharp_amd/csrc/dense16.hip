@@ -553,21 +553,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, const uint8_t *apan, int64_t N, 
 // Images: panel-plane q = 3 * (k / 8) + piece, [Kpad/8 * 3][rows][16 B] for both operands (weights at upload, src1 by the INIT kernel).
 // Workgroup 128 x 128, four waves of 64 x 64 (4 x 4 MFMA tiles); a stage is ONE k-step of 32 (4 panels x 3 pieces x 128 rows = 24 KB of
 // LDS, double-buffered), 96 MFMAs per wave and stage; the weights of the next stage travel into a second register set meanwhile.
-__device__ __forceinline__ void split3(float a, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
-    const uint32_t u = __float_as_uint(a);
-    const uint32_t b0 = u & 0xFFFF0000u;
-    const float r1 = a - __uint_as_float(b0);                       // exact
-    const uint32_t b1 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(b1);                      // exact, at most 8 significant bits
-    p0 = b0 >> 16; p1 = b1 >> 16; p2 = __float_as_uint(r2) >> 16;
-    // r4: an infinity or a NaN.  As written above, inf - inf put a NaN into the remainder pieces and every output that touched an
-    // infinite operand came out NaN where the reference's f32 product gives +-inf.  The value goes into the THIRD piece alone: of the six
-    // kept piece products only a2 * b0 (b0 * a2) then sees it -- against the other operand's LEADING piece, which is zero only if that operand
-    // is (inf * 0 is NaN in the reference too) -- while in the first piece it would meet remainder pieces that are zero for one operand in
-    // 256 (inf * 0).  A NaN whose payload sits in the low 16 bits keeps a set quiet bit, so truncation cannot turn it into an infinity.
-    // (Two infinities at the same k meet in no kept product: that one case gives NaN where the reference gives inf.)
-    if ((u & 0x7F800000u) == 0x7F800000u) { p0 = 0; p1 = 0; p2 = (u >> 16) | ((u & 0x007FFFFFu) ? 0x0040u : 0u); }
-}
+// (split3: common.h -- K3p's min-term product uses the same pieces)
 
 // INIT: src1 f32 rows -> split image; a thread owns 8 consecutive k of one row = one 16-byte entry of each of the three planes
 __global__ __launch_bounds__(256) void convert_act_split_kernel(const float *__restrict__ x, int64_t N, int64_t K, int64_t Kpad, int64_t ld1,

@@ -311,22 +311,23 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 //
 // r4 -- Q5_1 and Q4_1 (and through Q5_1 the Q5_K extension, whose super-blocks live as eight k-blocks of the planar Q5_1 form): the same loop on
 // int8 planes of the UNSIGNED values (nib | bit << 4) in 0..31, per block acc = fma(d0 * (float)sxy, d1, acc) -- the reference's
-// (d * sxy) * y.d (Ggml.cs:1344) -- and the min term m * (s0 + s1) as a matrix product: over a PAIR of k-blocks it is a K = 2 outer
-// product, one v_mfma_f32_32x32x2_f32 per tile and pair straight into the tile's accumulators (A = d1 * sum(a) of the column tile's
-// rows, B = m of the m-tile's rows, the two k-blocks of the pair in the two lane halves).  It is issued in the MIDDLE of the next
-// tile's scale-accumulates of the pair's second block (the int8 MFMA of that step has left the pipe by then, the next one is half a
-// step away), so its 16 passes hide under VALU work.  Order of an element's additions: block b, block b + 1, the pair's two min
-// terms (k-block order inside the instruction), next pair -- fixed by K, N and the type like everything else in this form.
+// (d * sxy) * y.d (Ggml.cs:1344) -- and the min terms m * (s0 + s1) as a matrix product of their own IN FRONT of the K loop: sixteen
+// k-blocks per v_mfma_f32_32x32x16_bf16, both operands as bf16 pieces that sum to the f32 value exactly (see the loop top).  Order of
+// an element's additions in a wave: the min terms of the wave's chunks (chunk c % 8 == wave, by K alone), then its k-blocks in order;
+// the waves' sums are added as for every type.  (The first form of this round -- one v_mfma_f32_32x32x2_f32 per tile and PAIR of
+// k-blocks inside the loop, 128 matrix passes per tile and 16 k-blocks instead of 40 / 48 -- is docs/experiments/r4_min_term_in_loop_f32.patch:
+// 85.5 us where this one takes 77 at 4096 x 11008 x 512.)
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 struct WI8 { i32x4 q[WMT]; float d[WMT]; };
 
-template <int TYPE>
+template <int TYPE, bool M3 = false>
 __global__ __launch_bounds__(KS * 64, 2)
-void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const float *__restrict__ wmn, const int8_t *__restrict__ a8,
-                        const float *__restrict__ ad, const int32_t *__restrict__ asum, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
-                        int nbk, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep) {
-    constexpr bool MIN = TYPE == GGML_TYPE_Q5_1;           // (Q4_1 runs this instantiation: its int8 planes hold 0..15)
+void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8,
+                        const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
+                        int nbk, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep,
+                        const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3) {
+    constexpr bool MIN = TYPE == GGML_TYPE_Q5_1, MINP = MIN;   // (Q4_1 runs this instantiation: its int8 planes hold 0..15)
 #ifndef K3P_DA_INPLACE
 #define K3P_DA_INPLACE MIN
 #endif
@@ -343,11 +344,9 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const int kb0 = wave * nloc;
 
     const rsrc_t rW = make_rsrc(qs, w_bytes), rD = make_rsrc(wd, w_bytes / 8), rA = make_rsrc(a8, a_bytes);
-    const rsrc_t rM = make_rsrc(MIN ? wmn : wd, w_bytes / 8), rS = make_rsrc(MIN ? (const void *)asum : (const void *)ad, a_bytes / 8);
-    uint32_t offW, offD, offA, offS;
+    uint32_t offW, offD, offA;
     auto set_offsets = [&](int m0_, int n0_) {
         offW = (uint32_t)((hh * Mpad + m0_ + l31) * 16); offD = (uint32_t)((m0_ + l31) * 4); offA = (uint32_t)((hh * Npad + n0_ + l31) * 16);
-        offS = (uint32_t)((n0_ + l31) * 4);
     };
     set_offsets(m0, n0);
     const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
@@ -361,20 +360,6 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
     WI8 w0, w1;
     i32x4 af[WNT];
-    // min term of the pair of k-blocks (b, b + 1), b even: lane half hh holds block b + hh -- the B operand (m of m-tile i's rows) and the
-    // integer block sums of column tile j's rows, requested at the start of the pair's first block
-    float mnp[MIN ? WMT : 1];
-    int sump[MIN ? WNT : 1];
-    auto load_pair = [&](int b) {
-        if constexpr (MIN) {
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-                mnp[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, (int)(offD + (uint32_t)hh * d_blk + 128u * i), (int)((uint32_t)(kb0 + b) * d_blk), 0));
-#pragma unroll
-            for (int j = 0; j < WNT; ++j)
-                sump[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(rS, (int)(offS + (uint32_t)hh * (uint32_t)(Npad * 4) + 128u * j), (int)((uint32_t)(kb0 + b) * (uint32_t)(Npad * 4)), 0);
-        }
-    };
     auto load_first = [&]() {
         load_w(w0, kb0);                                    // (requested first: the weights come from HBM, the table from L2)
 #pragma unroll
@@ -382,20 +367,106 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     };
     load_first();
     const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- the min-term product's pieces (see the loop top) ----
+    constexpr int NPIECE = M3 ? 3 : 2;                      // bf16 pieces of a min: Q5_1's is an f16 value (two hold it), Q4_1's an f32, Q5_K's an f32 product
+#ifndef K3P_MIN_PRE
+#define K3P_MIN_PRE 1                                       // chunks per wave requested ahead of the scale table (56 / 72 registers each, taken from the not-yet-live accumulators)
+#endif
+    constexpr int NPRE = MINP ? K3P_MIN_PRE : 1;            // (2 and 3 measured no better: what the product's loads cost is their bytes through L2, all workgroups at once, not their latency)
+    using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+    const int nchunks = (nbk + 15) / 16;
+    const rsrc_t rMP = make_rsrc(MINP ? mp3 : qs, MINP ? (uint32_t)(nchunks * 6) * (uint32_t)Mpad * 16u : 0u);
+    const rsrc_t rSP = make_rsrc(MINP ? sp3 : qs, MINP ? (uint32_t)(nchunks * 6) * (uint32_t)Npad * 16u : 0u);
+    // (a chunk's plane index 6c + piece is uniform: it travels in the scalar offset; the lane's row and k-group half in ONE per-lane offset per
+    // operand -- with everything in per-lane offsets the compiler kept 42 address registers and spilled them.  A chunk past the end of K is
+    // never requested; the second k-group of the last chunk exists in both piece planes, zero-filled: api.cpp alloc_weight, quantize.hip K1)
+    auto chunk_loads = [&](int c, i32x4 (&sa_)[WNT][3], i32x4 (&mb_)[WMT][NPIECE], int m0_, int n0_) {
+        const uint32_t vM = (uint32_t)((3 * hh) * Mpad + m0_ + l31) * 16u, vS = (uint32_t)((3 * hh) * Npad + n0_ + l31) * 16u;
+        if (c < nchunks) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                if (pc < NPIECE)                            // (the weights' pieces first: they come from HBM, the activations' from L2)
+#pragma unroll
+                    for (int i = 0; i < WMT; ++i)
+                        mb_[i][pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rMP, (int)(vM + 512u * i), (int)((uint32_t)(6 * c + pc) * (uint32_t)Mpad * 16u), 0));
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+                    sa_[j][pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rSP, (int)(vS + 512u * j), (int)((uint32_t)(6 * c + pc) * (uint32_t)Npad * 16u), 0));
+            }
+        } else {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) if (pc < NPIECE) mb_[i][pc] = i32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) sa_[j][pc] = i32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    // one tile's share of a chunk: the kept piece products, smallest first (activation piece PA x weight piece PB)
+    auto chunk_tile = [&](const i32x4 (&sj)[3], const i32x4 (&mi)[NPIECE], f32x16 a) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        static_for<6>([&](auto cc) {
+            constexpr int c6 = decltype(cc)::value;
+            if constexpr (PB[c6] < NPIECE)
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sj[PA[c6]]), __builtin_bit_cast(bf16x8, mi[PB[c6]]), a, 0, 0, 0);
+        });
+        return a;
+    };
   for (bool first = true;; first = false) {
     if (!first) __syncthreads();                            // (the previous tile's reduction has read its last partial sums)
+    // (Q5_1 / Q4_1 / Q5_K) the min terms m * (s0 + s1) of SIXTEEN k-blocks of a tile as a K = 16 matrix product on the bf16 cores: both
+    // operands live as three bf16 pieces that sum to the f32 value exactly (the weight's min plane at upload: ggml_hip_weight::mp3; d1 *
+    // (float)sum(a) = the Q8_1 s0 + s1 of Ggml.cs:820-821 from K1: act_planes::sp3), six of the nine piece products are kept (K10d's
+    // arithmetic, dense16.hip: every kept product is exact in f32, the dropped ones are below 2^-23 of the term; a Q5_1 min is an f16
+    // value -- two pieces, five products) -- 40 / 48 matrix passes per tile and 16 k-blocks where the f32 instruction took 128.  Chunk c
+    // (k-blocks 16c .. 16c + 15; lane half hh holds k-group 2c + hh) is wave c % 8's: by K alone, like everything else in an element's
+    // summation order.  The wave's first chunk is requested HERE, in front of the scale table's loads, while the accumulators'
+    // registers are still free.  (4096 x 11008 x 512: 77 us with the product, 71 without any min term, 86 with the f32 instruction inside
+    // the loop; the product's MFMAs alone cost 3.5 us, its loads alone 6 -- +15 % operand bytes through L2 with every workgroup asking at
+    // once, tools/k3p_trace.hip q51.)
+    i32x4 sa[NPRE][WNT][3], mb[NPRE][WMT][NPIECE];
+    if constexpr (MINP) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) chunk_loads(wave + KS * u, sa[u], mb[u], m0, n0);
+    }
     load_scale_table(tabD, ad, kb0, nloc, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     f32x16 acc[WMT][WNT];
+    if constexpr (MINP) {
+        // tile by tile: a tile's accumulator comes to life as the pieces of its m-tile die (slot 0 always runs: zeros where the wave has no chunk)
+        static_for<WMT * WNT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, i = t / WNT, j = t % WNT;
+            f32x16 a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            a = chunk_tile(sa[0][j], mb[0][i], a);
 #pragma unroll
-    for (int i = 0; i < WMT; ++i)
+            for (int u = 1; u < NPRE; ++u)
+                if (wave + KS * u < nchunks) a = chunk_tile(sa[u][j], mb[u][i], a);
+            acc[i][j] = a;
+        });
+    } else {
 #pragma unroll
-        for (int j = 0; j < WNT; ++j)
+        for (int i = 0; i < WMT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    }
+
+    // (Q5_1 / Q4_1 / Q5_K) the rest of the wave's min-term chunks (K beyond what the slots above hold): loads, then MFMAs, chunk by chunk
+    if constexpr (MINP) {
+        for (int c = wave + KS * NPRE; c < nchunks; c += KS) {
+            i32x4 sa_[WNT][3], mb_[WMT][NPIECE];
+            chunk_loads(c, sa_, mb_, m0, n0);
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) acc[i][j] = chunk_tile(sa_[j], mb_[i], acc[i][j]);
+        }
+    }
 
     // one k-block: local index b, weights in w; the next block's go into wn; column tile j's fragment is refetched behind its last MFMA.
     // The 16 row scales of a column tile are read during the LAST tile of the column tile before it (the order pins below are
@@ -403,29 +474,9 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     f32x4 da[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) da[q] = *(const f32x4 *)(tabD + 4 * hh + 8 * q);
-    // (Q5_1) the pair's A operands, d1 * (float)sum(a) = the Q8_1 s0 + s1 of Ggml.cs:820-821 (intent D3; the value the f16 / bf6 images
-    // carry in their `as` plane), computed at the start of the pair's second block; a k-block past the end of K has d1 = 0 in the table
-    float sap[MIN ? WNT : 1];
-    auto min_term = [&](auto tc) {
-        constexpr int t = decltype(tc)::value, j = t / WMT, i = t % WMT;
-        if constexpr (MIN) {
-            asm volatile("" : "+v"(acc[i][j]));             // (order pins: the MFMA stays where it is written, between two scale-accumulate groups)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sap[j], mnp[i], acc[i][j], 0, 0, 0);
-            asm volatile("" : "+v"(acc[i][j]));
-        }
-    };
-    auto block = [&](int b, WI8 &w, WI8 &wn, auto oddc) {
-        constexpr bool ODD = decltype(oddc)::value;
+    auto block = [&](int b, WI8 &w, WI8 &wn) {
         if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }   // (see the MX kernel)
         load_w(wn, kb0 + b + 1);
-        if constexpr (MIN) {
-            if constexpr (!ODD) {
-                load_pair(b);
-            } else {
-#pragma unroll
-                for (int j = 0; j < WNT; ++j) sap[j] = tabD[(b - 1 + hh) * (32 * WNT) + 32 * j + l31] * (float)sump[j];
-            }
-        }
         const float *dp = tabD + b * (32 * WNT) + 4 * hh;
         i32x16 x[2];
         x[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], w.q[0], zero, 0, 0, 0);
@@ -451,8 +502,6 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
             }
             static_for<4>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                // the min-term MFMA of the PREVIOUS tile of the pair's second block, between this tile's scale-accumulate groups
-                if constexpr (MIN && ODD && q == 2 && t >= 1) min_term(std::integral_constant<int, (t >= 1 ? t - 1 : 0)>{});
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if constexpr (TYPE == GGML_TYPE_Q8_0)
@@ -463,7 +512,6 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
                 // refetched into place, a whole tile step ahead of their next use)
                 if constexpr (DA_INPLACE && i == WMT - 1) da[q] = *(const f32x4 *)(dp + 32 * (j + 1) + 8 * q);
             });
-            if constexpr (MIN && ODD && t == WMT * WNT - 1) min_term(tc);      // (the pair's last tile: behind its own scale-accumulates)
             if constexpr (i == WMT - 1 && !DA_INPLACE) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) da[q] = dn[q];
@@ -475,8 +523,8 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
     for (int b = 0; b < nloc; b += 2) {                     // (the look-ahead of the last trip reads past the wave's range: never used)
-        block(b, w0, w1, std::false_type{});
-        block(b + 1, w1, w0, std::true_type{});
+        block(b, w0, w1);
+        block(b + 1, w1, w0);
     }
 #ifdef K3P_TRACE
     asm volatile("" : "+v"(acc[0][0]));
@@ -520,7 +568,7 @@ static unsigned persistent_grid(int tiles) {
 hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     const bool with_min = w->type == GGML_TYPE_Q5_1 || w->type == GGML_TYPE_Q4_1;
     const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : (w->type == GGML_TYPE_Q5_0 || with_min) ? w->i8p : nullptr;
-    if (pl.family != MMF_K3P_I8 || !planes || !w->d || (with_min && !w->m)) return hipErrorInvalidValue;
+    if (pl.family != MMF_K3P_I8 || !planes || !w->d || (with_min && (!w->m || !w->mp3 || !p.sp3))) return hipErrorInvalidValue;
     // applicability (at least 8 k-blocks per wave, the eight scale tables within 160 KB of LDS, every offset within 32 bits) and the
     // k-blocks per wave were decided by plan.cpp (plan_k3p_i8); the checks below only guard the kernel's assumptions
     const int nbkp = (int)pad_kblocks(w->nbk);
@@ -534,15 +582,17 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
     const size_t lds = tab > xch ? tab : xch;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     (void)hipGetLastError();
-#define Q8MID_GO(T) do { \
-        auto kern = gemm_q8_mid_kernel<T>; \
+#define Q8MID_GO(T, ...) do { \
+        auto kern = gemm_q8_mid_kernel<T, ##__VA_ARGS__>; \
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
-        kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, w->m, p.a8, p.ad, p.as, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
-                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep); } while (0)
+        kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
+                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep, w->mp3, p.sp3); } while (0)
     // (Q4_1: the kernel of Q5_1 -- unsigned values 0..15 on the int8 planes, the same min term)
-    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else if (w->type == GGML_TYPE_Q5_0) Q8MID_GO(GGML_TYPE_Q5_0); else Q8MID_GO(GGML_TYPE_Q5_1);
+    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else if (w->type == GGML_TYPE_Q5_0) Q8MID_GO(GGML_TYPE_Q5_0);
+    // (the min of a Q5_1 block is an f16 value: two bf16 pieces; Q4_1's is an f32, Q5_K's an f32 product: three)
+    else if (w->ext_type != 0 || w->type == GGML_TYPE_Q4_1) Q8MID_GO(GGML_TYPE_Q5_1, true); else Q8MID_GO(GGML_TYPE_Q5_1);
 #undef Q8MID_GO
     return hipGetLastError();
 }

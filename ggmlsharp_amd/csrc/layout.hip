@@ -287,6 +287,24 @@ __global__ void q5_to_i8_kernel(const uint8_t *__restrict__ qs, const uint32_t *
     *(uint4 *)(i8p + ((b * 2 + 1) * Mpad + m) * 16) = make_uint4(od[0], od[1], od[2], od[3]);
 }
 
+// Q5_1 / Q4_1 (and Q5_K in the Q5_1 form): the min plane [nbk][Mpad] f32 -> three bf16 piece planes per k-group of 8 blocks,
+// [ceil(nbk / 8) * 3][Mpad][16 B] (ggml_hip_weight::mp3; split3: the pieces sum to the f32 value exactly).  One thread per (row, k-group).
+__global__ void min_pieces_kernel(const float *__restrict__ mn, int64_t rows, int64_t Mpad, int64_t nbk, uint8_t *__restrict__ mp3) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = blockIdx.y;
+    if (m >= rows) return;
+    uint32_t w[3][4] = {};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t b = g * 8 + e;
+        uint32_t q0 = 0, q1 = 0, q2 = 0;
+        if (b < nbk) split3(mn[b * Mpad + m], q0, q1, q2);
+        w[0][e >> 1] |= q0 << (16 * (e & 1)); w[1][e >> 1] |= q1 << (16 * (e & 1)); w[2][e >> 1] |= q2 << (16 * (e & 1));
+    }
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *(uint4 *)(mp3 + ((g * 3 + pc) * Mpad + m) * 16) = make_uint4(w[pc][0], w[pc][1], w[pc][2], w[pc][3]);
+}
+
 // d / m / qh planes -> the mat-vec's tile-major side image (common.h ggml_hip_weight::gs); one thread per (row, k-block)
 __global__ void gemv_side_image_kernel(const float *__restrict__ d, const float *__restrict__ mm, const uint32_t *__restrict__ qh, int64_t Mpad,
                                        int64_t nbk, int np, uint32_t *__restrict__ gs) {
@@ -349,6 +367,13 @@ hipError_t launch_q5_to_i8(ggml_hip_weight *w, hipStream_t st) {
     if (w->type == GGML_TYPE_Q5_0) q5_to_i8_kernel<16, true><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
     else if (w->type == GGML_TYPE_Q5_1) q5_to_i8_kernel<0, true><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
     else q5_to_i8_kernel<0, false><<<grid, 256, 0, st>>>(w->qs, nullptr, w->M, w->Mpad, w->i8p);
+    return hipGetLastError();
+}
+
+hipError_t launch_min_pieces(ggml_hip_weight *w, hipStream_t st) {
+    if (!w->mp3 || !w->m || w->M <= 0 || w->nbk <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)((w->nbk + 7) / 8));
+    min_pieces_kernel<<<grid, 256, 0, st>>>(w->m, w->M, w->Mpad, w->nbk, w->mp3);
     return hipGetLastError();
 }
 

@@ -59,11 +59,13 @@ void plan_set_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 
 //   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q4_2, and Q5_0 / Q5_1 / Q8_0 in between,
 //   gemm_qmp.hip / gemm_q8s.hip -- the stage-free forms (257..512 rows; Q8_0 5..64 rows).
 // ggml_hip_debug_force_gemm forces one (test / developer switch; the product library reads no environment variable: GGML_HIP_GEMM is
-// honoured by -DGGML_HIP_DEV builds only).  Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images, 3 = the bf6 image.
+// honoured by -DGGML_HIP_DEV builds only).  Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images, 3 = the bf6 image;
+// 0 + ACT_IMAGE_MIN_PIECES (64) = the int8 planes and the min-term piece planes (K3p-int8 behind a Q5_1 / Q4_1 / Q5_K weight).
 // NOT a function of the number of weight rows: the signature has no M to consult.
 int plan_image_kind(int type, int64_t K, int64_t N) {
     const int force = plan_force_gemm();
-    if (q8_small_serves(type, K, N) || q8_mid_serves(type, K, N)) return 0;
+    if (q8_mid_serves(type, K, N)) return min_type(type) ? ACT_IMAGE_MIN_PIECES : 0;   // (image 0 + the min-term piece planes)
+    if (q8_small_serves(type, K, N)) return 0;
     if (N <= 4 || force == 1) return 0;
     // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
     // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them
@@ -125,7 +127,9 @@ bool plan_k3p_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // (32-bit buffer offsets, the look-ahead past a wave's range included -- the SAME bound the exception test of plan_mul_mat uses)
     if ((uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
     p.family = MMF_K3P_I8; p.image = 0; p.form = 0;
-    p.arith = 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0);        // Q8_0: fma(sumi, d1 * d0); others: fma(d0 * sumi, d1); min types: + MFMA per pair
+    // Q8_0: fma(sumi, d1 * d0); others: fma(d0 * sumi, d1); min types: + the min terms of 16 k-blocks as six bf16-piece MFMAs per tile
+    p.arith = 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0);
+    if (min_type(type)) p.flags |= MM_FLAG_MIN_PIECES;
     p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
     p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
     p.wgs = cdiv(M, 128) * cdiv(N, 64);

@@ -32,7 +32,8 @@ enum mm_family {
 // how K is divided among the partial sums of an element
 enum mm_kstyle { MMK_CHAIN = 0, MMK_STAGE_SETS = 1, MMK_RANGES = 2, MMK_WORKERS = 3 };
 
-enum { MM_FLAG_WIDE = 1, MM_FLAG_EPILOGUE_FUSED = 2, MM_FLAG_PERSISTENT = 4, MM_FLAG_Q8K = 8, MM_FLAG_NEEDS_WORK = 16 };
+enum { MM_FLAG_WIDE = 1, MM_FLAG_EPILOGUE_FUSED = 2, MM_FLAG_PERSISTENT = 4, MM_FLAG_Q8K = 8, MM_FLAG_NEEDS_WORK = 16,
+       MM_FLAG_MIN_PIECES = 32 /* INIT writes image 0 AND the three bf16 piece planes of d * sum (K3p-int8, min-term types) */ };
 
 // forms of the staged MX family (gemm_qmx.hip launch_typed): <WMT, WNT, WGM, WGN, KB, FB, KSP, VS>
 enum mx_form {

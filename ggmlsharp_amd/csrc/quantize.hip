@@ -77,9 +77,10 @@ __device__ __forceinline__ uint32_t bf6_code_q(int v) {
 template <int IMG, bool K8 = false>
 __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restrict__ x, int64_t N, int64_t nbk, int64_t ld1,
                                                           int8_t *__restrict__ a8, float *__restrict__ ad,
-                                                          int32_t *__restrict__ as, int64_t Npad) {
+                                                          int32_t *__restrict__ as, int64_t Npad, uint8_t *__restrict__ sp3 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = lane & 7;
+    float ds_mine = 0.0f;                                   // (IMG 0 with sp3) d * sum of k-block b0 + t of this lane's row
     const int64_t n = (int64_t)blockIdx.y * 32 + wave * 8 + (lane >> 3);
     const bool live = n < N;
     const int64_t nr = live ? n : N - 1;  // clamp loads, skip stores
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
         const int q2 = (int)rintf(v[j].z * qid);
         const int q3 = (int)rintf(v[j].w * qid);
         const int s = group8_sum(q0 + q1 + q2 + q3);
+        if (IMG == 0 && t == j) ds_mine = d * (float)s;     // (a k-block past the end of K: v = 0, so d = 0 and s = 0)
         if (IMG == 3) {
             // bf6 image of gemm_qmx.hip: a = 16*ah + al, ah = floor((a + 8) / 16) in [-8, 8], al in [-8, 7]; lane t owns
             // elements 4t..4t+3 = bits [24t, 24t+24) of both 192-bit fragments; the 4 lanes of a group (u = t & 3) hold
@@ -242,6 +244,19 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const float *__restri
                 ad[b * Npad + n] = d;
                 as[b * Npad + n] = s;
             }
+        }
+    }
+    // r4: the min-term operand of K3p-int8 (gemm_qmp.hip) -- d * (float)sum, the Q8_1 s0 + s1 of Ggml.cs:820-821, as three bf16 pieces that
+    // sum to it exactly; the workgroup column is one k-group of 8 blocks, the row's 8 lanes write its 16 bytes of each piece plane
+    if (IMG == 0 && sp3 != nullptr && live) {
+        uint32_t q0, q1, q2;
+        split3(ds_mine, q0, q1, q2);
+        uint8_t *o = sp3 + (((int64_t)blockIdx.x * 3) * Npad + n) * 16 + 2 * t;
+        *(uint16_t *)o = (uint16_t)q0; *(uint16_t *)(o + Npad * 16) = (uint16_t)q1; *(uint16_t *)(o + 2 * Npad * 16) = (uint16_t)q2;
+        // (the product takes k-groups in pairs: behind an odd count stands a k-group of zeros)
+        if ((gridDim.x & 1) && blockIdx.x == gridDim.x - 1) {
+            o += 3 * Npad * 16;
+            *(uint16_t *)o = 0; *(uint16_t *)(o + Npad * 16) = 0; *(uint16_t *)(o + 2 * Npad * 16) = 0;
         }
     }
 }
@@ -713,12 +728,18 @@ __global__ void q8_aos_to_planes_kernel(const uint8_t *__restrict__ in, int64_t 
 hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st, bool q8k) {
     if (N <= 0) return hipSuccess;
     const int64_t nbk = K / QK;
+    uint8_t *sp3 = nullptr;                                 // image 0 + the min-term piece planes (they live in the half of the a8 region image 0 leaves free)
+    if (image & ACT_IMAGE_MIN_PIECES) {
+        image &= ~ACT_IMAGE_MIN_PIECES;
+        if (image != 0 || nbk < 8 || !p.sp3) return hipErrorInvalidValue;   // (room: (nbk / 8 + 2) * 3 piece planes within the 2 nbk planes image 0 leaves free)
+        sp3 = p.sp3;
+    }
     dim3 grid((unsigned)((nbk + K1_BPB - 1) / K1_BPB), (unsigned)((N + 31) / 32));
     if (q8k) {                                              // Q8_K rule (kquants.hip): K is whole super-blocks, no bf6 image
         if (K % 256 != 0 || image == 3) return hipErrorInvalidValue;
         if (image == 1) quantize_act_kernel<1, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
         else if (image == 2) quantize_act_kernel<2, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
-        else quantize_act_kernel<0, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        else quantize_act_kernel<0, true><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad, sp3);
         return hipGetLastError();
     }
     if (image == 1)
@@ -738,7 +759,7 @@ hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1
         }
     }
     else
-        quantize_act_kernel<0><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad);
+        quantize_act_kernel<0><<<grid, 256, 0, st>>>(x, N, nbk, ld1, p.a8, p.ad, p.as, p.Npad, sp3);
     return hipGetLastError();
 }
 

@@ -163,6 +163,51 @@ def _decode_act_image(kind, raw, nbk, Npad, N):
     return q
 
 
+def _split3_bf16(v):
+    """an f32 array as three bf16 bit patterns that sum to it exactly (common.h split3: truncation, 8 + 8 + 8 significand bits)"""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    b0 = v.view(np.uint32) & np.uint32(0xFFFF0000)
+    r1 = v - b0.view(np.float32)
+    b1 = r1.view(np.uint32) & np.uint32(0xFFFF0000)
+    r2 = r1 - b1.view(np.float32)
+    return (b0 >> 16).astype(np.uint16), (b1 >> 16).astype(np.uint16), (r2.view(np.uint32) >> 16).astype(np.uint16)
+
+
+@pytest.mark.parametrize("t", [O.Q5_1, O.Q4_1])
+def test_min_term_piece_planes_hold_d_times_sum_exactly(dev, t):
+    """r4, K3p-int8 behind a min-term type: beside image 0, INIT writes d * (float)sum(q) -- the Q8_1 s0 + s1 of Ggml.cs:820-821 -- as three
+    bf16 pieces per k-block, eight k-blocks of a row to a 16-byte entry; the pieces must sum to the f32 value bit for bit, k-blocks past
+    the end of K and the k-group that completes the last pair must be zeros."""
+    from ggmlsharp_amd._lib import lib
+    for K, N in ((2048 + 96, 300), (4096, 512)):             # 67 k-blocks: 9 k-groups (the last holds 3 blocks), a tenth of zeros; 128: 16 k-groups
+        assert lib().ggml_hip_act_image_kind(t, K, N) == 64
+        x = np.ascontiguousarray(np.concatenate([_special_rows(K)[:8], _rand((N - 8, K))]))
+        w = dev.Weight.from_host(t, O.quantize_row(t, _rand((4, K))), K)
+        work = dev.alloc_work(t, K, N)
+        work.fill_(0x7F)
+        dev.mul_mat_init(w, torch.from_numpy(x).cuda(), work)
+        torch.cuda.synchronize()
+        raw = work.cpu().numpy()
+        nbk, Npad = K // 32, (N + 255) // 256 * 256
+        nba, nkg = (nbk + 3) // 4 * 4, (nbk + 7) // 8
+        ref = O.quantize_row(O.Q8_0, x).reshape(N, nbk, 36)
+        d = ref[:, :, :4].copy().view(np.float32).reshape(N, nbk)
+        sums = ref[:, :, 4:].copy().view(np.int8).astype(np.int32).sum(axis=2)
+        s = np.zeros((N, (nkg + (nkg & 1)) * 8), dtype=np.float32)
+        s[:, :nbk] = d * sums.astype(np.float32)
+        want = _split3_bf16(s)
+        base = nba * 2 * Npad * 16                            # the half of the image region the int8 image leaves free
+        planes = raw[base: base + (nkg + (nkg & 1)) * 3 * Npad * 16].view(np.uint16).reshape(-1, 3, Npad, 8)
+        for pc in range(3):
+            got = planes[:, pc, :N, :].transpose(1, 0, 2).reshape(N, -1)
+            assert np.array_equal(got, want[pc]), (K, N, pc)
+        # and the pieces do sum to the value (non-finite rows aside: those travel in the third piece alone)
+        fin = np.isfinite(s)
+        tot = sum((wp.astype(np.uint32) << 16).view(np.float32).astype(np.float64) for wp in want)
+        assert np.array_equal(tot[fin].astype(np.float32).view(np.uint32), s[fin].view(np.uint32))
+        w.free()
+
+
 @pytest.mark.parametrize("t,force", [(O.Q4_0, ""), (O.Q8_0, ""), (O.Q5_0, "f16"), (O.Q8_0, "f16")])
 def test_quantize_act_planes_match_oracle(dev, t, force):
     """INIT phase (Ggml.cs:6641-6654): whatever image the selected kernel wants, it must hold exactly the oracle's Q8_0 row."""

@@ -10,7 +10,7 @@ from ggmlsharp_amd import _lib
 
 F32, F16, Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0, Q5_K = 0, 1, 2, 3, 4, 6, 7, 8, 113
 QUANT = (Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0)
-WIDE, EPI, PERSIST, Q8K, NEEDS_WORK = 1, 2, 4, 8, 16
+WIDE, EPI, PERSIST, Q8K, NEEDS_WORK, MIN_PIECES = 1, 2, 4, 8, 16, 32
 FAM = {"gemv_fused": 1, "gemv_rows": 2, "k3s_mx": 3, "k3s_i8": 4, "k3p_mx": 5, "k3p_i8": 6, "mx": 7, "f16": 8, "i8": 9, "dense": 10,
        "dense_gemv": 11, "dense16": 12, "dense32": 13}
 KS = (32, 64, 256, 512, 1024, 2048, 2304, 4096, 4352, 11008, 16384, 20480, 22016, 32768)
@@ -82,6 +82,8 @@ def test_baseline_configs_get_the_kernels_design_md_names():
         assert (p.family, p.ksplit, p.kunit) == (FAM["k3p_i8"], 8, 44), t
         assert bool(p.flags & Q8K) == (t == Q5_K)
         assert bool(p.flags & EPI) == (t != Q5_K)
+        # the min-term types: INIT writes image 0 AND the bf16 piece planes of d * sum (kind 0 + 64); the others plain image 0
+        assert bool(p.flags & MIN_PIECES) == (t in (Q5_1, Q4_1, Q5_K)) and p.image_kind == (64 if t in (Q5_1, Q4_1, Q5_K) else 0), t
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     assert plan(Q8_0, 4096, 22016, 512).family == FAM["f16"]        # K > 20480: the eight scale tables do not fit LDS (decided in the plan)
     assert plan(F16, 4096, 4096, 4096).family == FAM["dense16"] and plan(F32, 4096, 4096, 4096).family == FAM["dense32"]

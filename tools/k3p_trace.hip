@@ -15,7 +15,8 @@
 
 int main(int argc, char **argv) {
     const int M = argc > 3 ? atoi(argv[1]) : 4096, K = argc > 3 ? atoi(argv[2]) : 4096, N = argc > 3 ? atoi(argv[3]) : 512;
-    const bool i8 = argc > 4 && !strcmp(argv[4], "i8");      // Q8_0 on the int8 form instead of Q4_0 on the MX form
+    const bool q51 = argc > 4 && !strcmp(argv[4], "q51");    // Q5_1 on the int8 form: the min-term product on the bf16 cores in front of the K loop
+    const bool i8 = q51 || (argc > 4 && !strcmp(argv[4], "i8"));      // Q8_0 on the int8 form instead of Q4_0 on the MX form
     const int nbk = K / 32, nbkp = (int)pad_kblocks(nbk), Mpad = (int)pad_rows(M), Npad = (int)pad_act(N);
     const size_t wa = (size_t)(nbkp + K_LOOKAHEAD) * Mpad * 16, wb = wa / 2, wdb = (size_t)(nbkp + K_LOOKAHEAD) * Mpad * 4;
     const size_t ab = (size_t)nbkp * 48 * Npad, adb = (size_t)nbkp * Npad * 4;
@@ -27,17 +28,32 @@ int main(int argc, char **argv) {
     auto fillf = [&](void *d, size_t n) { for (size_t i = 0; i < n / 4; ++i) { s = s * 1664525u + 1013904223u; f[i] = 0.5f + (float)(s >> 8) / 33554432.0f; } CK(hipMemcpy(d, f.data(), n, hipMemcpyHostToDevice)); };
     for (auto &w : W) {
         memset(&w, 0, sizeof(w));
-        w.type = i8 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_0; w.M = M; w.K = K; w.Mpad = Mpad; w.nbk = nbk;
+        w.type = q51 ? GGML_TYPE_Q5_1 : i8 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_0; w.M = M; w.K = K; w.Mpad = Mpad; w.nbk = nbk;
         CK(hipMalloc(&w.q6a, 2 * wa)); CK(hipMalloc(&w.q6b, wb)); CK(hipMalloc(&w.d, wdb));
         fill(w.q6a, 2 * wa); fill(w.q6b, wb); fillf(w.d, wdb);
         w.qs = w.q6a;                                         // (int8 planes: 32 B per row and k-block)
+        if (q51) {                                            // (piece planes: random finite bf16 values)
+            const size_t mpb = (size_t)((nbk + 15) / 16 * 2 * 3) * Mpad * 16;
+            w.i8p = w.q6a; w.m = w.d;
+            CK(hipMalloc(&w.mp3, mpb));
+            std::vector<uint16_t> hp(mpb / 2);
+            for (auto &v : hp) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3C00u | ((s >> 20) & 0x83FFu)); }
+            CK(hipMemcpy(w.mp3, hp.data(), mpb, hipMemcpyHostToDevice));
+        }
     }
     uint8_t *a6; float *ad, *dst;
     CK(hipMalloc(&a6, ab)); CK(hipMalloc(&ad, adb)); CK(hipMalloc(&dst, (size_t)N * M * 4));
     fill(a6, ab); fillf(ad, adb);
-    act_planes p; p.a8 = (int8_t *)a6; p.ad = ad; p.as = (int32_t *)ad; p.Npad = Npad;
+    act_planes p; p.a8 = (int8_t *)a6; p.ad = ad; p.as = (int32_t *)ad; p.Npad = Npad; p.sp3 = nullptr;
+    if (q51) {
+        const size_t spb = (size_t)((nbk + 15) / 16 * 2 * 3) * Npad * 16;
+        CK(hipMalloc(&p.sp3, spb));
+        std::vector<uint16_t> hp(spb / 2);
+        for (auto &v : hp) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3C00u | ((s >> 20) & 0x83FFu)); }
+        CK(hipMemcpy(p.sp3, hp.data(), spb, hipMemcpyHostToDevice));
+    }
     const mm_epilogue ep{0, nullptr, 0, nullptr, 0, 1.0f};
-    const mm_plan pl = plan_mul_mat(i8 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_0, 0, M, K, N, false);
+    const mm_plan pl = plan_mul_mat(q51 ? GGML_TYPE_Q5_1 : i8 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q4_0, 0, M, K, N, false);
     if (pl.family != (i8 ? MMF_K3P_I8 : MMF_K3P_MX)) { printf("this shape is not served by K3p (plan family %d)\n", pl.family); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int it = 0; it < 200; ++it) CK((i8 ? launch_gemm_q8_mid : launch_gemm_qmx_mid)(&W[it % copies], pl, p, N, dst, M, 0, ep));
