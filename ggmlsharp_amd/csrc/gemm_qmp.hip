@@ -69,22 +69,21 @@ __device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, 
 
 // This wave's slice of the row scales: nloc rows x 64 floats into its own LDS slice.  Rows at or past nbk_valid are ZERO, so a
 // k-block past the end of K adds (sumi * 0) * d0 = +0 whatever the operand registers hold.  Same wave writes and reads: no barrier.
+// By LDS-DMA (buffer_load ... lds: no registers, every piece of the slice in flight at once): one instruction moves four table rows
+// -- lane l fetches 16 bytes of row l / 16 -- to 1 KiB of the slice; rows at or past nbk_valid are beyond the descriptor and arrive as
+// zeros (the range check covers the scalar offset, and the DMA form writes the zeros: tools/oob_probe.hip).  r4: it was a loop of four
+// register loads per lane and trip -- three trips for K = 11008, each exposing a load latency with every workgroup of the launch
+// asking at once: 4.4 us in front of the K loop, now 2.8 (4096 x 11008 x 512 Q8_0: 72.2 -> 70.4 us, tools/k3p_trace.hip).
+typedef __attribute__((address_space(3))) void lds_void_p;
 __device__ __forceinline__ void load_scale_table(float *tabD, const float *__restrict__ ad, int kb0, int nloc, int nbk_valid, int Npad, int n0, int lane) {
-    const int npiece = nloc * (32 * WNT / 4);               // float4 pieces
-    for (int base = 0; base < npiece; base += 64 * 4) {
-        f32x4 td[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + lane + 64 * u, b = idx / (8 * WNT), c4 = idx % (8 * WNT);
-            const bool ok = idx < npiece && kb0 + b < nbk_valid;
-            td[u] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + lane + 64 * u;
-            if (idx < npiece) *(f32x4 *)(tabD + 4 * idx) = td[u];
-        }
-    }
+    const rsrc_t rT = make_rsrc(ad, (uint32_t)nbk_valid * (uint32_t)Npad * 4u);
+    const uint32_t voff = (uint32_t)(((lane >> 4) * Npad + 4 * (lane & 15)) * 4);
+    const int ngrp = nloc >> 2, rem = nloc & 3;
+    for (int g = 0; g < ngrp; ++g)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, (lds_void_p *)(tabD + 256 * g), 16, (int)voff, (int)((uint32_t)((kb0 + 4 * g) * Npad + n0) * 4u), 0, 0);
+    if (rem && lane < 16 * rem)                             // (the slice ends inside a group of four rows: the lanes of the rows past it stay out)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, (lds_void_p *)(tabD + 256 * ngrp), 16, (int)voff, (int)((uint32_t)((kb0 + 4 * ngrp) * Npad + n0) * 4u), 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // The waves' sums, added in wave order, four of the eight tiles per round (128 KB of LDS in 16-byte pieces); every wave takes its

@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
     const int nbk = K / 32, nbkp = (int)pad_kblocks(nbk), Mpad = (int)pad_rows(M), Npad = (int)pad_act(N);
     const size_t wa = (size_t)(nbkp + K_LOOKAHEAD) * Mpad * 16, wb = wa / 2, wdb = (size_t)(nbkp + K_LOOKAHEAD) * Mpad * 4;
     const size_t ab = (size_t)nbkp * 48 * Npad, adb = (size_t)nbkp * Npad * 4;
-    const int copies = 16;
+    const int copies = argc > 5 ? atoi(argv[5]) : 16;         // (1: the weights stay in the caches from launch to launch)
     std::vector<ggml_hip_weight> W(copies);
     std::vector<uint8_t> h(std::max(2 * wa, ab)); uint32_t s = 12345;
     auto fill = [&](void *d, size_t n) { for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = (uint8_t)(s >> 24); } CK(hipMemcpy(d, h.data(), n, hipMemcpyHostToDevice)); };
