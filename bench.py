@@ -168,7 +168,7 @@ def compute_kernel_name(qtype, M, K, N):
         return "?"
     name = FAMILY_NAME.get(pl.family, f"family {pl.family}")
     if pl.family == 6 and qtype in (Q5_K, 7, 3):
-        name += " + min term as one v_mfma_f32_32x32x2_f32 per tile and pair of k-blocks (r4)"
+        name += " + the min terms of 16 k-blocks as one bf16-piece matrix product (5 / 6 v_mfma_f32_32x32x16_bf16 per tile) ahead of the K loop (r4)"
     return f"{name}; plan: form {pl.form}, tile {pl.tile_m}x{pl.tile_n}, {pl.waves} waves, K in {pl.ksplit} partial sum(s), {pl.workgroups} workgroups"
 
 
