@@ -76,10 +76,11 @@ enum {  /* ggml_hip_mm_plan_t.flags */
     GGML_HIP_PLAN_WIDE = 1,            /* the 32-bit-offset exception applied */
     GGML_HIP_PLAN_EPILOGUE_FUSED = 2,  /* an add / scale node behind the product runs in the kernel's store phase */
     GGML_HIP_PLAN_PERSISTENT = 4, GGML_HIP_PLAN_Q8K = 8,
-    GGML_HIP_PLAN_NEEDS_WORK = 16      /* the product needs a work buffer of ggml_hip_mul_mat_work_size bytes */
+    GGML_HIP_PLAN_NEEDS_WORK = 16,     /* the product needs a work buffer of ggml_hip_mul_mat_work_size bytes */
+    GGML_HIP_PLAN_MIN_PIECES = 32      /* INIT writes image 0 AND the bf16 piece planes of d * sum (K3p-int8 behind Q5_1 / Q4_1 / Q5_K): image_kind 0 + 64 */
 };
 typedef struct ggml_hip_mm_plan_t {
-    int32_t  family, image_kind, form;       /* which kernel, what INIT writes (-1 nothing, 0..3 K1's images, 32 / 33 dense panels), which instantiation */
+    int32_t  family, image_kind, form;       /* which kernel, what INIT writes (-1 nothing, 0..3 K1's images, 0 + 64 image 0 with the min-term piece planes, 32 / 33 dense panels), which instantiation */
     uint32_t tree_id;                        /* hash of (arith, ksplit, kstyle, kunit): what fixes an element's bits */
     int32_t  arith, ksplit, kstyle, kunit;   /* kstyle: 0 one chain over K, 1 stage sets taken in turn, 2 contiguous ranges, 3 interleaved workers */
     int32_t  tile_m, tile_n, waves, tiles_per_wave;
@@ -95,7 +96,10 @@ int    ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_p
 void   ggml_hip_debug_force_gemm(int which);
 /* Step 1 alone with an explicit layout: every src1 row -> Q8_0 (quantize_row_q8_0, Ggml.cs:733-762, the loop of
  * Ggml.cs:6641-6654) written as image `image_kind` (see above) into d_work.  image_kind + 16 (kinds 0..2, K % 256 == 0):
- * the Q8_K rule of the k-quant extension instead (one scale per 256 elements; see GGML_HIP_TYPE_Q5_K). */
+ * the Q8_K rule of the k-quant extension instead (one scale per 256 elements; see GGML_HIP_TYPE_Q5_K).  image_kind + 64 (kind 0 only,
+ * K >= 256): beside image 0, d * (float)sum(q) of every block -- the Q8_1 s0 + s1 of Ggml.cs:820-821 -- as three bf16 pieces that sum to it
+ * exactly, in the half of the image region image 0 leaves free (same work size): what ggml_hip_act_image_kind returns for Q5_1 / Q4_1
+ * weights at 257..512 src1 rows, where the min terms run as a matrix product of their own (gemm_qmp.hip). */
 int    ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
                                  int image_kind, void *stream);
 
