@@ -178,7 +178,7 @@ def test_min_term_piece_planes_hold_d_times_sum_exactly(dev, t):
     """r4, K3p-int8 behind a min-term type: beside image 0, INIT writes d * (float)sum(q) -- the Q8_1 s0 + s1 of Ggml.cs:820-821 -- as three
     bf16 pieces per k-block, eight k-blocks of a row to a 16-byte entry; the pieces must sum to the f32 value bit for bit, k-blocks past
     the end of K and the k-group that completes the last pair must be zeros."""
-    from ggmlsharp_amd._lib import lib
+    from ggmlsharp_amd._lib import lib, check
     for K, N in ((2048 + 96, 300), (4096, 512)):             # 67 k-blocks: 9 k-groups (the last holds 3 blocks), a tenth of zeros; 128: 16 k-groups
         assert lib().ggml_hip_act_image_kind(t, K, N) == 64
         x = np.ascontiguousarray(np.concatenate([_special_rows(K)[:8], _rand((N - 8, K))]))
@@ -205,6 +205,16 @@ def test_min_term_piece_planes_hold_d_times_sum_exactly(dev, t):
         fin = np.isfinite(s)
         tot = sum((wp.astype(np.uint32) << 16).view(np.float32).astype(np.float64) for wp in want)
         assert np.array_equal(tot[fin].astype(np.float32).view(np.uint32), s[fin].view(np.uint32))
+        # the explicit-layout entry with the kind ggml_hip_act_image_kind names writes the same bytes; a kind the flag does not belong to is refused
+        work2 = dev.alloc_work(t, K, N)
+        work2.fill_(0x7F)
+        xd = torch.from_numpy(x).cuda()
+        check(lib().ggml_hip_quantize_act_dev(C.c_void_p(xd.data_ptr()), N, K, K, C.c_void_p(work2.data_ptr()), work2.numel(), 64, None), "quantize_act")
+        torch.cuda.synchronize()
+        raw2 = work2.cpu().numpy()
+        assert np.array_equal(raw2[base: base + (nkg + (nkg & 1)) * 3 * Npad * 16].view(np.uint16).reshape(-1, 3, Npad, 8)[:, :, :N, :], planes[:, :, :N, :])
+        assert np.array_equal(raw2[:nbk * 2 * Npad * 16].reshape(nbk, 2, Npad, 16)[:, :, :N, :], raw[:nbk * 2 * Npad * 16].reshape(nbk, 2, Npad, 16)[:, :, :N, :])
+        assert lib().ggml_hip_quantize_act_dev(C.c_void_p(xd.data_ptr()), N, K, K, C.c_void_p(work2.data_ptr()), work2.numel(), 64 + 3, None) != 0
         w.free()
 
 
