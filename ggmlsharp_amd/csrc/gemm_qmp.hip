@@ -68,7 +68,7 @@ __device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, 
 }
 
 // This wave's slice of the row scales: nloc rows x 64 floats into its own LDS slice.  Rows at or past nbk_valid are ZERO, so a
-// k-block past the end of K adds (sumi * 0) * d0 = +0 whatever the operand registers hold.  Same wave writes and reads: no barrier.
+// k-block past the end of K adds (sumi * 0) * d0 = +0 whatever the operand registers hold.  Same wave writes and reads.
 // By LDS-DMA (buffer_load ... lds: no registers, every piece of the slice in flight at once): one instruction moves four table rows
 // -- lane l fetches 16 bytes of row l / 16 -- to 1 KiB of the slice; rows at or past nbk_valid are beyond the descriptor and arrive as
 // zeros (the range check covers the scalar offset, and the DMA form writes the zeros: tools/oob_probe.hip).  r4: it was a loop of four
@@ -83,7 +83,10 @@ __device__ __forceinline__ void load_scale_table(float *tabD, const float *__res
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, (lds_void_p *)(tabD + 256 * g), 16, (int)voff, (int)((uint32_t)((kb0 + 4 * g) * Npad + n0) * 4u), 0, 0);
     if (rem && lane < 16 * rem)                             // (the slice ends inside a group of four rows: the lanes of the rows past it stay out)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, (lds_void_p *)(tabD + 256 * ngrp), 16, (int)voff, (int)((uint32_t)((kb0 + 4 * ngrp) * Npad + n0) * 4u), 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // A DMA's LDS write is complete for a reader only after vmcnt(0) AND lgkmcnt(0), and the workgroup barrier is the customary third part
+    // of the wait (quantize.hip K1b: with vmcnt(0) alone, now and then half of every 128-byte line still held the previous contents).
+    // Every wave of the workgroup comes through here once per tile, so the barrier is uniform.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // The waves' sums, added in wave order, four of the eight tiles per round (128 KB of LDS in 16-byte pieces); every wave takes its
