@@ -73,6 +73,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 #ifdef K3M_CLOCK            // tools/k3m_clock.hip: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) every wave spends in the K loop
 __device__ unsigned long long k3m_clock_buf[8192 * 2];
+__device__ unsigned int k3m_where_buf[8192 * 2];             // HW_ID and XCC_ID of the wave: which CU / SIMD / wave slot / XCD ran it
 #endif
 
 // WMT x WNT 32x32 tiles per wave, WGM x WGN waves per workgroup, KB k-blocks per LDS stage
@@ -383,7 +384,10 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     // of one round (at most two workgroups per CU): with more rounds the early finisher's place is taken by the next workgroup at once,
     // and its store tail overlaps that workgroup's start (32000 x 4096 x 2048: 586 us without, 589 with).
 #ifndef GGML_MX_PRIO
-#define GGML_MX_PRIO 3
+#define GGML_MX_PRIO 15
+#endif
+#ifndef GGML_MX_PRIO_ON
+#define GGML_MX_PRIO_ON 8
 #endif
     bool younger = false;
     if constexpr (WGM * WGN * KSP == 4 && GGML_MX_PRIO != 0) {
@@ -393,7 +397,10 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
     }
     for (int it = 0; it < niter; ++it) {
         if constexpr (WGM * WGN * KSP == 4 && GGML_MX_PRIO != 0) {
-            if (younger) { if (it % GGML_MX_PRIO != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            // (priority on GGML_MX_PRIO_ON stages of every GGML_MX_PRIO.  With 2 of 3 the younger workgroup finished 6.5 us BEFORE the older one,
+            // with 1 of 2 4.7 us behind it; 8 of 15: 138.1 | 139.2 us (tools/k3m_clock.hip, K loop median by wave slot).  What is left of
+            // the spread is between XCDs -- the odd ones run ~5 % slower on the boxes looked at, in-kernel clock 1.71 against 1.82 GHz.)
+            if (younger) { if (it % GGML_MX_PRIO < GGML_MX_PRIO_ON) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         }
         int sn = sc + KV, pn = pass;
         if (VS > 1 && sn >= nstages) { pn = pass + 1; sn = pn < VS ? grp * VS + pn : nstages; }
@@ -423,6 +430,9 @@ void gemm_qmx_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict_
         const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
         const size_t slot = (size_t)blockIdx.x * (WGM * WGN * KSP) + wave_all;
         if (lane == 0 && slot < 8192) { k3m_clock_buf[2 * slot] = c1 - clk_c0; k3m_clock_buf[2 * slot + 1] = r1 - clk_r0; }
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        if (lane == 0 && slot < 8192) { k3m_where_buf[2 * slot] = hw; k3m_where_buf[2 * slot + 1] = xcc; }
     }
 #endif
 

@@ -110,6 +110,25 @@ int main(int argc, char **argv) {
                "K loop %.1f us; board power median %.0f W (min %.0f, max %.0f; %zu samples), hwmon sclk median %.0f MHz\n",
                mode, M, K, N, launches, seconds, last_ms * 1e3 / 50, ghz.size(), med(ghz), ghz.empty() ? -1 : ghz[ghz.size() / 10], ghz.empty() ? -1 : ghz[ghz.size() * 9 / 10],
                med(loop_us), med(P2), P2.empty() ? -1 : P2.front(), P2.empty() ? -1 : P2.back(), P2.size(), med(F2));
+        if (rnd) {                     // (r4) ... and WHERE the slow ones ran: K loop by XCD, by wave slot of the SIMD (0 = the older workgroup of the CU), by SIMD
+            std::vector<unsigned> wh(8192 * 2);
+            CK(hipMemcpyFromSymbol(wh.data(), HIP_SYMBOL(k3m_where_buf), wh.size() * 4));
+            auto report = [&](const char *what, int nkeys, auto key) {
+                printf("       K loop median by %s:", what);
+                for (int k = 0; k < nkeys; ++k) {
+                    std::vector<double> v;
+                    for (int i = 0; i < 8192; ++i) if (t[2 * i + 1] > 0 && key(wh[2 * i], wh[2 * i + 1]) == k) v.push_back(t[2 * i + 1] * 0.01);
+                    std::sort(v.begin(), v.end());
+                    if (!v.empty()) printf("  %d: %.1f (%zu)", k, v[v.size() / 2], v.size());
+                }
+                printf("\n");
+            };
+            report("XCD", 8, [](unsigned, unsigned xcc) { return (int)(xcc & 15); });
+            report("wave slot", 4, [](unsigned hw, unsigned) { return (int)(hw & 15); });
+            report("SIMD", 4, [](unsigned hw, unsigned) { return (int)((hw >> 4) & 3); });
+            report("shader engine", 8, [](unsigned hw, unsigned) { return (int)((hw >> 13) & 7); });
+            report("CU in its array", 16, [](unsigned hw, unsigned) { return (int)((hw >> 8) & 15); });
+        }
         if (!loop_us.empty())          // (r4) how far apart the waves finish their K loops: two workgroups share a CU, one wave of each per SIMD
             printf("       K loop per wave: min %.1f  p10 %.1f  p25 %.1f  median %.1f  p75 %.1f  p90 %.1f  max %.1f us\n", loop_us.front(), loop_us[loop_us.size() / 10],
                    loop_us[loop_us.size() / 4], med(loop_us), loop_us[loop_us.size() * 3 / 4], loop_us[loop_us.size() * 9 / 10], loop_us.back());
