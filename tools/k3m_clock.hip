@@ -124,6 +124,14 @@ int main(int argc, char **argv) {
                 printf("\n");
             };
             report("XCD", 8, [](unsigned, unsigned xcc) { return (int)(xcc & 15); });
+            printf("       in-kernel clock median by XCD (GHz):");
+            for (int k = 0; k < 8; ++k) {
+                std::vector<double> v;
+                for (int i = 0; i < 8192; ++i) if (t[2 * i + 1] > 0 && (int)(wh[2 * i + 1] & 15) == k) v.push_back((double)t[2 * i] / (double)t[2 * i + 1] * 0.1);
+                std::sort(v.begin(), v.end());
+                if (!v.empty()) printf("  %d: %.3f", k, v[v.size() / 2]);
+            }
+            printf("\n");
             report("wave slot", 4, [](unsigned hw, unsigned) { return (int)(hw & 15); });
             report("SIMD", 4, [](unsigned hw, unsigned) { return (int)((hw >> 4) & 3); });
             report("shader engine", 8, [](unsigned hw, unsigned) { return (int)((hw >> 13) & 7); });
