@@ -6,4 +6,5 @@ timeout -k 10 400 python tools/sweep_parity.py 11 300 > gpurun_out/val_sweep_par
 timeout -k 10 400 python tools/sweep_parity.py 12 300 > gpurun_out/val_sweep_parity_b.log 2>&1 || exit 3
 timeout -k 10 300 python tools/sweep_push.py 5 200 > gpurun_out/val_sweep_push.log 2>&1 || exit 4
 timeout -k 10 300 python tools/sweep_epilogue.py 5 200 > gpurun_out/val_sweep_epi.log 2>&1 || exit 5
+timeout -k 10 600 python tools/sweep_k3p.py 7 150 > gpurun_out/val_sweep_k3p.log 2>&1 || exit 6
 echo ok
