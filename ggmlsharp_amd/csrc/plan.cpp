@@ -31,11 +31,18 @@ bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LD
 bool q8_small_serves(int type, int64_t K, int64_t N) {
     return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 / Q5_1 / Q4_1, 257..512 rows, 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type, N and K alone
-// (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against 58; beyond
-// K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
+// Q8_0 / Q5_0 / Q5_1 (257..2048 rows) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
+// 58; beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
+// r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
+// one round of the chip (A/B in one gpurun call, staged | K3p): Q8_0 4096 x 11008 x 1024 165 | 131 us, x 2048 320 | 257, 8192 x 8192 x 1024
+// 249 | 183, Q5_0 4096 x 4096 x 2048 125 | 102, Q5_1 4096 x 11008 x 2048 421 | 274; it loses from 4096 rows on (4096^3 195 | 219) and on a
+// vocabulary-sized matrix (32000 x 4096 x 2048 797 | 839: accepted, the choice may not look at M); Q4_1 (whose staged form is the MX
+// kernel) wins up to 1024 rows (4096 x 11008 x 1024 163 | 138) and loses at 2048 (112 | 126).
 bool q8_mid_serves(int type, int64_t K, int64_t N) {
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= 512 &&
+    static const int nmax = dev_env_int("GGML_HIP_K3P_NMAX", 0);   // developer A/B switch
+    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : 2048;
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }
 
@@ -57,7 +64,7 @@ void plan_set_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 
 //   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q5_1 / Q8_0 on prompt-sized batches (N <= 512, K split in the
 //                workgroup) and from 1024 rows up,
 //   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q4_2, and Q5_0 / Q5_1 / Q8_0 in between,
-//   gemm_qmp.hip / gemm_q8s.hip -- the stage-free forms (257..512 rows; Q8_0 5..64 rows).
+//   gemm_qmp.hip / gemm_q8s.hip -- the stage-free forms (257..512 rows, the int8 types up to 2048; Q8_0 5..64 rows).
 // ggml_hip_debug_force_gemm forces one (test / developer switch; the product library reads no environment variable: GGML_HIP_GEMM is
 // honoured by -DGGML_HIP_DEV builds only).  Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images, 3 = the bf6 image;
 // 0 + ACT_IMAGE_MIN_PIECES (64) = the int8 planes and the min-term piece planes (K3p-int8 behind a Q5_1 / Q4_1 / Q5_K weight).
