@@ -227,6 +227,11 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
         const int64_t t64 = cdiv(M, 64) * cdiv(N, 64);
         return take(var == 23 || (var != 24 && t64 <= 256) ? MXF_S4_H64 : MXF_S2V2_H64);
     }
+    // developer A/B switch.  r4, K3p-MX above 512 rows against the staged MX forms, staged | K3p: 4096 x 4096 x 1024 51.7 | 55.7 us, x 2048 84.5 |
+    // 109.5, 4096 x 11008 x 1024 128.8 | 126.6, 11008 x 4096 x 1024 132.4 | 152.9, 8192 x 8192 x 1024 163 | 186: the staged forms keep that range
+    // (the int8 types' staged forms do not: q8_mid_serves)
+    static const int k3p_nmax = dev_env_int("GGML_HIP_K3P_MX_NMAX", 512);
+    if (q40 && N > 512 && N <= k3p_nmax && nbk >= 64 && plan_k3p_mx(p, M, Mpad, K, N)) return;
     if (N <= 512 && nbk >= 8 && var != 3) {
         // 257 .. 512 rows, K >= 2048, Q4_0: K3p (gemm_qmp.hip).  By N and K alone (GGML_HIP_K3P=1: the staged form, A/B).
         if (q40) {
