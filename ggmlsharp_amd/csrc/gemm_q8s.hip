@@ -1,4 +1,4 @@
-// gemm_q8s.hip -- K3s-i8: Q8_0 batches of 5 .. 64 rows on the int8 matrix cores, the stage-free form of gemm_qmx.hip K3s.
+// gemm_q8s.hip -- K3s-i8: Q8_0 (r4: and Q5_0) batches of 5 .. 64 rows on the int8 matrix cores, the stage-free form of gemm_qmx.hip K3s.
 // (Its own translation unit for its compile flags: with SLP vectorization the packed f32 forms of the scale-accumulate want
 // aligned register tuples across the loop over K and the looped kernels spill -- 256 registers + 0.1 .. 1.4 KB of scratch against
 // 119 registers without it; Makefile FLAGS_gemm_q8s.hip.)
@@ -29,7 +29,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 // a wave requests its first NB blocks before anything else (K <= 4096: all of them; longer K: round after round), keeps its
 // slice of the row scales in its own LDS slice; the waves' sums are added in wave order, every wave taking its share of the rows.
 // Arithmetic per block as in the kernel above: acc = fma((float)sumi, d1 * d0, acc) (Ggml.cs:1377-1378).
-template <int KS, int NB, bool ROT, int WMT>
+template <int KS, int NB, bool ROT, int WMT, bool Q5 = false>
 __device__ __forceinline__
 void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                         float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
@@ -105,7 +105,9 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
 #pragma unroll
             for (int k = 0; k < WMT; ++k)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[k][4 * q + e] = fmaf((float)t[k][4 * q + e], da[e] * dw[k], acc[k][4 * q + e]);
+                for (int e = 0; e < 4; ++e)
+                    if constexpr (Q5) acc[k][4 * q + e] = fmaf(dw[k] * (float)t[k][4 * q + e], da[e], acc[k][4 * q + e]);      // (d * sxy) * y.d, Ggml.cs:1296-1298
+                    else acc[k][4 * q + e] = fmaf((float)t[k][4 * q + e], da[e] * dw[k], acc[k][4 * q + e]);                    // Ggml.cs:1377-1378
         }
     };
     if constexpr (!ROT) {
@@ -150,12 +152,12 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     }
 }
 
-template <int KS, int NB, bool ROT, int WMT>
+template <int KS, int NB, bool ROT, int WMT, bool Q5>
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                           float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
                           uint32_t w_bytes, uint32_t a_bytes) {
-    gemm_q8_small_body<KS, NB, ROT, WMT>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
+    gemm_q8_small_body<KS, NB, ROT, WMT, Q5>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
 }
 
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
@@ -227,7 +229,11 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     const int nbkp = (int)pad_kblocks(w->nbk);
     const int nloc = pl.nloc, wmt = pl.wmt;
     const int ncol = (int)((N + 31) / 32);
-    if (pl.family != MMF_K3S_I8 || w->type != GGML_TYPE_Q8_0 || !w->qs || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
+    // r4: Q5_0 too -- its int8 operand planes (ggml_hip_weight::i8p, built at upload for K3p) have Q8_0's layout; only the order of the two
+    // scale multiplications differs.  (It ran the staged f16 forms here: 4096 x 4096 x 64 16.3 us against Q8_0's 7.8.)
+    const bool q5 = w->type == GGML_TYPE_Q5_0;
+    const uint8_t *planes = q5 ? w->i8p : w->qs;
+    if (pl.family != MMF_K3S_I8 || !(q5 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
@@ -237,13 +243,14 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     const int lds = tab > xch ? tab : xch;
     dim3 grid((unsigned)(ntw * ncol));
     (void)hipGetLastError();                                // (the value returned below is this launch's, not an earlier call's)
-#define Q8S_GO(NB, ROT, WMT) do { \
-        auto kern = gemm_q8_small_kernel<KS, NB, ROT, WMT>; \
+#define Q8S_GO1(NB, ROT, WMT, Q5) do { \
+        auto kern = gemm_q8_small_kernel<KS, NB, ROT, WMT, Q5>; \
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
-        kern<<<grid, KS * 64, lds, st>>>(w->qs, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw, \
+        kern<<<grid, KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw, \
                                       (uint32_t)wq_bytes, (uint32_t)aq_bytes); } while (0)
+#define Q8S_GO(NB, ROT, WMT) do { if (q5) Q8S_GO1(NB, ROT, WMT, true); else Q8S_GO1(NB, ROT, WMT, false); } while (0)
     // one tile per workgroup: a wave's range in 8 / 16 slots, longer K in rounds of 16; two tiles (more than 256 tile groups): 8 slots,
     // in rounds beyond K = 2048
     if (wmt == 2) { if (nloc <= 8) Q8S_GO(8, false, 2); else Q8S_GO(8, true, 2); }
@@ -251,6 +258,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     else if (nloc <= 16) Q8S_GO(16, false, 1);
     else Q8S_GO(16, true, 1);
 #undef Q8S_GO
+#undef Q8S_GO1
     return hipGetLastError();
 }
 

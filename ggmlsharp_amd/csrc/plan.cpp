@@ -27,9 +27,9 @@ int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return
 constexpr int K3P_LDS = 160 * 1024;
 bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LDS; }               // the waves' row-scale tables
 
-// Q8_0, 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
+// Q8_0 (r4: and Q5_0, on its int8 operand planes), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
 bool q8_small_serves(int type, int64_t K, int64_t N) {
-    return type == GGML_TYPE_Q8_0 && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 / Q5_1 (257..2048 rows) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
@@ -109,7 +109,7 @@ void plan_gemv(mm_plan &p, int type, int64_t M, int64_t K, int64_t N, bool fused
     if (fused && N >= 1 && N <= 4) p.flags |= MM_FLAG_EPILOGUE_FUSED;
 }
 
-bool plan_k3s_i8(mm_plan &p, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
+bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
     const int nbkp = (int)pad_kblocks(K / QK);
     const int nloc = (int)cdiv(nbkp, KS8);
     const int ncol = (int)cdiv(N, 32);
@@ -120,7 +120,7 @@ bool plan_k3s_i8(mm_plan &p, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
     const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : t32 <= 256 ? 1 : 2;
     p.family = MMF_K3S_I8; p.image = 0;
     p.form = wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
-    p.arith = 200; p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;
+    p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
     p.nloc = nloc; p.wmt = wmt;
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
@@ -373,7 +373,7 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     int kind = wide ? 0 : plan_image_kind(type, K, N);
     bool no_fused = false;
     if (q8_small_serves(type, K, N) && ext_type == 0) {
-        if (plan_k3s_i8(p, M, Mpad, K, N)) { p.flags |= MM_FLAG_NEEDS_WORK; return p; }
+        if (plan_k3s_i8(p, type, M, Mpad, K, N)) { p.flags |= MM_FLAG_NEEDS_WORK; return p; }
         wide = true; kind = 0; no_fused = true;             // (its planes are beyond the form's offsets: the two-step forms below)
     }
     if (q8_mid_serves(type, K, N)) {                        // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)
