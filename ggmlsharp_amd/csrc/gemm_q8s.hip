@@ -29,11 +29,11 @@ __device__ __forceinline__ void static_for(F &&f) {
 // a wave requests its first NB blocks before anything else (K <= 4096: all of them; longer K: round after round), keeps its
 // slice of the row scales in its own LDS slice; the waves' sums are added in wave order, every wave taking its share of the rows.
 // Arithmetic per block as in the kernel above: acc = fma((float)sumi, d1 * d0, acc) (Ggml.cs:1377-1378).
-template <int KS, int NB, bool ROT, int WMT, bool Q5 = false>
+template <int KS, int NB, bool ROT, int WMT, bool Q5 = false, bool MINT = false>
 __device__ __forceinline__
 void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                         float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
-                        uint32_t w_bytes, uint32_t a_bytes, int wg) {
+                        uint32_t w_bytes, uint32_t a_bytes, int wg, const uint8_t *__restrict__ mp3 = nullptr, const uint8_t *__restrict__ sp3 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -90,6 +90,41 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (r4, Q5_1) the min terms m * (s0 + s1) of sixteen k-blocks of a tile as one K = 16 product on the bf16 cores, in front of the wave's
+    // blocks -- gemm_qmp.hip's min-term product on this kernel's tiles: both operands as bf16 pieces that sum to the f32 value exactly
+    // (ggml_hip_weight::mp3 from the upload, act_planes::sp3 = d1 * (float)sum(a) from K1), a Q5_1 min is an f16 value (two pieces, five
+    // products); chunk c (k-blocks 16c .. 16c + 15, k-group 2c + lane half) is wave c % KS's, by K alone.
+    if constexpr (MINT) {
+        using f32x16 = __attribute__((ext_vector_type(16))) float;
+        using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+        const int nchunks = (nbk + 15) / 16;
+        const __amdgpu_buffer_rsrc_t rMP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mp3), 0, (int)((uint32_t)(nchunks * 6) * (uint32_t)Mpad * 16u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sp3), 0, (int)((uint32_t)(nchunks * 6) * (uint32_t)Npad * 16u), 0x00020000);
+        const uint32_t vM = (uint32_t)((3 * hh) * Mpad + m0 + l31) * 16u, vS = (uint32_t)((3 * hh) * Npad + n0 + l31) * 16u;
+        for (int c = wave; c < nchunks; c += KS) {
+            i32x4 sa[3], mb[WMT][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                if (pc < 2)
+#pragma unroll
+                    for (int t = 0; t < WMT; ++t)
+                        mb[t][pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rMP, (int)(vM + 512u * t), (int)((uint32_t)(6 * c + pc) * (uint32_t)Mpad * 16u), 0));
+                sa[pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rSP, (int)vS, (int)((uint32_t)(6 * c + pc) * (uint32_t)Npad * 16u), 0));
+            }
+            constexpr int PA[5] = {2, 1, 1, 0, 0}, PB[5] = {0, 1, 0, 1, 0};   // smallest products first (activation piece x weight piece)
+#pragma unroll
+            for (int t = 0; t < WMT; ++t) {
+                f32x16 a;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = acc[t][r];
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[PA[k]]), __builtin_bit_cast(bf16x8, mb[t][PB[k]]), a, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = a[r];
+            }
+        }
+    }
 
     auto block = [&](int i, auto uc) {                      // block i of the wave out of slot u
         constexpr int u = decltype(uc)::value;
@@ -152,12 +187,12 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     }
 }
 
-template <int KS, int NB, bool ROT, int WMT, bool Q5>
+template <int KS, int NB, bool ROT, int WMT, int TY>       // TY: 0 Q8_0, 1 Q5_0, 2 Q5_1 (Q5_0's block term + the min-term product)
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                           float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
-                          uint32_t w_bytes, uint32_t a_bytes) {
-    gemm_q8_small_body<KS, NB, ROT, WMT, Q5>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
+                          uint32_t w_bytes, uint32_t a_bytes, const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3) {
+    gemm_q8_small_body<KS, NB, ROT, WMT, TY != 0, TY == 2>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x, mp3, sp3);
 }
 
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
@@ -231,9 +266,12 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     const int ncol = (int)((N + 31) / 32);
     // r4: Q5_0 too -- its int8 operand planes (ggml_hip_weight::i8p, built at upload for K3p) have Q8_0's layout; only the order of the two
     // scale multiplications differs.  (It ran the staged f16 forms here: 4096 x 4096 x 64 16.3 us against Q8_0's 7.8.)
-    const bool q5 = w->type == GGML_TYPE_Q5_0;
+    // ... and Q5_1 (9 .. 64 rows): Q5_0's block term on planes of the unsigned values + the min-term product in front of the blocks
+    // (4096 x 4096 x 64 17.3 us on the staged forms, 4096 x 11008 x 32 36.4).
+    const bool q51 = w->type == GGML_TYPE_Q5_1, q5 = w->type == GGML_TYPE_Q5_0 || q51;
     const uint8_t *planes = q5 ? w->i8p : w->qs;
     if (pl.family != MMF_K3S_I8 || !(q5 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
+    if (q51 && (!w->mp3 || !p.sp3 || w->ext_type != 0)) return hipErrorInvalidValue;
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
@@ -243,14 +281,14 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     const int lds = tab > xch ? tab : xch;
     dim3 grid((unsigned)(ntw * ncol));
     (void)hipGetLastError();                                // (the value returned below is this launch's, not an earlier call's)
-#define Q8S_GO1(NB, ROT, WMT, Q5) do { \
-        auto kern = gemm_q8_small_kernel<KS, NB, ROT, WMT, Q5>; \
+#define Q8S_GO1(NB, ROT, WMT, TY) do { \
+        auto kern = gemm_q8_small_kernel<KS, NB, ROT, WMT, TY>; \
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<grid, KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw, \
-                                      (uint32_t)wq_bytes, (uint32_t)aq_bytes); } while (0)
-#define Q8S_GO(NB, ROT, WMT) do { if (q5) Q8S_GO1(NB, ROT, WMT, true); else Q8S_GO1(NB, ROT, WMT, false); } while (0)
+                                      (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->mp3, p.sp3); } while (0)
+#define Q8S_GO(NB, ROT, WMT) do { if (q51) Q8S_GO1(NB, ROT, WMT, 2); else if (q5) Q8S_GO1(NB, ROT, WMT, 1); else Q8S_GO1(NB, ROT, WMT, 0); } while (0)
     // one tile per workgroup: a wave's range in 8 / 16 slots, longer K in rounds of 16; two tiles (more than 256 tile groups): 8 slots,
     // in rounds beyond K = 2048
     if (wmt == 2) { if (nloc <= 8) Q8S_GO(8, false, 2); else Q8S_GO(8, true, 2); }

@@ -29,7 +29,8 @@ bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LD
 
 // Q8_0 (r4: and Q5_0, on its int8 operand planes), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
 bool q8_small_serves(int type, int64_t K, int64_t N) {
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N >= 5 && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
+    // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1) && N >= (type == GGML_TYPE_Q5_1 ? 9 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 / Q5_1 (257..2048 rows) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
@@ -72,7 +73,7 @@ void plan_set_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 
 int plan_image_kind(int type, int64_t K, int64_t N) {
     const int force = plan_force_gemm();
     if (q8_mid_serves(type, K, N)) return min_type(type) ? ACT_IMAGE_MIN_PIECES : 0;   // (image 0 + the min-term piece planes)
-    if (q8_small_serves(type, K, N)) return 0;
+    if (q8_small_serves(type, K, N)) return min_type(type) ? ACT_IMAGE_MIN_PIECES : 0;
     if (N <= 4 || force == 1) return 0;
     // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
     // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them
@@ -119,8 +120,9 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     const int64_t t32 = cdiv(M, 32) * ncol;
     const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : t32 <= 256 ? 1 : 2;
     p.family = MMF_K3S_I8; p.image = 0;
+    if (type == GGML_TYPE_Q5_1) p.flags |= MM_FLAG_MIN_PIECES;
     p.form = wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
-    p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
+    p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : type == GGML_TYPE_Q5_1 ? 2 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
     p.nloc = nloc; p.wmt = wmt;
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;

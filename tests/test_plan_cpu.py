@@ -85,6 +85,16 @@ def test_baseline_configs_get_the_kernels_design_md_names():
         # the min-term types: INIT writes image 0 AND the bf16 piece planes of d * sum (kind 0 + 64); the others plain image 0
         assert bool(p.flags & MIN_PIECES) == (t in (Q5_1, Q4_1, Q5_K)) and p.image_kind == (64 if t in (Q5_1, Q4_1, Q5_K) else 0), t
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
+    # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
+    assert plan(Q5_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 32).image_kind == 0
+    p = plan(Q5_1, 4096, 4096, 32)
+    assert p.family == FAM["k3s_i8"] and p.image_kind == 64 and (p.flags & MIN_PIECES)
+    assert plan(Q5_1, 4096, 4096, 8).family == FAM["gemv_fused"]                    # (up to 8 rows its fused mat-vec is as fast)
+    assert len({plan(t, 4096, 4096, 32).tree_id for t in (Q8_0, Q5_0, Q5_1)}) == 3   # three different arithmetics, three trees
+    # r4: K3p serves the int8 types up to 2048 rows, Q4_1 up to 1024; Q4_0 (MX) up to 512
+    assert plan(Q8_0, 4096, 11008, 2048).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 11008, 2049).family != FAM["k3p_i8"]
+    assert plan(Q4_1, 4096, 4096, 1024).family == FAM["k3p_i8"] and plan(Q4_1, 4096, 4096, 1025).family == FAM["mx"]
+    assert plan(Q4_0, 4096, 4096, 513).family == FAM["mx"]
     assert plan(Q8_0, 4096, 22016, 512).family == FAM["f16"]        # K > 20480: the eight scale tables do not fit LDS (decided in the plan)
     assert plan(F16, 4096, 4096, 4096).family == FAM["dense16"] and plan(F32, 4096, 4096, 4096).family == FAM["dense32"]
     assert plan(F32, 64, 128, 256).family == FAM["dense"]           # config 1 (Test1-style f32 64 x 128 x 256)
