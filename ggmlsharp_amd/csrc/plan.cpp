@@ -32,7 +32,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1) && N >= (type == GGML_TYPE_Q5_1 ? 9 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 / Q5_1 (257..2048 rows) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// Q8_0 / Q5_0 (257..2048 rows), Q5_1 (257 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
 // 58; beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
 // r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
@@ -42,7 +42,10 @@ bool q8_small_serves(int type, int64_t K, int64_t N) {
 // kernel) wins up to 1024 rows (4096 x 11008 x 1024 163 | 138) and loses at 2048 (112 | 126).
 bool q8_mid_serves(int type, int64_t K, int64_t N) {
     static const int nmax = dev_env_int("GGML_HIP_K3P_NMAX", 0);   // developer A/B switch
-    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : 2048;
+    // (Q5_1 -- and Q5_K, which lives as Q5_1 -- has no upper bound: its staged form pays the min term per block in the loop, and the
+    // stage-free form with the min terms as a product of their own beats it at every size looked at: 4096^3 299 | 243 us, 4096 x 11008 x 4096
+    // 734 | 548, 11008 x 4096 x 4096 932 | 614, 32000 x 4096 x 4096 2527 | 1774, 4096 x 4096 x 8192 597 | 451)
+    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 2048;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }

@@ -95,6 +95,7 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q8_0, 4096, 11008, 2048).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 11008, 2049).family != FAM["k3p_i8"]
     assert plan(Q4_1, 4096, 4096, 1024).family == FAM["k3p_i8"] and plan(Q4_1, 4096, 4096, 1025).family == FAM["mx"]
     assert plan(Q4_0, 4096, 4096, 513).family == FAM["mx"]
+    assert plan(Q5_1, 4096, 4096, 4096).family == FAM["k3p_i8"] and plan(Q5_K, 4096, 11008, 8192).family == FAM["k3p_i8"]   # (Q5_1 / Q5_K: no upper bound)
     assert plan(Q8_0, 4096, 22016, 512).family == FAM["f16"]        # K > 20480: the eight scale tables do not fit LDS (decided in the plan)
     assert plan(F16, 4096, 4096, 4096).family == FAM["dense16"] and plan(F32, 4096, 4096, 4096).family == FAM["dense32"]
     assert plan(F32, 64, 128, 256).family == FAM["dense"]           # config 1 (Test1-style f32 64 x 128 x 256)
