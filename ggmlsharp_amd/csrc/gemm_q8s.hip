@@ -29,7 +29,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 // a wave requests its first NB blocks before anything else (K <= 4096: all of them; longer K: round after round), keeps its
 // slice of the row scales in its own LDS slice; the waves' sums are added in wave order, every wave taking its share of the rows.
 // Arithmetic per block as in the kernel above: acc = fma((float)sumi, d1 * d0, acc) (Ggml.cs:1377-1378).
-template <int KS, int NB, bool ROT, int WMT, bool Q5 = false, bool MINT = false>
+template <int KS, int NB, bool ROT, int WMT, bool Q5 = false, int MINT = 0>     // MINT: bf16 pieces of the weight's min (0: no min term; 2: Q5_1; 3: Q5_K)
 __device__ __forceinline__
 void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                         float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
@@ -102,24 +102,26 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
         const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sp3), 0, (int)((uint32_t)(nchunks * 6) * (uint32_t)Npad * 16u), 0x00020000);
         const uint32_t vM = (uint32_t)((3 * hh) * Mpad + m0 + l31) * 16u, vS = (uint32_t)((3 * hh) * Npad + n0 + l31) * 16u;
         for (int c = wave; c < nchunks; c += KS) {
-            i32x4 sa[3], mb[WMT][2];
+            i32x4 sa[3], mb[WMT][MINT ? MINT : 1];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
-                if (pc < 2)
+                if (pc < MINT)
 #pragma unroll
                     for (int t = 0; t < WMT; ++t)
                         mb[t][pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rMP, (int)(vM + 512u * t), (int)((uint32_t)(6 * c + pc) * (uint32_t)Mpad * 16u), 0));
                 sa[pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rSP, (int)vS, (int)((uint32_t)(6 * c + pc) * (uint32_t)Npad * 16u), 0));
             }
-            constexpr int PA[5] = {2, 1, 1, 0, 0}, PB[5] = {0, 1, 0, 1, 0};   // smallest products first (activation piece x weight piece)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first (activation piece x weight piece)
 #pragma unroll
             for (int t = 0; t < WMT; ++t) {
                 f32x16 a;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] = acc[t][r];
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[PA[k]]), __builtin_bit_cast(bf16x8, mb[t][PB[k]]), a, 0, 0, 0);
+                static_for<6>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (PB[k] < MINT)             // (a Q5_1 min is an f16 value: two pieces, five products; Q5_K's is an f32 product: three, six)
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[PA[k]]), __builtin_bit_cast(bf16x8, mb[t][PB[k]]), a, 0, 0, 0);
+                });
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = a[r];
             }
@@ -187,12 +189,12 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     }
 }
 
-template <int KS, int NB, bool ROT, int WMT, int TY>       // TY: 0 Q8_0, 1 Q5_0, 2 Q5_1 (Q5_0's block term + the min-term product)
+template <int KS, int NB, bool ROT, int WMT, int TY>       // TY: 0 Q8_0, 1 Q5_0, 2 Q5_1 (Q5_0's block term + the min-term product), 3 Q5_K in the Q5_1 form (three min pieces)
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                           float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
                           uint32_t w_bytes, uint32_t a_bytes, const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3) {
-    gemm_q8_small_body<KS, NB, ROT, WMT, TY != 0, TY == 2>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x, mp3, sp3);
+    gemm_q8_small_body<KS, NB, ROT, WMT, TY != 0, (TY >= 2 ? TY : 0)>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x, mp3, sp3);
 }
 
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
@@ -271,7 +273,8 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     const bool q51 = w->type == GGML_TYPE_Q5_1, q5 = w->type == GGML_TYPE_Q5_0 || q51;
     const uint8_t *planes = q5 ? w->i8p : w->qs;
     if (pl.family != MMF_K3S_I8 || !(q5 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
-    if (q51 && (!w->mp3 || !p.sp3 || w->ext_type != 0)) return hipErrorInvalidValue;
+    if (q51 && (!w->mp3 || !p.sp3)) return hipErrorInvalidValue;
+    const bool q5k = q51 && w->ext_type != 0;               // (the Q5_K extension: activations by the Q8_K rule, three min pieces)
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
@@ -288,7 +291,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
         if (attr != hipSuccess) return attr; \
         kern<<<grid, KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw, \
                                       (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->mp3, p.sp3); } while (0)
-#define Q8S_GO(NB, ROT, WMT) do { if (q51) Q8S_GO1(NB, ROT, WMT, 2); else if (q5) Q8S_GO1(NB, ROT, WMT, 1); else Q8S_GO1(NB, ROT, WMT, 0); } while (0)
+#define Q8S_GO(NB, ROT, WMT) do { if (q5k) Q8S_GO1(NB, ROT, WMT, 3); else if (q51) Q8S_GO1(NB, ROT, WMT, 2); else if (q5) Q8S_GO1(NB, ROT, WMT, 1); else Q8S_GO1(NB, ROT, WMT, 0); } while (0)
     // one tile per workgroup: a wave's range in 8 / 16 slots, longer K in rounds of 16; two tiles (more than 256 tile groups): 8 slots,
     // in rounds beyond K = 2048
     if (wmt == 2) { if (nloc <= 8) Q8S_GO(8, false, 2); else Q8S_GO(8, true, 2); }

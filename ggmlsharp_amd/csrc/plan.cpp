@@ -377,8 +377,8 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     bool wide = (nba + K_LOOKAHEAD) * (uint64_t)Mpad * 32 > LIM32;
     int kind = wide ? 0 : plan_image_kind(type, K, N);
     bool no_fused = false;
-    if (q8_small_serves(type, K, N) && ext_type == 0) {
-        if (plan_k3s_i8(p, type, M, Mpad, K, N)) { p.flags |= MM_FLAG_NEEDS_WORK; return p; }
+    if (q8_small_serves(type, K, N)) {                      // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
+        if (plan_k3s_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
         wide = true; kind = 0; no_fused = true;             // (its planes are beyond the form's offsets: the two-step forms below)
     }
     if (q8_mid_serves(type, K, N)) {                        // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)

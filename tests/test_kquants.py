@@ -164,7 +164,9 @@ def test_mul_mat_q5_K_matches_the_restatement(dev):
     import torch
     for (M, K, N) in ((96, 256, 1), (300, 1024, 3), (128, 512, 8), (515, 768, 40), (256, 2048, 130), (640, 1024, 300),
                       (130, 512, 600), (257, 768, 1100),
-                      (200, 2048, 300), (130, 4352, 512)):      # r4: K3p on the int8 planes of the planar Q5_1 form (257..512 rows, K >= 2048)
+                      (200, 2048, 300), (130, 4352, 512),       # r4: K3p on the int8 planes of the planar Q5_1 form (from 257 rows, K >= 2048)
+                      (200, 2048, 1100), (130, 2304, 2500),      #     ... which has no upper bound for this type
+                      (300, 2048, 33), (130, 4352, 64), (515, 2304, 9)):   # r4: the batched-decode form K3s-int8 (9..64 rows, K >= 2048)
         for raw in (False, True):
             rows = _random_blocks(M * K // 256).reshape(M, -1) if raw else KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
             x = _rand((N, K))
@@ -174,6 +176,12 @@ def test_mul_mat_q5_K_matches_the_restatement(dev):
             _close(got, ref, f"Q5_K {M}x{K}x{N} raw={raw}", K)
     # a row shard is bitwise a column slice of the whole (the multi-GPU promise holds for the extension too)
     M, K, N = 300, 1024, 70
+    rows = KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
+    xd = torch.from_numpy(_rand((N, K))).cuda()
+    whole = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K), xd)
+    part = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K, row_begin=100, row_end=260), xd)
+    assert torch.equal(part, whole[:, 100:260])
+    M, K, N = 300, 2048, 40                                # ... in the batched-decode form as well
     rows = KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
     xd = torch.from_numpy(_rand((N, K))).cuda()
     whole = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K), xd)
