@@ -432,7 +432,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         off_gs = total; total += (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (plan_force_gemm() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
-        if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
+        if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q4_2) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
         // the min plane as three bf16 pieces (K3p-int8's min-term product): whole pairs of k-groups, zero past the end of K
         if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_mp = total; total += (size_t)((w->nbk + 15) / 16 * 2 * 3) * w->Mpad * 16; }
         if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
@@ -459,7 +459,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         w->gs = (uint32_t *)((uint8_t *)base + off_gs);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
         if (q5k) w->khdr = (uint8_t *)base + off_kh;
-        if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) w->i8p = (uint8_t *)base + off_i8;
+        if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q4_2) w->i8p = (uint8_t *)base + off_i8;
         if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) w->mp3 = (uint8_t *)base + off_mp;
     }
     *out = w;

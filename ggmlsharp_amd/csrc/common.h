@@ -61,7 +61,7 @@ struct ggml_hip_weight {
     uint8_t *q6a;     // bf6 (e3m2) digit codes, [nbk][NF][Mpad][16 B] = the first 16 bytes of each 24-byte MFMA fragment
     uint8_t *q6b;     //   (element e at bits [6e, 6e+5]) and [nbk][NF][Mpad][8 B] = the last 8; NF = 1 (Q4_0, Q4_1: nib - 8)
                       //   or 2 (Q5_0, Q8_0: w = 16 * wh + wl, fragment 0 = wl, fragment 1 = wh) -- gemm_qmx.hip
-    uint8_t *i8p;     // Q5_0 / Q5_1 / Q4_1 (the latter two unsigned, no - 16): int8 operand planes of the int8 matrix cores, [nbk][2][Mpad][16 B] like Q8_0's qs -- plane h byte j =
+    uint8_t *i8p;     // Q5_0 / Q5_1 / Q4_1 (the latter two unsigned, no - 16; r4: Q4_2 too, nib - 8): int8 operand planes of the int8 matrix cores, [nbk][2][Mpad][16 B] like Q8_0's qs -- plane h byte j =
                       //   element 2j + h, value (nib | bit << 4) - 16 (Ggml.cs:1285-1289); built once at upload (layout.hip), 1 B / weight
                       //   beside the 0.69 B / weight of the format, for prompt-sized batches (gemm_qmp.hip)
     void    *dense;

@@ -29,11 +29,12 @@ __device__ __forceinline__ void static_for(F &&f) {
 // a wave requests its first NB blocks before anything else (K <= 4096: all of them; longer K: round after round), keeps its
 // slice of the row scales in its own LDS slice; the waves' sums are added in wave order, every wave taking its share of the rows.
 // Arithmetic per block as in the kernel above: acc = fma((float)sumi, d1 * d0, acc) (Ggml.cs:1377-1378).
-template <int KS, int NB, bool ROT, int WMT, bool Q5 = false, int MINT = 0>     // MINT: bf16 pieces of the weight's min (0: no min term; 2: Q5_1; 3: Q5_K)
+template <int KS, int NB, bool ROT, int WMT, bool Q5 = false, int MINT = 0, bool Q42 = false>     // MINT: bf16 pieces of the weight's min (0: no min term; 2: Q5_1; 3: Q5_K); Q42: two 16-element blocks per k-block
 __device__ __forceinline__
 void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                         float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
-                        uint32_t w_bytes, uint32_t a_bytes, int wg, const uint8_t *__restrict__ mp3 = nullptr, const uint8_t *__restrict__ sp3 = nullptr) {
+                        uint32_t w_bytes, uint32_t a_bytes, int wg, const uint8_t *__restrict__ mp3 = nullptr, const uint8_t *__restrict__ sp3 = nullptr,
+                        const float *__restrict__ wm = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -44,13 +45,14 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     // its table row is zero, so it adds (sumi * 0) = +0
     auto blk = [&](int i) { const int kb = kb0 + (i < nloc ? i : nloc - 1); return kb < nbk ? kb : nbk - 1; };
 
-    struct WB { i32x4 q[WMT]; float d[WMT]; };
+    struct WB { i32x4 q[WMT]; float d[WMT]; float m[Q42 ? WMT : 1]; };   // (Q4_2: m = the scale of the k-block's second 16-element block)
     WB wb[NB];
     i32x4 ab[NB];
     // raw buffer addressing: one 32-bit offset per lane and plane, the k-block in the scalar offset (planes past their end read 0)
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(qs), 0, (int)w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wd), 0, (int)(w_bytes / 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a8), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q42 ? wm : wd), 0, (int)(w_bytes / 8), 0x00020000);
     const uint32_t offW = (uint32_t)((hh * Mpad + m0 + l31) * 16), offD = (uint32_t)((m0 + l31) * 4), offA = (uint32_t)((hh * Npad + n0 + l31) * 16);
     const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
     auto load_blk = [&](WB &f, i32x4 &a, int i) {
@@ -60,6 +62,7 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
         for (int t = 0; t < WMT; ++t) {
             f.q[t] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(offW + 512u * t), (int)(kb * w_blk), 0));
             f.d[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(offD + 128u * t), (int)(kb * d_blk), 0));
+            if constexpr (Q42) f.m[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, (int)(offD + 128u * t), (int)(kb * d_blk), 0));
         }
     };
 
@@ -133,9 +136,36 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
         WB &w = wb[u];
         i32x16 t[WMT];
         float dw[WMT];
+        const float *dp = tabD + i * 32 + 4 * hh;
+        if constexpr (Q42) {
+            // Q4_2 (r4): a k-block is two 16-element blocks with a scale each (Ggml.cs:1217-1252): bytes 0..7 of both operand planes are the
+            // first block's elements, bytes 8..15 the second's -- one v_mfma_i32_32x32x16_i8 per half gives sumi_0 and sumi_1 apart;
+            // sumf += (d0 * yd) * sumi_0, then += (d1 * yd) * sumi_1 (its second scale rides in the m plane)
+            i32x16 t2[WMT];
+            float dm[WMT];
+            const long a_lo = (long)(uint32_t)ab[u][0] | ((long)ab[u][1] << 32), a_hi = (long)(uint32_t)ab[u][2] | ((long)ab[u][3] << 32);
+#pragma unroll
+            for (int k = 0; k < WMT; ++k) {
+                const long w_lo = (long)(uint32_t)w.q[k][0] | ((long)w.q[k][1] << 32), w_hi = (long)(uint32_t)w.q[k][2] | ((long)w.q[k][3] << 32);
+                t[k] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a_lo, w_lo, zero, 0, 0, 0);
+                t2[k] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a_hi, w_hi, zero, 0, 0, 0);
+                dw[k] = w.d[k]; dm[k] = w.m[k];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 da = *(const f32x4 *)(dp + 8 * q);
+#pragma unroll
+                for (int k = 0; k < WMT; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[k][4 * q + e] = fmaf(dw[k] * da[e], (float)t[k][4 * q + e], acc[k][4 * q + e]);
+                        acc[k][4 * q + e] = fmaf(dm[k] * da[e], (float)t2[k][4 * q + e], acc[k][4 * q + e]);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < WMT; ++k) { t[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ab[u], w.q[k], zero, 0, 0, 0); dw[k] = w.d[k]; }
-        const float *dp = tabD + i * 32 + 4 * hh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 da = *(const f32x4 *)(dp + 8 * q);
@@ -189,12 +219,13 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     }
 }
 
-template <int KS, int NB, bool ROT, int WMT, int TY>       // TY: 0 Q8_0, 1 Q5_0, 2 Q5_1 (Q5_0's block term + the min-term product), 3 Q5_K in the Q5_1 form (three min pieces)
+template <int KS, int NB, bool ROT, int WMT, int TY>       // TY: 0 Q8_0, 1 Q5_0, 2 Q5_1 (Q5_0's block term + the min-term product), 3 Q5_K in the Q5_1 form (three min pieces), 4 Q4_2 (two 16-element blocks per k-block)
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                           float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
-                          uint32_t w_bytes, uint32_t a_bytes, const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3) {
-    gemm_q8_small_body<KS, NB, ROT, WMT, TY != 0, (TY >= 2 ? TY : 0)>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x, mp3, sp3);
+                          uint32_t w_bytes, uint32_t a_bytes, const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3, const float *__restrict__ wm) {
+    gemm_q8_small_body<KS, NB, ROT, WMT, TY == 1 || TY == 2 || TY == 3, (TY == 2 || TY == 3 ? TY : 0), TY == 4>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw,
+                                                                                                     w_bytes, a_bytes, (int)blockIdx.x, mp3, sp3, wm);
 }
 
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
@@ -270,9 +301,13 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     // scale multiplications differs.  (It ran the staged f16 forms here: 4096 x 4096 x 64 16.3 us against Q8_0's 7.8.)
     // ... and Q5_1 (9 .. 64 rows): Q5_0's block term on planes of the unsigned values + the min-term product in front of the blocks
     // (4096 x 4096 x 64 17.3 us on the staged forms, 4096 x 11008 x 32 36.4).
+    // ... and Q4_2 (17 .. 64 rows; the mat-vec serves it up to 16): int8 planes of nib - 8 (built at upload, r4), two K = 16 MFMAs per block
+    // (4096 x 4096 x 32 40.3 us on the staged int8 kernel).
+    const bool q42 = w->type == GGML_TYPE_Q4_2;
     const bool q51 = w->type == GGML_TYPE_Q5_1, q5 = w->type == GGML_TYPE_Q5_0 || q51;
-    const uint8_t *planes = q5 ? w->i8p : w->qs;
-    if (pl.family != MMF_K3S_I8 || !(q5 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
+    const uint8_t *planes = q5 || q42 ? w->i8p : w->qs;
+    if (q42 && !w->m) return hipErrorInvalidValue;
+    if (pl.family != MMF_K3S_I8 || !(q5 || q42 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
     if (q51 && (!w->mp3 || !p.sp3)) return hipErrorInvalidValue;
     const bool q5k = q51 && w->ext_type != 0;               // (the Q5_K extension: activations by the Q8_K rule, three min pieces)
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
@@ -290,8 +325,8 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<grid, KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw, \
-                                      (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->mp3, p.sp3); } while (0)
-#define Q8S_GO(NB, ROT, WMT) do { if (q5k) Q8S_GO1(NB, ROT, WMT, 3); else if (q51) Q8S_GO1(NB, ROT, WMT, 2); else if (q5) Q8S_GO1(NB, ROT, WMT, 1); else Q8S_GO1(NB, ROT, WMT, 0); } while (0)
+                                      (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->mp3, p.sp3, w->m); } while (0)
+#define Q8S_GO(NB, ROT, WMT) do { if (q42) Q8S_GO1(NB, ROT, WMT, 4); else if (q5k) Q8S_GO1(NB, ROT, WMT, 3); else if (q51) Q8S_GO1(NB, ROT, WMT, 2); else if (q5) Q8S_GO1(NB, ROT, WMT, 1); else Q8S_GO1(NB, ROT, WMT, 0); } while (0)
     // one tile per workgroup: a wave's range in 8 / 16 slots, longer K in rounds of 16; two tiles (more than 256 tile groups): 8 slots,
     // in rounds beyond K = 2048
     if (wmt == 2) { if (nloc <= 8) Q8S_GO(8, false, 2); else Q8S_GO(8, true, 2); }

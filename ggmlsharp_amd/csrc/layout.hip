@@ -366,6 +366,7 @@ hipError_t launch_q5_to_i8(ggml_hip_weight *w, hipStream_t st) {
     dim3 grid((unsigned)((w->M + 255) / 256), (unsigned)w->nbk);
     if (w->type == GGML_TYPE_Q5_0) q5_to_i8_kernel<16, true><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
     else if (w->type == GGML_TYPE_Q5_1) q5_to_i8_kernel<0, true><<<grid, 256, 0, st>>>(w->qs, w->qh, w->M, w->Mpad, w->i8p);
+    else if (w->type == GGML_TYPE_Q4_2) q5_to_i8_kernel<8, false><<<grid, 256, 0, st>>>(w->qs, nullptr, w->M, w->Mpad, w->i8p);   // nib - 8 (Ggml.cs:1231-1235)
     else q5_to_i8_kernel<0, false><<<grid, 256, 0, st>>>(w->qs, nullptr, w->M, w->Mpad, w->i8p);
     return hipGetLastError();
 }

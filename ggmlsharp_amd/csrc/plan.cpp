@@ -30,7 +30,9 @@ bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LD
 // Q8_0 (r4: and Q5_0, on its int8 operand planes), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
 bool q8_small_serves(int type, int64_t K, int64_t N) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1) && N >= (type == GGML_TYPE_Q5_1 ? 9 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
+    // (Q4_2 from 17 rows: its mat-vec serves up to 16)
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (257..2048 rows), Q5_1 (257 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
@@ -125,7 +127,7 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     p.family = MMF_K3S_I8; p.image = 0;
     if (type == GGML_TYPE_Q5_1) p.flags |= MM_FLAG_MIN_PIECES;
     p.form = wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
-    p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : type == GGML_TYPE_Q5_1 ? 2 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
+    p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : type == GGML_TYPE_Q5_1 ? 2 : type == GGML_TYPE_Q4_2 ? 3 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
     p.nloc = nloc; p.wmt = wmt;
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
