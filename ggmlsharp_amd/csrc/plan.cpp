@@ -34,7 +34,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N) {
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 (257..2048 rows), Q5_1 (257 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// Q8_0 / Q5_0 (257..3072 rows), Q5_1 (257 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
 // 58; beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
 // r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
@@ -47,7 +47,7 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // (Q5_1 -- and Q5_K, which lives as Q5_1 -- has no upper bound: its staged form pays the min term per block in the loop, and the
     // stage-free form with the min terms as a product of their own beats it at every size looked at: 4096^3 299 | 243 us, 4096 x 11008 x 4096
     // 734 | 548, 11008 x 4096 x 4096 932 | 614, 32000 x 4096 x 4096 2527 | 1774, 4096 x 4096 x 8192 597 | 451)
-    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 2048;
+    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 3072;   // (Q8_0 / Q5_0, 2048 -> 3072: 4096 x 11008 x 3072 439 | 392 us, 4096 x 4096 x 2560 182 | 167, x 3072 178 | 175, x 3584 186 | 200)
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }
@@ -210,7 +210,11 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     };
     // 8 tiles per wave only where the registers allow it: one weight digit and one scale plane (Q4_0); only above 512 rows: up to 512
     // rows every form splits K (two, four or eight ways by N and K) and this one does not
-    if (q40 && (tm256 * tn128 >= 384 || var == 30) && N > 512) return take(var == 2 ? MXF_256x128_ALT : MXF_256x128);
+    // 256 x 128 tiles as soon as the 128 x 128 form would need MORE than one round of the chip (2 workgroups per CU: 512): r4 -- the bound
+    // was 384 of these tiles (1.5 rounds of them), and between 257 and 383 the 128 x 128 form ran a second, nearly empty round:
+    // 11008 x 4096 x 768 131 -> 114 us, 8192 x 8192 x 1025 257 -> 221, 4096 x 11008 x 2304 341 -> 294, 14336 x 4096 x 640 133 -> 113 (same tree: both unsplit)
+    static const int t256 = dev_env_int("GGML_HIP_MX_T256", 257);   // developer A/B switch
+    if (q40 && (tm256 * tn128 >= t256 || var == 30) && N > 512) return take(var == 2 ? MXF_256x128_ALT : MXF_256x128);
     // Batches up to 128 rows (Q4_1: 256): 32-row weight tiles with K split four ways inside the workgroup; the same four-way tree on
     // taller tiles where those cover the chip.  The choice of the SPLIT depends on N and K only; the tile height follows the tile count.
     if (N <= (q40 || var == 20 ? 128 : 256) && nbk >= 16 && var != 3 && var != 9) {
@@ -282,7 +286,8 @@ void plan_f16(mm_plan &p, int type, int64_t M, int64_t K, int64_t N) {
         return take(h >= 64 ? F16F_S4_H64 : F16F_S4_H32);
     }
     if (N <= 512 && nbk >= 8) return take(F16F_S2_H128);
-    if (big >= 384) return take(F16F_256x128);
+    static const int t256 = dev_env_int("GGML_HIP_Q16_T256", 384);   // developer A/B switch
+    if (big >= t256) return take(F16F_256x128);
     static const int tile64 = dev_env_int("GGML_HIP_Q16_T64", 0);   // developer A/B switch: 1 = never, 2 = always
     if (tile64 == 2 || (!mn && tile64 != 1 && cdiv(M, 128) * cdiv(N, 64) <= 256)) return take(F16F_64x64);
     return take(F16F_128x64);
@@ -321,8 +326,9 @@ void plan_dense(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_
                 p.arith = 700 + shape16; p.wgs = cdiv(M, tm) * cdiv(N, tn);
                 p.tiles_per_wave = tm * tn / 1024 * ks / waves > 0 ? tm * tn / 1024 * ks / waves : 1;
             };
+            static const int d16t = dev_env_int("GGML_HIP_D16_T256", 384);   // developer A/B switch
             if (N > 512 && shape != 1)   // (v_mfma_f32_16x16x32_f16, by N alone: the two tile sizes sum alike)
-                return cdiv(M, 256) * tn128 >= 384 ? take(D16F_S_256x128, 256, 128, 4, 1, 1) : take(D16F_S_128x128, 128, 128, 4, 1, 1);
+                return cdiv(M, 256) * tn128 >= d16t ? take(D16F_S_256x128, 256, 128, 4, 1, 1) : take(D16F_S_128x128, 128, 128, 4, 1, 1);
             if (N > 512 && cdiv(M, 256) * tn128 >= 384) return take(D16F_256x128, 256, 128, 4, 1, 0);
             if (N <= 128 && nst >= 8 && var != 9)
                 return var == 1 || (var != 2 && tm128 * cdiv(N, 64) >= 80) ? take(D16F_S4_H128, 128, 64, 16, 4, 0) : take(D16F_S4_H32, 32, 64, 4, 4, 0);
