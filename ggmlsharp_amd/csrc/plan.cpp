@@ -251,7 +251,8 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
         }
         return take(var == 17 || (var != 16 && tm128 * cdiv(N, 64) >= 1536) ? MXF_S2_H128 : MXF_S2_H64);
     }
-    if (tm128 * tn128 >= 384) return take(MXF_128x128);
+    static const int t128 = dev_env_int("GGML_HIP_MX_T128", 384);   // developer A/B switch (r4: 257 and 129 measured -- 4096 x 4096 x 1280 67 | 73 | 72 us, 4096 x 11008 x 1280 170 | 183 | 172: 384 stays)
+    if (tm128 * tn128 >= t128) return take(MXF_128x128);
     // a short, wide product (a row shard of a multi-GPU split): 64 x 64 tiles of four 1-tile waves wherever the 128 x 64 grid leaves
     // CUs idle -- the same unsplit K loop per element, the same bits, only the geometry follows M (Q4_0 only: see `arith` above)
     if (q40 && (var == 32 || (var != 31 && tm128 * cdiv(N, 64) <= 256))) return take(MXF_64x64);
