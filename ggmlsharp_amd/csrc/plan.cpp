@@ -334,7 +334,9 @@ void plan_dense(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_
             if (N <= 128 && nst >= 8 && var != 9)
                 return var == 1 || (var != 2 && tm128 * cdiv(N, 64) >= 80) ? take(D16F_S4_H128, 128, 64, 16, 4, 0) : take(D16F_S4_H32, 32, 64, 4, 4, 0);
             if (N <= 512 && nst >= 4 && var != 9 && var != 8) {
-                if (var == 5 || (var == 0 && tm128 * tn128 >= 512)) return take(D16F_V2_128x128, 128, 128, 4, 2, 0);
+                // (r4: from 257 tiles on, it was 512 -- the 8-wave form below holds one workgroup per CU, so 257..511 tiles ran it in two rounds, the
+                // second nearly empty: 11008 x 4096 x 512 87.9 -> 75.7 us, x 257 85.7 -> 69.9, 14336 x 4096 x 512 94.0 -> 84.9; 256 tiles: level)
+                if (var == 5 || (var == 0 && tm128 * tn128 > 256)) return take(D16F_V2_128x128, 128, 128, 4, 2, 0);
                 if (var == 7 || (var != 6 && tm128 * tn128 >= 160)) return take(D16F_S2_128x128, 128, 128, 8, 2, 0);
                 return take(D16F_S2_128x64, 128, 64, 8, 2, 0);
             }
