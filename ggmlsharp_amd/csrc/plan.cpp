@@ -27,7 +27,8 @@ int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return
 constexpr int K3P_LDS = 160 * 1024;
 bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LDS; }               // the waves' row-scale tables
 
-// Q8_0 (r4: and Q5_0, on its int8 operand planes), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode form on the int8 matrix cores (gemm_q8s.hip) -- image 0
+// Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode
+// form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
 bool q8_small_serves(int type, int64_t K, int64_t N) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 17 rows: its mat-vec serves up to 16)
