@@ -181,6 +181,77 @@ __global__ __launch_bounds__(256) void dense_f32_big_kernel(const float *__restr
         }
 }
 
+// ---- F32 weights, 17 .. 256 src1 rows (r4): K split over the eight waves of a workgroup.  The tile kernels above give a workgroup the whole
+//      K: at these sizes a 4096 x 4096 matrix is 64 .. 256 tiles of 64 x 64, every wave runs 2048 sixteen-pass MFMAs one after the other and the
+//      launch takes a flat 120 us whatever N is (the weights stream in 12).  Here a workgroup owns ONE 32 x 32 tile and each wave an eighth of
+//      K (a contiguous range of whole 32-k stages), staged through the wave's own LDS slice (no workgroup barrier in the K loop: a thread
+//      brings 16 consecutive k of one row of each operand, 16-byte pieces where src1 allows it, the next stage's loads fly during this
+//      stage's MFMAs); the eight partial tiles are added in wave order through LDS, every wave taking two of the sixteen accumulator
+//      registers.  Arithmetic inside a range as above (k ascending, two per v_mfma_f32_32x32x2_f32); tree: 8 contiguous ranges -- by K alone.
+template <bool VEC>
+__global__ __launch_bounds__(512) void dense_f32_ksplit_kernel(const float *__restrict__ w, const float *__restrict__ x, float *__restrict__ dst,
+                                                              int64_t M, int64_t N, int64_t K, int64_t ld1, int64_t ldd, int kr) {
+    extern __shared__ __attribute__((aligned(16))) float sS[];   // 8 * 2 * 32 * DLD floats (66 KB: dynamic, opted in by the launcher) -- per wave 32 rows of src1 and 32 of weights, 32 k each (+ pad)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 32, n0 = (int64_t)blockIdx.y * 32;
+    float *sX = sS + wave * (2 * 32 * DLD), *sW = sX + 32 * DLD;
+    const int srow = lane >> 1, sk = (lane & 1) * 16;        // a lane stages 16 consecutive k of one row of each operand
+    const int64_t xr = (n0 + srow) < N ? (n0 + srow) : (N - 1);
+    const int64_t kb = (int64_t)wave * kr, ke = kb + kr < K ? kb + kr : K;      // this wave's range (whole stages; may be empty)
+    const float *xp = x + xr * ld1 + sk;
+    const float *wp = w + (m0 + srow) * K + sk;              // < Mpad rows (padded rows are zero)
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float4 xv[4], wv[4];
+    auto load = [&](int64_t k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (VEC) xv[e] = *(const float4 *)(xp + k0 + 4 * e);
+            else { const float *q = xp + k0 + 4 * e; xv[e] = make_float4(q[0], q[1], q[2], q[3]); }
+            wv[e] = *(const float4 *)(wp + k0 + 4 * e);      // (rows of the resident copy: K % 4 == 0 keeps them 16-byte aligned)
+        }
+    };
+    if (kb < ke) load(kb);
+    for (int64_t k0 = kb; k0 < ke; k0 += DK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float *px = &sX[srow * DLD + sk + 4 * e], *pw = &sW[srow * DLD + sk + 4 * e];
+            px[0] = xv[e].x; px[1] = xv[e].y; px[2] = xv[e].z; px[3] = xv[e].w;
+            pw[0] = wv[e].x; pw[1] = wv[e].y; pw[2] = wv[e].z; pw[3] = wv[e].w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (k0 + DK < ke) load(k0 + DK);                     // the next stage's loads fly during this stage's MFMAs
+#pragma unroll
+        for (int s = 0; s < DK / 2; ++s) {
+            const float a = sX[l31 * DLD + 2 * s + hh];
+            const float b = sW[l31 * DLD + 2 * s + hh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // (the slice is rewritten by the next trip)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- the waves' partial tiles, added in wave order; wave v takes accumulator registers 2v and 2v + 1 ----
+    __syncthreads();
+    float *xch = sS + lane;                                   // [wave][register][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64] = acc[r];
+    __syncthreads();
+    const int64_t m = m0 + l31;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 2 * wave + q;
+        float v = xch[r * 64];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) v += xch[(g * 16 + r) * 64];
+        const int64_t n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (n < N && m < M) dst[n * ldd + m] = v;
+    }
+}
+
 // ---- N <= 8 (more rows in passes of 8): mat-vec, bandwidth-bound.  One wave per DGR weight rows: lanes stride K in 16-byte
 //      pieces, f32 products and f32 partial sums per lane (the reference sums the same products in f64, Ggml.cs:2633 / 2644:
 //      ~1e-6 relative at these K), a fixed xor-shuffle tree across the wave.  F16 weights: src1 is rounded to Half first
@@ -278,6 +349,22 @@ hipError_t launch_dense(const ggml_hip_weight *w, const mm_plan &pl, const float
     dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
     // K % 32 == 0 keeps every 8-element piece of a stage inside the row
     const bool vec = w->K % DK == 0 && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    if (pl.form == DNF_KSPLIT) {                            // F32, 17 .. 256 rows, K % 256 == 0 (plan.cpp): a wave's range is K / 8, whole stages
+        if (f16 || w->K % 256 != 0) return hipErrorInvalidValue;
+        const dim3 g2((unsigned)((w->M + 31) / 32), (unsigned)((N + 31) / 32));
+        const int kr = (int)(w->K / 8);
+        const size_t lds = (size_t)8 * 2 * 32 * DLD * 4;
+        (void)hipGetLastError();
+#define DKS_GO(V) do { \
+            auto kern = dense_f32_ksplit_kernel<V>; \
+            static PerDeviceOnce once; \
+            const hipError_t attr = once.max_dynamic_lds((const void *)kern, (int)lds); \
+            if (attr != hipSuccess) return attr; \
+            kern<<<g2, 512, lds, st>>>((const float *)w->dense, x, dst, w->M, N, w->K, ld1, ldd, kr); } while (0)
+        if (vec) DKS_GO(true); else DKS_GO(false);           // (a strided or misaligned src1: the same sums from scalar loads)
+#undef DKS_GO
+        return hipGetLastError();
+    }
     {   // F32 weights, enough 128 x 128 tiles to fill the chip (plan.cpp): the big-tile kernel (bitwise the same result; it reads src1 in
         // 16-byte pieces -- a strided or misaligned src1 takes the 64 x 64 kernel, whose fma chain is the same)
         const int64_t tm = (w->M + 127) / 128, tn = (N + 127) / 128;

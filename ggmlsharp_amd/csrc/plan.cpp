@@ -356,6 +356,16 @@ void plan_dense(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_
             return;
         }
     }
+    static const bool oldd = dev_env_set("GGML_HIP_DENSE_OLD");   // developer A/B switch
+    // r4: F32 weights, 5 .. 256 src1 rows, K a multiple of 256 from 1024 on: 32 x 32 tiles with K split over the workgroup's eight waves
+    // (dense.hip dense_f32_ksplit_kernel: the tile kernels run a flat 120 us at 4096 x 4096 whatever N is).  By N and K alone.
+    static const int ksn = dev_env_int("GGML_HIP_D32_KS_NMIN", 5);   // developer A/B switch (17: the mat-vec form keeps 5..16 rows)
+    if (!f16 && N >= ksn && N <= 256 && K % 256 == 0 && K >= 1024 && !oldd) {
+        p.family = MMF_DENSE; p.form = DNF_KSPLIT;
+        p.arith = 740; p.ksplit = 8; p.kstyle = MMK_RANGES; p.kunit = (int)(K / 256);
+        p.tile_m = p.tile_n = 32; p.waves = 8; p.tiles_per_wave = 1; p.wgs = cdiv(M, 32) * cdiv(N, 32);
+        return;
+    }
     // dense.hip.  Mat-vec form up to 16 rows (passes of 8 columns; rows of the resident copy are K elements apart: 16-byte pieces need
     // K % 8 (f16) / K % 4 (f32)); else the 64 x 64 tile kernel (F32: 128 x 128 tiles where they fill the chip -- bitwise the same result)
     if (N <= 16 && K % (f16 ? 8 : 4) == 0 && K >= 512) {
@@ -365,7 +375,6 @@ void plan_dense(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_
         return;
     }
     const int64_t tm = cdiv(M, 128), tn = cdiv(N, 128);
-    static const bool oldd = dev_env_set("GGML_HIP_DENSE_OLD");   // developer A/B switch
     const bool bigt = !f16 && K % 32 == 0 && !oldd && tm * tn >= 256 && tm * tn < (1 << 30) && Mpad % 128 == 0;
     p.family = MMF_DENSE; p.form = bigt ? DNF_BIG : DNF_TILE;
     p.arith = 730 + (f16 ? 1 : 0); p.ksplit = 1; p.kstyle = MMK_CHAIN; p.kunit = 32;

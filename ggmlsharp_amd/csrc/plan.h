@@ -58,7 +58,7 @@ enum i8_form { I8F_64x64 = 0, I8F_128x128 };
 // dense16.hip F16 forms
 enum d16_form { D16F_S_256x128 = 0, D16F_S_128x128, D16F_256x128, D16F_S4_H128, D16F_S4_H32, D16F_V2_128x128, D16F_S2_128x128, D16F_S2_128x64, D16F_128x128 };
 // dense.hip
-enum dense_form { DNF_TILE = 0, DNF_BIG = 1 };
+enum dense_form { DNF_TILE = 0, DNF_BIG = 1, DNF_KSPLIT = 2 /* F32, 17..256 rows: 32 x 32 tiles, K over the workgroup's eight waves */ };
 
 struct mm_plan {
     int family;           // mm_family

@@ -100,6 +100,10 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q8_0, 4096, 22016, 512).family == FAM["f16"]        # K > 20480: the eight scale tables do not fit LDS (decided in the plan)
     assert plan(F16, 4096, 4096, 4096).family == FAM["dense16"] and plan(F32, 4096, 4096, 4096).family == FAM["dense32"]
     assert plan(F32, 64, 128, 256).family == FAM["dense"]           # config 1 (Test1-style f32 64 x 128 x 256)
+    # r4: F32 at 5..256 rows, K % 256 == 0 from 1024 on: K split over the workgroup's eight waves (one tree whatever M is)
+    a, b = plan(F32, 4096, 4096, 64), plan(F32, 100, 4096, 64)
+    assert (a.family, a.form, a.ksplit, a.tile_m, a.tile_n) == (FAM["dense"], 2, 8, 32, 32) and a.tree_id == b.tree_id
+    assert plan(F32, 4096, 4096, 4).family == FAM["dense_gemv"] and plan(F32, 4096, 4000, 64).form != 2
     assert plan(F32, 4096, 4096, 257).family == FAM["dense32"] and plan(F32, 4096, 4096, 256).family == FAM["dense"]
 
 
