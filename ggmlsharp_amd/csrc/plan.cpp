@@ -35,9 +35,8 @@ bool q8_small_serves(int type, int64_t K, int64_t N) {
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 (257..3072 rows), Q5_1 (257 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
-// N and K alone (below 257 rows a 4096-row matrix gives the form fewer workgroups than the chip has CUs: 4096 x 11008 x 256 64 us against
-// 58; beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
+// Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// N and K alone (beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
 // r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
 // one round of the chip (A/B in one gpurun call, staged | K3p): Q8_0 4096 x 11008 x 1024 165 | 131 us, x 2048 320 | 257, 8192 x 8192 x 1024
 // 249 | 183, Q5_0 4096 x 4096 x 2048 125 | 102, Q5_1 4096 x 11008 x 2048 421 | 274; it loses from 4096 rows on (4096^3 195 | 219) and on a
@@ -49,7 +48,13 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // stage-free form with the min terms as a product of their own beats it at every size looked at: 4096^3 299 | 243 us, 4096 x 11008 x 4096
     // 734 | 548, 11008 x 4096 x 4096 932 | 614, 32000 x 4096 x 4096 2527 | 1774, 4096 x 4096 x 8192 597 | 451)
     const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 3072;   // (Q8_0 / Q5_0, 2048 -> 3072: 4096 x 11008 x 3072 439 | 392 us, 4096 x 4096 x 2560 182 | 167, x 3072 178 | 175, x 3584 186 | 200)
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N > 256 && N <= top &&
+    // lower bound, r4: 129 rows for Q8_0 / Q5_0 / Q5_1 (it was 257 for all).  One round of 128 x 64 tiles costs the same whatever N is, the staged
+    // K-split forms below it grow with N and with M: staged | K3p at 129 .. 256 rows -- 11008 x 4096 x 129 / 192 / 256 58.5 | 44.7, 60.0 | 47.7, 61.4 | 48.3 us,
+    // 8192 x 8192 x 192 (Q5_0) 61.0 | 44.1, Q5_1 11008 x 4096 x 192 70.6 | 52.9; 4096 x 4096 x 129 / 192 / 256 20.0 | 23.0, 22.1 | 24.1, 23.7 | 24.6 (the price),
+    // 4096 x 11008 x 192 / 256 48.9 | 51.2, 55.4 | 52.1.  Q4_1 keeps 257: its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6).
+    static const int nmin_dev = dev_env_int("GGML_HIP_K3P_NMIN", 0);   // developer A/B switch
+    const int64_t nmin = nmin_dev > 0 ? nmin_dev : type == GGML_TYPE_Q4_1 ? 257 : 129;
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }
 

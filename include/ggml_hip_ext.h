@@ -99,7 +99,7 @@ void   ggml_hip_debug_force_gemm(int which);
  * the Q8_K rule of the k-quant extension instead (one scale per 256 elements; see GGML_HIP_TYPE_Q5_K).  image_kind + 64 (kind 0 only,
  * K >= 256): beside image 0, d * (float)sum(q) of every block -- the Q8_1 s0 + s1 of Ggml.cs:820-821 -- as three bf16 pieces that sum to it
  * exactly, in the half of the image region image 0 leaves free (same work size): what ggml_hip_act_image_kind returns for Q5_1 / Q4_1
- * weights from 257 src1 rows up (Q4_1: ..1024) and for Q5_1 at 9..64, where the min terms run as a matrix product of their own
+ * weights from 129 src1 rows up (Q4_1: 257..1024) and for Q5_1 at 9..64, where the min terms run as a matrix product of their own
  * (gemm_qmp.hip, gemm_q8s.hip). */
 int    ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
                                  int image_kind, void *stream);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Targeted sweep of K3p (gemm_qmp.hip; 257..512 src1 rows, the int8 types up to 2048, K / 32 >= 64): every type it serves, K from the smallest the form takes to the
+"""Targeted sweep of K3p (gemm_qmp.hip; 257..512 src1 rows, the int8 types from 129 and up to 3072 / without bound, K / 32 >= 64): every type it serves, K from the smallest the form takes to the
 largest its LDS tables allow (chunks of the min-term product: none for some waves, ragged last chunk, five per wave), ragged M and N,
 persistent grids; fp64 evaluation of the same block arithmetic + a random row shard must be the bitwise slice.  Developer tool, GPU box."""
 import os
@@ -16,7 +16,7 @@ nbad = ntot = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     t = int(rng.choice(list(TYPES)))
     kb = int(rng.choice(KB)); K = 32 * kb
-    N = int(rng.choice([257, 258, 288, 300, 320, 321, 383, 384, 449, 480, 511, 512, 513, 600, 768, 1000, 1024, 1025, 1500, 2047, 2048, 2049, 3000, 4096]))   # (r4: the int8 types up to 2048 rows, Q5_1 without bound)
+    N = int(rng.choice([129, 130, 160, 200, 255, 256, 257, 258, 288, 300, 320, 321, 383, 384, 449, 480, 511, 512, 513, 600, 768, 1000, 1024, 1025, 1500, 2047, 2048, 2049, 3000, 4096]))   # (r4: the int8 types up to 2048 rows, Q5_1 without bound)
     M = int(rng.choice([1, 31, 100, 128, 129, 700, 1000, 4096, 5000, 9000] if kb <= 200 else [100, 700, 1000, 3000]))
     g = torch.Generator(device="cuda"); g.manual_seed(1000 + it)
     w = torch.randn((M, K), generator=g, device="cuda")
