@@ -787,6 +787,10 @@ def main():
                 "q5_0_ffn512_up": side_config(device, 11008, 4096, 512, copies=8, iters=60, qtype=Q5_0),
                 # ... and Q5_K itself as an UNPINNED EXTRA (upstream format, no oracle in the reference; ggml_hip.h GGML_HIP_TYPE_Q5_K)
                 "q5_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q5_K),
+                # r4, beyond BASELINE's sizes: what the widened plan ranges serve -- K3p-int8 above 512 rows, K3s-int8 for Q5_0
+                "q8_0_ffn1024": side_config(device, 4096, 11008, 1024, copies=6, iters=40, qtype=Q8_0),
+                "q5_k_ffn2048_unpinned_extra": side_config(device, 4096, 11008, 2048, copies=6, iters=20, qtype=Q5_K),
+                "q5_0_batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100, qtype=Q5_0),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
                 "vocab512_shard_of_8": side_config(device, 4000, 4096, 512, copies=24, iters=100),      # what each rank of config 5's 8-GPU split computes
                 # the dense case of the path (north_star: MFMA utilisation for the dense f16 / f32 mul_mat)
