@@ -337,7 +337,8 @@ void plan_dense(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_
             if (N > 512 && shape != 1)   // (v_mfma_f32_16x16x32_f16, by N alone: the two tile sizes sum alike)
                 return cdiv(M, 256) * tn128 >= d16t ? take(D16F_S_256x128, 256, 128, 4, 1, 1) : take(D16F_S_128x128, 128, 128, 4, 1, 1);
             if (N > 512 && cdiv(M, 256) * tn128 >= 384) return take(D16F_256x128, 256, 128, 4, 1, 0);
-            if (N <= 128 && nst >= 8 && var != 9)
+            static const int s4n = dev_env_int("GGML_HIP_D16_S4_NMAX", 128);   // developer A/B switch (r4: 256 measured -- 4096 x 4096 x 192 level, 11008 x 4096 x 160 44.8 | 65.9 us: 128 stays)
+            if (N <= s4n && nst >= 8 && var != 9)
                 return var == 1 || (var != 2 && tm128 * cdiv(N, 64) >= 80) ? take(D16F_S4_H128, 128, 64, 16, 4, 0) : take(D16F_S4_H32, 32, 64, 4, 4, 0);
             if (N <= 512 && nst >= 4 && var != 9 && var != 8) {
                 // (r4: from 257 tiles on, it was 512 -- the 8-wave form below holds one workgroup per CU, so 257..511 tiles ran it in two rounds, the
