@@ -69,7 +69,7 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     // ---- this wave's slice of the row scales: rows x 32 floats, straight into its own LDS slice (rows past its range: zero) ----
     const int trows = (nloc + NB - 1) / NB * NB;            // whole rounds of NB slots: rows past the wave's range are zero
     float *const tabD = (float *)smem8 + (size_t)wave * trows * 32;
-    constexpr int TP = 8;                                   // float4 pieces per lane (nloc <= 64)
+    constexpr int TP = 8;                                   // float4 pieces per lane and round: 64 table rows
     f32x4 td[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -82,6 +82,19 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     for (int j = 0; j < TP; ++j) {
         const int idx = lane + 64 * j;
         if (idx < trows * 8) *(f32x4 *)(tabD + 4 * idx) = td[j];
+    }
+    if (trows > 64) {                                       // (r4: a second round of pieces -- 65 .. 128 k-blocks per wave, K up to 32768; it was K <= 16384)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = lane + 64 * (j + TP), b = idx >> 3, c4 = idx & 7;
+            const bool ok = b < nloc && kb0 + b < nbk;
+            td[j] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = lane + 64 * (j + TP);
+            if (idx < trows * 8) *(f32x4 *)(tabD + 4 * idx) = td[j];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -253,7 +266,7 @@ hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_p
     const int nbkp = (int)pad_kblocks(w[0]->nbk);
     const int nloc = (nbkp + KS - 1) / KS;
     const int ncol = (int)((N + 31) / 32);
-    if (nloc > 64 || p.Npad < 32 * ncol) return hipErrorNotSupported;
+    if (nloc > 128 || p.Npad < 32 * ncol) return hipErrorNotSupported;
     int64_t t32 = 0;
     for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32 * ncol;
     const int wmt = t32 <= 256 ? 1 : 2;
@@ -307,7 +320,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     const bool q51 = w->type == GGML_TYPE_Q5_1, q5 = w->type == GGML_TYPE_Q5_0 || q51;
     const uint8_t *planes = q5 || q42 ? w->i8p : w->qs;
     if (q42 && !w->m) return hipErrorInvalidValue;
-    if (pl.family != MMF_K3S_I8 || !(q5 || q42 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 64 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
+    if (pl.family != MMF_K3S_I8 || !(q5 || q42 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 128 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
     if (q51 && (!w->mp3 || !p.sp3)) return hipErrorInvalidValue;
     const bool q5k = q51 && w->ext_type != 0;               // (the Q5_K extension: activations by the Q8_K rule, three min pieces)
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;

@@ -658,7 +658,7 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     //      Rows past the wave's range are ZERO: a slot that holds a clamped (repeated) pair then adds (sumi * 0) * d0 = +0. ----
     const int trows = ROT ? nloc : 2 * NP;
     float *const tabD = (float *)smem + (size_t)wave * trows * 32;
-    constexpr int TP = 8;                                   // float4 pieces per lane and plane (nloc <= 64)
+    constexpr int TP = 8;                                   // float4 pieces per lane and round: 64 table rows
     f32x4 td[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -673,6 +673,20 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
         const int idx = lane + 64 * j;
         if (idx < trows * 8) {
             *(f32x4 *)(tabD + 4 * idx) = td[j];
+        }
+    }
+    if (trows > 64) {                                       // (r4: a second round of pieces -- 65 .. 128 k-blocks per wave, K up to 32768; it was K <= 16384)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = lane + 64 * (j + TP), b = idx >> 3, c4 = idx & 7;
+            const bool ok = b < nloc && kb0 + b < nbkp;
+            const size_t e = (size_t)(kb0 + (ok ? b : 0)) * Npad + n0 + 4 * c4;
+            td[j] = ok ? *(const f32x4 *)(ad + e) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = lane + 64 * (j + TP);
+            if (idx < trows * 8) *(f32x4 *)(tabD + 4 * idx) = td[j];
         }
     }
     // (same wave wrote and reads: LDS operations of one wave complete in order; the compiler needs the fence)
@@ -914,7 +928,7 @@ hipError_t launch_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes 
     const uint64_t nba = (uint64_t)nbkp;
     const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4;
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
-    if (nloc > 64 || wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;    // (the plan never sends such a shape here)
+    if (nloc > 128 || wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;    // (the plan never sends such a shape here)
     const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
     const int ncol = (int)((N + 31) / 32);                  // 32-column slices of src1: one workgroup per tile group and slice
     if (p.Npad < 32 * ncol) return hipErrorInvalidValue;
@@ -949,7 +963,7 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
     const int nbkp = (int)pad_kblocks(w[0]->nbk);
     int nloc = (nbkp + KS - 1) / KS;
     nloc += nloc & 1;
-    if (w[0]->nbk < 64 || nloc > 64) return hipErrorNotSupported;
+    if (w[0]->nbk < 64 || nloc > 128) return hipErrorNotSupported;
     const uint64_t nba = (uint64_t)nbkp;
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
     if (a_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;

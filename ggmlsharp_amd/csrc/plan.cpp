@@ -33,7 +33,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 17 rows: its mat-vec serves up to 16)
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 512 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
@@ -125,7 +125,7 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     const int nbkp = (int)pad_kblocks(K / QK);
     const int nloc = (int)cdiv(nbkp, KS8);
     const int ncol = (int)cdiv(N, 32);
-    if (nloc > 64) return false;
+    if (nloc > 128) return false;                           // (two rounds of table pieces: K <= 32768; r4 -- it was one round, K <= 16384)
     if ((uint64_t)nbkp * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)nbkp * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
     static const int geo = dev_env_int("GGML_HIP_Q8S_TILES", 0);   // developer A/B switch: 1 / 2 tiles per workgroup whatever M
     const int64_t t32 = cdiv(M, 32) * ncol;
@@ -174,7 +174,7 @@ bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     const int nbkp = (int)pad_kblocks(K / QK);
     int nloc = (int)cdiv(nbkp, KS8);
     nloc += nloc & 1;                                       // pairs of blocks stay inside one wave
-    if (nloc > 64) return false;                            // (the table pieces a lane holds: K <= 16384)
+    if (nloc > 128) return false;                           // (the table pieces a lane holds, two rounds of eight: K <= 32768; r4 -- it was K <= 16384)
     if (((uint64_t)nbkp + K_LOOKAHEAD) * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)nbkp * 48 * (uint64_t)pad_act(N) > LIM32) return false;
     static const int geo = dev_env_int("GGML_HIP_K3S_GEO", 0);   // developer A/B switch: 1 / 2 / 4 = that many tiles per workgroup whatever M
     const int ncol = (int)cdiv(N, 32);

@@ -42,5 +42,33 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
         nbad += 1
         print(f"BAD {TYPES[t]} M{M} K{K} N{N}: {bad} elements, max err/rms {(err.max() / rms).item():.2e}, shard mismatch {shard_bad}", flush=True)
     W.free()
+# r4: the batched-decode forms (K3s, 5..64 rows) over long K -- one and two rounds of table pieces (K <= 16384 | <= 32768), beyond: the staged forms
+for it in range(40):
+    t = int(rng.choice(list(TYPES) + [4]))
+    K = 32 * int(rng.choice([512, 513, 640, 896, 1000, 1024, 1025]))
+    N = int(rng.choice([5, 9, 17, 31, 32, 33, 64]))
+    M = int(rng.choice([100, 700, 3000]))
+    g = torch.Generator(device="cuda"); g.manual_seed(5000 + it)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    rows = device.quantize_rows(t, w)
+    W = device.Weight.from_device(t, rows, K)
+    got = device.mul_mat(W, x)
+    wd = device.dequantize_rows(t, rows, K).double()
+    xq = device.dequantize_rows(8, device.quantize_rows(8, x.contiguous()), K).double()
+    ref = xq @ wd.T
+    err = (got.double() - ref).abs()
+    rms = ref.pow(2).mean().sqrt()
+    floor = max(1e-6, 8 * 2.0 ** -24 * (K / 32) ** 0.5) * rms
+    bad = int((err > torch.maximum(1e-3 * ref.abs(), floor)).sum().item())
+    ntot += 1
+    r0 = int(rng.integers(0, M - 16)); r1 = int(rng.integers(r0 + 1, M + 1))
+    Ws = device.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+    shard_bad = 0 if torch.equal(device.mul_mat(Ws, x), got[:, r0:r1]) else 1
+    Ws.free()
+    if bad or shard_bad or not torch.isfinite(got).all():
+        nbad += 1
+        print(f"BAD (decode form) type {t} M{M} K{K} N{N}: {bad} elements, max err/rms {(err.max() / rms).item():.2e}, shard mismatch {shard_bad}", flush=True)
+    W.free()
 print(f"K3p sweep: {ntot} shapes, {nbad} bad")
 sys.exit(1 if nbad else 0)
