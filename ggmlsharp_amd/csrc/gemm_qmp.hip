@@ -52,6 +52,8 @@ __device__ unsigned long long k3p_trace_buf[4096 * 8];
 #endif
 
 constexpr int KS = 8;          // waves per workgroup = K ranges
+constexpr int K3P_TABLE_ROWS = 80;   // k-blocks of a wave's scale table that fit whole (8 waves x 80 x 256 B = the 160 KB): K <= 20480; beyond, slices (SLICED)
+constexpr int K3P_SLICE_ROWS = 78;   // ... of at most 78 rows (the int8 loop keeps one spare row behind the last wave's slice)
 constexpr int WMT = 4;         // 32-row weight tiles per wave (two lane-half pairs)
 constexpr int WNT = 2;         // 32-column tiles of src1 per wave
 
@@ -142,11 +144,13 @@ __device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[WMT][WNT], uint8_
 struct WFrag { u32x4 lo[WMT / 2]; u32x2 hi[WMT / 2]; float d[WMT / 2]; };   // lanes 0..31: m-tile 2p, lanes 32..63: m-tile 2p + 1
 struct AFrag { u32x4 lo[WNT]; u32x2 hi[WNT]; };
 
+template <bool SLICED>   // (SLICED: the scale tables are refilled inside the K loop -- K > 19968; the one-table form compiles without the test)
 __global__ __launch_bounds__(KS * 64, 2)
 void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
                          const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad,
                          int Npad, int nbkp, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w6a_bytes, uint32_t wd_bytes,
-                         uint32_t a_bytes, const mm_epilogue ep) {
+                         uint32_t a_bytes, const mm_epilogue ep, int ch_arg) {
+    const int ch = SLICED ? ch_arg : nloc;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -189,7 +193,9 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
         }
     };
 
-    float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
+    // (r4: the wave's scale table holds `ch` k-blocks at a time -- all of its range up to K = 20480, beyond that (eight whole tables would not
+    // fit the 160 KB of LDS) the range goes through the slice in two or more refills, every wave of the workgroup at the same trip)
+    float *const tabD = (float *)smem + (size_t)wave * ch * (32 * WNT);
     WFrag wl;                                               // the NEXT k-block's weights, as loaded (lane halves = the m-tiles of a pair)
     AFrag af;                                               // activation fragments: column tile j is refetched as soon as its last MFMA has issued
     load_w(wl, kb0);                                        // (requested first: the weights come from HBM, the table from L2)
@@ -197,7 +203,7 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (bool first = true;; first = false) {
     if (!first) __syncthreads();                            // (the previous tile's reduction has read its last partial sums: the tables may go over them)
-    load_scale_table(tabD, ad, kb0, nloc, nbkp, Npad, n0, lane);   // (K1b writes the k-blocks K is padded to as zeros)
+    load_scale_table(tabD, ad, kb0, ch, nbkp, Npad, n0, lane);   // (K1b writes the k-blocks K is padded to as zeros)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -225,7 +231,14 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 #ifdef K3P_TRACE
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
-    for (int b = 0; b < nloc; ++b) {
+    for (int b = 0, tb = 0; b < nloc; ++b, ++tb) {
+        if (SLICED && tb == ch) {                                  // (uniform over the workgroup: the next `ch` rows of every wave's table)
+            tb = 0;
+            load_scale_table(tabD, ad, kb0 + b, nloc - b < ch ? nloc - b : ch, nbkp, Npad, n0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         // Two waves share a SIMD and the older one wins every arbitration: left alone, waves 0..3 finish their K range a quarter
         // early and waves 4..7 run the rest at one wave per SIMD (tools/k3p_trace.hip: 15.8 against 21.5 us).  The younger half
         // takes priority on most k-blocks, so both halves finish together.
@@ -251,7 +264,7 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
             dw[2 * p] = __builtin_bit_cast(float, d0u); dw[2 * p + 1] = __builtin_bit_cast(float, d1u);
         }
         load_w(wl, kb0 + b + 1);
-        const float *dp = tabD + b * (32 * WNT) + 4 * hh;
+        const float *dp = tabD + (SLICED ? tb : b) * (32 * WNT) + 4 * hh;
         f32x16 x[2];
         {
             const i32x8 A0 = {(int)af.lo[0][0], (int)af.lo[0][1], (int)af.lo[0][2], (int)af.lo[0][3], (int)af.hi[0][0], (int)af.hi[0][1], 0, 0};
@@ -323,15 +336,16 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 struct WI8 { i32x4 q[WMT]; float d[WMT]; };
 
-template <int TYPE, bool M3 = false>
+template <int TYPE, bool M3 = false, bool SLICED = false>
 __global__ __launch_bounds__(KS * 64, 2)
 void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8,
                         const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
                         int nbk, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep,
-                        const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3) {
+                        const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3, int ch_arg) {
+    const int ch = SLICED ? ch_arg : nloc;
     constexpr bool MIN = TYPE == GGML_TYPE_Q5_1, MINP = MIN;   // (Q4_1 runs this instantiation: its int8 planes hold 0..15)
 #ifndef K3P_DA_INPLACE
-#define K3P_DA_INPLACE MIN
+#define K3P_DA_INPLACE (MIN || SLICED)   // (the sliced forms: their extra live state took the scale look-ahead registers to scratch -- Q8_0 4096 x 28672 x 512 197 us)
 #endif
     constexpr bool DA_INPLACE = K3P_DA_INPLACE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -359,7 +373,7 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
             f.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
         }
     };
-    float *const tabD = (float *)smem + (size_t)wave * nloc * (32 * WNT);
+    float *const tabD = (float *)smem + (size_t)wave * ch * (32 * WNT);   // (`ch` k-blocks of the wave's range at a time: see the MX kernel)
     WI8 w0, w1;
     i32x4 af[WNT];
     auto load_first = [&]() {
@@ -432,7 +446,7 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) chunk_loads(wave + KS * u, sa[u], mb[u], m0, n0);
     }
-    load_scale_table(tabD, ad, kb0, nloc, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
+    load_scale_table(tabD, ad, kb0, ch, nbk, Npad, n0, lane);    // (image 0 does not write the k-blocks K is padded to: rows from nbk on are zero)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -477,10 +491,10 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
 #pragma unroll
     for (int q = 0; q < 4; ++q) da[q] = *(const f32x4 *)(tabD + 4 * hh + 8 * q);
     i32x16 x[2];                                            // the products of the tile at hand and of the next one (x[0]: handed from block to block)
-    auto block = [&](int b, WI8 &w, WI8 &wn) {
+    auto block = [&](int b, int tb, WI8 &w, WI8 &wn) {     // (tb: the block's row in the table slice)
         if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }   // (see the MX kernel)
         load_w(wn, kb0 + b + 1);
-        const float *dp = tabD + b * (32 * WNT) + 4 * hh;
+        const float *dp = tabD + tb * (32 * WNT) + 4 * hh;
         // (x[0] arrives from the previous k-block: the product of a block's FIRST tile is issued in front of the previous block's last
         // scale-accumulates -- issued here it stood back to back with the second tile's, and the first conversion waited out both)
         static_for<WMT * WNT>([&](auto tc) {
@@ -538,9 +552,18 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
     x[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], w0.q[0], zero, 0, 0, 0);
-    for (int b = 0; b < nloc; b += 2) {                     // (the look-ahead of the last trip reads past the wave's range: never used)
-        block(b, w0, w1);
-        block(b + 1, w1, w0);
+    for (int b = 0, tb = 0; b < nloc; b += 2, tb += 2) {    // (the look-ahead of the last trip reads past the wave's range: never used)
+        if (SLICED && tb == ch) {                           // (K beyond 19968: the next `ch` rows of every wave's table; `ch` is even.  The scales the last
+            tb = 0;                                         // tile prefetched from the row behind the slice are replaced here)
+            load_scale_table(tabD, ad, kb0 + b, nloc - b < ch ? nloc - b : ch, nbk, Npad, n0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) da[q] = *(const f32x4 *)(tabD + 4 * hh + 8 * q);
+        }
+        block(b, SLICED ? tb : b, w0, w1);
+        block(b + 1, (SLICED ? tb : b) + 1, w1, w0);
     }
 #ifdef K3P_TRACE
     asm volatile("" : "+v"(acc[0][0]));
@@ -594,22 +617,27 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
     if ((uint64_t)(KS * nloc + 2) * 2 * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 2 * (uint64_t)p.Npad * 16 > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
-    const size_t tab = (size_t)KS * nloc * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
+    // (K > 20480: table slices of `ch` k-blocks per wave, + one row behind the last slice for the loop's look-ahead of the next row's scales)
+    const bool sliced = nloc > K3P_TABLE_ROWS;
+    const int nch = (nloc + K3P_SLICE_ROWS - 1) / K3P_SLICE_ROWS, ch = sliced ? ((nloc + nch - 1) / nch + 1) & ~1 : nloc;
+    const size_t tab = ((size_t)KS * ch + (sliced ? 1 : 0)) * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
     const size_t lds = tab > xch ? tab : xch;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 || ch > nloc) return hipErrorInvalidValue;
     (void)hipGetLastError();
-#define Q8MID_GO(T, ...) do { \
-        auto kern = gemm_q8_mid_kernel<T, ##__VA_ARGS__>; \
+#define Q8MID_GO(...) do { if (sliced) Q8MID_GO1(__VA_ARGS__, true); else Q8MID_GO1(__VA_ARGS__, false); } while (0)
+#define Q8MID_GO1(...) do { \
+        auto kern = gemm_q8_mid_kernel<__VA_ARGS__>; \
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
-                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep, w->mp3, p.sp3); } while (0)
+                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep, w->mp3, p.sp3, ch); } while (0)
     // (Q4_1: the kernel of Q5_1 -- unsigned values 0..15 on the int8 planes, the same min term)
-    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0); else if (w->type == GGML_TYPE_Q5_0) Q8MID_GO(GGML_TYPE_Q5_0);
+    if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0, false); else if (w->type == GGML_TYPE_Q5_0) Q8MID_GO(GGML_TYPE_Q5_0, false);
     // (the min of a Q5_1 block is an f16 value: two bf16 pieces; Q4_1's is an f32, Q5_K's an f32 product: three)
-    else if (w->ext_type != 0 || w->type == GGML_TYPE_Q4_1) Q8MID_GO(GGML_TYPE_Q5_1, true); else Q8MID_GO(GGML_TYPE_Q5_1);
+    else if (w->ext_type != 0 || w->type == GGML_TYPE_Q4_1) Q8MID_GO(GGML_TYPE_Q5_1, true); else Q8MID_GO(GGML_TYPE_Q5_1, false);
 #undef Q8MID_GO
+#undef Q8MID_GO1
     return hipGetLastError();
 }
 
@@ -626,15 +654,18 @@ hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, const mm_plan &pl, act_
     if ((uint64_t)(KS * nloc + 2) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 48 * (uint64_t)p.Npad > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
     const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
-    const size_t tab = (size_t)KS * nloc * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
+    const bool sliced = nloc > K3P_TABLE_ROWS;
+    const int nch = (nloc + K3P_TABLE_ROWS - 1) / K3P_TABLE_ROWS, ch = (nloc + nch - 1) / nch;
+    const size_t tab = (size_t)KS * ch * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
     const size_t lds = tab > xch ? tab : xch;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static PerDeviceOnce once;
-    const hipError_t attr = once.max_dynamic_lds((const void *)gemm_qmx_mid_kernel, 160 * 1024);
+    auto kern = sliced ? gemm_qmx_mid_kernel<true> : gemm_qmx_mid_kernel<false>;
+    static PerDeviceOnce once[2];
+    const hipError_t attr = once[sliced].max_dynamic_lds((const void *)kern, 160 * 1024);
     if (attr != hipSuccess) return attr;
     (void)hipGetLastError();
-    gemm_qmx_mid_kernel<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N,
+    kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N,
                                                                                      (int)w->Mpad, (int)p.Npad, nbkp, nloc, (int)ldd, tiles_m, tiles_n,
-                                                                                     (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, ep);
+                                                                                     (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, ep, ch);
     return hipGetLastError();
 }

@@ -24,8 +24,9 @@ int64_t gemv_rows_max(int t) { return t == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N : GE
 constexpr int KS8 = 8;
 int k3p_mx_nloc(int64_t K) { return (int)cdiv(pad_kblocks(K / QK), KS8); }
 int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return n + (n & 1); }      // two k-blocks per trip (and the min term goes by pairs)
-constexpr int K3P_LDS = 160 * 1024;
-bool k3p_lds_ok(int nloc) { return (size_t)KS8 * nloc * 64 * 4 <= (size_t)K3P_LDS; }               // the waves' row-scale tables
+// the waves' row-scale tables: the whole range of a wave up to 80 k-blocks (K <= 20480), beyond that in refills inside the K loop (r4; it was
+// a hard limit at K = 20480) -- up to four slices of 78, K <= 79872 (the 32-bit offsets of the planes end earlier for wide matrices)
+bool k3p_lds_ok(int nloc) { return nloc <= 4 * 78; }
 
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode
 // form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
@@ -35,8 +36,8 @@ bool q8_small_serves(int type, int64_t K, int64_t N) {
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 20480: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
-// N and K alone (beyond K = 20480 the eight waves' scale tables do not fit the 160 KB of LDS: ADVICE r3 -- the limit used to live in the launcher only).
+// Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
 // r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
 // one round of the chip (A/B in one gpurun call, staged | K3p): Q8_0 4096 x 11008 x 1024 165 | 131 us, x 2048 320 | 257, 8192 x 8192 x 1024
 // 249 | 183, Q5_0 4096 x 4096 x 2048 125 | 102, Q5_1 4096 x 11008 x 2048 421 | 274; it loses from 4096 rows on (4096^3 195 | 219) and on a

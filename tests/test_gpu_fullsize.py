@@ -335,6 +335,28 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     W.free()
 
 
+@pytest.mark.parametrize("t", [Q4_0, 3, Q5_0, 7, Q8_0])
+@pytest.mark.parametrize("K", [20512, 28672, 60000 // 32 * 32])
+def test_k3p_beyond_one_scale_table_slices_refill_inside_the_K_loop(dev, t, K):
+    """K > 20480 (a 70B model's ffn-down at prompt sizes): the eight waves' scale tables no longer fit the 160 KB of LDS whole; the K loop
+    goes through them in two to four slices (gemm_qmp.hip SLICED; it was the staged forms' territory up to round 3).  The ragged first
+    case is one k-block past the old limit; fp64 evaluation of the same block arithmetic, and row shards are the bitwise slices."""
+    M, N = 3000, 300 if t != 3 else 320                    # (Q4_1 runs the form from 257 rows)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7 * t + K)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    rows = dev.quantize_rows(t, w)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    _check_fp64(dev, t, rows, x, full, K)
+    for (r0, r1) in ((0, 1000), (2100, 2100 + 777)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, K, r0, r1)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("N", [128, 512])
 def test_dense_f16_vocabulary_sized_matrix_and_its_shards_share_one_tree(dev, N):
     """F16, up to 512 src1 rows: a 32000-row matrix used to reach the unsplit 256 x 128 form (384 tiles and more) while its 4000-row

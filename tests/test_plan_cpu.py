@@ -99,7 +99,9 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q8_0, 4096, 4096, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 4096, 128).family != FAM["k3p_i8"]   # (from 129 rows: Q8_0 / Q5_0 / Q5_1)
     assert plan(Q4_1, 4096, 4096, 256).family == FAM["mx"] and plan(Q4_1, 4096, 4096, 257).family == FAM["k3p_i8"]      # (Q4_1: from 257)
     assert plan(Q5_1, 4096, 4096, 4096).family == FAM["k3p_i8"] and plan(Q5_K, 4096, 11008, 8192).family == FAM["k3p_i8"]   # (Q5_1 / Q5_K: no upper bound)
-    assert plan(Q8_0, 4096, 22016, 512).family == FAM["f16"]        # K > 20480: the eight scale tables do not fit LDS (decided in the plan)
+    # r4: K > 19968 -- the eight scale tables no longer fit LDS whole: K3p refills them in slices (up to four: K <= 79872), beyond that the staged forms
+    assert plan(Q8_0, 4096, 22016, 512).family == FAM["k3p_i8"] and plan(Q4_0, 4096, 28672, 512).family == FAM["k3p_mx"]
+    assert plan(Q8_0, 4096, 79872, 512).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 79904, 512).family == FAM["f16"]
     assert plan(F16, 4096, 4096, 4096).family == FAM["dense16"] and plan(F32, 4096, 4096, 4096).family == FAM["dense32"]
     assert plan(F32, 64, 128, 256).family == FAM["dense"]           # config 1 (Test1-style f32 64 x 128 x 256)
     # r4: F32 at 5..256 rows, K % 256 == 0 from 1024 on: K split over the workgroup's eight waves (one tree whatever M is)

@@ -11,7 +11,7 @@ from ggmlsharp_amd import device  # noqa: E402
 device.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 TYPES = {2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
-KB = [64, 65, 66, 71, 79, 80, 81, 95, 96, 97, 127, 128, 129, 143, 144, 200, 257, 344, 400, 512, 513, 639, 640]
+KB = [64, 65, 66, 71, 79, 80, 81, 95, 96, 97, 127, 128, 129, 143, 144, 200, 257, 344, 400, 512, 513, 617, 623, 624, 625, 639, 640, 641, 688, 896, 1000, 1024, 1249, 1873, 2000]   # (from 625: the scale tables in two to four slices)
 nbad = ntot = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     t = int(rng.choice(list(TYPES)))
