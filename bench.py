@@ -74,9 +74,9 @@ def stats(ts):
 
 
 Q5_0, Q8_0 = 6, 8
-Q5_K = 113                                            # extension type (upstream k-quant format; absent from the reference)
-BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36, Q5_K: 22}   # Ggml.cs:76-82; Q5_K: 176 B per 256 weights
-TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0", Q5_K: "Q5_K"}
+Q5_K, Q4_K = 113, 112                                 # extension types (upstream k-quant format; absent from the reference)
+BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36, Q5_K: 22, Q4_K: 18}   # Ggml.cs:76-82; Q5_K: 176 B per 256 weights, Q4_K: 144
+TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q4_K: "Q4_K"}
 
 
 def make_weights_q4_0(M, K, seed, qtype=Q4_0):
@@ -84,10 +84,10 @@ def make_weights_q4_0(M, K, seed, qtype=Q4_0):
     from ggmlsharp_amd import device
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
-    if qtype == Q5_K:
+    if qtype in (Q5_K, Q4_K):
         # no device quantizer for the extension type: raw super-blocks with every bit pattern of scales / quants and small
         # finite half scales (d, dmin) -- valid Q5_K data with the toggle rate of real weights
-        rows = torch.randint(0, 256, (M, K // 256, 176), generator=g, device="cuda", dtype=torch.uint8)
+        rows = torch.randint(0, 256, (M, K // 256, 176 if qtype == Q5_K else 144), generator=g, device="cuda", dtype=torch.uint8)
         hdr = torch.tensor([0.01, 0.02], dtype=torch.float16, device="cuda").view(torch.uint8)
         rows[:, :, 0:4] = hdr
         return rows.view(M, -1)
@@ -167,7 +167,7 @@ def compute_kernel_name(qtype, M, K, N):
     if _lib.lib().ggml_hip_mm_plan(qtype, M, K, N, C.byref(pl)) != 0:
         return "?"
     name = FAMILY_NAME.get(pl.family, f"family {pl.family}")
-    if pl.family == 6 and qtype in (Q5_K, 7, 3):
+    if pl.family == 6 and qtype in (Q5_K, Q4_K, 7, 3):
         name += " + the min terms of 16 k-blocks as one bf16-piece matrix product (5 / 6 v_mfma_f32_32x32x16_bf16 per tile) ahead of the K loop (r4)"
     return f"{name}; plan: form {pl.form}, tile {pl.tile_m}x{pl.tile_n}, {pl.waves} waves, K in {pl.ksplit} partial sum(s), {pl.workgroups} workgroups"
 
@@ -790,6 +790,7 @@ def main():
                 # r4, beyond BASELINE's sizes: what the widened plan ranges serve -- K3p-int8 above 512 rows, K3s-int8 for Q5_0
                 "q8_0_ffn1024": side_config(device, 4096, 11008, 1024, copies=6, iters=40, qtype=Q8_0),
                 "q5_k_ffn2048_unpinned_extra": side_config(device, 4096, 11008, 2048, copies=6, iters=20, qtype=Q5_K),
+                "q4_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q4_K),   # (r4: Q4_K, the same resident form and kernels)
                 "q5_0_batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100, qtype=Q5_0),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
                 "vocab512_shard_of_8": side_config(device, 4000, 4096, 512, copies=24, iters=100),      # what each rank of config 5's 8-GPU split computes

@@ -402,10 +402,11 @@ static DeviceCtx *call_slot() {
     return slot(b >= 0 ? b : 0);
 }
 
-static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_weight **out, bool q5k = false) {
+static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_weight **out, int kq_type = 0) {
     ggml_hip_weight *w = new ggml_hip_weight();
     memset(w, 0, sizeof *w);
-    w->ext_type = q5k ? GGML_HIP_TYPE_Q5_K : 0;
+    const bool q5k = kq_type != 0;                          // (a k-quant weight in the planar Q5_1 form: Q5_K, Q4_K)
+    w->ext_type = kq_type;
     static std::atomic<uint64_t> next_uid{1};
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
     size_t off_qs = 0, off_d = 0, off_m = 0, off_qh = 0, off_6a = 0, off_6b = 0, off_kh = 0, off_gs = 0, off_i8 = 0, off_mp = 0, total = 0;
@@ -473,20 +474,21 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
     if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
     *out = nullptr;
     // Q5_K (unpinned extra, kquants.hip): super-blocks of 256 are re-laid-out as eight k-blocks of the planar Q5_1 form
-    const bool q5k = type == GGML_HIP_TYPE_Q5_K;
+    // (r4: Q4_K the same way -- its super-block is Q5_K's without the fifth-bit bytes; the fifth-bit plane stays zero)
+    const bool q5k = is_kquant(type);
     if (q5k) {
         if (!rows || ne00 <= 0 || ne01 < 0 || row_begin < 0 || row_end < row_begin || row_end > ne01) return fail(GGML_HIP_ERR_ARG, "bad weight arguments");
-        if (ne00 % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K: ne00 %% 256 != 0 (QK_K)");
-        if (nb01 < (uint64_t)(ne00 / 256) * 176) return fail(GGML_HIP_ERR_SHAPE, "nb01 smaller than a row");
+        if (ne00 % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: ne00 %% 256 != 0 (QK_K)");
+        if (nb01 < (uint64_t)(ne00 / 256) * kquant_bytes(type)) return fail(GGML_HIP_ERR_SHAPE, "nb01 smaller than a row");
         int rc = c ? GGML_HIP_OK : ensure_init();
         if (rc) return rc;
         if (!c) c = call_slot();
         rc = c->make_current();
         if (rc) return rc;
         const int64_t rows_n = row_end - row_begin;
-        const uint64_t rb = (uint64_t)(ne00 / 256) * 176;
+        const uint64_t rb = (uint64_t)(ne00 / 256) * kquant_bytes(type);
         ggml_hip_weight *w = nullptr;
-        rc = alloc_weight(c, GGML_TYPE_Q5_1, ne00, rows_n, &w, true);
+        rc = alloc_weight(c, GGML_TYPE_Q5_1, ne00, rows_n, &w, type);
         if (rc) return rc;
         hipError_t e = hipMemsetAsync(w->qs, 0, w->bytes, st);
         void *staging = nullptr;
@@ -494,16 +496,16 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
             e = hipMalloc(&staging, (size_t)rows_n * rb);
             if (e == hipSuccess)
                 e = hipMemcpy2DAsync(staging, rb, (const uint8_t *)rows + (uint64_t)row_begin * nb01, nb01, rb, (size_t)rows_n, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = launch_q5k_to_planar((const uint8_t *)staging, rb, 0, rows_n, w, st);
+            if (e == hipSuccess) e = launch_q5k_to_planar(type, (const uint8_t *)staging, rb, 0, rows_n, w, st);
         } else if (e == hipSuccess) {
-            e = launch_q5k_to_planar((const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
+            e = launch_q5k_to_planar(type, (const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
         }
         if (e == hipSuccess) e = launch_q5_to_i8(w, st);      // (the planar Q5_1 form's int8 operand planes: gemm_qmp.hip serves prompt-sized batches)
         if (e == hipSuccess) e = launch_min_pieces(w, st);
         if (e == hipSuccess) e = launch_gemv_side_image(w, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (staging) (void)hipFree(staging);
-        if (e != hipSuccess) { (void)hipFree(w->qs); delete w; return fail(GGML_HIP_ERR_RUNTIME, "Q5_K weight upload: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(w->qs); delete w; return fail(GGML_HIP_ERR_RUNTIME, "k-quant weight upload: %s", hipGetErrorString(e)); }
         *out = w;
         return GGML_HIP_OK;
     }
@@ -569,8 +571,8 @@ using namespace ghip;
 
 extern "C" {
 
-int ggml_hip_blck_size(int type) { return type == GGML_HIP_TYPE_Q5_K ? 256 : (type >= 0 && type < GGML_TYPE_COUNT) ? BLCK[type] : 0; }
-size_t ggml_hip_type_size(int type) { return type == GGML_HIP_TYPE_Q5_K ? 176 : (type >= 0 && type < GGML_TYPE_COUNT) ? TSIZE[type] : 0; }
+int ggml_hip_blck_size(int type) { return is_kquant(type) ? 256 : (type >= 0 && type < GGML_TYPE_COUNT) ? BLCK[type] : 0; }
+size_t ggml_hip_type_size(int type) { return is_kquant(type) ? kquant_bytes(type) : (type >= 0 && type < GGML_TYPE_COUNT) ? TSIZE[type] : 0; }
 
 int ggml_hip_device_count(void) {
     int n = 0;
@@ -644,12 +646,12 @@ int ggml_hip_weight_download(const ggml_hip_weight *w, void *host_rows, void *st
     rc = weight_device_current(w);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t row_bytes = w->ext_type == GGML_HIP_TYPE_Q5_K ? (size_t)(w->K / 256) * 176 : TSIZE[w->type] * (size_t)(w->K / BLCK[w->type]);
+    const size_t row_bytes = w->ext_type != 0 ? (size_t)(w->K / 256) * kquant_bytes(w->ext_type) : TSIZE[w->type] * (size_t)(w->K / BLCK[w->type]);
     const size_t total = row_bytes * (size_t)w->M;
     if (total == 0) return GGML_HIP_OK;
     void *staging = nullptr;
     HIP_TRY(hipMalloc(&staging, total));
-    hipError_t e = w->ext_type == GGML_HIP_TYPE_Q5_K ? launch_planar_to_q5k(w, (uint8_t *)staging, st) : launch_planar_to_aos(w, (uint8_t *)staging, st);
+    hipError_t e = w->ext_type != 0 ? launch_planar_to_q5k(w, (uint8_t *)staging, st) : launch_planar_to_aos(w, (uint8_t *)staging, st);
     if (e == hipSuccess) e = hipMemcpyAsync(host_rows, staging, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(staging);
@@ -672,7 +674,7 @@ int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? (w->ext_type ? w
 
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
     if (K <= 0 || N <= 0) return 0;
-    if (type == GGML_HIP_TYPE_Q5_K) type = GGML_TYPE_Q5_1;      // same operand images
+    if (is_kquant(type)) type = GGML_TYPE_Q5_1;                 // same operand images
     if (type == GGML_TYPE_F16) return (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 2;   // src1 as Half (Ggml.cs:3356-3357), padded
     if (type == GGML_TYPE_F32) return N > 256 ? (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 6 : 0;   // src1 as three bf16 pieces (dense16.hip K10d; the reference needs none)
     if (!is_q(type)) return 0;
@@ -700,21 +702,21 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     if (rc) return rc;
     act_planes p = act_carve(d_work, w->K, pad_act(N));
     HIP_TRY(launch_quantize_act(d_src1, N, w->K, ld1, p, weight_image_kind(w, N), (hipStream_t)stream,
-                                w->ext_type == GGML_HIP_TYPE_Q5_K));     // k-quant weights: the Q8_K rule (one scale per 256)
+                                w->ext_type != 0));                      // k-quant weights: the Q8_K rule (one scale per 256)
     return GGML_HIP_OK;
 }
 
-int ggml_hip_act_image_kind(int type, int64_t K, int64_t N) { return act_image_kind(type == GGML_HIP_TYPE_Q5_K ? GGML_TYPE_Q5_1 : type, K, N); }
+int ggml_hip_act_image_kind(int type, int64_t K, int64_t N) { return act_image_kind(is_kquant(type) ? GGML_TYPE_Q5_1 : type, K, N); }
 void ggml_hip_debug_force_gemm(int which) { plan_set_force_gemm(which); }
 
 // the plan of mul_mat(type, M, K, N) as ggml_hip_mul_mat_dev will run it; no device is needed (tests/test_plan_cpu.py)
 int ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_plan_t *out) {
     if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
-    const bool q5k = type == GGML_HIP_TYPE_Q5_K;
+    const bool q5k = is_kquant(type);
     const int t = q5k ? GGML_TYPE_Q5_1 : type;
     if (t < 0 || t >= GGML_TYPE_COUNT || !weight_type_ok(t)) return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type", type);
     if (M <= 0 || K <= 0 || N <= 0 || K % BLCK[t] != 0 || (is_q(t) && K % QK != 0) || (q5k && K % 256 != 0)) return fail(GGML_HIP_ERR_SHAPE, "bad shape");
-    const mm_plan p = plan_mul_mat(t, q5k ? GGML_HIP_TYPE_Q5_K : 0, M, K, N, true);
+    const mm_plan p = plan_mul_mat(t, q5k ? type : 0, M, K, N, true);
     out->family = p.family; out->image_kind = p.image | ((p.flags & MM_FLAG_MIN_PIECES) ? ACT_IMAGE_MIN_PIECES : 0); out->form = p.form; out->tree_id = plan_tree_id(p);
     out->ksplit = p.ksplit; out->kstyle = p.kstyle; out->kunit = p.kunit; out->arith = p.arith;
     out->tile_m = p.tile_m; out->tile_n = p.tile_n; out->waves = p.waves; out->tiles_per_wave = p.tiles_per_wave;
@@ -1038,9 +1040,9 @@ int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_
 int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, int64_t k, float *d_y, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;
     if (!d_y || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
-    if (type == GGML_HIP_TYPE_Q5_K) {                           // unpinned extra (kquants.hip)
-        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K: k %% 256 != 0");
-        HIP_TRY(launch_dequantize_q5k(d_blocks, nrows, k, d_y, (hipStream_t)stream));
+    if (is_kquant(type)) {                                      // unpinned extra (kquants.hip)
+        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: k %% 256 != 0");
+        HIP_TRY(launch_dequantize_q5k(type, d_blocks, nrows, k, d_y, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
     if (!wq_ok(type))

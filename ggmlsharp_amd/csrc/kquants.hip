@@ -1,4 +1,4 @@
-// kquants.hip -- Q5_K weights (and the Q8_K activation rule) as an UNPINNED EXTRA.
+// kquants.hip -- Q5_K (r4: and Q4_K) weights (and the Q8_K activation rule) as an UNPINNED EXTRA.
 //
 // The reference has no k-quants (TypeDefinitions.cs:153-169 stops at Q8_1; `grep -i q5_K` over /root/reference finds
 // nothing -- SURVEY 8(a) row K), BASELINE.json's north_star and config 4 name them anyway.  What is built here follows the
@@ -7,6 +7,7 @@
 //     w[e] = d * sc_j * q[e] - dmin * m_j,  j = e / 32, sc_j / m_j the 6-bit entries of scales[] (get_scale_min_k4),
 //     q[e] = 4 low bits from qs (element 64 g + l: low nibble of qs[32 g + l], 64 g + 32 + l: its high nibble) + bit
 //     (2 g) / (2 g + 1) of qh[l] as the fifth bit
+//     block_q4_K = { half d; half dmin; u8 scales[12]; u8 qs[128] }                    144 bytes: the same without the fifth bits (q in 0..15)
 //     block_q8_K = { float d; i8 qs[256]; i16 bsums[16] }: iscale = -128 / (the first element of largest magnitude),
 //     q = min(127, round-half-even(iscale * x)), d = 1 / iscale
 //     dot per super-block: (d * dy) * sum_j sc_j * <q_j, a_j>  -  (dmin * dy) * sum_j m_j * bsum_j
@@ -43,6 +44,8 @@ __device__ __forceinline__ void scale_min_k4(int j, const uint8_t *q, uint32_t &
 }
 
 // one thread per (row, 32-element sub-block); rows fastest so the planar stores coalesce
+// (Q5 = false: Q4_K -- 144-byte super-blocks, the nibbles straight behind the 16 header bytes, no fifth bits)
+template <bool Q5>
 __global__ void q5k_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_t nb01, int64_t row_begin, int64_t rows, int64_t Mpad,
                                      uint8_t *__restrict__ qs, uint32_t *__restrict__ qh, float *__restrict__ d, float *__restrict__ mm,
                                      uint8_t *__restrict__ khdr) {
@@ -51,8 +54,8 @@ __global__ void q5k_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_t n
     if (m >= rows) return;
     const int64_t sb = b >> 3;
     const int j = (int)(b & 7), g = j >> 1, hi = j & 1;
-    const uint8_t *blk = aos + (uint64_t)(row_begin + m) * nb01 + (uint64_t)sb * 176;
-    const uint8_t *scales = blk + 4, *qhs = blk + 16, *ql = blk + 48 + 32 * g;
+    const uint8_t *blk = aos + (uint64_t)(row_begin + m) * nb01 + (uint64_t)sb * (Q5 ? 176 : 144);
+    const uint8_t *scales = blk + 4, *qhs = blk + 16, *ql = blk + (Q5 ? 48 : 16) + 32 * g;
     uint32_t sc, mn;
     scale_min_k4(j, scales, sc, mn);
     const float dd = h2f(*(const uint16_t *)blk), dmin = h2f(*(const uint16_t *)(blk + 2));
@@ -64,7 +67,7 @@ __global__ void q5k_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_t n
     for (int l = 0; l < 32; ++l) {
         const uint32_t nib = hi ? (uint32_t)(ql[l] >> 4) : (uint32_t)(ql[l] & 15u);
         w[l >> 3] |= nib << (4 * (l & 7));                  // byte l/2 = element l | element l+1 << 4 (the Q5_1 plane's order)
-        hbits |= (uint32_t)((qhs[l] >> j) & 1u) << l;
+        if constexpr (Q5) hbits |= (uint32_t)((qhs[l] >> j) & 1u) << l;
     }
     *(uint4 *)(qs + pi * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     qh[pi] = hbits;
@@ -73,12 +76,13 @@ __global__ void q5k_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_t n
 }
 
 // exact inverse: one thread per (row, super-block)
+template <bool Q5>
 __global__ void planar_to_q5k_kernel(uint8_t *__restrict__ aos, uint64_t nb01, int64_t rows, int64_t Mpad, const uint8_t *__restrict__ qs,
                                      const uint32_t *__restrict__ qh, const uint8_t *__restrict__ khdr) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t sb = blockIdx.y;
     if (m >= rows) return;
-    uint8_t *blk = aos + (uint64_t)m * nb01 + (uint64_t)sb * 176;
+    uint8_t *blk = aos + (uint64_t)m * nb01 + (uint64_t)sb * (Q5 ? 176 : 144);
     const uint4 h = *(const uint4 *)(khdr + (sb * Mpad + m) * 16);
     // (176-byte blocks are only 16-byte aligned when nb01 is: write bytes)
     const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
@@ -90,7 +94,7 @@ __global__ void planar_to_q5k_kernel(uint8_t *__restrict__ aos, uint64_t nb01, i
         const uint4 w4 = *(const uint4 *)(qs + pi * 16);
         const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
         const uint32_t hb = qh[pi];
-        uint8_t *ql = blk + 48 + 32 * (j >> 1);
+        uint8_t *ql = blk + (Q5 ? 48 : 16) + 32 * (j >> 1);
         for (int l = 0; l < 32; ++l) {
             const uint32_t nib = (w[l >> 3] >> (4 * (l & 7))) & 15u;
             if (j & 1) ql[l] = (uint8_t)((ql[l] & 0x0Fu) | (nib << 4));
@@ -98,45 +102,49 @@ __global__ void planar_to_q5k_kernel(uint8_t *__restrict__ aos, uint64_t nb01, i
             qhb[l] |= (uint8_t)(((hb >> l) & 1u) << j);
         }
     }
-    for (int l = 0; l < 32; ++l) blk[16 + l] = qhb[l];
+    if constexpr (Q5) for (int l = 0; l < 32; ++l) blk[16 + l] = qhb[l];
 }
 
-// dequantize_row_q5_K of the published format: one thread per (row-major) sub-block of 32 outputs
+// dequantize_row_q5_K (Q5 = false: dequantize_row_q4_K) of the published format: one thread per (row-major) sub-block of 32 outputs
+template <bool Q5>
 __global__ void dequantize_q5k_kernel(const uint8_t *__restrict__ in, int64_t nsub, float *__restrict__ y) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsub) return;
-    const uint8_t *blk = in + (s >> 3) * 176;
+    const uint8_t *blk = in + (s >> 3) * (Q5 ? 176 : 144);
     const int j = (int)(s & 7), g = j >> 1, hi = j & 1;
     uint32_t sc, mn;
     scale_min_k4(j, blk + 4, sc, mn);
     const float d1 = h2f(*(const uint16_t *)blk) * (float)sc, m1 = h2f(*(const uint16_t *)(blk + 2)) * (float)mn;
-    const uint8_t *ql = blk + 48 + 32 * g, *qhs = blk + 16;
+    const uint8_t *ql = blk + (Q5 ? 48 : 16) + 32 * g, *qhs = blk + 16;
     float *o = y + s * 32;
     for (int l = 0; l < 32; ++l) {
-        const int q = (int)(hi ? (ql[l] >> 4) : (ql[l] & 15)) + (((qhs[l] >> j) & 1) ? 16 : 0);
+        const int q = (int)(hi ? (ql[l] >> 4) : (ql[l] & 15)) + (Q5 && ((qhs[l] >> j) & 1) ? 16 : 0);
         o[l] = d1 * (float)q - m1;                          // upstream: d1 * q - m1, one multiply then one subtract
     }
 }
 
 }  // namespace
 
-hipError_t launch_q5k_to_planar(const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st) {
+hipError_t launch_q5k_to_planar(int kq_type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st) {
     if (rows <= 0) return hipSuccess;
     dim3 grid((unsigned)((rows + 127) / 128), (unsigned)w->nbk);
-    q5k_to_planar_kernel<<<grid, 128, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->qs, w->qh, w->d, w->m, w->khdr);
+    if (kq_type == GGML_HIP_TYPE_Q5_K) q5k_to_planar_kernel<true><<<grid, 128, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->qs, w->qh, w->d, w->m, w->khdr);
+    else q5k_to_planar_kernel<false><<<grid, 128, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->qs, w->qh, w->d, w->m, w->khdr);
     return hipGetLastError();
 }
 
 hipError_t launch_planar_to_q5k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st) {
     if (w->M <= 0) return hipSuccess;
     dim3 grid((unsigned)((w->M + 127) / 128), (unsigned)(w->nbk / 8));
-    planar_to_q5k_kernel<<<grid, 128, 0, st>>>(aos, (uint64_t)(w->nbk / 8) * 176, w->M, w->Mpad, w->qs, w->qh, w->khdr);
+    if (w->ext_type == GGML_HIP_TYPE_Q5_K) planar_to_q5k_kernel<true><<<grid, 128, 0, st>>>(aos, (uint64_t)(w->nbk / 8) * 176, w->M, w->Mpad, w->qs, w->qh, w->khdr);
+    else planar_to_q5k_kernel<false><<<grid, 128, 0, st>>>(aos, (uint64_t)(w->nbk / 8) * 144, w->M, w->Mpad, w->qs, w->qh, w->khdr);
     return hipGetLastError();
 }
 
-hipError_t launch_dequantize_q5k(const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st) {
+hipError_t launch_dequantize_q5k(int kq_type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st) {
     const int64_t nsub = nrows * (k / 32);
     if (nsub <= 0) return hipSuccess;
-    dequantize_q5k_kernel<<<dim3((unsigned)((nsub + 127) / 128)), 128, 0, st>>>((const uint8_t *)blocks, nsub, y);
+    if (kq_type == GGML_HIP_TYPE_Q5_K) dequantize_q5k_kernel<true><<<dim3((unsigned)((nsub + 127) / 128)), 128, 0, st>>>((const uint8_t *)blocks, nsub, y);
+    else dequantize_q5k_kernel<false><<<dim3((unsigned)((nsub + 127) / 128)), 128, 0, st>>>((const uint8_t *)blocks, nsub, y);
     return hipGetLastError();
 }

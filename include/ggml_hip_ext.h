@@ -28,6 +28,10 @@ extern "C" {
  * _from_device / _download, ggml_hip_mul_mat{,_init,_compute}_dev, ggml_hip_mul_mat_work_size and
  * ggml_hip_dequantize_rows_dev only -- never inside a ggml_tensor (the reference cannot express the type). */
 #define GGML_HIP_TYPE_Q5_K 113
+/* r4: Q4_K of the same published format -- { half d; half dmin; u8 scales[12]; u8 qs[128] }, 144 bytes per 256 weights, the super-block of
+ * Q5_K without its fifth-bit bytes and with the same scale / min packing and the same dot rule against Q8_K.  It lives in the same resident
+ * form (eight k-blocks of the planar Q5_1 form, fifth-bit plane zero) and runs the same kernels; the same "unpinned extra" status. */
+#define GGML_HIP_TYPE_Q4_K 112
 
 
 /* OPT-IN, and a deviation from the reference's contract (which leaves EVERY node's data in host memory, Ggml.cs:3539-3704):

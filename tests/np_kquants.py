@@ -153,3 +153,55 @@ def quantize_q5_K(x):
     blocks[:, 16:48] = qh.astype(np.uint8)
     blocks[:, 48:176] = qs.reshape(nb, 128).astype(np.uint8)
     return blocks
+
+
+# ---------------------------------------------------------------- Q4_K (r4): the same super-block without the fifth bits
+Q4K_BYTES = 144
+
+
+def q4_K_as_q5_K(blocks):
+    """[nb, 144] Q4_K super-blocks { half d; half dmin; u8 scales[12]; u8 qs[128] } -> the [nb, 176] Q5_K super-blocks with the same
+    meaning (fifth-bit bytes zero).  The published dequantize_row_q4_K / ggml_vec_dot_q4_K_q8_K are Q5_K's formulas with q in 0..15:
+    element 64 g + l = low nibble of qs[32 g + l] under (sc, m)[2 g], 64 g + 32 + l = its high nibble under (sc, m)[2 g + 1],
+    y = (d * sc) * q - (dmin * m); the dot against Q8_K the same two terms per super-block."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, Q4K_BYTES)
+    out = np.zeros((blocks.shape[0], Q5K_BYTES), dtype=np.uint8)
+    out[:, 0:16] = blocks[:, 0:16]
+    out[:, 48:176] = blocks[:, 16:144]
+    return out
+
+
+def dequantize_q4_K(blocks):
+    return dequantize_q5_K(q4_K_as_q5_K(blocks))
+
+
+def mul_mat_q4_K(wrows, x):
+    M = wrows.shape[0]
+    return mul_mat_q5_K(q4_K_as_q5_K(wrows.reshape(-1, Q4K_BYTES)).reshape(M, -1), x)
+
+
+def quantize_q4_K(x):
+    """A simple VALID Q4_K encoder for test data (not upstream's search): the affine code of quantize_q5_K with 15 steps."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 8, 32)
+    lo = np.minimum(x.min(axis=2), 0.0)
+    hi = np.maximum(x.max(axis=2), lo + 1e-30)
+    scale = (hi - lo) / 15.0
+    off = -lo
+    d16 = (np.maximum(scale.max(axis=1), 1e-30) / 63.0).astype(np.float16)
+    dmin16 = (np.maximum(off.max(axis=1), 1e-30) / 63.0).astype(np.float16)
+    df, dminf = d16.astype(np.float32), dmin16.astype(np.float32)
+    sc = np.clip(np.rint(scale / np.maximum(df[:, None], 1e-30)), 1, 63).astype(np.uint32)
+    m = np.clip(np.rint(off / np.maximum(dminf[:, None], 1e-30)), 0, 63).astype(np.uint32)
+    d1 = df[:, None] * sc
+    m1 = dminf[:, None] * m
+    q = np.clip(np.rint((x + m1[:, :, None]) / np.maximum(d1[:, :, None], 1e-30)), 0, 15).astype(np.uint32)
+    nb = x.shape[0]
+    blocks = np.zeros((nb, Q4K_BYTES), dtype=np.uint8)
+    blocks[:, 0:2] = d16.reshape(-1, 1).view(np.uint8)
+    blocks[:, 2:4] = dmin16.reshape(-1, 1).view(np.uint8)
+    blocks[:, 4:16] = pack_scales(sc, m)
+    qs = np.zeros((nb, 4, 32), dtype=np.uint32)
+    for g in range(4):
+        qs[:, g] = q[:, 2 * g] | (q[:, 2 * g + 1] << 4)
+    blocks[:, 16:144] = qs.reshape(nb, 128).astype(np.uint8)
+    return blocks

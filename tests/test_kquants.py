@@ -11,16 +11,18 @@ import np_kquants as KQ
 import oracle_lib as O
 
 RNG = np.random.default_rng(4242)
-Q5_K = 113
+Q5_K, Q4_K = 113, 112
+# per type: super-block bytes, the test encoder, the restated dequantize and mul_mat
+KQT = {Q5_K: (176, KQ.quantize_q5_K, KQ.dequantize_q5_K, KQ.mul_mat_q5_K), Q4_K: (144, KQ.quantize_q4_K, KQ.dequantize_q4_K, KQ.mul_mat_q4_K)}
 
 
 def _rand(shape, scale=1.0):
     return (RNG.standard_normal(shape) * scale).astype(np.float32)
 
 
-def _random_blocks(nb):
+def _random_blocks(nb, t=Q5_K):
     """raw super-blocks: every bit pattern of scales / qh / qs, finite half scales"""
-    b = RNG.integers(0, 256, size=(nb, 176), dtype=np.uint8)
+    b = RNG.integers(0, 256, size=(nb, KQT[t][0]), dtype=np.uint8)
     b[:, 0:2] = (RNG.random(nb).astype(np.float32) * 0.02 + 0.001).astype(np.float16).reshape(-1, 1).view(np.uint8)
     b[:, 2:4] = (RNG.random(nb).astype(np.float32) * 0.05).astype(np.float16).reshape(-1, 1).view(np.uint8)
     return b
@@ -49,6 +51,27 @@ def test_simple_quantizer_is_a_valid_encoding_close_to_its_input():
     err = np.abs(y - x).reshape(40, 8, 32).max(axis=2)
     rng = (np.maximum(x.reshape(40, 8, 32).max(axis=2), 0) - np.minimum(x.reshape(40, 8, 32).min(axis=2), 0))
     assert np.all(err <= 0.08 * np.maximum(rng.max(axis=1, keepdims=True), 1e-6) + 1e-6)   # 5-bit code with 6-bit super-scales
+
+
+def test_q4_K_restatement_by_hand_and_its_encoder():
+    """Q4_K (r4): the super-block of Q5_K without the fifth-bit bytes -- one block by hand, then the encoder round trip"""
+    b = np.zeros((1, 144), dtype=np.uint8)
+    b[0, 0:2] = np.array([0.5], np.float16).view(np.uint8)            # d
+    b[0, 2:4] = np.array([0.25], np.float16).view(np.uint8)           # dmin
+    sc = np.array([[1, 2, 3, 40, 5, 6, 7, 8]]); m = np.array([[0, 1, 2, 3, 50, 5, 6, 7]])
+    b[0, 4:16] = KQ.pack_scales(sc, m)
+    b[0, 16 + 32 * 1 + 5] = 0xA7          # g = 1, l = 5: element 69 -> 7 under (sc, m)[2], element 101 -> 10 under (sc, m)[3]
+    y = KQ.dequantize_q4_K(b)[0]
+    assert y[69] == np.float32(0.5 * 3 * 7 - 0.25 * 2) and y[101] == np.float32(0.5 * 40 * 10 - 0.25 * 3)
+    assert y[0] == 0.0 and y[33] == np.float32(-0.25) and y[128] == np.float32(-0.25 * 50)     # q = 0: minus the sub-block's min
+    x = _rand((20, 256), 2.0)
+    err = np.abs(KQ.dequantize_q4_K(KQ.quantize_q4_K(x)) - x).max()
+    assert err <= 0.15 * (x.max() - x.min())                          # 4-bit code with 6-bit super-scales
+    w = KQ.quantize_q4_K(_rand((4, 256))).reshape(1, -1)
+    xx = _rand((1, 1024))
+    d8, q8, _ = KQ.quantize_q8_K(xx.reshape(-1, 256))
+    exact = float(KQ.dequantize_q4_K(w).astype(np.float64).reshape(-1) @ (q8.astype(np.float64) * d8.astype(np.float64)[:, None]).reshape(-1))
+    assert abs(float(KQ.mul_mat_q4_K(w, xx)[0, 0]) - exact) <= 1e-5 * max(1.0, abs(exact))
 
 
 def test_q8_K_rule():
@@ -92,27 +115,30 @@ def dev():
 
 
 @gpu
-def test_dequantize_q5_K_bit_exact(dev):
+@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+def test_dequantize_q5_K_bit_exact(dev, t):
     import torch
     for nb in (1, 7, 64):
-        b = np.concatenate([_random_blocks(nb), KQ.quantize_q5_K(_rand((nb, 256), 3.0))])
-        want = KQ.dequantize_q5_K(b)
-        got = dev.dequantize_rows(Q5_K, torch.from_numpy(b.reshape(1, -1)).cuda(), b.shape[0] * 256).cpu().numpy().reshape(-1, 256)
+        b = np.concatenate([_random_blocks(nb, t), KQT[t][1](_rand((nb, 256), 3.0))])
+        want = KQT[t][2](b)
+        got = dev.dequantize_rows(t, torch.from_numpy(b.reshape(1, -1)).cuda(), b.shape[0] * 256).cpu().numpy().reshape(-1, 256)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 @gpu
-def test_upload_download_roundtrip_is_byte_exact_and_type_reported(dev):
+@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+def test_upload_download_roundtrip_is_byte_exact_and_type_reported(dev, t):
     from ggmlsharp_amd._lib import lib
     M, K = 70, 768
-    rows = _random_blocks(M * K // 256).reshape(M, -1)
-    W = dev.Weight.from_host(Q5_K, rows, K)
-    assert lib().ggml_hip_weight_type(W.handle) == Q5_K and lib().ggml_hip_weight_rows(W.handle) == M
+    rows = _random_blocks(M * K // 256, t).reshape(M, -1)
+    W = dev.Weight.from_host(t, rows, K)
+    assert lib().ggml_hip_weight_type(W.handle) == t and lib().ggml_hip_weight_rows(W.handle) == M
+    assert lib().ggml_hip_type_size(t) == KQT[t][0] and lib().ggml_hip_blck_size(t) == 256
     assert np.array_equal(W.download().reshape(M, -1), rows)
-    shard = dev.Weight.from_host(Q5_K, rows, K, row_begin=11, row_end=40)
+    shard = dev.Weight.from_host(t, rows, K, row_begin=11, row_end=40)
     assert np.array_equal(shard.download().reshape(29, -1), rows[11:40])
     h = C.c_void_p()
-    assert lib().ggml_hip_weight_upload(Q5_K, rows.ctypes.data_as(C.c_void_p), 700, M, 528, 0, M, None, C.byref(h)) == -3   # K % 256
+    assert lib().ggml_hip_weight_upload(t, rows.ctypes.data_as(C.c_void_p), 700, M, 528, 0, M, None, C.byref(h)) == -3   # K % 256
 
 
 @gpu
@@ -158,8 +184,9 @@ def _close(got, ref, what, K):
 
 
 @gpu
-def test_mul_mat_q5_K_matches_the_restatement(dev):
-    """every kernel form behind the Q5_1 image of a Q5_K weight: mat-vec (N <= 8, two-step), f16 MFMA with 4- / 2-way K split
+@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+def test_mul_mat_q5_K_matches_the_restatement(dev, t):
+    """(r4: Q4_K through the same resident form and kernels)  every kernel form behind the Q5_1 image of a Q5_K weight: mat-vec (N <= 8, two-step), f16 MFMA with 4- / 2-way K split
     and unsplit, int8 MFMA; ragged M and N; raw random super-blocks as well as quantized normal data"""
     import torch
     for (M, K, N) in ((96, 256, 1), (300, 1024, 3), (128, 512, 8), (515, 768, 40), (256, 2048, 130), (640, 1024, 300),
@@ -168,29 +195,30 @@ def test_mul_mat_q5_K_matches_the_restatement(dev):
                       (200, 2048, 1100), (130, 2304, 2500),      #     ... which has no upper bound for this type
                       (300, 2048, 33), (130, 4352, 64), (515, 2304, 9)):   # r4: the batched-decode form K3s-int8 (9..64 rows, K >= 2048)
         for raw in (False, True):
-            rows = _random_blocks(M * K // 256).reshape(M, -1) if raw else KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
+            rows = _random_blocks(M * K // 256, t).reshape(M, -1) if raw else KQT[t][1](_rand((M * K // 256, 256))).reshape(M, -1)
             x = _rand((N, K))
-            ref = KQ.mul_mat_q5_K(rows, x)
-            W = dev.Weight.from_host(Q5_K, rows, K)
+            ref = KQT[t][3](rows, x)
+            W = dev.Weight.from_host(t, rows, K)
             got = dev.mul_mat(W, torch.from_numpy(x).cuda()).cpu().numpy()
-            _close(got, ref, f"Q5_K {M}x{K}x{N} raw={raw}", K)
+            _close(got, ref, f"k-quant {t} {M}x{K}x{N} raw={raw}", K)
     # a row shard is bitwise a column slice of the whole (the multi-GPU promise holds for the extension too)
     M, K, N = 300, 1024, 70
-    rows = KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
+    rows = KQT[t][1](_rand((M * K // 256, 256))).reshape(M, -1)
     xd = torch.from_numpy(_rand((N, K))).cuda()
-    whole = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K), xd)
-    part = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K, row_begin=100, row_end=260), xd)
+    whole = dev.mul_mat(dev.Weight.from_host(t, rows, K), xd)
+    part = dev.mul_mat(dev.Weight.from_host(t, rows, K, row_begin=100, row_end=260), xd)
     assert torch.equal(part, whole[:, 100:260])
     M, K, N = 300, 2048, 40                                # ... in the batched-decode form as well
-    rows = KQ.quantize_q5_K(_rand((M * K // 256, 256))).reshape(M, -1)
+    rows = KQT[t][1](_rand((M * K // 256, 256))).reshape(M, -1)
     xd = torch.from_numpy(_rand((N, K))).cuda()
-    whole = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K), xd)
-    part = dev.mul_mat(dev.Weight.from_host(Q5_K, rows, K, row_begin=100, row_end=260), xd)
+    whole = dev.mul_mat(dev.Weight.from_host(t, rows, K), xd)
+    part = dev.mul_mat(dev.Weight.from_host(t, rows, K, row_begin=100, row_end=260), xd)
     assert torch.equal(part, whole[:, 100:260])
 
 
 @gpu
-def test_mul_mat_q5_K_at_config_4s_size_on_a_sample(dev):
+@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+def test_mul_mat_q5_K_at_config_4s_size_on_a_sample(dev, t):
     """BASELINE config 4 names Q5_K at 4096 x 11008 x 512: the literal type at its literal size.  64 weight rows x 64 src1 rows of
     the device result against the numpy restatement (there is no oracle for k-quants: unpinned extra), and a 512-row shard is the
     bitwise column slice of the whole.  Weights: valid super-blocks quantized from normal data for the sampled rows, random
@@ -198,17 +226,17 @@ def test_mul_mat_q5_K_at_config_4s_size_on_a_sample(dev):
     import torch
     M, K, N = 4096, 11008, 512
     rs = np.random.default_rng(20264)
-    rows = _random_blocks(M * K // 256).reshape(M, -1)
+    rows = _random_blocks(M * K // 256, t).reshape(M, -1)
     ms = np.sort(rs.choice(M, size=64, replace=False))
     ns = np.sort(rs.choice(N, size=64, replace=False))
-    rows[ms[::2]] = KQ.quantize_q5_K(_rand((32 * K // 256, 256))).reshape(32, -1)      # half of the sample: real quantized data
+    rows[ms[::2]] = KQT[t][1](_rand((32 * K // 256, 256))).reshape(32, -1)      # half of the sample: real quantized data
     x = _rand((N, K))
-    W = dev.Weight.from_host(Q5_K, rows, K)
+    W = dev.Weight.from_host(t, rows, K)
     xd = torch.from_numpy(x).cuda()
     got = dev.mul_mat(W, xd)
-    ref = KQ.mul_mat_q5_K(rows[ms], x[ns])
-    _close(got.cpu().numpy()[np.ix_(ns, ms)], ref, f"Q5_K {M}x{K}x{N} (64 x 64 sample)", K)
-    Ws = dev.Weight.from_host(Q5_K, rows, K, row_begin=1024, row_end=1536)
+    ref = KQT[t][3](rows[ms], x[ns])
+    _close(got.cpu().numpy()[np.ix_(ns, ms)], ref, f"k-quant {t} {M}x{K}x{N} (64 x 64 sample)", K)
+    Ws = dev.Weight.from_host(t, rows, K, row_begin=1024, row_end=1536)
     assert torch.equal(dev.mul_mat(Ws, xd), got[:, 1024:1536])
     Ws.free()
     W.free()
