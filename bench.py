@@ -84,13 +84,7 @@ def make_weights_q4_0(M, K, seed, qtype=Q4_0):
     from ggmlsharp_amd import device
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
-    if qtype in (Q5_K, Q4_K):
-        # no device quantizer for the extension type: raw super-blocks with every bit pattern of scales / quants and small
-        # finite half scales (d, dmin) -- valid Q5_K data with the toggle rate of real weights
-        rows = torch.randint(0, 256, (M, K // 256, 176 if qtype == Q5_K else 144), generator=g, device="cuda", dtype=torch.uint8)
-        hdr = torch.tensor([0.01, 0.02], dtype=torch.float16, device="cuda").view(torch.uint8)
-        rows[:, :, 0:4] = hdr
-        return rows.view(M, -1)
+    # (r4: the extension types too -- kquants.hip quantize_kq_kernel, the published reference quantizers restated; rounds 2-3 fed random bytes)
     w = torch.randn((M, K), generator=g, device="cuda", dtype=torch.float32)
     return device.quantize_rows(qtype, w)
 
@@ -247,6 +241,9 @@ def dense_config(device, wtype, M, K, N, iters):
     stream = torch.cuda.current_stream()
     for _ in range(3):
         device.mul_mat(W, x, out=out, work=work)
+    # (r4: the clock preheat every other config has -- the weights above are made on an idle chip, and 20 launches straight after an idle
+    # stretch read 0.138 ms where the same launches a second into a busy stretch read 0.120: tools/experiments/dense_order.py)
+    preheat(lambda: device.mul_mat(W, x, out=out, work=work), PREHEAT_S / 2)
     t = float(np.median(per_call_ms(lambda: device.mul_mat(W, x, out=out, work=work), iters, stream)))
     tf = 2.0 * M * K * N / t / 1e9
     # MI355X_MICROARCH.md: dense f16 / bf16 MFMA ~2.5 PF.  F32 (above 256 src1 rows): each operand split exactly into three bf16 pieces,
@@ -254,7 +251,7 @@ def dense_config(device, wtype, M, K, N, iters):
     peak = 2500.0 if wtype == 1 else 2500.0 / 6
     W.free()
     res = {"workload": f"{'F16' if wtype == 1 else 'F32'} mul_mat M={M} K={K} N={N} (INIT + COMPUTE)", "ms_per_step": round(t, 5),
-           "gflops": round(tf * 1e3, 1),
+           "gflops": round(tf * 1e3, 1), "timing": f"median of {iters} launches after {PREHEAT_S / 2:.1f} s of untimed launches of the same call",
            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4)}}
     if wtype != 1:
         res["roofline"]["note"] = "f32-equivalent TFLOP/s against 2.5 PF bf16 / 6 MFMAs per product; the f32 matrix instruction's own peak is 157 TF"

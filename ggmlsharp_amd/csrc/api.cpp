@@ -1030,6 +1030,12 @@ int ggml_hip_rms_norm_mul_rows_dev(const float *d_x, const float *d_g, float *d_
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream) {
     if (nrows <= 0) return GGML_HIP_OK;  // empty input: nothing to do (buffers may be null)
     if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
+    if (is_kquant(type)) {                                      // unpinned extra (kquants.hip, r4)
+        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: k %% 256 != 0");
+        if (((uintptr_t)d_x & 15) != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: the rows must be 16-byte aligned");
+        HIP_TRY(launch_quantize_kq(type, d_x, nrows, k, d_blocks, (hipStream_t)stream));
+        return GGML_HIP_OK;
+    }
     if (!(wq_ok(type) || type == GGML_TYPE_Q8_1))
         return fail(GGML_HIP_ERR_TYPE, "quantize: unsupported type %d", type);
     if (k % QK != 0) return fail(GGML_HIP_ERR_SHAPE, "k %% 32 != 0 (Ggml.cs:336)");

@@ -285,6 +285,7 @@ static inline size_t kquant_bytes(int t) { return t == GGML_HIP_TYPE_Q5_K ? 176 
 hipError_t launch_q5k_to_planar(int kq_type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_q5k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_dequantize_q5k(int kq_type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
+hipError_t launch_quantize_kq(int kq_type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st);   // x: contiguous rows, 16-byte aligned
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
 hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,
                                 hipStream_t st);

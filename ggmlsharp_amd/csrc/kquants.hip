@@ -123,6 +123,132 @@ __global__ void dequantize_q5k_kernel(const uint8_t *__restrict__ in, int64_t ns
     }
 }
 
+// ---- r4: a device quantizer for the two extension types --------------------------------------------------------------------------------
+// quantize_row_q5_K_reference / _q4_K_reference of the published format (ggml k_quants, 2023-06), restated: per 32-element sub-block
+// make_qkx1_quants(32, nmax, x, L, &min, 5) -- an affine code over [min(0, min x), max x], its scale refitted up to five times by least
+// squares (scale = sum (x - min) l / sum l^2, min = mean(x - scale l) capped at 0) until no code changes; then the eight scales / mins of a
+// super-block as 6-bit multiples of d = max scale / 63 and dmin = max min / 63 (halves), and the codes again under the ROUNDED scales:
+// l = nearest((x + dmin m) / (d sc)) in 0..nmax.  Every float operation is a binary32 operation in the order written (the library is
+// built with -ffp-contract=off), nearest = round half to even.  UNPINNED like the rest of the extension: tests/np_kquants.py restates the
+// same steps and the device bytes are compared with its bytes; neither was run against upstream.
+// Eight lanes per super-block (one sub-block each), the super-block's maxima and the bit transpositions by width-8 shuffles.
+template <bool Q5>
+__global__ void quantize_kq_kernel(const float *__restrict__ x, int64_t nsb, uint8_t *__restrict__ out) {
+    constexpr int NMAX = Q5 ? 31 : 15, BYTES = Q5 ? 176 : 144;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t sb_raw = tid >> 3;
+    const bool active = sb_raw < nsb;
+    const int64_t sb = active ? sb_raw : nsb - 1;           // (idle lanes of the last group shadow the last super-block: the shuffles want every lane)
+    const int j = (int)(tid & 7);
+    const float *xs = x + sb * 256 + 32 * j;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 t = ((const float4 *)xs)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+    int L[32];
+    float mn = v[0], mx = v[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) { if (v[i] < mn) mn = v[i]; if (v[i] > mx) mx = v[i]; }
+    float scale = 0.0f, the_min = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) L[i] = -1;                 // (upstream compares with an uninitialised L on the first try: every code "changes")
+    if (mx == mn) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) L[i] = 0;
+    } else {
+        if (mn > 0.0f) mn = 0.0f;
+        float iscale = (float)NMAX / (mx - mn);
+        scale = 1.0f / iscale;
+        for (int itry = 0; itry < 5; ++itry) {
+            float sumlx = 0.0f;
+            int suml2 = 0;
+            bool changed = false;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                int l = (int)rintf(iscale * (v[i] - mn));
+                l = l < 0 ? 0 : l > NMAX ? NMAX : l;
+                if (l != L[i]) { L[i] = l; changed = true; }
+                sumlx += (v[i] - mn) * (float)l;
+                suml2 += l * l;
+            }
+            scale = sumlx / (float)suml2;
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) sum += v[i] - scale * (float)L[i];
+            mn = sum / 32.0f;
+            if (mn > 0.0f) mn = 0.0f;
+            iscale = 1.0f / scale;
+            if (!changed) break;
+        }
+        the_min = -mn;
+    }
+    // the super-block's largest scale and min (upstream: `if (scale > max_scale)` from 0)
+    float max_scale = scale > 0.0f ? scale : 0.0f, max_min = the_min > 0.0f ? the_min : 0.0f;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const float a = __shfl_xor(max_scale, o, 8), b = __shfl_xor(max_min, o, 8);
+        if (a > max_scale) max_scale = a;
+        if (b > max_min) max_min = b;
+    }
+    const float inv_scale = max_scale > 0.0f ? 63.0f / max_scale : 0.0f, inv_min = max_min > 0.0f ? 63.0f / max_min : 0.0f;
+    int ls = (int)rintf(inv_scale * scale), lm = (int)rintf(inv_min * the_min);
+    ls = (ls & 255) > 63 ? 63 : (ls & 255);                 // (upstream stores nearest_int in a uint8_t, then MIN(63, .))
+    lm = (lm & 255) > 63 ? 63 : (lm & 255);
+    const _Float16 dh = (_Float16)(max_scale / 63.0f), dminh = (_Float16)(max_min / 63.0f);
+    const float dd = (float)dh * (float)ls;
+    if (dd != 0.0f) {
+        const float dm = (float)dminh * (float)lm;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            int l = (int)rintf((v[i] + dm) / dd);
+            L[i] = l < 0 ? 0 : l > NMAX ? NMAX : l;
+        }
+    }
+    uint8_t *blk = out + sb * BYTES;
+    // header: d, dmin, scales[12] (lane 0, with every lane's ls / lm)
+    int lsa[8], lma[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { lsa[q] = __shfl(ls, q, 8); lma[q] = __shfl(lm, q, 8); }
+    if (active && j == 0) {
+        *(uint16_t *)blk = __builtin_bit_cast(uint16_t, dh);
+        *(uint16_t *)(blk + 2) = __builtin_bit_cast(uint16_t, dminh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            blk[4 + q] = (uint8_t)(lsa[q] | ((lsa[q + 4] >> 4) << 6));
+            blk[8 + q] = (uint8_t)(lma[q] | ((lma[q + 4] >> 4) << 6));
+            blk[12 + q] = (uint8_t)((lsa[q + 4] & 15) | ((lma[q + 4] & 15) << 4));
+        }
+    }
+    // nibbles: sub-blocks 2g / 2g + 1 share the bytes qs[32 g ..]: the even lane writes both
+    uint32_t lo[8];                                         // this lane's 32 low nibbles as bytes-to-be (four per word), and its fifth bits
+    uint32_t hb = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        lo[i >> 2] |= (uint32_t)(L[i] & 15) << (8 * (i & 3));
+        hb |= (uint32_t)((L[i] >> 4) & 1) << i;
+    }
+    uint8_t *ql = blk + (Q5 ? 48 : 16) + 32 * (j >> 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t other = __shfl_xor(lo[i], 1, 8);     // (the odd lane's nibbles go to the high halves)
+        if (active && !(j & 1)) ((uint32_t *)ql)[i] = lo[i] | (other << 4);
+    }
+    if constexpr (Q5) {                                     // qh[l] bit q = the fifth bit of element l of sub-block q: lane j writes bytes 4 j .. 4 j + 3
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t h = __shfl(hb, q, 8);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) word |= ((h >> (4 * j + b)) & 1u) << (8 * b + q);
+        }
+        if (active) ((uint32_t *)(blk + 16))[j] = word;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_q5k_to_planar(int kq_type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st) {
@@ -146,5 +272,14 @@ hipError_t launch_dequantize_q5k(int kq_type, const void *blocks, int64_t nrows,
     if (nsub <= 0) return hipSuccess;
     if (kq_type == GGML_HIP_TYPE_Q5_K) dequantize_q5k_kernel<true><<<dim3((unsigned)((nsub + 127) / 128)), 128, 0, st>>>((const uint8_t *)blocks, nsub, y);
     else dequantize_q5k_kernel<false><<<dim3((unsigned)((nsub + 127) / 128)), 128, 0, st>>>((const uint8_t *)blocks, nsub, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_kq(int kq_type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st) {
+    const int64_t nsb = nrows * (k / 256);
+    if (nsb <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((nsb * 8 + 127) / 128);
+    if (kq_type == GGML_HIP_TYPE_Q5_K) quantize_kq_kernel<true><<<dim3(grid), 128, 0, st>>>(x, nsb, (uint8_t *)blocks);
+    else quantize_kq_kernel<false><<<dim3(grid), 128, 0, st>>>(x, nsb, (uint8_t *)blocks);
     return hipGetLastError();
 }

@@ -25,8 +25,9 @@ extern "C" {
  * (SURVEY 8(a) row K), while BASELINE.json's north_star and config 4 name Q5_K.  Built to the PUBLISHED upstream format
  * (ggml k_quants, 2023-06: 176-byte super-blocks of 256 weights; activations by the Q8_K rule) as an unpinned extra: no oracle
  * exists in the reference, tests/np_kquants.py restates the published algorithm.  Accepted by ggml_hip_weight_upload /
- * _from_device / _download, ggml_hip_mul_mat{,_init,_compute}_dev, ggml_hip_mul_mat_work_size and
- * ggml_hip_dequantize_rows_dev only -- never inside a ggml_tensor (the reference cannot express the type). */
+ * _from_device / _download, ggml_hip_mul_mat{,_init,_compute}_dev, ggml_hip_mul_mat_work_size,
+ * ggml_hip_dequantize_rows_dev and (r4) ggml_hip_quantize_rows_dev (quantize_row_q5_K_reference / _q4_K_reference of the published
+ * format restated: make_qkx1_quants per sub-block, 6-bit scales / mins against the super-block's d / dmin) only -- never inside a ggml_tensor (the reference cannot express the type). */
 #define GGML_HIP_TYPE_Q5_K 113
 /* r4: Q4_K of the same published format -- { half d; half dmin; u8 scales[12]; u8 qs[128] }, 144 bytes per 256 weights, the super-block of
  * Q5_K without its fifth-bit bytes and with the same scale / min packing and the same dot rule against Q8_K.  It lives in the same resident

@@ -205,3 +205,88 @@ def quantize_q4_K(x):
         qs[:, g] = q[:, 2 * g] | (q[:, 2 * g + 1] << 4)
     blocks[:, 16:144] = qs.reshape(nb, 128).astype(np.uint8)
     return blocks
+
+
+# ---------------------------------------------------------------- r4: the published quantizers, restated (what kquants.hip quantize_kq_kernel follows)
+def make_qkx1_quants(x, nmax, ntry=5):
+    """x [ns, 32] f32 -> (scale [ns], the_min [ns], L [ns, 32] int32): the affine code over [min(0, min x), max x], its scale refitted by
+    least squares until no code changes (at most `ntry` times).  Every float operation a binary32 operation in upstream's order."""
+    F = np.float32
+    x = np.ascontiguousarray(x, dtype=F)
+    ns = x.shape[0]
+    mn = x.min(axis=1).astype(F)
+    mx = x.max(axis=1).astype(F)
+    flat = mx == mn
+    mn = np.where(mn > 0, F(0), mn).astype(F)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        iscale = (F(nmax) / (mx - mn).astype(F)).astype(F)
+        scale = (F(1) / iscale).astype(F)
+        L = np.full((ns, 32), -1, dtype=np.int64)
+        live = ~flat                                                   # sub-blocks still iterating
+        for _ in range(ntry):
+            if not live.any():
+                break
+            sumlx = np.zeros(ns, dtype=F)
+            suml2 = np.zeros(ns, dtype=np.int64)
+            changed = np.zeros(ns, dtype=bool)
+            Lnew = L.copy()
+            for i in range(32):
+                t = (x[:, i] - mn).astype(F)
+                l = np.clip(np.rint((iscale * t).astype(F)), 0, nmax).astype(np.int64)
+                changed |= l != L[:, i]
+                Lnew[:, i] = l
+                sumlx = (sumlx + (t * l.astype(F)).astype(F)).astype(F)
+                suml2 += l * l
+            sc_new = (sumlx / suml2.astype(F)).astype(F)
+            s = np.zeros(ns, dtype=F)
+            for i in range(32):
+                s = (s + (x[:, i] - (sc_new * Lnew[:, i].astype(F)).astype(F)).astype(F)).astype(F)
+            mn_new = (s / F(32)).astype(F)
+            mn_new = np.where(mn_new > 0, F(0), mn_new).astype(F)
+            L = np.where(live[:, None], Lnew, L)
+            scale = np.where(live, sc_new, scale).astype(F)
+            mn = np.where(live, mn_new, mn).astype(F)
+            iscale = np.where(live, (F(1) / scale).astype(F), iscale).astype(F)
+            live = live & changed
+    L = np.where(flat[:, None], 0, L)
+    return np.where(flat, F(0), scale).astype(F), np.where(flat, F(0), -mn).astype(F), L
+
+
+def quantize_kq_reference(x, bits):
+    """quantize_row_q5_K_reference (bits = 5) / quantize_row_q4_K_reference (bits = 4): x [nb, 256] f32 -> super-blocks [nb, 176 | 144]"""
+    F = np.float32
+    nmax = (1 << bits) - 1
+    x = np.ascontiguousarray(x, dtype=F).reshape(-1, 256)
+    nb = x.shape[0]
+    scale, mins, L = make_qkx1_quants(x.reshape(-1, 32), nmax)
+    scale, mins, L = scale.reshape(nb, 8), mins.reshape(nb, 8), L.reshape(nb, 8, 32)
+    max_scale = np.maximum(scale.max(axis=1), F(0)).astype(F)
+    max_min = np.maximum(mins.max(axis=1), F(0)).astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv_scale = np.where(max_scale > 0, (F(63) / max_scale).astype(F), F(0)).astype(F)
+        inv_min = np.where(max_min > 0, (F(63) / max_min).astype(F), F(0)).astype(F)
+        ls = np.rint((inv_scale[:, None] * scale).astype(F)).astype(np.int64) & 255       # (a uint8_t in upstream)
+        lm = np.rint((inv_min[:, None] * mins).astype(F)).astype(np.int64) & 255
+        ls, lm = np.minimum(ls, 63), np.minimum(lm, 63)
+        d16 = (max_scale / F(63)).astype(F).astype(np.float16)
+        dmin16 = (max_min / F(63)).astype(F).astype(np.float16)
+        dd = (d16.astype(F)[:, None] * ls.astype(F)).astype(F)
+        dm = (dmin16.astype(F)[:, None] * lm.astype(F)).astype(F)
+        l2 = np.clip(np.rint(((x.reshape(nb, 8, 32) + dm[:, :, None]).astype(F) / dd[:, :, None]).astype(F)), 0, nmax)
+    L = np.where((dd != 0)[:, :, None], np.nan_to_num(l2).astype(np.int64), L).astype(np.uint32)
+    blocks = np.zeros((nb, Q5K_BYTES if bits == 5 else Q4K_BYTES), dtype=np.uint8)
+    blocks[:, 0:2] = d16.reshape(-1, 1).view(np.uint8)
+    blocks[:, 2:4] = dmin16.reshape(-1, 1).view(np.uint8)
+    blocks[:, 4:16] = pack_scales(ls, lm)
+    qs = np.zeros((nb, 4, 32), dtype=np.uint32)
+    qh = np.zeros((nb, 32), dtype=np.uint32)
+    for g in range(4):
+        qs[:, g] = (L[:, 2 * g] & 0xF) | ((L[:, 2 * g + 1] & 0xF) << 4)
+        qh |= ((L[:, 2 * g] >> 4) & 1) << (2 * g)
+        qh |= ((L[:, 2 * g + 1] >> 4) & 1) << (2 * g + 1)
+    if bits == 5:
+        blocks[:, 16:48] = qh.astype(np.uint8)
+        blocks[:, 48:176] = qs.reshape(nb, 128).astype(np.uint8)
+    else:
+        blocks[:, 16:144] = qs.reshape(nb, 128).astype(np.uint8)
+    return blocks

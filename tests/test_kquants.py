@@ -74,6 +74,25 @@ def test_q4_K_restatement_by_hand_and_its_encoder():
     assert abs(float(KQ.mul_mat_q4_K(w, xx)[0, 0]) - exact) <= 1e-5 * max(1.0, abs(exact))
 
 
+def test_published_quantizers_restated_are_valid_and_tighter_than_the_simple_encoder():
+    """quantize_row_q5_K_reference / _q4_K_reference as restated (r4; what the device quantizer follows): valid super-blocks whose
+    decode is at least as close to the input as the simple test encoder's; upstream's own corner: a constant sub-block decodes to 0
+    (make_qkx1_quants returns scale 0, min 0 when max == min), an all-zero super-block to zeros with d = dmin = 0."""
+    x = _rand((60, 256), 2.0)
+    x[3] = 0.0
+    x[5] = np.abs(x[5])                                               # no negative value: min stays 0
+    for bits, simple, deq, nbytes in ((5, KQ.quantize_q5_K, KQ.dequantize_q5_K, 176), (4, KQ.quantize_q4_K, KQ.dequantize_q4_K, 144)):
+        b = KQ.quantize_kq_reference(x, bits)
+        assert b.shape == (60, nbytes) and not b[3].any()
+        y = deq(b)
+        e_ref, e_simple = np.sqrt(((y - x) ** 2).mean()), np.sqrt(((deq(simple(x)) - x) ** 2).mean())
+        assert e_ref <= 1.02 * e_simple and np.abs(y - x).max() <= (0.12 if bits == 5 else 0.25) * 2.0 * 3.5
+        sc, m = KQ.unpack_scales(b[:, 4:16])
+        assert sc.max() <= 63 and m.max() <= 63 and (sc.max(axis=1)[np.arange(60) != 3] == 63).all()   # the largest scale of a super-block maps to 63
+    c = np.full((1, 256), 5.0, dtype=np.float32)
+    assert not KQ.dequantize_q5_K(KQ.quantize_kq_reference(c, 5)).any()
+
+
 def test_q8_K_rule():
     x = np.zeros((3, 256), dtype=np.float32)
     x[0, 7] = -4.0
@@ -123,6 +142,32 @@ def test_dequantize_q5_K_bit_exact(dev, t):
         want = KQT[t][2](b)
         got = dev.dequantize_rows(t, torch.from_numpy(b.reshape(1, -1)).cuda(), b.shape[0] * 256).cpu().numpy().reshape(-1, 256)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@gpu
+@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+def test_device_quantizer_writes_the_restated_reference_quantizers_bytes(dev, t):
+    """ggml_hip_quantize_rows_dev for the extension types (r4): byte for byte the super-blocks of tests/np_kquants.py quantize_kq_reference
+    -- normal data at several scales, a zero row, a non-negative row, constant sub-blocks, a single outlier, ragged tail of the grid"""
+    import torch
+    for (nrows, K, scale) in ((1, 256, 1.0), (7, 768, 3.0), (33, 2048, 0.01), (5, 11008, 40.0)):
+        x = _rand((nrows, K), scale)
+        x[0, :256] = 0.0
+        if nrows > 1:
+            x[1] = np.abs(x[1])
+            x[2, 32:64] = -1.5
+            x[2, 300] = 1000.0
+        want = KQ.quantize_kq_reference(x.reshape(-1, 256), 5 if t == Q5_K else 4).reshape(nrows, -1)
+        got = dev.quantize_rows(t, torch.from_numpy(x).cuda()).cpu().numpy()
+        assert got.shape == want.shape
+        bad = np.nonzero((got != want).reshape(-1, KQT[t][0]).any(axis=1))[0]
+        assert bad.size == 0, f"type {t} {nrows}x{K}: super-blocks {bad[:8]} differ"
+        # and the weight made from them multiplies like the restatement says
+    x = _rand((64, 1024))
+    rows = dev.quantize_rows(t, torch.from_numpy(x).cuda())
+    a = _rand((20, 1024))
+    got = dev.mul_mat(dev.Weight.from_device(t, rows, 1024), torch.from_numpy(a).cuda()).cpu().numpy()
+    _close(got, KQT[t][3](rows.cpu().numpy(), a), f"k-quant {t} from the device quantizer", 1024)
 
 
 @gpu
