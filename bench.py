@@ -74,9 +74,9 @@ def stats(ts):
 
 
 Q5_0, Q8_0 = 6, 8
-Q5_K, Q4_K = 113, 112                                 # extension types (upstream k-quant format; absent from the reference)
-BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36, Q5_K: 22, Q4_K: 18}   # Ggml.cs:76-82; Q5_K: 176 B per 256 weights, Q4_K: 144
-TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q4_K: "Q4_K"}
+Q5_K, Q4_K, Q6_K = 113, 112, 114                      # extension types (upstream k-quant format; absent from the reference)
+BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36, Q5_K: 22, Q4_K: 18, Q6_K: 26.25}   # Ggml.cs:76-82; per 32 weights -- Q5_K: 176 B per 256, Q4_K: 144, Q6_K: 210
+TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q4_K: "Q4_K", Q6_K: "Q6_K"}
 
 
 def make_weights_q4_0(M, K, seed, qtype=Q4_0):
@@ -788,6 +788,8 @@ def main():
                 "q8_0_ffn1024": side_config(device, 4096, 11008, 1024, copies=6, iters=40, qtype=Q8_0),
                 "q5_k_ffn2048_unpinned_extra": side_config(device, 4096, 11008, 2048, copies=6, iters=20, qtype=Q5_K),
                 "q4_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q4_K),   # (r4: Q4_K, the same resident form and kernels)
+                "q6_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=6, iters=40, qtype=Q6_K),   # (r4: Q6_K in the planar Q4_2 form on int8 planes: the staged int8 kernel)
+                "q6_k_batch1_unpinned_extra": side_config(device, 4096, 4096, 1, copies=32, iters=100, qtype=Q6_K),    #     ... and its decode step (the batched-decode form from one row)
                 "q5_0_batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100, qtype=Q5_0),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
                 "vocab512_shard_of_8": side_config(device, 4000, 4096, 512, copies=24, iters=100),      # what each rank of config 5's 8-GPU split computes

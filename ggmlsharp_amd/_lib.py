@@ -22,12 +22,13 @@ GGML_MAX_NODES = 4096
 F32, F16, Q4_0, Q4_1, Q4_2, Q4_3, Q5_0, Q5_1, Q8_0, Q8_1, I8, I16, I32 = range(13)
 Q5_K = 113   # extension (include/ggml_hip_ext.h GGML_HIP_TYPE_Q5_K): upstream k-quant format, absent from the reference
 Q4_K = 112   # ... and GGML_HIP_TYPE_Q4_K (r4): the same super-block without the fifth-bit bytes
+Q6_K = 114   # ... and GGML_HIP_TYPE_Q6_K (r4): sixteen sub-blocks of 16 six-bit weights, resident in the planar Q4_2 form on int8 planes
 TYPE_NAME = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q4_1: "q4_1", Q4_2: "q4_2", Q4_3: "q4_3", Q5_0: "q5_0",
              Q5_1: "q5_1", Q8_0: "q8_0", Q8_1: "q8_1", I8: "i8", I16: "i16", I32: "i32"}
 BLCK_SIZE = {F32: 1, F16: 1, Q4_0: 32, Q4_1: 32, Q4_2: 16, Q4_3: 16, Q5_0: 32, Q5_1: 32, Q8_0: 32, Q8_1: 32,
-             I8: 1, I16: 1, I32: 1, Q5_K: 256, Q4_K: 256}
+             I8: 1, I16: 1, I32: 1, Q5_K: 256, Q4_K: 256, Q6_K: 256}
 TYPE_SIZE = {F32: 4, F16: 2, Q4_0: 20, Q4_1: 24, Q4_2: 10, Q4_3: 12, Q5_0: 22, Q5_1: 24, Q8_0: 36, Q8_1: 44,
-             I8: 1, I16: 2, I32: 4, Q5_K: 176, Q4_K: 144}
+             I8: 1, I16: 2, I32: 4, Q5_K: 176, Q4_K: 144, Q6_K: 210}
 
 GGML_OP_NONE, GGML_OP_ADD, GGML_OP_MUL_MAT, GGML_OP_CPY = 0, 2, 20, 22
 GGML_OP_SILU = 17

@@ -436,7 +436,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q4_2) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
         // the min plane as three bf16 pieces (K3p-int8's min-term product): whole pairs of k-groups, zero past the end of K
         if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_mp = total; total += (size_t)((w->nbk + 15) / 16 * 2 * 3) * w->Mpad * 16; }
-        if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * 16; }   // super-block headers, for the byte-exact download
+        if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * (kq_type == GGML_HIP_TYPE_Q6_K ? 32 : 16); }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
             off_6a = total; total += (size_t)nba * nf * w->Mpad * 16;
@@ -488,7 +488,8 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
         const int64_t rows_n = row_end - row_begin;
         const uint64_t rb = (uint64_t)(ne00 / 256) * kquant_bytes(type);
         ggml_hip_weight *w = nullptr;
-        rc = alloc_weight(c, GGML_TYPE_Q5_1, ne00, rows_n, &w, type);
+        const bool q6k = type == GGML_HIP_TYPE_Q6_K;           // (the planar Q4_2 form on int8 planes: kquants.hip)
+        rc = alloc_weight(c, kquant_resident_type(type), ne00, rows_n, &w, type);
         if (rc) return rc;
         hipError_t e = hipMemsetAsync(w->qs, 0, w->bytes, st);
         void *staging = nullptr;
@@ -496,12 +497,12 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
             e = hipMalloc(&staging, (size_t)rows_n * rb);
             if (e == hipSuccess)
                 e = hipMemcpy2DAsync(staging, rb, (const uint8_t *)rows + (uint64_t)row_begin * nb01, nb01, rb, (size_t)rows_n, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = launch_q5k_to_planar(type, (const uint8_t *)staging, rb, 0, rows_n, w, st);
+            if (e == hipSuccess) e = q6k ? launch_q6k_to_planar((const uint8_t *)staging, rb, 0, rows_n, w, st) : launch_q5k_to_planar(type, (const uint8_t *)staging, rb, 0, rows_n, w, st);
         } else if (e == hipSuccess) {
-            e = launch_q5k_to_planar(type, (const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
+            e = q6k ? launch_q6k_to_planar((const uint8_t *)rows, nb01, row_begin, rows_n, w, st) : launch_q5k_to_planar(type, (const uint8_t *)rows, nb01, row_begin, rows_n, w, st);
         }
-        if (e == hipSuccess) e = launch_q5_to_i8(w, st);      // (the planar Q5_1 form's int8 operand planes: gemm_qmp.hip serves prompt-sized batches)
-        if (e == hipSuccess) e = launch_min_pieces(w, st);
+        if (e == hipSuccess && !q6k) e = launch_q5_to_i8(w, st);      // (the planar Q5_1 form's int8 operand planes: gemm_qmp.hip serves prompt-sized batches; Q6_K's converter writes them itself)
+        if (e == hipSuccess && !q6k) e = launch_min_pieces(w, st);
         if (e == hipSuccess) e = launch_gemv_side_image(w, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (staging) (void)hipFree(staging);
@@ -651,7 +652,8 @@ int ggml_hip_weight_download(const ggml_hip_weight *w, void *host_rows, void *st
     if (total == 0) return GGML_HIP_OK;
     void *staging = nullptr;
     HIP_TRY(hipMalloc(&staging, total));
-    hipError_t e = w->ext_type != 0 ? launch_planar_to_q5k(w, (uint8_t *)staging, st) : launch_planar_to_aos(w, (uint8_t *)staging, st);
+    hipError_t e = w->ext_type == GGML_HIP_TYPE_Q6_K ? launch_planar_to_q6k(w, (uint8_t *)staging, st)
+                   : w->ext_type != 0 ? launch_planar_to_q5k(w, (uint8_t *)staging, st) : launch_planar_to_aos(w, (uint8_t *)staging, st);
     if (e == hipSuccess) e = hipMemcpyAsync(host_rows, staging, total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(staging);
@@ -674,7 +676,7 @@ int ggml_hip_weight_type(const ggml_hip_weight *w) { return w ? (w->ext_type ? w
 
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N) {
     if (K <= 0 || N <= 0) return 0;
-    if (is_kquant(type)) type = GGML_TYPE_Q5_1;                 // same operand images
+    if (is_kquant(type)) type = kquant_resident_type(type);     // same operand images
     if (type == GGML_TYPE_F16) return (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 2;   // src1 as Half (Ggml.cs:3356-3357), padded
     if (type == GGML_TYPE_F32) return N > 256 ? (size_t)dense16_kpad(K) * (size_t)pad_act(N) * 6 : 0;   // src1 as three bf16 pieces (dense16.hip K10d; the reference needs none)
     if (!is_q(type)) return 0;
@@ -706,14 +708,14 @@ int ggml_hip_mul_mat_init_dev(const ggml_hip_weight *w, const float *d_src1, int
     return GGML_HIP_OK;
 }
 
-int ggml_hip_act_image_kind(int type, int64_t K, int64_t N) { return act_image_kind(is_kquant(type) ? GGML_TYPE_Q5_1 : type, K, N); }
+int ggml_hip_act_image_kind(int type, int64_t K, int64_t N) { return act_image_kind(is_kquant(type) ? kquant_resident_type(type) : type, K, N); }
 void ggml_hip_debug_force_gemm(int which) { plan_set_force_gemm(which); }
 
 // the plan of mul_mat(type, M, K, N) as ggml_hip_mul_mat_dev will run it; no device is needed (tests/test_plan_cpu.py)
 int ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_plan_t *out) {
     if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
     const bool q5k = is_kquant(type);
-    const int t = q5k ? GGML_TYPE_Q5_1 : type;
+    const int t = q5k ? kquant_resident_type(type) : type;
     if (t < 0 || t >= GGML_TYPE_COUNT || !weight_type_ok(t)) return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type", type);
     if (M <= 0 || K <= 0 || N <= 0 || K % BLCK[t] != 0 || (is_q(t) && K % QK != 0) || (q5k && K % 256 != 0)) return fail(GGML_HIP_ERR_SHAPE, "bad shape");
     const mm_plan p = plan_mul_mat(t, q5k ? type : 0, M, K, N, true);
@@ -1031,9 +1033,10 @@ int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_
     if (nrows <= 0) return GGML_HIP_OK;  // empty input: nothing to do (buffers may be null)
     if (!d_x || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (is_kquant(type)) {                                      // unpinned extra (kquants.hip, r4)
-        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: k %% 256 != 0");
-        if (((uintptr_t)d_x & 15) != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: the rows must be 16-byte aligned");
-        HIP_TRY(launch_quantize_kq(type, d_x, nrows, k, d_blocks, (hipStream_t)stream));
+        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "k-quants: k %% 256 != 0");
+        if (((uintptr_t)d_x & 15) != 0) return fail(GGML_HIP_ERR_SHAPE, "k-quants: the rows must be 16-byte aligned");
+        if (type == GGML_HIP_TYPE_Q6_K) HIP_TRY(launch_quantize_q6k(d_x, nrows, k, d_blocks, (hipStream_t)stream));
+        else HIP_TRY(launch_quantize_kq(type, d_x, nrows, k, d_blocks, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
     if (!(wq_ok(type) || type == GGML_TYPE_Q8_1))
@@ -1047,8 +1050,9 @@ int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, 
     if (nrows <= 0) return GGML_HIP_OK;
     if (!d_y || !d_blocks) return fail(GGML_HIP_ERR_ARG, "null argument");
     if (is_kquant(type)) {                                      // unpinned extra (kquants.hip)
-        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: k %% 256 != 0");
-        HIP_TRY(launch_dequantize_q5k(type, d_blocks, nrows, k, d_y, (hipStream_t)stream));
+        if (k % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "k-quants: k %% 256 != 0");
+        if (type == GGML_HIP_TYPE_Q6_K) HIP_TRY(launch_dequantize_q6k(d_blocks, nrows, k, d_y, (hipStream_t)stream));
+        else HIP_TRY(launch_dequantize_q5k(type, d_blocks, nrows, k, d_y, (hipStream_t)stream));
         return GGML_HIP_OK;
     }
     if (!wq_ok(type))

@@ -74,8 +74,8 @@ struct ggml_hip_weight {
     uint8_t *mp3;     // Q5_1 / Q4_1 (and the Q5_K extension living in the Q5_1 form): the min plane split EXACTLY into three bf16 pieces,
                       //   [ceil(nbk / 8) * 3 (+ pad to whole pairs of k-groups)][Mpad][16 B]: plane 3 * (b / 8) + piece holds 8 consecutive k-blocks of a row --
                       //   the B operand of v_mfma_f32_32x32x16_bf16 for K3p's min-term product (gemm_qmp.hip); 0.19 B / weight
-    uint8_t *khdr;    // Q5_K / Q4_K only: the 16 header bytes (d, dmin, scales[12]) of every super-block, [K/256][Mpad][16 B]
-    int      ext_type; // 0, or GGML_HIP_TYPE_Q5_K / _Q4_K: the weight was uploaded as k-quant super-blocks and lives in the planar Q5_1 form (type == Q5_1)
+    uint8_t *khdr;    // k-quants only (Q6_K: 32 B per super-block, scales[16] + d): the 16 header bytes (d, dmin, scales[12]) of every super-block, [K/256][Mpad][16 B]
+    int      ext_type; // 0, or GGML_HIP_TYPE_Q5_K / _Q4_K (type == Q5_1) / _Q6_K (type == Q4_2): the weight was uploaded as k-quant super-blocks and lives in the planar Q5_1 form (type == Q5_1)
     size_t   bytes;
     int      device;
     uint64_t uid;     // never reused: identifies the weight in cached launch graphs
@@ -280,12 +280,19 @@ hipError_t launch_push_columns(const float *src, int64_t lds, int64_t N, int64_t
 hipError_t launch_quantize_act(const float *x, int64_t N, int64_t K, int64_t ld1, act_planes p, int image, hipStream_t st, bool q8k = false);
 // kquants.hip (Q5_K as an unpinned extra: the published upstream format, no oracle in the reference)
 // (r4: Q4_K beside it -- the same super-block without the fifth-bit bytes: `kq_type` = GGML_HIP_TYPE_Q5_K or _Q4_K; a weight's own ext_type)
-static inline bool is_kquant(int t) { return t == GGML_HIP_TYPE_Q5_K || t == GGML_HIP_TYPE_Q4_K; }
-static inline size_t kquant_bytes(int t) { return t == GGML_HIP_TYPE_Q5_K ? 176 : 144; }   // per 256 weights
+static inline bool is_kquant(int t) { return t == GGML_HIP_TYPE_Q5_K || t == GGML_HIP_TYPE_Q4_K || t == GGML_HIP_TYPE_Q6_K; }
+static inline size_t kquant_bytes(int t) { return t == GGML_HIP_TYPE_Q5_K ? 176 : t == GGML_HIP_TYPE_Q6_K ? 210 : 144; }   // per 256 weights
+// the reference type whose resident planar form (and kernels) a k-quant weight lives in: Q5_K / Q4_K as Q5_1, Q6_K as Q4_2 (two scales per k-block)
+static inline int kquant_resident_type(int t) { return t == GGML_HIP_TYPE_Q6_K ? GGML_TYPE_Q4_2 : GGML_TYPE_Q5_1; }
 hipError_t launch_q5k_to_planar(int kq_type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st);
 hipError_t launch_planar_to_q5k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
 hipError_t launch_dequantize_q5k(int kq_type, const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
 hipError_t launch_quantize_kq(int kq_type, const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st);   // x: contiguous rows, 16-byte aligned
+// (Q6_K: its own converters -- the planar Q4_2 form on int8 planes)
+hipError_t launch_q6k_to_planar(const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st);
+hipError_t launch_planar_to_q6k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st);
+hipError_t launch_dequantize_q6k(const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st);
+hipError_t launch_quantize_q6k(const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st);
 hipError_t launch_q8_aos_to_planes(int q8type, const void *blocks, int64_t N, int64_t K, act_planes p, hipStream_t st);
 hipError_t launch_quantize_rows(int type, int src_type, const void *x, int64_t ld, int64_t nrows, int64_t k, void *blocks,
                                 hipStream_t st);

@@ -65,8 +65,14 @@ __device__ __forceinline__ uint32_t q5_hi(uint32_t qh, int i, int sel) {
     return (t * 0x00410410u) & 0x10101010u;
 }
 
+// r4: a pseudo-type for weights that live in the planar Q4_2 form ON INT8 PLANES (the Q6_K extension, kquants.hip): Q8_0's operand path
+// (the planes go to LDS as they are) with Q4_2's arithmetic (two 16-element sub-blocks per k-block, the second's scale in the m plane)
+constexpr int GQ_TYPE_I8X2 = 100;
+template <int TYPE> constexpr bool W_I8 = TYPE == GGML_TYPE_Q8_0 || TYPE == GQ_TYPE_I8X2;      // weights: int8 planes, no unpacking
+template <int TYPE> constexpr bool TWO_SC = TYPE == GGML_TYPE_Q4_2 || TYPE == GQ_TYPE_I8X2;    // two sub-block sums and scales per k-block
+
 template <int TYPE> struct Traits {
-    static constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // second weight plane
+    static constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TWO_SC<TYPE>;   // second weight plane
     static constexpr bool MIN = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1;                              // ... that is a min
     static constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
 };
@@ -144,15 +150,15 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
     constexpr int SA_PER_THREAD = (BKB * TN + 255) / 256;
     constexpr int SW_PER_THREAD = (BKB * TM + 255) / 256;
     const uint32_t a_blk = (uint32_t)(2 * Npad * 16);
-    const uint32_t w_blk = (uint32_t)(Mpad * (TYPE == GGML_TYPE_Q8_0 ? 32 : 16));
-    uint32_t offA[A_PER_THREAD], offW[TYPE == GGML_TYPE_Q8_0 ? W8_PER_THREAD : W_PER_THREAD], offH[W_PER_THREAD];
+    const uint32_t w_blk = (uint32_t)(Mpad * (W_I8<TYPE> ? 32 : 16));
+    uint32_t offA[A_PER_THREAD], offW[W_I8<TYPE> ? W8_PER_THREAD : W_PER_THREAD], offH[W_PER_THREAD];
     uint32_t offDa[SA_PER_THREAD], offDw[SW_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
         const int c = tid + 256 * i, bh = c / TN, row = c % TN;          // bh = bb * 2 + half
         offA[i] = (uint32_t)(bh >> 1) * a_blk + (uint32_t)(((bh & 1) * Npad + n0 + row) * 16);
     }
-    if (TYPE == GGML_TYPE_Q8_0) {
+    if (W_I8<TYPE>) {
 #pragma unroll
         for (int i = 0; i < W8_PER_THREAD; ++i) {
             const int c = tid + 256 * i, bh = c / TM, row = c % TM;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
             const uint32_t off = offA[i] - (bb >= left ? (uint32_t)bb * a_blk : 0u);
             glds16(gA + off, sp + (size_t)(c - lane) * 16);              // wave-uniform LDS base, hardware adds lane*16
         }
-        if (TYPE == GGML_TYPE_Q8_0) {
+        if (W_I8<TYPE>) {
             uint8_t *sW = sp + T::A_BYTES;
 #pragma unroll
             for (int i = 0; i < W8_PER_THREAD; ++i) {
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
     };
 
     auto store_weights = [&](int s) {
-        if (TYPE == GGML_TYPE_Q8_0) return;
+        if (W_I8<TYPE>) return;
         uint8_t *sW = stage_ptr(s) + T::A_BYTES;
 #pragma unroll
         for (int i = 0; i < W_PER_THREAD; ++i) {
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
         i32x4 af[RING][IT], bf[RING][JT];
         float dw[RING][JT], mw[RING][JT];
         f32x4 da[2][4], sa[2][4];
-        i32x16 tacc[2], tacc2[TYPE == GGML_TYPE_Q4_2 ? 2 : 1];   // Q4_2: the second 16-element block's sums
+        i32x16 tacc[2], tacc2[TWO_SC<TYPE> ? 2 : 1];   // Q4_2: the second 16-element block's sums
         const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
         auto load_block = [&](auto bbc) {   // operand fragments + per-lane weight scales of k-block bb
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
         };
         auto mfma_tile = [&](auto tc) {
             constexpr int t = decltype(tc)::value, bb = t / (IT * JT), i = (t / JT) % IT, j = t % JT;
-            if constexpr (TYPE == GGML_TYPE_Q4_2) {
+            if constexpr (TWO_SC<TYPE>) {
                 const i32x4 a = af[bb % RING][i], b = bf[bb % RING][j];
                 const long a0 = (long)(((uint64_t)(uint32_t)a[1] << 32) | (uint32_t)a[0]), a1 = (long)(((uint64_t)(uint32_t)a[3] << 32) | (uint32_t)a[2]);
                 const long b0 = (long)(((uint64_t)(uint32_t)b[1] << 32) | (uint32_t)b[0]), b1 = (long)(((uint64_t)(uint32_t)b[3] << 32) | (uint32_t)b[2]);
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void gemm_q_kernel(const uint8_t *__restric
                 const float sc = da[g & 1][r >> 2][r & 3] * dwj;
                 acc[i][j][r >> 2][r & 3] = fmaf((float)tt[r], sc, acc[i][j][r >> 2][r & 3]);
             }
-            if constexpr (TYPE == GGML_TYPE_Q4_2) {   // sumf += (d1 * yd) * sumi_1 (Ggml.cs:1250): the second block's scale rides in the m plane
+            if constexpr (TWO_SC<TYPE>) {   // sumf += (d1 * yd) * sumi_1 (Ggml.cs:1250): the second block's scale rides in the m plane
                 const i32x16 t2 = tacc2[t & 1];
                 const float dw2 = mw[bb % RING][j];
 #pragma unroll
@@ -452,7 +458,7 @@ hipError_t launch_cfg(const ggml_hip_weight *w, act_planes p, int64_t N, float *
     if (attr != hipSuccess) return attr;
     const int tiles_m = (int)((w->M + T::TM - 1) / T::TM), tiles_n = (int)((N + T::TN - 1) / T::TN);
     dim3 grid((unsigned)(tiles_m * tiles_n));
-    kern<<<grid, 256, T::LDS, st>>>(w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad, w->nbk, ldd,
+    kern<<<grid, 256, T::LDS, st>>>(TYPE == GQ_TYPE_I8X2 ? w->i8p : w->qs, w->qh, w->d, w->m, p.a8, p.ad, p.as, dst, w->M, N, w->Mpad, p.Npad, w->nbk, ldd,
                                     tiles_m, tiles_n);
     return hipGetLastError();
 }
@@ -473,7 +479,9 @@ hipError_t launch_gemm_q(const ggml_hip_weight *w, const mm_plan &pl, act_planes
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0>(w, pl, p, N, dst, ldd, st);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1>(w, pl, p, N, dst, ldd, st);
     case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0>(w, pl, p, N, dst, ldd, st);
-    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2>(w, pl, p, N, dst, ldd, st);
+    case GGML_TYPE_Q4_2:
+        if (w->ext_type != 0) return w->i8p ? launch_typed<GQ_TYPE_I8X2>(w, pl, p, N, dst, ldd, st) : hipErrorInvalidValue;   // (Q6_K: the form's values live on the int8 planes only)
+        return launch_typed<GGML_TYPE_Q4_2>(w, pl, p, N, dst, ldd, st);
     case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1>(w, pl, p, N, dst, ldd, st);
     case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0>(w, pl, p, N, dst, ldd, st);
     default: return hipErrorInvalidValue;

@@ -249,6 +249,181 @@ __global__ void quantize_kq_kernel(const float *__restrict__ x, int64_t nsb, uin
     }
 }
 
+// ---- r4: Q6_K ------------------------------------------------------------------------------------------------------------------------------
+//     block_q6_K = { u8 ql[128]; u8 qh[64]; i8 scales[16]; half d }                    210 bytes per 256 weights
+//     w[e] = d * scales[e / 16] * (q[e] - 32);  per half n of 128 elements and l < 32, element 128 n + 32 c + l has its low four bits in the
+//     low (c < 2) or high (c >= 2) nibble of ql[64 n + 32 (c & 1) + l] and its two high bits in bits 2 c, 2 c + 1 of qh[32 n + l]
+//     dot against Q8_K per super-block: (d * dy) * sum_j scales[j] * <q_j - 32, a_j>
+// Resident form: a 32-element k-block is two 16-element sub-blocks with a scale each -- the structure of the reference's Q4_2 (two blocks per
+// Q8_0 block, Ggml.cs:1217-1252) -- so a super-block becomes eight k-blocks of the planar Q4_2 form: int8 operand planes of q - 32 (the
+// layout of Q8_0's planes), the first sub-block's effective scale d * sc (exact in f32: 11 + 8 bits) in the d plane, the second's in the m
+// plane.  The int8 kernels that take two scales per k-block serve it (gemm_q8s.hip Q42, gemm_q.hip's int8-plane two-scale form); the
+// nibble plane of the Q4_2 form stays empty.  32 header bytes per super-block (scales[16], d) are kept for the byte-exact download.
+// one thread per (row, k-block)
+__global__ void q6k_to_planar_kernel(const uint8_t *__restrict__ aos, uint64_t nb01, int64_t row_begin, int64_t rows, int64_t Mpad,
+                                     uint8_t *__restrict__ i8p, float *__restrict__ d, float *__restrict__ mm, uint8_t *__restrict__ khdr) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (m >= rows) return;
+    const int64_t sb = b >> 3;
+    const int bq = (int)(b & 7), n = bq >> 2, c = bq & 3;
+    const uint8_t *blk = aos + (uint64_t)(row_begin + m) * nb01 + (uint64_t)sb * 210;
+    const uint8_t *ql = blk + 64 * n + 32 * (c & 1), *qh = blk + 128 + 32 * n;
+    const int8_t *sc = (const int8_t *)(blk + 192);
+    const float dd = h2f((uint16_t)(blk[208] | ((uint16_t)blk[209] << 8)));
+    const int64_t pi = b * Mpad + m;
+    d[pi] = dd * (float)sc[2 * bq];                         // exact: 11 + 8 significant bits
+    mm[pi] = dd * (float)sc[2 * bq + 1];
+    uint32_t ev[4] = {0, 0, 0, 0}, od[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const uint32_t nib = c < 2 ? (uint32_t)(ql[t] & 15u) : (uint32_t)(ql[t] >> 4);
+        const int v = (int)(nib | (((uint32_t)(qh[t] >> (2 * c)) & 3u) << 4)) - 32;
+        const uint32_t byte = (uint32_t)(uint8_t)(int8_t)v << (8 * ((t >> 1) & 3));
+        if (t & 1) od[t >> 3] |= byte; else ev[t >> 3] |= byte;      // plane h byte j = element 2 j + h
+    }
+    *(uint4 *)(i8p + ((b * 2 + 0) * Mpad + m) * 16) = make_uint4(ev[0], ev[1], ev[2], ev[3]);
+    *(uint4 *)(i8p + ((b * 2 + 1) * Mpad + m) * 16) = make_uint4(od[0], od[1], od[2], od[3]);
+    if (bq == 0) {
+        uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 18; ++i) h[i >> 2] |= (uint32_t)blk[192 + i] << (8 * (i & 3));
+        uint4 *o = (uint4 *)(khdr + (sb * Mpad + m) * 32);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    }
+}
+
+// exact inverse: one thread per (row, super-block)
+__global__ void planar_to_q6k_kernel(uint8_t *__restrict__ aos, uint64_t nb01, int64_t rows, int64_t Mpad, const uint8_t *__restrict__ i8p,
+                                     const uint8_t *__restrict__ khdr) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t sb = blockIdx.y;
+    if (m >= rows) return;
+    uint8_t *blk = aos + (uint64_t)m * nb01 + (uint64_t)sb * 210;
+    for (int i = 0; i < 192; ++i) blk[i] = 0;
+    for (int bq = 0; bq < 8; ++bq) {
+        const int n = bq >> 2, c = bq & 3;
+        uint8_t *ql = blk + 64 * n + 32 * (c & 1), *qh = blk + 128 + 32 * n;
+        const int64_t b = sb * 8 + bq;
+        for (int hsel = 0; hsel < 2; ++hsel) {
+            const uint4 w4 = *(const uint4 *)(i8p + ((b * 2 + hsel) * Mpad + m) * 16);
+            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+            for (int j = 0; j < 16; ++j) {
+                const int t = 2 * j + hsel;
+                const uint32_t q = (uint32_t)((int)(int8_t)((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) + 32);
+                ql[t] |= (uint8_t)(c < 2 ? (q & 15u) : ((q & 15u) << 4));
+                qh[t] |= (uint8_t)((q >> 4) << (2 * c));
+            }
+        }
+    }
+    const uint8_t *h = khdr + (sb * Mpad + m) * 32;
+    for (int i = 0; i < 18; ++i) blk[192 + i] = h[i];
+}
+
+// dequantize_row_q6_K of the published format: one thread per (row-major) k-block of 32 outputs
+__global__ void dequantize_q6k_kernel(const uint8_t *__restrict__ in, int64_t nkb, float *__restrict__ y) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nkb) return;
+    const uint8_t *blk = in + (s >> 3) * 210;
+    const int bq = (int)(s & 7), n = bq >> 2, c = bq & 3;
+    const uint8_t *ql = blk + 64 * n + 32 * (c & 1), *qh = blk + 128 + 32 * n;
+    const int8_t *sc = (const int8_t *)(blk + 192);
+    const float dd = h2f((uint16_t)(blk[208] | ((uint16_t)blk[209] << 8)));
+    const float d0 = dd * (float)sc[2 * bq], d1 = dd * (float)sc[2 * bq + 1];
+    float *o = y + s * 32;
+    for (int t = 0; t < 32; ++t) {
+        const uint32_t nib = c < 2 ? (uint32_t)(ql[t] & 15u) : (uint32_t)(ql[t] >> 4);
+        const int v = (int)(nib | (((uint32_t)(qh[t] >> (2 * c)) & 3u) << 4)) - 32;
+        o[t] = (t < 16 ? d0 : d1) * (float)v;               // upstream: d * sc[is] * q, left to right
+    }
+}
+
+// quantize_row_q6_K_reference with make_qx_quants in its plain form (no least-squares refinement of the sub-block scales: a VALID encoder of
+// the published structure, stated as such in include/ggml_hip_ext.h; tests/np_kquants.py quantize_q6_K is the same steps): sixteen lanes per
+// super-block, one sub-block each.
+__global__ void quantize_q6k_kernel(const float *__restrict__ x, int64_t nsb, uint8_t *__restrict__ out) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t sb_raw = tid >> 4;
+    const bool active = sb_raw < nsb;
+    const int64_t sb = active ? sb_raw : nsb - 1;
+    const int j = (int)(tid & 15);
+    const float *xs = x + sb * 256 + 16 * j;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 t = ((const float4 *)xs)[i];
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+    float amax = 0.0f, mx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float ax = fabsf(v[i]); if (ax > amax) { amax = ax; mx = v[i]; } }
+    const float iscale = amax != 0.0f ? -32.0f / mx : 0.0f;
+    const float scale = amax != 0.0f ? 1.0f / iscale : 0.0f;
+    int L[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int l = (int)rintf(iscale * v[i]);
+        l = l < -32 ? -32 : l > 31 ? 31 : l;
+        L[i] = amax != 0.0f ? l + 32 : 0;
+    }
+    // the first sub-block scale of largest magnitude
+    float best = fabsf(scale);
+    int bidx = j;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float ob = __shfl_xor(best, o, 16);
+        const int oi = __shfl_xor(bidx, o, 16);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    const float max_scale = __shfl(scale, bidx, 16);
+    const bool zero = best == 0.0f;
+    const float isc = zero ? 0.0f : -128.0f / max_scale;
+    const _Float16 dh = zero ? (_Float16)0.0f : (_Float16)(1.0f / isc);
+    int sc = (int)rintf(isc * scale);
+    sc = zero ? 0 : sc > 127 ? 127 : sc;
+    const float dd = (float)dh * (float)sc;
+    if (dd != 0.0f) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            int l = (int)rintf(v[i] / dd);
+            l = l < -32 ? -32 : l > 31 ? 31 : l;
+            L[i] = l + 32;
+        }
+    }
+    if (zero) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) L[i] = 0;
+    }
+    uint8_t *blk = out + sb * 210;
+    const int n = j >> 3, c = (j >> 1) & 3, half = j & 1;   // element 16 j + i = 128 n + 32 c + (16 half + i)
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};    // sixteen bytes-to-be: low nibbles / the two high bits
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        lo[i >> 2] |= (uint32_t)(L[i] & 15) << (8 * (i & 3));
+        hi[i >> 2] |= (uint32_t)(L[i] >> 4) << (8 * (i & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t plo = __shfl_xor(lo[k], 4, 16);      // the lane with c ^ 2: the other nibble of the same ql bytes
+        const uint32_t h2 = __shfl_xor(hi[k], 2, 16), h4 = __shfl_xor(hi[k], 4, 16), h6 = __shfl_xor(hi[k], 6, 16);   // c ^ 1, c ^ 2, c ^ 3
+        if (active && c < 2) {
+            const uint32_t word = lo[k] | (plo << 4);
+            uint8_t *q = blk + 64 * n + 32 * (c & 1) + 16 * half + 4 * k;
+            q[0] = (uint8_t)word; q[1] = (uint8_t)(word >> 8); q[2] = (uint8_t)(word >> 16); q[3] = (uint8_t)(word >> 24);
+        }
+        if (active && c == 0) {
+            const uint32_t word = hi[k] | (h2 << 2) | (h4 << 4) | (h6 << 6);
+            uint8_t *q = blk + 128 + 32 * n + 16 * half + 4 * k;
+            q[0] = (uint8_t)word; q[1] = (uint8_t)(word >> 8); q[2] = (uint8_t)(word >> 16); q[3] = (uint8_t)(word >> 24);
+        }
+    }
+    if (active) {
+        blk[192 + j] = (uint8_t)(int8_t)sc;
+        if (j == 0) { const uint16_t hb = __builtin_bit_cast(uint16_t, dh); blk[208] = (uint8_t)hb; blk[209] = (uint8_t)(hb >> 8); }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_q5k_to_planar(int kq_type, const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st) {
@@ -281,5 +456,33 @@ hipError_t launch_quantize_kq(int kq_type, const float *x, int64_t nrows, int64_
     const unsigned grid = (unsigned)((nsb * 8 + 127) / 128);
     if (kq_type == GGML_HIP_TYPE_Q5_K) quantize_kq_kernel<true><<<dim3(grid), 128, 0, st>>>(x, nsb, (uint8_t *)blocks);
     else quantize_kq_kernel<false><<<dim3(grid), 128, 0, st>>>(x, nsb, (uint8_t *)blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_q6k_to_planar(const uint8_t *aos, uint64_t nb01, int64_t row_begin, int64_t rows, ggml_hip_weight *w, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    dim3 grid((unsigned)((rows + 127) / 128), (unsigned)w->nbk);
+    q6k_to_planar_kernel<<<grid, 128, 0, st>>>(aos, nb01, row_begin, rows, w->Mpad, w->i8p, w->d, w->m, w->khdr);
+    return hipGetLastError();
+}
+
+hipError_t launch_planar_to_q6k(const ggml_hip_weight *w, uint8_t *aos, hipStream_t st) {
+    if (w->M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((w->M + 127) / 128), (unsigned)(w->nbk / 8));
+    planar_to_q6k_kernel<<<grid, 128, 0, st>>>(aos, (uint64_t)(w->nbk / 8) * 210, w->M, w->Mpad, w->i8p, w->khdr);
+    return hipGetLastError();
+}
+
+hipError_t launch_dequantize_q6k(const void *blocks, int64_t nrows, int64_t k, float *y, hipStream_t st) {
+    const int64_t nkb = nrows * (k / 32);
+    if (nkb <= 0) return hipSuccess;
+    dequantize_q6k_kernel<<<dim3((unsigned)((nkb + 127) / 128)), 128, 0, st>>>((const uint8_t *)blocks, nkb, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_q6k(const float *x, int64_t nrows, int64_t k, void *blocks, hipStream_t st) {
+    const int64_t nsb = nrows * (k / 256);
+    if (nsb <= 0) return hipSuccess;
+    quantize_q6k_kernel<<<dim3((unsigned)((nsb * 16 + 127) / 128)), 128, 0, st>>>(x, nsb, (uint8_t *)blocks);
     return hipGetLastError();
 }

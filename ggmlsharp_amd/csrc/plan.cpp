@@ -30,11 +30,12 @@ bool k3p_lds_ok(int nloc) { return nloc <= 4 * 78; }
 
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode
 // form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
-bool q8_small_serves(int type, int64_t K, int64_t N) {
+bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
-    // (Q4_2 from 17 rows: its mat-vec serves up to 16)
+    // (Q4_2 from 17 rows: its mat-vec serves up to 16 -- i8_only: the Q6_K extension lives in this form on its int8 planes alone, the mat-vec
+    // reads nibbles: the batched-decode form takes it from one row on)
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N + 1 : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 1 : GEMV_WIDE_MAX_N + 1) : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
@@ -405,7 +406,8 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     bool wide = (nba + K_LOOKAHEAD) * (uint64_t)Mpad * 32 > LIM32;
     int kind = wide ? 0 : plan_image_kind(type, K, N);
     bool no_fused = false;
-    if (q8_small_serves(type, K, N)) {                      // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
+    const bool i8_only = ext_type != 0 && type == GGML_TYPE_Q4_2;   // (Q6_K: no nibble plane -- the int8 forms only)
+    if (q8_small_serves(type, K, N, i8_only)) {             // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
         if (plan_k3s_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
         wide = true; kind = 0; no_fused = true;             // (its planes are beyond the form's offsets: the two-step forms below)
     }
@@ -417,7 +419,7 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     if (kind == 0) {
         if (one_call && N <= GEMV_MAX_N && ext_type == 0 && !no_fused) { plan_gemv(p, type, M, K, N, true); return p; }
         p.flags |= MM_FLAG_NEEDS_WORK;
-        if (N <= gemv_rows_max(type)) { plan_gemv(p, type, M, K, N, false); return p; }
+        if (N <= gemv_rows_max(type) && !i8_only) { plan_gemv(p, type, M, K, N, false); return p; }
         plan_i8(p, type, M, N);
         return p;
     }

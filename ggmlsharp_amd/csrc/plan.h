@@ -80,7 +80,8 @@ struct mm_plan {
     int nloc, wmt;
 };
 
-// the plan of mul_mat(type, M, K, N); ext_type = GGML_HIP_TYPE_Q5_K for a k-quant weight living in the planar Q5_1 form (type = Q5_1).
+// the plan of mul_mat(type, M, K, N); ext_type = GGML_HIP_TYPE_Q5_K / _Q4_K for a k-quant weight living in the planar Q5_1 form (type = Q5_1),
+// _Q6_K for one living in the planar Q4_2 form on int8 planes alone (type = Q4_2).
 // one_call = the product is computed by one entry (ggml_hip_mul_mat_dev: the fused mat-vec exists); false = the COMPUTE-only entry.
 mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bool one_call = true);
 uint32_t plan_tree_id(const mm_plan &p);

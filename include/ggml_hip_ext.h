@@ -33,6 +33,12 @@ extern "C" {
  * Q5_K without its fifth-bit bytes and with the same scale / min packing and the same dot rule against Q8_K.  It lives in the same resident
  * form (eight k-blocks of the planar Q5_1 form, fifth-bit plane zero) and runs the same kernels; the same "unpinned extra" status. */
 #define GGML_HIP_TYPE_Q4_K 112
+/* r4: Q6_K of the same published format -- { u8 ql[128]; u8 qh[64]; i8 scales[16]; half d }, 210 bytes per 256 weights: sixteen sub-blocks
+ * of 16 six-bit weights (q - 32) with a signed 8-bit scale each, no min.  Resident as eight k-blocks of the planar Q4_2 form (two scales per
+ * k-block) on int8 operand planes; served by the int8 kernels that take two scales per k-block (the batched-decode form up to 64 src1 rows,
+ * the staged int8 form elsewhere).  ggml_hip_quantize_rows_dev: quantize_row_q6_K_reference WITHOUT the least-squares refinement of the
+ * sub-block scales (make_qx_quants in its plain form) -- a valid encoder of the published structure.  Unpinned like the other two. */
+#define GGML_HIP_TYPE_Q6_K 114
 
 
 /* OPT-IN, and a deviation from the reference's contract (which leaves EVERY node's data in host memory, Ggml.cs:3539-3704):

@@ -290,3 +290,95 @@ def quantize_kq_reference(x, bits):
     else:
         blocks[:, 16:144] = qs.reshape(nb, 128).astype(np.uint8)
     return blocks
+
+
+# ---------------------------------------------------------------- Q6_K (r4): 16 sub-blocks of 16 weights with signed 8-bit scales
+Q6K_BYTES = 210
+
+
+def q6_values(blocks):
+    """[nb, 210] block_q6_K { u8 ql[128]; u8 qh[64]; i8 scales[16]; half d } -> the 6-bit values minus 32, [nb, 256] int32 in element order
+    (dequantize_row_q6_K's unpacking: per half n of 128 elements and l < 32, element 128 n + 32 c + l takes the low (c < 2) or high (c >= 2)
+    nibble of ql[64 n + 32 (c & 1) + l] and bits 2 c, 2 c + 1 of qh[32 n + l])"""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, Q6K_BYTES)
+    ql = blocks[:, 0:128].astype(np.int32).reshape(-1, 2, 2, 32)        # [nb, n, c & 1, l]
+    qh = blocks[:, 128:192].astype(np.int32).reshape(-1, 2, 32)
+    out = np.empty((blocks.shape[0], 2, 4, 32), dtype=np.int32)
+    for c in range(4):
+        nib = (ql[:, :, c & 1] & 0xF) if c < 2 else (ql[:, :, c & 1] >> 4)
+        out[:, :, c] = (nib | (((qh >> (2 * c)) & 3) << 4)) - 32
+    return out.reshape(-1, 256)
+
+
+def dequantize_q6_K(blocks):
+    """y[e] = d * scales[e / 16] * q[e], the product d * sc first (upstream: `d * sc[is] * q`, left to right), every operation a binary32 rounding"""
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, Q6K_BYTES)
+    d = blocks[:, 208:210].copy().view(np.float16).astype(np.float32).reshape(-1, 1)
+    sc = blocks[:, 192:208].copy().view(np.int8).astype(np.float32)
+    ds = (d * sc).astype(np.float32)                                     # [nb, 16]
+    q = q6_values(blocks).reshape(-1, 16, 16).astype(np.float32)
+    return (ds[:, :, None] * q).astype(np.float32).reshape(-1, 256)
+
+
+def mul_mat_q6_K(wrows, x):
+    """wrows [M, K/256*210] uint8, x [N, K] f32 -> [N, M]: ggml_vec_dot_q6_K_q8_K per element -- per super-block (d * dy) * sum_j sc_j <q_j, a_j>,
+    the integer sums exact; evaluated in f64 (a checker for the path's tolerance, not a bit-level one)"""
+    M = wrows.shape[0]
+    N, K = x.shape
+    nb = K // 256
+    d8, q8, _ = quantize_q8_K(x.reshape(-1, 256))
+    d8, q8 = d8.reshape(N, nb).astype(np.float64), q8.reshape(N, nb, 16, 16).astype(np.float64)
+    w = wrows.reshape(M * nb, Q6K_BYTES)
+    dw = w[:, 208:210].copy().view(np.float16).astype(np.float64).reshape(M, nb)
+    sc = w[:, 192:208].copy().view(np.int8).astype(np.float64).reshape(M, nb, 16)
+    q = q6_values(w).astype(np.float64).reshape(M, nb, 16, 16)
+    dots = np.einsum("mbjl,nbjl->nmbj", q, q8)
+    isum = (dots * sc[None]).sum(axis=3)
+    return (dw[None] * d8[:, None, :] * isum).sum(axis=2).astype(np.float32)
+
+
+def pack_q6(L):
+    """L [nb, 256] values 0..63 -> (ql [nb, 128], qh [nb, 64]) uint8 (the inverse of q6_values' unpacking)"""
+    L = L.astype(np.uint32).reshape(-1, 2, 4, 32)
+    ql = np.zeros((L.shape[0], 2, 2, 32), dtype=np.uint32)
+    qh = np.zeros((L.shape[0], 2, 32), dtype=np.uint32)
+    for c in range(4):
+        ql[:, :, c & 1] |= (L[:, :, c] & 0xF) << (0 if c < 2 else 4)
+        qh |= (L[:, :, c] >> 4) << (2 * c)
+    return ql.reshape(-1, 128).astype(np.uint8), qh.reshape(-1, 64).astype(np.uint8)
+
+
+def quantize_q6_K(x):
+    """quantize_row_q6_K_reference with make_qx_quants in its plain form (rmse_type 0: no least-squares refinement of the sub-block scales
+    -- upstream's default searches; this is a VALID encoder of the same structure, and what kquants.hip's device quantizer follows):
+    per sub-block of 16 the element of largest magnitude maps to -32 (scale = max / -32); the 16 scales as signed 8-bit multiples of
+    d = (the scale of largest magnitude) / -128 (a half); the codes again under the rounded scales, l = nearest(x / (d sc)) in -32..31."""
+    F = np.float32
+    x = np.ascontiguousarray(x, dtype=F).reshape(-1, 16, 16)
+    nb = x.shape[0]
+    ax = np.abs(x)
+    idx = np.argmax(ax, axis=2)
+    mx = np.take_along_axis(x, idx[:, :, None], axis=2)[:, :, 0]
+    amax = np.take_along_axis(ax, idx[:, :, None], axis=2)[:, :, 0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iscale = np.where(amax != 0, (F(-32) / mx).astype(F), F(0)).astype(F)
+        scale = np.where(amax != 0, (F(1) / iscale).astype(F), F(0)).astype(F)           # [nb, 16]
+        L = np.where((amax != 0)[:, :, None], np.clip(np.rint((iscale[:, :, None] * x).astype(F)), -32, 31) + 32, 0).astype(np.int64)
+        j = np.argmax(np.abs(scale), axis=1)                                            # the first scale of largest magnitude
+        max_scale = scale[np.arange(nb), j]
+        zero = np.abs(max_scale) == 0
+        isc = np.where(zero, F(0), (F(-128) / max_scale).astype(F)).astype(F)
+        d16 = np.where(zero, F(0), (F(1) / isc).astype(F)).astype(np.float16)
+        sc = np.minimum(np.rint((isc[:, None] * scale).astype(F)), 127).astype(np.int64)
+        dd = (d16.astype(F)[:, None] * sc.astype(F)).astype(F)
+        l2 = np.clip(np.rint((x / dd[:, :, None]).astype(F)), -32, 31) + 32
+    L = np.where((dd != 0)[:, :, None], np.nan_to_num(l2).astype(np.int64), L)
+    L = np.where(zero[:, None, None], 0, L)                                               # (upstream: memset(y, 0) for an all-zero super-block)
+    sc = np.where(zero[:, None], 0, sc)
+    blocks = np.zeros((nb, Q6K_BYTES), dtype=np.uint8)
+    ql, qh = pack_q6(L.reshape(nb, 256))
+    blocks[:, 0:128] = ql
+    blocks[:, 128:192] = qh
+    blocks[:, 192:208] = sc.astype(np.int8).view(np.uint8)
+    blocks[:, 208:210] = d16.reshape(-1, 1).view(np.uint8)
+    return blocks

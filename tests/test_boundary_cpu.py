@@ -78,7 +78,7 @@ def test_type_tables():
     L = _lib.lib()
     for t, s in _lib.TYPE_SIZE.items():
         assert L.ggml_hip_type_size(t) == s and L.ggml_hip_blck_size(t) == _lib.BLCK_SIZE[t]
-        if t in (_lib.Q5_K, _lib.Q4_K):       # the k-quant extension is a device-level type only: the reference (and its mirror) cannot express it
+        if t in (_lib.Q5_K, _lib.Q4_K, _lib.Q6_K):       # the k-quant extension is a device-level type only: the reference (and its mirror) cannot express it
             assert L.ggml_type_size(t) == 0 and L.ggml_blck_size(t) == 0
             continue
         assert L.ggml_type_size(t) == s and L.ggml_blck_size(t) == _lib.BLCK_SIZE[t]

@@ -11,9 +11,13 @@ import np_kquants as KQ
 import oracle_lib as O
 
 RNG = np.random.default_rng(4242)
-Q5_K, Q4_K = 113, 112
+Q5_K, Q4_K, Q6_K = 113, 112, 114
 # per type: super-block bytes, the test encoder, the restated dequantize and mul_mat
-KQT = {Q5_K: (176, KQ.quantize_q5_K, KQ.dequantize_q5_K, KQ.mul_mat_q5_K), Q4_K: (144, KQ.quantize_q4_K, KQ.dequantize_q4_K, KQ.mul_mat_q4_K)}
+KQT = {Q5_K: (176, KQ.quantize_q5_K, KQ.dequantize_q5_K, KQ.mul_mat_q5_K), Q4_K: (144, KQ.quantize_q4_K, KQ.dequantize_q4_K, KQ.mul_mat_q4_K),
+       Q6_K: (210, KQ.quantize_q6_K, KQ.dequantize_q6_K, KQ.mul_mat_q6_K)}
+# the restated quantizer the device quantizer follows
+REFQ = {Q5_K: lambda x: KQ.quantize_kq_reference(x, 5), Q4_K: lambda x: KQ.quantize_kq_reference(x, 4), Q6_K: KQ.quantize_q6_K}
+ALL_KQ = [Q5_K, Q4_K, Q6_K]
 
 
 def _rand(shape, scale=1.0):
@@ -23,6 +27,9 @@ def _rand(shape, scale=1.0):
 def _random_blocks(nb, t=Q5_K):
     """raw super-blocks: every bit pattern of scales / qh / qs, finite half scales"""
     b = RNG.integers(0, 256, size=(nb, KQT[t][0]), dtype=np.uint8)
+    if t == Q6_K:                                          # every bit pattern of ql / qh / the signed scales; d a small finite half
+        b[:, 208:210] = (RNG.random(nb).astype(np.float32) * 0.002 + 0.0001).astype(np.float16).reshape(-1, 1).view(np.uint8)
+        return b
     b[:, 0:2] = (RNG.random(nb).astype(np.float32) * 0.02 + 0.001).astype(np.float16).reshape(-1, 1).view(np.uint8)
     b[:, 2:4] = (RNG.random(nb).astype(np.float32) * 0.05).astype(np.float16).reshape(-1, 1).view(np.uint8)
     return b
@@ -93,6 +100,36 @@ def test_published_quantizers_restated_are_valid_and_tighter_than_the_simple_enc
     assert not KQ.dequantize_q5_K(KQ.quantize_kq_reference(c, 5)).any()
 
 
+def test_q6_K_restatement_by_hand_and_its_encoder():
+    """Q6_K (r4): 16 sub-blocks of 16 six-bit weights (q - 32) with signed 8-bit scales -- one element by hand, pack / unpack, the encoder"""
+    b = np.zeros((1, 210), dtype=np.uint8)
+    b[0, 64 + 32 + 5] = 0xB0               # n = 1, c = 3 (high nibble of ql[64 n + 32 (c & 1) + l]), l = 5: element 128 + 96 + 5 = 229
+    b[0, 128 + 32 + 5] = 0b10000000        # bits 6, 7 of qh[32 n + l]: the two high bits = 2
+    sc = np.zeros(16, dtype=np.int8)
+    sc[229 // 16] = -7
+    b[0, 192:208] = sc.view(np.uint8)
+    b[0, 208:210] = np.array([0.5], np.float16).view(np.uint8)
+    v = KQ.q6_values(b)[0]
+    assert v[229] == (0xB | (2 << 4)) - 32 and (v != -32).sum() == 1
+    y = KQ.dequantize_q6_K(b)[0]
+    assert y[229] == np.float32(0.5 * -7 * 11) and y[224] == np.float32(0.5 * -7 * -32) and y[0] == 0.0
+    L = RNG.integers(0, 64, size=(5, 256))
+    ql, qh = KQ.pack_q6(L)
+    bb = np.zeros((5, 210), dtype=np.uint8)
+    bb[:, :128], bb[:, 128:192] = ql, qh
+    assert np.array_equal(KQ.q6_values(bb) + 32, L)
+    x = _rand((30, 256), 2.0)
+    x[3] = 0.0
+    blocks = KQ.quantize_q6_K(x)
+    assert not blocks[3].any()
+    assert np.abs(KQ.dequantize_q6_K(blocks) - x).max() <= 0.04 * np.abs(x).max()          # 6-bit code with 8-bit super-scales
+    w = KQ.quantize_q6_K(_rand((4, 256))).reshape(1, -1)
+    xx = _rand((1, 1024))
+    d8, q8, _ = KQ.quantize_q8_K(xx.reshape(-1, 256))
+    exact = float(KQ.dequantize_q6_K(w).astype(np.float64).reshape(-1) @ (q8.astype(np.float64) * d8.astype(np.float64)[:, None]).reshape(-1))
+    assert abs(float(KQ.mul_mat_q6_K(w, xx)[0, 0]) - exact) <= 1e-5 * max(1.0, abs(exact))
+
+
 def test_q8_K_rule():
     x = np.zeros((3, 256), dtype=np.float32)
     x[0, 7] = -4.0
@@ -134,7 +171,7 @@ def dev():
 
 
 @gpu
-@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+@pytest.mark.parametrize("t", ALL_KQ)
 def test_dequantize_q5_K_bit_exact(dev, t):
     import torch
     for nb in (1, 7, 64):
@@ -145,7 +182,7 @@ def test_dequantize_q5_K_bit_exact(dev, t):
 
 
 @gpu
-@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+@pytest.mark.parametrize("t", ALL_KQ)
 def test_device_quantizer_writes_the_restated_reference_quantizers_bytes(dev, t):
     """ggml_hip_quantize_rows_dev for the extension types (r4): byte for byte the super-blocks of tests/np_kquants.py quantize_kq_reference
     -- normal data at several scales, a zero row, a non-negative row, constant sub-blocks, a single outlier, ragged tail of the grid"""
@@ -157,7 +194,7 @@ def test_device_quantizer_writes_the_restated_reference_quantizers_bytes(dev, t)
             x[1] = np.abs(x[1])
             x[2, 32:64] = -1.5
             x[2, 300] = 1000.0
-        want = KQ.quantize_kq_reference(x.reshape(-1, 256), 5 if t == Q5_K else 4).reshape(nrows, -1)
+        want = REFQ[t](x.reshape(-1, 256)).reshape(nrows, -1)
         got = dev.quantize_rows(t, torch.from_numpy(x).cuda()).cpu().numpy()
         assert got.shape == want.shape
         bad = np.nonzero((got != want).reshape(-1, KQT[t][0]).any(axis=1))[0]
@@ -171,7 +208,7 @@ def test_device_quantizer_writes_the_restated_reference_quantizers_bytes(dev, t)
 
 
 @gpu
-@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+@pytest.mark.parametrize("t", ALL_KQ)
 def test_upload_download_roundtrip_is_byte_exact_and_type_reported(dev, t):
     from ggmlsharp_amd._lib import lib
     M, K = 70, 768
@@ -229,7 +266,7 @@ def _close(got, ref, what, K):
 
 
 @gpu
-@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+@pytest.mark.parametrize("t", ALL_KQ)
 def test_mul_mat_q5_K_matches_the_restatement(dev, t):
     """(r4: Q4_K through the same resident form and kernels)  every kernel form behind the Q5_1 image of a Q5_K weight: mat-vec (N <= 8, two-step), f16 MFMA with 4- / 2-way K split
     and unsplit, int8 MFMA; ragged M and N; raw random super-blocks as well as quantized normal data"""
@@ -262,7 +299,7 @@ def test_mul_mat_q5_K_matches_the_restatement(dev, t):
 
 
 @gpu
-@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+@pytest.mark.parametrize("t", ALL_KQ)
 def test_mul_mat_q5_K_at_config_4s_size_on_a_sample(dev, t):
     """BASELINE config 4 names Q5_K at 4096 x 11008 x 512: the literal type at its literal size.  64 weight rows x 64 src1 rows of
     the device result against the numpy restatement (there is no oracle for k-quants: unpinned extra), and a 512-row shard is the

@@ -8,7 +8,7 @@ import pytest
 
 from ggmlsharp_amd import _lib
 
-F32, F16, Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0, Q5_K, Q4_K = 0, 1, 2, 3, 4, 6, 7, 8, 113, 112
+F32, F16, Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0, Q5_K, Q4_K, Q6_K = 0, 1, 2, 3, 4, 6, 7, 8, 113, 112, 114
 QUANT = (Q4_0, Q4_1, Q4_2, Q5_0, Q5_1, Q8_0)
 WIDE, EPI, PERSIST, Q8K, NEEDS_WORK, MIN_PIECES = 1, 2, 4, 8, 16, 32
 FAM = {"gemv_fused": 1, "gemv_rows": 2, "k3s_mx": 3, "k3s_i8": 4, "k3p_mx": 5, "k3p_i8": 6, "mx": 7, "f16": 8, "i8": 9, "dense": 10,
@@ -25,11 +25,11 @@ def plan(t, M, K, N):
     return out
 
 
-@pytest.mark.parametrize("t", QUANT + (F16, F32, Q5_K, Q4_K))
+@pytest.mark.parametrize("t", QUANT + (F16, F32, Q5_K, Q4_K, Q6_K))
 def test_summation_tree_is_a_function_of_type_K_and_N_only(t):
     checked = wide_seen = 0
     for K in KS:
-        if t in (Q5_K, Q4_K) and K % 256:
+        if t in (Q5_K, Q4_K, Q6_K) and K % 256:
             continue
         for N in NS:
             trees = {}
@@ -86,6 +86,10 @@ def test_baseline_configs_get_the_kernels_design_md_names():
         assert bool(p.flags & MIN_PIECES) == (t in (Q5_1, Q4_1, Q5_K)) and p.image_kind == (64 if t in (Q5_1, Q4_1, Q5_K) else 0), t
     a, b = plan(Q4_K, 4096, 11008, 512), plan(Q5_K, 4096, 11008, 512)     # r4: Q4_K lives in Q5_K's resident form and gets its plans
     assert (a.family, a.form, a.tree_id, a.flags, a.image_kind) == (b.family, b.form, b.tree_id, b.flags, b.image_kind)
+    # r4: Q6_K lives in the planar Q4_2 form on int8 planes alone: the batched-decode form from ONE row (the mat-vec reads nibbles), the staged int8 form elsewhere
+    assert plan(Q6_K, 4096, 4096, 1).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
+    assert plan(Q6_K, 4096, 4096, 65).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 1).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
+    assert plan(Q6_K, 4096, 4096, 8).tree_id != plan(Q4_2, 4096, 4096, 32).tree_id              # (activations by the Q8_K rule: another tree)
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
     assert plan(Q5_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 32).image_kind == 0

@@ -13,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggmlsharp_amd import device  # noqa: E402
 
-TYPES = {"q4_0": 2, "q4_1": 3, "q4_2": 4, "q5_0": 6, "q5_1": 7, "q8_0": 8}
+TYPES = {"q4_0": 2, "q4_1": 3, "q4_2": 4, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q5_k": 113, "q4_k": 112, "q6_k": 114}   # (the k-quant extras: timing only, --no-check -- their activations follow the Q8_K rule)
 
 
 def ev_ms(fn, iters):
@@ -102,11 +102,11 @@ def run(tname, M, K, N, iters, check=True, copies=1):
             for _ in range(reps):
                 full()
         t_graph = ev_ms(gr.replay, 20) / reps
-        ab1 = M * (K // 32) * {"q4_0": 20, "q4_1": 24, "q4_2": 20, "q5_0": 22, "q5_1": 24, "q8_0": 36}[tname] + 4 * K * N + 4 * M * N
+        ab1 = M * (K // 32) * {"q4_0": 20, "q4_1": 24, "q4_2": 20, "q5_0": 22, "q5_1": 24, "q8_0": 36, "q5_k": 22, "q4_k": 18, "q6_k": 26.25}[tname] + 4 * K * N + 4 * M * N
         print(f"   graph-replayed whole mul_mat (fused, {copies} rotating weight copies): {t_graph * 1e3:7.2f} us/call  "
               f"{ab1 / t_graph / 1e6:8.1f} GB/s algorithmic", flush=True)
     flops = 2.0 * M * K * N
-    blk = {"q4_0": 20, "q4_1": 24, "q4_2": 20, "q5_0": 22, "q5_1": 24, "q8_0": 36}[tname]   # bytes per 32 weights
+    blk = {"q4_0": 20, "q4_1": 24, "q4_2": 20, "q5_0": 22, "q5_1": 24, "q8_0": 36, "q5_k": 22, "q4_k": 18, "q6_k": 26.25}[tname]   # bytes per 32 weights
     ab = M * (K // 32) * blk + 4 * K * N + 4 * M * N
     print(f"{tname} M{M} K{K} N{N}: init {t_init * 1e3:8.1f} us  compute {t_comp * 1e3:8.1f} us  "
           f"{flops / t_comp / 1e9:9.1f} TOP/s  {ab / (t_init + t_comp) / 1e6:8.1f} GB/s  {msg}", flush=True)
