@@ -52,8 +52,7 @@ __device__ unsigned long long k3p_trace_buf[4096 * 8];
 #endif
 
 constexpr int KS = 8;          // waves per workgroup = K ranges
-constexpr int K3P_TABLE_ROWS = 80;   // k-blocks of a wave's scale table that fit whole (8 waves x 80 x 256 B = the 160 KB): K <= 20480; beyond, slices (SLICED)
-constexpr int K3P_SLICE_ROWS = 78;   // ... of at most 78 rows (the int8 loop keeps one spare row behind the last wave's slice)
+// (K3P_TABLE_ROWS / K3P_SLICE_ROWS / K3P_MAX_SLICES: plan.h -- the scale tables whole up to K = 20480, in slices beyond: SLICED)
 constexpr int WMT = 4;         // 32-row weight tiles per wave (two lane-half pairs)
 constexpr int WNT = 2;         // 32-column tiles of src1 per wave
 

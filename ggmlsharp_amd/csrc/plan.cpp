@@ -26,7 +26,7 @@ int k3p_mx_nloc(int64_t K) { return (int)cdiv(pad_kblocks(K / QK), KS8); }
 int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return n + (n & 1); }      // two k-blocks per trip (and the min term goes by pairs)
 // the waves' row-scale tables: the whole range of a wave up to 80 k-blocks (K <= 20480), beyond that in refills inside the K loop (r4; it was
 // a hard limit at K = 20480) -- up to four slices of 78, K <= 79872 (the 32-bit offsets of the planes end earlier for wide matrices)
-bool k3p_lds_ok(int nloc) { return nloc <= 4 * 78; }
+bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode
 // form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)

@@ -60,6 +60,10 @@ enum d16_form { D16F_S_256x128 = 0, D16F_S_128x128, D16F_256x128, D16F_S4_H128, 
 // dense.hip
 enum dense_form { DNF_TILE = 0, DNF_BIG = 1, DNF_KSPLIT = 2 /* F32, 17..256 rows: 32 x 32 tiles, K over the workgroup's eight waves */ };
 
+// K3p (gemm_qmp.hip): k-blocks of a wave's scale table -- 80 fit whole (8 waves x 80 x 256 B = the 160 KB of LDS: K <= 20480); beyond that the
+// K loop refills slices of at most 78 rows (the int8 loop keeps one spare row behind the last wave's slice), four slices at most (K <= 79872)
+constexpr int K3P_TABLE_ROWS = 80, K3P_SLICE_ROWS = 78, K3P_MAX_SLICES = 4;
+
 struct mm_plan {
     int family;           // mm_family
     int image;            // what INIT writes: 0 int8 planes, 1 / 2 f16 images, 3 bf6 image; -1 nothing (fused mat-vec, dense f32 direct);
