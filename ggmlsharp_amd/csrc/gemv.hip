@@ -290,7 +290,12 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
 // PRO: the rms_norm -> mul prologue (common.h mm_prologue): the quantized row is (x * rms_scale) * g, computed here.
 // MULTI: several weight matrices behind one activation matrix (common.h mv_set) -- its own kernels below: with the per-item
 // selects in every kernel the single-matrix call lost 5-12 % (4096 x 4096: 4.6 -> 5.2 us)
-template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO, bool MULTI>
+// K8 (r4): the activations are quantized by the Q8_K rule of the k-quant extension (kquants.hip; quantize.hip K1 with K8 = true: one scale per 256
+// elements, iscale = -128 / the first element of largest magnitude, q = min(127, nearest(iscale x))): a wave consumes HALF a super-block at four
+// places of a chunk, so the scales of all (column, super-block) pairs are computed once per workgroup into LDS ahead of the items -- behind the
+// first item's loads, like the rms_norm prologue's row scale -- and the wave-private quantization reads them.  K <= 32768 (128 super-blocks).
+constexpr int GV_K8_SB = 128;
+template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO, bool MULTI, bool K8 = false>
 __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *__restrict__ x, int64_t ld1, int64_t nbk, int N, int ntiles,
                                                 const mm_epilogue &ep, const mm_prologue &pro) {
     static_assert(GV_ROWS == 16 && GV_NKQ == 4, "lane = (row, k-lane) with 4 k-lanes per wave");
@@ -313,6 +318,8 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
     bool staged = false;
     int parity = 0;
     __shared__ float sScale[NC];
+    __shared__ float sK8[K8 ? NC * GV_K8_SB * 2 : 1];      // (column, super-block) -> iscale, d
+    static_assert(!(K8 && (PRO || MULTI)), "the Q8_K rule: the plain single-matrix call only");
     constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
     constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
     constexpr int NP = 1 + (HAS_M ? 1 : 0) + (HAS_H ? 1 : 0);
@@ -420,7 +427,54 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
         if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
         __syncthreads();
     } else {
-        if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
+        if constexpr (!K8) {
+            if (nitems > 0) { load_x(0, 0); load_item(0, q, q2, dw, mw, hb); }
+        } else {
+            const int nsb = (int)(nbk >> 3);                // (K % 256 == 0 for the k-quants)
+            // K1's own arrangement (quantize.hip, K8 = true): EIGHT LANES per super-block, lane t holding elements 32 j + 4 t .. + 3 of its eight
+            // k-blocks, joined by three DPP steps -- 64 super-blocks per trip of the workgroup (a wave per super-block and six rounds of
+            // ds_bpermute shuffles measured 4096 x 4096 x 1 / x 4 6.5 / 12.9 us against the reference types' 4.0 / 6.8).  The first trip's loads
+            // go out BEHIND the first item's activations and IN FRONT of its weights (vector-memory results return in issue order).
+            const int g8 = tid >> 3, t8 = tid & 7;
+            float4 e8[8];
+            auto k8_load = [&](int base) {
+                const int item = base + g8;
+                const int it2 = item < N * nsb ? item : 0;
+                const float *src = x + (int64_t)(it2 / nsb) * ld1 + (int64_t)(it2 % nsb) * 256 + 4 * t8;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) e8[jb] = *(const float4 *)(src + 32 * jb);
+            };
+            auto k8_reduce = [&](int base) {
+                const int item = base + g8;
+                float am = 0.0f, mx = 0.0f;
+                int ix = 0;                                 // this lane's first element of largest magnitude (element order)
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    const float e[4] = {e8[jb].x, e8[jb].y, e8[jb].z, e8[jb].w};
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        if (fabsf(e[q4]) > am) { am = fabsf(e[q4]); mx = e[q4]; ix = 32 * jb + 4 * t8 + q4; }
+                }
+                auto join = [&](float oa, float om, int oi) {   // the larger magnitude wins, equal magnitudes the earlier element
+                    const bool take = oa > am || (oa == am && oi < ix);
+                    am = take ? oa : am; mx = take ? om : mx; ix = take ? oi : ix;
+                };
+                join(dpp_f<DPP_XOR1>(am), dpp_f<DPP_XOR1>(mx), dpp_i<DPP_XOR1>(ix));
+                join(dpp_f<DPP_XOR2>(am), dpp_f<DPP_XOR2>(mx), dpp_i<DPP_XOR2>(ix));
+                join(dpp_f<DPP_HALF_MIRROR>(am), dpp_f<DPP_HALF_MIRROR>(mx), dpp_i<DPP_HALF_MIRROR>(ix));
+                const float isc = am != 0.0f ? -128.0f / mx : 0.0f;
+                if (t8 == 0 && item < N * nsb) {
+                    const int c = item / nsb, sb = item % nsb;
+                    sK8[(c * GV_K8_SB + sb) * 2] = isc; sK8[(c * GV_K8_SB + sb) * 2 + 1] = am != 0.0f ? 1.0f / isc : 0.0f;
+                }
+            };
+            if (nitems > 0) load_x(0, 0);
+            k8_load(0);
+            if (nitems > 0) load_item(0, q, q2, dw, mw, hb);
+            k8_reduce(0);
+            for (int base = GV_THREADS / 8; base < N * nsb; base += GV_THREADS / 8) { k8_load(base); k8_reduce(base); }
+            __syncthreads();
+        }
     }
 
     // one item: INIT arithmetic for this wave's blocks (first item of a single-chunk K, every item otherwise), block dots on
@@ -460,10 +514,19 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
                         *(float4 *)(pro.y_out + e) = vp;
                     }
                 }
-                float amax = fmaxf(fmaxf(fabsf(vp.x), fabsf(vp.y)), fmaxf(fabsf(vp.z), fabsf(vp.w)));
-                amax = group8_max(amax);
-                const float d = amax / 127.0f;                  // Ggml.cs:751
-                const float id = d != 0.0f ? 1.0f / d : 0.0f;   // Ggml.cs:752
+                float d, id;
+                if constexpr (K8) {                              // the super-block's scale, computed ahead of the items
+                    const int cc = c < N ? c : N - 1;
+                    const int sbi = (int)((cb + (live ? bl : 0)) >> 3);
+                    id = sK8[(cc * GV_K8_SB + sbi) * 2]; d = sK8[(cc * GV_K8_SB + sbi) * 2 + 1];
+                    vp = make_float4(fminf(127.0f, rintf(vp.x * id)), fminf(127.0f, rintf(vp.y * id)), fminf(127.0f, rintf(vp.z * id)), fminf(127.0f, rintf(vp.w * id)));
+                    id = 1.0f;                                   // (vp holds the quants: x * 1 and the nearest integer of an integer are exact)
+                } else {
+                    float amax = fmaxf(fmaxf(fabsf(vp.x), fabsf(vp.y)), fmaxf(fabsf(vp.z), fabsf(vp.w)));
+                    amax = group8_max(amax);
+                    d = amax / 127.0f;                           // Ggml.cs:751
+                    id = d != 0.0f ? 1.0f / d : 0.0f;            // Ggml.cs:752
+                }
                 const int q0 = (int)rintf(vp.x * id), q1 = (int)rintf(vp.y * id);   // Ggml.cs:758-759 (D1, D2)
                 const int q2_ = (int)rintf(vp.z * id), q3 = (int)rintf(vp.w * id);
                 const int sum = group8_sum(q0 + q1 + q2_ + q3);
@@ -604,13 +667,13 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
 
 // one weight matrix: the arguments as they always were (the set of one is built in registers; a kernel that takes the whole
 // mv_set in its argument segment ran the single-matrix call 5 % slower: 4096 x 4096 4.60 -> 4.85 us)
-template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO = false>
+template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO = false, bool K8 = false>
 __global__ __launch_bounds__(GV_THREADS, (NC <= 2 && !PRO ? 4 : 2)) void gemv_fused_kernel(   // two resident workgroups per CU up to 2 columns (4 columns: 133 registers, spills under 128)
     const uint8_t *__restrict__ qs, const uint32_t *__restrict__ gs, const float *__restrict__ x, int64_t ld1, float *__restrict__ dst,
     int64_t M, int64_t Mpad, int64_t nbk, int64_t ldd, int N, int ntiles, const mm_epilogue ep, const mm_prologue pro) {
     mv_set ws;
     ws.n = 1; ws.qs[0] = qs; ws.gs[0] = gs; ws.dst[0] = dst; ws.M[0] = M; ws.Mpad[0] = Mpad; ws.ldd[0] = ldd;
-    gemv_fused_body<TYPE, NC, GV_ROWS, SC, PRO, false>(ws, x, ld1, nbk, N, ntiles, ep, pro);
+    gemv_fused_body<TYPE, NC, GV_ROWS, SC, PRO, false, K8>(ws, x, ld1, nbk, N, ntiles, ep, pro);
 }
 // several weight matrices behind one activation matrix (common.h mv_set)
 template <int TYPE, int NC, int GV_ROWS, bool SC, bool PRO>
@@ -636,7 +699,13 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         if (N <= 4) {
 #define GVF_ARGS w->qs, w->gs, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep
 #define GVF_LAUNCH(NC) do { \
-        if (t_prologue) { \
+        if (w->ext_type != 0) {                 /* a k-quant weight (planar Q5_1 form): activations by the Q8_K rule */ \
+            if constexpr (TYPE == GGML_TYPE_Q5_1) { \
+                if (t_prologue || ep.mode != 0 || w->nbk % 8 != 0 || w->nbk / 8 > GV_K8_SB) return hipErrorNotSupported; \
+                if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
+                else gemv_fused_kernel<TYPE, NC, ROWS, false, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
+            } else return hipErrorNotSupported; \
+        } else if (t_prologue) { \
             if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
             else gemv_fused_kernel<TYPE, NC, ROWS, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
         } else if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
@@ -650,6 +719,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         }
     }
     if (ep.mode != 0 || t_prologue) return hipErrorNotSupported;          // (callers ask gemv_fused_has_epilogue first)
+    if (FUSED && w->ext_type != 0) return hipErrorNotSupported;           // (the block-staged fused form quantizes by the Q8_0 rule: plan.cpp keeps k-quants off it)
 #define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->gs, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);

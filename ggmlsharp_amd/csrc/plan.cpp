@@ -417,7 +417,9 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     }
     if (wide) p.flags |= MM_FLAG_WIDE;
     if (kind == 0) {
-        if (one_call && N <= GEMV_MAX_N && ext_type == 0 && !no_fused) { plan_gemv(p, type, M, K, N, true); return p; }
+        // (r4: the k-quants of the planar Q5_1 form have a fused mat-vec too, up to 4 rows and K = 32768 -- gemv.hip K8: the Q8_K rule in the kernel)
+        const bool kq_fused = ext_type != 0 && type == GGML_TYPE_Q5_1 && N <= 4 && K % 256 == 0 && K / 256 <= 128;
+        if (one_call && N <= GEMV_MAX_N && (ext_type == 0 || kq_fused) && !no_fused) { plan_gemv(p, type, M, K, N, true); return p; }
         p.flags |= MM_FLAG_NEEDS_WORK;
         if (N <= gemv_rows_max(type) && !i8_only) { plan_gemv(p, type, M, K, N, false); return p; }
         plan_i8(p, type, M, N);

@@ -299,6 +299,44 @@ def test_mul_mat_q5_K_matches_the_restatement(dev, t):
 
 
 @gpu
+@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+def test_fused_mat_vec_with_the_Q8_K_rule_equals_the_two_step_form_bitwise(dev, t):
+    """up to 4 src1 rows the one-call entry runs the fused mat-vec with the Q8_K rule inside the kernel (gemv.hip K8, r4; K <= 32768): the
+    same quants, the same summation tree as INIT + the mat-vec on K1's image -- so the same bits; and both against the restatement.
+    One chunk of K (<= 4096), several, a ragged last chunk, the largest K the form takes, a K beyond it (two-step by plan)."""
+    import torch
+    from ggmlsharp_amd._lib import lib
+    import ctypes as C
+    for (M, K, N) in ((100, 256, 1), (515, 4096, 1), (515, 4096, 2), (300, 4096, 3), (300, 4096, 4), (130, 11008, 1), (130, 11008, 4),
+                      (70, 32768, 2), (70, 33024, 1), (4096, 4096, 1)):
+        rows = KQT[t][1](_rand((M * K // 256, 256))).reshape(M, -1)
+        x = _rand((N, K), 2.0)
+        x[0, 256:512] = 0.0                                   # an all-zero super-block: scale 0
+        if K >= 1024:
+            x[0, 700] = -x[0, 900]                            # equal magnitudes inside one super-block: the first decides the sign
+        W = dev.Weight.from_host(t, rows, K)
+        xd = torch.from_numpy(x).cuda()
+        pl = _lib_plan(t, M, K, N)
+        assert (pl.family == 1) == (K <= 32768), (K, pl.family)            # 1 = the fused mat-vec
+        one = dev.mul_mat(W, xd)
+        work = dev.alloc_work(t, K, N)
+        dev.mul_mat_init(W, xd, work)
+        two = torch.empty_like(one)
+        dev.mul_mat_compute(W, N, two, work)
+        assert torch.equal(one, two), (t, M, K, N)
+        _close(one.cpu().numpy(), KQT[t][3](rows, x), f"k-quant {t} fused mat-vec {M}x{K}x{N}", K)
+        W.free()
+
+
+def _lib_plan(t, M, K, N):
+    import ctypes as C
+    from ggmlsharp_amd import _lib
+    out = _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(out)) == 0
+    return out
+
+
+@gpu
 @pytest.mark.parametrize("t", ALL_KQ)
 def test_mul_mat_q5_K_at_config_4s_size_on_a_sample(dev, t):
     """BASELINE config 4 names Q5_K at 4096 x 11008 x 512: the literal type at its literal size.  64 weight rows x 64 src1 rows of

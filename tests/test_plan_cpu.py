@@ -86,6 +86,10 @@ def test_baseline_configs_get_the_kernels_design_md_names():
         assert bool(p.flags & MIN_PIECES) == (t in (Q5_1, Q4_1, Q5_K)) and p.image_kind == (64 if t in (Q5_1, Q4_1, Q5_K) else 0), t
     a, b = plan(Q4_K, 4096, 11008, 512), plan(Q5_K, 4096, 11008, 512)     # r4: Q4_K lives in Q5_K's resident form and gets its plans
     assert (a.family, a.form, a.tree_id, a.flags, a.image_kind) == (b.family, b.form, b.tree_id, b.flags, b.image_kind)
+    # r4: the k-quants of the planar Q5_1 form have a fused mat-vec (the Q8_K rule in the kernel) up to 4 rows and K = 32768; beyond: two steps
+    assert plan(Q5_K, 4096, 4096, 1).family == FAM["gemv_fused"] and plan(Q4_K, 4096, 4096, 4).family == FAM["gemv_fused"]
+    assert plan(Q5_K, 4096, 4096, 5).family == FAM["gemv_rows"] and plan(Q5_K, 4096, 33024, 1).family == FAM["gemv_rows"]
+    assert plan(Q5_K, 4096, 4096, 1).tree_id == plan(Q5_K, 100, 4096, 1).tree_id
     # r4: Q6_K lives in the planar Q4_2 form on int8 planes alone: the batched-decode form from ONE row (the mat-vec reads nibbles), the staged int8 form elsewhere
     assert plan(Q6_K, 4096, 4096, 1).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
     assert plan(Q6_K, 4096, 4096, 65).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 1).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]

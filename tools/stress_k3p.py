@@ -15,7 +15,8 @@ g = torch.Generator(device="cuda"); g.manual_seed(5)
 wo = device.Weight.from_device(2, device.quantize_rows(2, torch.randn((2048, 1024), generator=g, device="cuda")), 1024)
 xo = torch.randn((1024, 1024), generator=g, device="cuda") * 37.0
 nbad = 0
-for (M, K, N) in ((4096, 4096, 512), (4096, 11008, 512), (700, 2336, 257), (9000, 2048, 300), (4096, 4096, 1024), (9000, 4096, 2048), (11008, 4096, 129), (5000, 2048, 200)):
+for (M, K, N) in ((4096, 4096, 512), (4096, 11008, 512), (700, 2336, 257), (9000, 2048, 300), (4096, 4096, 1024), (9000, 4096, 2048), (11008, 4096, 129), (5000, 2048, 200),
+                  (1000, 28672, 300), (700, 20512, 257)):    # (r4: the sliced forms -- the tables are refilled by DMA inside the K loop)
     for t in TYPES:
         w = torch.randn((M, K), generator=g, device="cuda")
         W = device.Weight.from_device(t, device.quantize_rows(t, w), K)
