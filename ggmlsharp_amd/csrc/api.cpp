@@ -431,7 +431,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         off_d = total; total += plane;
         if (has_min_plane(type)) { off_m = total; total += plane; }
         if (has_qh_plane(type)) { off_qh = total; total += plane; }
-        off_gs = total; total += kq_type == GGML_HIP_TYPE_Q6_K ? 0 : (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh (Q6_K: no mat-vec reads it)
+        off_gs = total; total += (size_t)w->nbk * w->Mpad * 4 * gemv_side_planes(type);       // the mat-vec's tile-major copy of d / m / qh
         const bool q4 = type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1;
         with6 = q4 || (plan_force_gemm() == 3 && (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q8_0));
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q4_2) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
@@ -504,7 +504,7 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
         }
         if (e == hipSuccess && !q6k) e = launch_q5_to_i8(w, st);      // (the planar Q5_1 form's int8 operand planes: gemm_qmp.hip serves prompt-sized batches; Q6_K's converter writes them itself)
         if (e == hipSuccess && !q6k) e = launch_min_pieces(w, st);
-        if (e == hipSuccess && !q6k) e = launch_gemv_side_image(w, st);
+        if (e == hipSuccess) e = launch_gemv_side_image(w, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (staging) (void)hipFree(staging);
         if (e != hipSuccess) { (void)hipFree(w->qs); delete w; return fail(GGML_HIP_ERR_RUNTIME, "k-quant weight upload: %s", hipGetErrorString(e)); }

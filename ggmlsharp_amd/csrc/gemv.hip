@@ -32,6 +32,12 @@ namespace {
 #define GV_WORKERS (GV_WAVES * GV_NKQ) // k-workers per workgroup
 #define GV_CHUNK 128  // k-blocks of activations staged in LDS at a time (N <= 8)
 // wider batches (9..16 src1 rows, two-step form only) stage fewer k-blocks at a time so that the image still fits 64 KB of LDS
+// r4: a pseudo-type for weights living in the planar Q4_2 form ON INT8 PLANES (the Q6_K extension, kquants.hip): Q8_0's operand loads (two planes of
+// int8 per k-block, no unpacking) with Q4_2's arithmetic (two 16-element sub-blocks per k-block, the second's scale in the m plane)
+constexpr int GV_TYPE_I8X2 = 100;
+template <int TYPE> constexpr bool GV_W_I8 = TYPE == GGML_TYPE_Q8_0 || TYPE == GV_TYPE_I8X2;
+template <int TYPE> constexpr bool GV_TWO_SC = TYPE == GGML_TYPE_Q4_2 || TYPE == GV_TYPE_I8X2;
+
 template <int NC> struct GvChunk { static constexpr int value = NC <= 8 ? GV_CHUNK : 64; };
 #ifndef GV_NT
 #define GV_NT 1       // non-temporal weight loads (A/B: -DGV_NT=0)
@@ -113,8 +119,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
         const int nbc = (int)((nbk - cb) < CH ? (nbk - cb) : CH);
 
         // 1. all of this lane's weight loads for the chunk go out first (4 x 16 B + scales in flight per lane, 512 lanes)
-        uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
-        constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
+        uint4 q[BPL], q2[GV_W_I8<TYPE> ? BPL : 1];
+        constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || GV_TWO_SC<TYPE>;   // Q4_2: second scale
         constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
         constexpr int NP = 1 + (HAS_M ? 1 : 0) + (HAS_H ? 1 : 0);
         float dw[BPL], mw[HAS_M ? BPL : 1];
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
             const bool ok = bl < nbc;
             const int64_t b = cb + (ok ? bl : 0);
             // once-read weight stream: non-temporal loads (MI355X_MICROARCH.md nt-weights: issued -> landed -18 %)
-            if (TYPE == GGML_TYPE_Q8_0) {
+            if (GV_W_I8<TYPE>) {
                 q[j] = ld_w(qs + ((b * 2 + 0) * Mpad + row) * 16);
                 q2[j] = ld_w(qs + ((b * 2 + 1) * Mpad + row) * 16);
             } else {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
             const int bl = (u + GV_WORKERS * j) < nbc ? (u + GV_WORKERS * j) : 0;
             const uint32_t qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
             uint32_t lo[4], hi[4];
-            if (TYPE == GGML_TYPE_Q8_0) {
+            if (GV_W_I8<TYPE>) {
                 lo[0] = q[j].x; lo[1] = q[j].y; lo[2] = q[j].z; lo[3] = q[j].w;
                 hi[0] = q2[j].x; hi[1] = q2[j].y; hi[2] = q2[j].z; hi[3] = q2[j].w;
             } else {
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_q_kernel(const uint8_t *__res
                 const uint4 a1 = sA[(bl * 2 + 1) * NC + c];
                 const float da = sD[bl * NC + c];
                 const int sa = sS[bl * NC + c];
-                if (TYPE == GGML_TYPE_Q4_2) {
+                if (GV_TWO_SC<TYPE>) {
                     // elements 0..15 (the first 16-element block, scale dw) are words 0, 1 of both planes, 16..31 (scale
                     // mw) words 2, 3: sumf += (d0 * yd) * sumi_0; sumf += (d1 * yd) * sumi_1 (Ggml.cs:1249-1250)
                     int s0 = 0, s1 = 0;
@@ -320,7 +326,7 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
     __shared__ float sScale[NC];
     __shared__ float sK8[K8 ? NC * GV_K8_SB * 2 : 1];      // (column, super-block) -> iscale, d
     static_assert(!(K8 && (PRO || MULTI)), "the Q8_K rule: the plain single-matrix call only");
-    constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || TYPE == GGML_TYPE_Q4_2;   // Q4_2: second scale
+    constexpr bool HAS_M = TYPE == GGML_TYPE_Q4_1 || TYPE == GGML_TYPE_Q5_1 || GV_TWO_SC<TYPE>;   // Q4_2: second scale
     constexpr bool HAS_H = TYPE == GGML_TYPE_Q5_0 || TYPE == GGML_TYPE_Q5_1;
     constexpr int NP = 1 + (HAS_M ? 1 : 0) + (HAS_H ? 1 : 0);
 
@@ -360,7 +366,7 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
     // (the look-ahead form: one column, and three / four -- 11008 x 4096 x 4 15.6 -> 12.6 us, 32000 x 4096 x 4 29.6 -> 23.3 with
     // one workgroup per CU; two columns measured level to worse: 11008 x 4096 x 2 8.3 -> 9.1 us)
     constexpr bool PF = SC && (NC == 1 || NC == 4);
-    uint4 q[BPL], q2[TYPE == GGML_TYPE_Q8_0 ? BPL : 1], qn[PF ? BPL : 1], q2n[PF && TYPE == GGML_TYPE_Q8_0 ? BPL : 1];
+    uint4 q[BPL], q2[GV_W_I8<TYPE> ? BPL : 1], qn[PF ? BPL : 1], q2n[PF && GV_W_I8<TYPE> ? BPL : 1];
     float dw[BPL], mw[HAS_M ? BPL : 1], dwn[PF ? BPL : 1], mwn[PF && HAS_M ? BPL : 1];
     uint32_t hb[HAS_H ? BPL : 1], hbn[PF && HAS_H ? BPL : 1];
     // the weight stream of one item (4 x 16 B + scales in flight per lane)
@@ -378,7 +384,7 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
             const int bl = u + GV_WORKERS * j;
             const bool ok = bl < nbc;
             const int64_t b = cb + (ok ? bl : 0);
-            if (TYPE == GGML_TYPE_Q8_0) {
+            if (GV_W_I8<TYPE>) {
                 Q[j] = ld_w(qs + ((b * 2 + 0) * Mpad + row) * 16);
                 Q2[j] = ld_w(qs + ((b * 2 + 1) * Mpad + row) * 16);
             } else {
@@ -556,7 +562,7 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
             const float mwj = HAS_M && ok ? MW[HAS_M ? j : 0] : 0.0f;
             const uint32_t qq[4] = {Q[j].x, Q[j].y, Q[j].z, Q[j].w};
             uint32_t lo[4], hi[4];
-            if (TYPE == GGML_TYPE_Q8_0) {
+            if (GV_W_I8<TYPE>) {
                 lo[0] = Q[j].x; lo[1] = Q[j].y; lo[2] = Q[j].z; lo[3] = Q[j].w;
                 hi[0] = Q2[j].x; hi[1] = Q2[j].y; hi[2] = Q2[j].z; hi[3] = Q2[j].w;
             } else {
@@ -580,7 +586,7 @@ __device__ __forceinline__ void gemv_fused_body(const mv_set &ws, const float *_
                 const uint4 a1 = *(const uint4 *)(myq + i * QSLOT + (c * 2 + 1) * 16);
                 const float da = myd[i * NC + c];
                 const int sa = mys[i * NC + c];
-                if (TYPE == GGML_TYPE_Q4_2) {
+                if (GV_TWO_SC<TYPE>) {
                     int s0 = 0, s1 = 0;
                     s0 = dot4(lo[0], a0.x, s0); s0 = dot4(lo[1], a0.y, s0); s0 = dot4(hi[0], a1.x, s0); s0 = dot4(hi[1], a1.y, s0);
                     s1 = dot4(lo[2], a0.z, s1); s1 = dot4(lo[3], a0.w, s1); s1 = dot4(hi[2], a1.z, s1); s1 = dot4(hi[3], a1.w, s1);
@@ -697,15 +703,16 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
         // up to 4 columns; 5..8 stay on the block-staged kernel below (118 registers = two resident workgroups per CU; the
         // wave-private form needs 146 there: 32000 x 4096 x 8 41.9 against 48.5 us)
         if (N <= 4) {
-#define GVF_ARGS w->qs, w->gs, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep
+#define GVF_ARGS (TYPE == GV_TYPE_I8X2 ? w->i8p : w->qs), w->gs, x, ld1, dst, w->M, w->Mpad, w->nbk, ldd, (int)N, ntiles, ep
 #define GVF_LAUNCH(NC) do { \
         if (w->ext_type != 0) {                 /* a k-quant weight (planar Q5_1 form): activations by the Q8_K rule */ \
-            if constexpr (TYPE == GGML_TYPE_Q5_1) { \
-                if (t_prologue || ep.mode != 0 || w->nbk % 8 != 0 || w->nbk / 8 > GV_K8_SB) return hipErrorNotSupported; \
+            if constexpr (TYPE == GGML_TYPE_Q5_1 || TYPE == GV_TYPE_I8X2) { \
+                if (t_prologue || ep.mode != 0 || w->nbk % 8 != 0 || w->nbk / 8 > GV_K8_SB || (TYPE == GV_TYPE_I8X2 && !w->i8p)) return hipErrorNotSupported; \
                 if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
                 else gemv_fused_kernel<TYPE, NC, ROWS, false, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
             } else return hipErrorNotSupported; \
-        } else if (t_prologue) { \
+        } else if constexpr (TYPE == GV_TYPE_I8X2) return hipErrorNotSupported;   /* (the form exists for the k-quant extension only) */ \
+        else if (t_prologue) { \
             if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
             else gemv_fused_kernel<TYPE, NC, ROWS, false, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, *t_prologue); \
         } else if (w->nbk <= GV_CHUNK) gemv_fused_kernel<TYPE, NC, ROWS, true><<<grid, GV_THREADS, 0, st>>>(GVF_ARGS, mm_prologue{nullptr, 0, nullptr, nullptr}); \
@@ -720,7 +727,7 @@ hipError_t launch_rows(const ggml_hip_weight *w, const float *x, int64_t ld1, ac
     }
     if (ep.mode != 0 || t_prologue) return hipErrorNotSupported;          // (callers ask gemv_fused_has_epilogue first)
     if (FUSED && w->ext_type != 0) return hipErrorNotSupported;           // (the block-staged fused form quantizes by the Q8_0 rule: plan.cpp keeps k-quants off it)
-#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>(w->qs, w->gs, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
+#define GV_LAUNCH(NC) gemv_q_kernel<TYPE, NC, FUSED, ROWS><<<grid, GV_THREADS, 0, st>>>((TYPE == GV_TYPE_I8X2 ? w->i8p : w->qs), w->gs, x, ld1, p.a8, p.ad, p.as, dst, w->M, w->Mpad, p.Npad, w->nbk, ldd, (int)N, ntiles)
     if (N <= 1) GV_LAUNCH(1);
     else if (N <= 2) GV_LAUNCH(2);
     else if (N <= 4) GV_LAUNCH(4);
@@ -748,7 +755,9 @@ hipError_t launch_any(const ggml_hip_weight *w, const float *x, int64_t ld1, act
     case GGML_TYPE_Q4_0: return launch_typed<GGML_TYPE_Q4_0, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
     case GGML_TYPE_Q4_1: return launch_typed<GGML_TYPE_Q4_1, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
     case GGML_TYPE_Q5_0: return launch_typed<GGML_TYPE_Q5_0, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
-    case GGML_TYPE_Q4_2: return launch_typed<GGML_TYPE_Q4_2, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
+    case GGML_TYPE_Q4_2:
+        if (w->ext_type != 0) return w->i8p ? launch_typed<GV_TYPE_I8X2, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep) : hipErrorInvalidValue;   // (Q6_K: int8 planes)
+        return launch_typed<GGML_TYPE_Q4_2, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
     case GGML_TYPE_Q5_1: return launch_typed<GGML_TYPE_Q5_1, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
     case GGML_TYPE_Q8_0: return launch_typed<GGML_TYPE_Q8_0, FUSED>(w, x, ld1, p, N, dst, ldd, st, ep);
     default: return hipErrorInvalidValue;

@@ -32,10 +32,10 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
-    // (Q4_2 from 17 rows: its mat-vec serves up to 16 -- i8_only: the Q6_K extension lives in this form on its int8 planes alone, the mat-vec
-    // reads nibbles: the batched-decode form takes it from one row on)
+    // (Q4_2 from 17 rows: its mat-vec serves up to 16 -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
+    // (gemv.hip GV_TYPE_I8X2) serves up to 4 rows, the batched-decode form takes it from 5)
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 1 : GEMV_WIDE_MAX_N + 1) : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
@@ -418,10 +418,10 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     if (wide) p.flags |= MM_FLAG_WIDE;
     if (kind == 0) {
         // (r4: the k-quants of the planar Q5_1 form have a fused mat-vec too, up to 4 rows and K = 32768 -- gemv.hip K8: the Q8_K rule in the kernel)
-        const bool kq_fused = ext_type != 0 && type == GGML_TYPE_Q5_1 && N <= 4 && K % 256 == 0 && K / 256 <= 128;
+        const bool kq_fused = ext_type != 0 && (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) && N <= 4 && K % 256 == 0 && K / 256 <= 128;
         if (one_call && N <= GEMV_MAX_N && (ext_type == 0 || kq_fused) && !no_fused) { plan_gemv(p, type, M, K, N, true); return p; }
         p.flags |= MM_FLAG_NEEDS_WORK;
-        if (N <= gemv_rows_max(type) && !i8_only) { plan_gemv(p, type, M, K, N, false); return p; }
+        if (N <= (i8_only ? 4 : gemv_rows_max(type))) { plan_gemv(p, type, M, K, N, false); return p; }   // (Q6_K: the mat-vec on int8 planes up to 4 rows, then K3s / the staged form)
         plan_i8(p, type, M, N);
         return p;
     }

@@ -299,7 +299,7 @@ def test_mul_mat_q5_K_matches_the_restatement(dev, t):
 
 
 @gpu
-@pytest.mark.parametrize("t", [Q5_K, Q4_K])
+@pytest.mark.parametrize("t", ALL_KQ)
 def test_fused_mat_vec_with_the_Q8_K_rule_equals_the_two_step_form_bitwise(dev, t):
     """up to 4 src1 rows the one-call entry runs the fused mat-vec with the Q8_K rule inside the kernel (gemv.hip K8, r4; K <= 32768): the
     same quants, the same summation tree as INIT + the mat-vec on K1's image -- so the same bits; and both against the restatement.

@@ -90,9 +90,11 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q5_K, 4096, 4096, 1).family == FAM["gemv_fused"] and plan(Q4_K, 4096, 4096, 4).family == FAM["gemv_fused"]
     assert plan(Q5_K, 4096, 4096, 5).family == FAM["gemv_rows"] and plan(Q5_K, 4096, 33024, 1).family == FAM["gemv_rows"]
     assert plan(Q5_K, 4096, 4096, 1).tree_id == plan(Q5_K, 100, 4096, 1).tree_id
-    # r4: Q6_K lives in the planar Q4_2 form on int8 planes alone: the batched-decode form from ONE row (the mat-vec reads nibbles), the staged int8 form elsewhere
-    assert plan(Q6_K, 4096, 4096, 1).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
-    assert plan(Q6_K, 4096, 4096, 65).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 1).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
+    # r4: Q6_K lives in the planar Q4_2 form on int8 planes alone: its own mat-vec up to 4 rows (fused with the Q8_K rule up to K = 32768), the
+    # batched-decode form at 5..64 rows, the staged int8 form's two-scale instantiation elsewhere
+    assert plan(Q6_K, 4096, 4096, 1).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 1024, 4).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 33024, 1).family == FAM["gemv_rows"]
+    assert plan(Q6_K, 4096, 4096, 5).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
+    assert plan(Q6_K, 4096, 4096, 65).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
     assert plan(Q6_K, 4096, 4096, 8).tree_id != plan(Q4_2, 4096, 4096, 32).tree_id              # (activations by the Q8_K rule: another tree)
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
