@@ -789,7 +789,8 @@ def main():
                 "q5_k_ffn2048_unpinned_extra": side_config(device, 4096, 11008, 2048, copies=6, iters=20, qtype=Q5_K),
                 "q4_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=8, iters=60, qtype=Q4_K),   # (r4: Q4_K, the same resident form and kernels)
                 "q6_k_ffn512_unpinned_extra": side_config(device, 4096, 11008, 512, copies=6, iters=40, qtype=Q6_K),   # (r4: Q6_K in the planar Q4_2 form on int8 planes: the staged int8 kernel)
-                "q6_k_batch1_unpinned_extra": side_config(device, 4096, 4096, 1, copies=32, iters=100, qtype=Q6_K),    #     ... and its decode step (the batched-decode form from one row)
+                "q6_k_batch1_unpinned_extra": side_config(device, 4096, 4096, 1, copies=32, iters=100, qtype=Q6_K),    #     ... and its decode step (its own mat-vec on the int8 planes, the Q8_K rule fused)
+                "q5_k_batch1_unpinned_extra": side_config(device, 4096, 4096, 1, copies=32, iters=100, qtype=Q5_K),    # (r4: the k-quants' fused mat-vec -- the Q8_K rule inside the kernel)
                 "q5_0_batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100, qtype=Q5_0),
                 "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
                 "vocab512_shard_of_8": side_config(device, 4000, 4096, 512, copies=24, iters=100),      # what each rank of config 5's 8-GPU split computes
