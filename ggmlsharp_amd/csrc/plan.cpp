@@ -34,8 +34,9 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 17 rows: its mat-vec serves up to 16 -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
     // (gemv.hip GV_TYPE_I8X2) serves up to 4 rows, the batched-decode form takes it from 5)
+    static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : 5) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : k3s_nmin) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
@@ -90,7 +91,10 @@ int plan_image_kind(int type, int64_t K, int64_t N) {
     if (N <= 4 || force == 1) return 0;
     // 5..8 rows: the mat-vec kernel -- except where the batched-decode form of gemm_qmx.hip exists (Q4_0 / Q4_1, K >= 2048): from 5 rows
     // on it runs the same INIT image and kernel as 9..32 rows, with the epilogues and the projection groups that come with them
-    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= 64)) return 0;
+    // (r4, A/B of whole calls in one gpurun call, K3s from 5 | the fused mat-vec up to 8: 4096 x 4096 x 8 Q4_0 10.3 | 10.1 us, Q8_0 10.8 | 9.9 -- level --
+    // 4096 x 11008 x 8 20.1 | 25.6, 11008 x 4096 x 8 15.6 | 18.4, 32000 x 4096 x 8 26.5 | 40.2: 5 stays)
+    static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch: the batched-decode forms from this many rows
+    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= 64 && N >= k3s_nmin)) return 0;
     if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
