@@ -35,8 +35,16 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     // (Q4_2 from 17 rows: its mat-vec serves up to 16 -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
     // (gemv.hip GV_TYPE_I8X2) serves up to 4 rows, the batched-decode form takes it from 5)
     static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch
+    // Upper bound.  The form re-reads a weight tile once per 32 src1 rows, so beyond 64 rows it pays by M -- and the choice may not follow M.
+    // The two-scale types (Q4_2, and the Q6_K extension in its form) have only the staged int8 kernel behind it, 2 x slower than the others'
+    // forms: r4, up to 256 rows (A/B in one call, staged | this form: 4096 x 4096 x 65 / 128 / 256 42.9 | 15.2, 41.5 | 15.8, 48.5 | 29.9 us,
+    // 4096 x 11008 x 128 / 192 122 | 39.4, 124 | 73.6, 11008 x 4096 x 128 / 192 58.6 | 51.1, 97.9 | 80.4; the price: 32000 x 4096 x 128 120 | 134).
+    // The one-scale types keep 64: 4096 x 4096 x 128 19.0 | 11.6 and 4096 x 11008 x 128 43.0 | 26.7, but 11008 x 4096 x 128 32.4 | 41.9 and
+    // 32000 x 4096 x 128 69 | 114 -- their staged K-split forms are good, and a choice by M would change the summation tree.
+    static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 256);  // developer A/B switch: the two-scale types' upper bound
+    static const int k3s_nmax = dev_env_int("GGML_HIP_K3S_NMAX", 64);           // ... and the one-scale types' 
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : k3s_nmin) && N <= 64 && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).

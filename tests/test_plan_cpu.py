@@ -94,7 +94,9 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     # batched-decode form at 5..64 rows, the staged int8 form's two-scale instantiation elsewhere
     assert plan(Q6_K, 4096, 4096, 1).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 1024, 4).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 33024, 1).family == FAM["gemv_rows"]
     assert plan(Q6_K, 4096, 4096, 5).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
-    assert plan(Q6_K, 4096, 4096, 65).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
+    # (r4: the two-scale types -- Q4_2 and Q6_K in its form -- stay on the batched-decode form up to 256 rows: only the staged int8 kernel is behind it)
+    assert plan(Q6_K, 4096, 4096, 256).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 11008, 192).family == FAM["k3s_i8"] and plan(Q8_0, 4096, 4096, 65).family != FAM["k3s_i8"]
+    assert plan(Q6_K, 4096, 4096, 257).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
     assert plan(Q6_K, 4096, 4096, 8).tree_id != plan(Q4_2, 4096, 4096, 32).tree_id              # (activations by the Q8_K rule: another tree)
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too

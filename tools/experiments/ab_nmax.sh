@@ -4,7 +4,7 @@
 # round-4 bounds of plan.cpp (K3p ranges, tile-count thresholds, the dense forms) were all measured with it.
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out && rm -f gpurun_out/ab_nmax.log
 export GGML_HIP_LIB=$GRAFT_REPO_ROOT/ggmlsharp_amd/lib/libggml_hip_dev.so
-for v in 5 9 5 9; do
-  echo "== K3S_NMIN $v (5: the batched-decode forms from 5 rows; 9: the fused mat-vec up to 8) -- compare the graph-replayed whole calls" >> gpurun_out/ab_nmax.log
-  GGML_HIP_K3S_NMIN=$v timeout -k 10 400 python tools/kbench.py --no-check --cfg q4_0:4096:4096:5 q4_0:4096:4096:8 q8_0:4096:4096:5 q8_0:4096:4096:8 q4_0:4096:11008:5 q4_0:4096:11008:8 q8_0:4096:11008:8 q5_0:4096:11008:6 q4_0:11008:4096:8 q8_0:11008:4096:8 q4_0:32000:4096:8 q4_0:4096:8192:8 --iters 20 >> gpurun_out/ab_nmax.log 2>&1 || exit 1
+for v in 64 128 64 128; do
+  echo "== K3S_NMAX $v (the one-scale int8 types on the batched-decode form up to this many rows; beyond: the staged forms)" >> gpurun_out/ab_nmax.log
+  GGML_HIP_K3S_NMAX=$v timeout -k 10 400 python tools/kbench.py --cfg q8_0:4096:4096:65 q8_0:4096:4096:96 q8_0:4096:4096:128 q5_0:4096:4096:128 q5_1:4096:4096:96 q5_1:4096:4096:128 q8_0:4096:11008:96 q8_0:4096:11008:128 q5_1:4096:11008:128 q8_0:11008:4096:128 q5_0:11008:4096:96 q8_0:32000:4096:128 q8_0:8192:8192:128 --iters 20 >> gpurun_out/ab_nmax.log 2>&1 || exit 1
 done
