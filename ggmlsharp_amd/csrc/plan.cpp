@@ -42,7 +42,12 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     // The one-scale types keep 64: 4096 x 4096 x 128 19.0 | 11.6 and 4096 x 11008 x 128 43.0 | 26.7, but 11008 x 4096 x 128 32.4 | 41.9 and
     // 32000 x 4096 x 128 69 | 114 -- their staged K-split forms are good, and a choice by M would change the summation tree.
     static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 256);  // developer A/B switch: the two-scale types' upper bound
-    static const int k3s_nmax = dev_env_int("GGML_HIP_K3S_NMAX", 64);           // ... and the one-scale types' 
+    // ... except behind a LONG K (from 11008: a down projection's shape, more columns than rows in every model family looked at), where the
+    // staged forms' K split is at its worst and M is small -- up to 128 rows there (staged | this form at 128 rows unless noted: 4096 x 11008
+    // 43.0 | 26.7, 5120 x 13824 64.7 | 57.3, Q5_1 x 96 72.7 | 36.3, 8192 x 28672 151 | 120, Q5_0 132 | 119; the price is a square or tall matrix
+    // with such a K: 11008 x 11008 78 | 93).  K = 8192 is mixed (8192 x 8192 41.6 | 38.1, 28672 x 8192 124 | 166) and stays at 64.
+    static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
+    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K >= 11008 ? 128 : 64;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }

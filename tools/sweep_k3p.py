@@ -43,10 +43,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
         print(f"BAD {TYPES[t]} M{M} K{K} N{N}: {bad} elements, max err/rms {(err.max() / rms).item():.2e}, shard mismatch {shard_bad}", flush=True)
     W.free()
 # r4: the batched-decode forms (K3s, 5..64 rows) over long K -- one and two rounds of table pieces (K <= 16384 | <= 32768), beyond: the staged forms
-for it in range(40):
-    t = int(rng.choice(list(TYPES) + [4]))
-    K = 32 * int(rng.choice([512, 513, 640, 896, 1000, 1024, 1025]))
-    N = int(rng.choice([5, 9, 17, 31, 32, 33, 64]))
+for it in range(80):
+    t = int(rng.choice(list(TYPES) + [4, 4]))
+    K = 32 * int(rng.choice([344, 345, 432, 512, 513, 640, 896, 1000, 1024, 1025]))
+    N = int(rng.choice([5, 9, 17, 31, 32, 33, 64, 65, 96, 100, 128, 129, 200, 256]))   # (r4: behind K >= 11008 the one-scale types stay on the form up to 128 rows, the two-scale ones up to 256 whatever K)
     M = int(rng.choice([100, 700, 3000]))
     g = torch.Generator(device="cuda"); g.manual_seed(5000 + it)
     w = torch.randn((M, K), generator=g, device="cuda")
