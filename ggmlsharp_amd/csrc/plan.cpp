@@ -246,7 +246,11 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
         const int64_t t64 = cdiv(M, 64) * cdiv(N, 64);
         if (q4) {
             // up to 64 rows, K >= 2048: the stage-free form K3s (by N and K alone; GGML_HIP_MX_TILE=26: the staged form, A/B)
-            static const int ncmax = dev_env_int("GGML_HIP_K3S_COLS", 2);   // developer A/B switch: 1 = K3s up to 32 rows only
+            // (r4: up to 128 rows behind K >= 11008, the rule and the reason of q8_small_serves -- staged | this form at 128 rows: 4096 x 11008 36.1 | 25.0 us,
+            // Q4_1 49.5 | 28.3, 8192 x 28672 110 | 96.5; 11008 x 11008 66.4 | 83.5 is the price; behind a shorter K it pays by M: 4096 x 4096 16.1 | 13.1
+            // but 11008 x 4096 29.0 | 37.3, 32000 x 4096 67.9 | 87.5)
+            static const int ncmax_dev = dev_env_int("GGML_HIP_K3S_COLS", 0);   // developer A/B switch: 1 = K3s up to 32 rows only (0: the rule)
+            const int ncmax = ncmax_dev > 0 ? ncmax_dev : K >= 11008 ? 4 : 2;
             if (N <= 32 * ncmax && nbk >= 64 && var != 25 && var != 26 && plan_k3s_mx(p, type, M, Mpad, K, N)) return;
         }
         if (N <= 32 && var != 25) {

@@ -101,6 +101,7 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     # r4: behind a long K (>= 11008, a down projection) the one-scale int8 types stay on the batched-decode form up to 128 rows
     assert plan(Q8_0, 4096, 11008, 128).family == FAM["k3s_i8"] and plan(Q5_1, 5120, 13824, 96).family == FAM["k3s_i8"] and plan(Q5_K, 4096, 11008, 128).family == FAM["k3s_i8"]
     assert plan(Q8_0, 4096, 11008, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 8192, 128).family != FAM["k3s_i8"]
+    assert plan(Q4_0, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 8192, 28672, 96).family == FAM["k3s_mx"] and plan(Q4_0, 4096, 4096, 128).family == FAM["mx"]
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
     assert plan(Q5_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 32).image_kind == 0
