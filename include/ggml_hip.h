@@ -223,7 +223,9 @@ int    ggml_hip_mul_mat_compute_dev(const ggml_hip_weight *w, int64_t N, float *
 /* ---------------- Seam 2: row functions (quantize_fns_t, TypeDefs:334-342) ----------------
  * Batched device variants: rows are contiguous, k elements each, blocks in reference format.
  * quantize: Q4_0 (Ggml.cs:334-377), Q4_1 (487-528), Q5_0 (609-653), Q8_0 (733-762), Q8_1 (781-823).
- * dequantize: Q4_0 (886-910), Q4_1 (962-987), Q5_0 (1025-1061), Q8_0 (1104-1122).  Bit-exact. */
+ * dequantize: Q4_0 (886-910), Q4_1 (962-987), Q5_0 (1025-1061), Q8_0 (1104-1122).  Bit-exact.
+ * (Both also take the k-quant extension types of ggml_hip_ext.h -- GGML_HIP_TYPE_Q4_K / Q5_K / Q6_K, k % 256 == 0, rows 16-byte aligned --
+ * which the reference does not have: see there for what "exact" means for them.) */
 int ggml_hip_quantize_rows_dev(int type, const float *d_x, int64_t nrows, int64_t k, void *d_blocks, void *stream);
 int ggml_hip_dequantize_rows_dev(int type, const void *d_blocks, int64_t nrows, int64_t k, float *d_y, void *stream);
 /* Host-pointer forms with exactly the slot signatures' argument meaning (x, y, k) / (n, s, vx, vy);
