@@ -32,9 +32,13 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
-    // (Q4_2 from 17 rows: its mat-vec serves up to 16 -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
+    // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
     // (gemv.hip GV_TYPE_I8X2) serves up to 4 rows, the batched-decode form takes it from 5)
     static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch
+    // (Q4_2: from 9 rows -- r4; it was 17, its mat-vec's two-step form serving 9..16: mat-vec | this form at 16 rows 4096 x 4096 11.7 | 9.5 us,
+    // 4096 x 11008 27.2 | 22.7, 11008 x 4096 30.2 | 16.6, 32000 x 4096 78.5 | 35.2; from 5 rows the whole calls are mixed -- 4096 x 4096 x 8 10.5 | 12.9,
+    // 32000 x 4096 x 8 44.2 | 38.9 -- so its fused mat-vec keeps 5..8)
+    static const int k3s_nmin_2sc = dev_env_int("GGML_HIP_K3S_NMIN_2SC", GEMV_MAX_N + 1);   // developer A/B switch: Q4_2's lower bound
     // Upper bound.  The form re-reads a weight tile once per 32 src1 rows, so beyond 64 rows it pays by M -- and the choice may not follow M.
     // The two-scale types (Q4_2, and the Q6_K extension in its form) have only the staged int8 kernel behind it, 2 x slower than the others'
     // forms: r4, up to 256 rows (A/B in one call, staged | this form: 4096 x 4096 x 65 / 128 / 256 42.9 | 15.2, 41.5 | 15.8, 48.5 | 29.9 us,
@@ -49,7 +53,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
     const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K >= 11008 ? 128 : 64;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : GEMV_WIDE_MAX_N + 1) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).

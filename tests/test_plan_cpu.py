@@ -108,7 +108,8 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     p = plan(Q5_1, 4096, 4096, 32)
     assert p.family == FAM["k3s_i8"] and p.image_kind == 64 and (p.flags & MIN_PIECES)
     assert plan(Q5_1, 4096, 4096, 8).family == FAM["gemv_fused"]                    # (up to 8 rows its fused mat-vec is as fast)
-    assert plan(Q4_2, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 4096, 16).family in (FAM["gemv_rows"], FAM["gemv_fused"])   # (its mat-vec serves up to 16 rows)
+    assert plan(Q4_2, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 4096, 9).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 4096, 8).family == FAM["gemv_fused"]   # (r4: from 9 rows; its mat-vec keeps up to 8, and 9..16 where K < 2048)
+    assert plan(Q4_2, 4096, 1024, 16).family == FAM["gemv_rows"]
     assert len({plan(t, 4096, 4096, 32).tree_id for t in (Q8_0, Q5_0, Q5_1, Q4_2)}) == 4   # four different arithmetics, four trees
     # r4: K3p serves Q8_0 / Q5_0 up to 3072 rows, Q4_1 up to 1024, Q5_1 / Q5_K without bound; Q4_0 (MX) up to 512
     assert plan(Q8_0, 4096, 11008, 3072).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 11008, 3073).family != FAM["k3p_i8"]
