@@ -314,7 +314,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     // scale multiplications differs.  (It ran the staged f16 forms here: 4096 x 4096 x 64 16.3 us against Q8_0's 7.8.)
     // ... and Q5_1 (9 .. 64 rows): Q5_0's block term on planes of the unsigned values + the min-term product in front of the blocks
     // (4096 x 4096 x 64 17.3 us on the staged forms, 4096 x 11008 x 32 36.4).
-    // ... and Q4_2 (17 .. 64 rows; the mat-vec serves it up to 16): int8 planes of nib - 8 (built at upload, r4), two K = 16 MFMAs per block
+    // ... and Q4_2 (9 .. 256 rows -- it was 17 .. 64; plan.cpp q8_small_serves has the measurements): int8 planes of nib - 8 (built at upload, r4), two K = 16 MFMAs per block
     // (4096 x 4096 x 32 40.3 us on the staged int8 kernel).
     const bool q42 = w->type == GGML_TYPE_Q4_2;
     const bool q51 = w->type == GGML_TYPE_Q5_1, q5 = w->type == GGML_TYPE_Q5_0 || q51;

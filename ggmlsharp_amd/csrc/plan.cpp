@@ -17,7 +17,7 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 constexpr uint64_t LIM32 = 0xFFFFFFFFull;                  // 32-bit buffer offsets
 
 // src1 rows up to which the mat-vec kernel serves a type (two-step form above GEMV_MAX_N): the types with small-batch MFMA
-// configurations leave it at 8; Q4_2, which only has the int8 kernel's 64 x 64 tiles behind it, stays on it up to 16
+// configurations leave it at 8; Q4_2 stays on it up to 16 where the batched-decode form does not reach (K < 2048, K > 32768: q8_small_serves)
 int64_t gemv_rows_max(int t) { return t == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N : GEMV_MAX_N; }
 
 // ---- K3p / K3s / q8s geometry of K: contiguous ranges of k-blocks, one per wave (KS = 8 waves) ----

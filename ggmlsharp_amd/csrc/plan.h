@@ -15,7 +15,7 @@
 enum mm_family {
     MMF_NONE = 0,
     MMF_GEMV_FUSED = 1,   // gemv.hip K2f / K2: INIT + COMPUTE in one launch, N <= 8
-    MMF_GEMV_ROWS = 2,    // gemv.hip two-step form on K1's planes (Q4_2 up to 16 rows; the COMPUTE-only entry for N <= 8)
+    MMF_GEMV_ROWS = 2,    // gemv.hip two-step form on K1's planes (Q4_2 at 9..16 rows where K < 2048; the COMPUTE-only entry for N <= 8)
     MMF_K3S_MX = 3,       // gemm_qmx.hip K3s: stage-free batched decode, MX
     MMF_K3S_I8 = 4,       // gemm_q8s.hip: the same on the int8 cores (Q8_0)
     MMF_K3P_MX = 5,       // gemm_qmp.hip K3p: prompt-sized batches, MX (Q4_0)
