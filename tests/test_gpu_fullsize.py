@@ -357,6 +357,32 @@ def test_k3p_beyond_one_scale_table_slices_refill_inside_the_K_loop(dev, t, K):
     W.free()
 
 
+@pytest.mark.parametrize("t,K,N", [(4, 4096, 9), (4, 4096, 16), (4, 2048, 200), (4, 4096, 256), (Q8_0, 11008, 100), (Q8_0, 11008, 128), (Q5_0, 13824, 96),
+                                   (7, 11008, 128), (Q4_0, 11008, 128), (3, 11008, 96)])
+def test_batched_decode_forms_beyond_their_round_3_ranges(dev, t, K, N):
+    """The stage-free batched-decode forms (gemm_q8s.hip, gemm_qmx.hip K3s) where the end of round 4 put them (plan.cpp q8_small_serves, plan_mx):
+    the two-scale type Q4_2 from 9 rows up to 256, every other type up to 128 rows behind K >= 11008 -- three and more column tiles per weight
+    tile.  fp64 evaluation of the block arithmetic; a row shard is the bitwise slice (the form is chosen by type, K and N alone)."""
+    import ctypes as C
+    from ggmlsharp_amd import _lib
+    M = 3000
+    pl = _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pl)) == 0 and pl.family in (3, 4), (t, K, N, pl.family)   # 3 / 4 = K3s MX / int8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(31 * t + K + N)
+    w = torch.randn((M, K), generator=g, device="cuda")
+    x = torch.randn((N, K), generator=g, device="cuda") * 2
+    rows = dev.quantize_rows(t, w)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    _check_fp64(dev, t, rows, x, full, K)
+    for (r0, r1) in ((0, 1000), (2100, 2100 + 777)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, K, N, r0, r1)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("N", [128, 512])
 def test_dense_f16_vocabulary_sized_matrix_and_its_shards_share_one_tree(dev, N):
     """F16, up to 512 src1 rows: a 32000-row matrix used to reach the unsplit 256 x 128 form (384 tiles and more) while its 4000-row
