@@ -275,7 +275,8 @@ def test_mul_mat_q5_K_matches_the_restatement(dev, t):
                       (130, 512, 600), (257, 768, 1100),
                       (200, 2048, 300), (130, 4352, 512),       # r4: K3p on the int8 planes of the planar Q5_1 form (from 257 rows, K >= 2048)
                       (200, 2048, 1100), (130, 2304, 2500),      #     ... which has no upper bound for this type
-                      (300, 2048, 33), (130, 4352, 64), (515, 2304, 9)):   # r4: the batched-decode form K3s-int8 (9..64 rows, K >= 2048)
+                      (300, 2048, 33), (130, 4352, 64), (515, 2304, 9),    # r4: the batched-decode form K3s-int8 (9..64 rows, K >= 2048)
+                      (130, 11008, 100), (96, 2048, 250)):                 #     ... up to 128 rows behind K >= 11008 (Q6_K: up to 256 whatever K)
         for raw in (False, True):
             rows = _random_blocks(M * K // 256, t).reshape(M, -1) if raw else KQT[t][1](_rand((M * K // 256, 256))).reshape(M, -1)
             x = _rand((N, K))
