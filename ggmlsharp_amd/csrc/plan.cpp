@@ -30,11 +30,14 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode
 // form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
-bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
+bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
     // (gemv.hip GV_TYPE_I8X2) serves up to 4 rows, the batched-decode form takes it from 5)
     static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch
+    // (the k-quants of the Q5_1 form: their fused mat-vec ends at 4 rows, 5..8 run INIT + the mat-vec -- measured against this form from 5, whole
+    // calls: 4096 x 4096 x 8 11.2 | 12.0 us, 4096 x 11008 x 8 22.1 | 25.1, 32000 x 4096 x 8 38.0 | 40.6: 9 stays for them too)
+    static const int k3s_nmin_kq = dev_env_int("GGML_HIP_K3S_NMIN_KQ", 9);   // developer A/B switch
     // (Q4_2: from 9 rows -- r4; it was 17, its mat-vec's two-step form serving 9..16: mat-vec | this form at 16 rows 4096 x 4096 11.7 | 9.5 us,
     // 4096 x 11008 27.2 | 22.7, 11008 x 4096 30.2 | 16.6, 32000 x 4096 78.5 | 35.2; from 5 rows the whole calls are mixed -- 4096 x 4096 x 8 10.5 | 12.9,
     // 32000 x 4096 x 8 44.2 | 38.9 -- so its fused mat-vec keeps 5..8)
@@ -53,7 +56,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false) {
     static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
     const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K >= 11008 ? 128 : 64;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? 9 : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
@@ -432,7 +435,7 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     int kind = wide ? 0 : plan_image_kind(type, K, N);
     bool no_fused = false;
     const bool i8_only = ext_type != 0 && type == GGML_TYPE_Q4_2;   // (Q6_K: no nibble plane -- the int8 forms only)
-    if (q8_small_serves(type, K, N, i8_only)) {             // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
+    if (q8_small_serves(type, K, N, i8_only, ext_type != 0)) {             // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
         if (plan_k3s_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
         wide = true; kind = 0; no_fused = true;             // (its planes are beyond the form's offsets: the two-step forms below)
     }
