@@ -405,7 +405,7 @@ static DeviceCtx *call_slot() {
 static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_weight **out, int kq_type = 0) {
     ggml_hip_weight *w = new ggml_hip_weight();
     memset(w, 0, sizeof *w);
-    const bool q5k = kq_type != 0;                          // (a k-quant weight in the planar Q5_1 form: Q5_K, Q4_K)
+    const bool kq = kq_type != 0;                           // (a k-quant weight: Q5_K / Q4_K in the planar Q5_1 form, Q6_K in the planar Q4_2 form)
     w->ext_type = kq_type;
     static std::atomic<uint64_t> next_uid{1};
     w->type = type; w->M = M; w->K = K; w->Mpad = pad_rows(M > 0 ? M : 1); w->device = c->device; w->uid = next_uid.fetch_add(1);
@@ -437,7 +437,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q4_2) { off_i8 = total; total += (size_t)nba * w->Mpad * 32; }   // int8 operand planes (gemm_qmp.hip), zero past the end of K
         // the min plane as three bf16 pieces (K3p-int8's min-term product): whole pairs of k-groups, zero past the end of K
         if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) { off_mp = total; total += (size_t)((w->nbk + 15) / 16 * 2 * 3) * w->Mpad * 16; }
-        if (q5k) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * (kq_type == GGML_HIP_TYPE_Q6_K ? 32 : 16); }   // super-block headers, for the byte-exact download
+        if (kq) { off_kh = total; total += (size_t)(w->nbk / 8 + 1) * w->Mpad * (kq_type == GGML_HIP_TYPE_Q6_K ? 32 : 16); }   // super-block headers, for the byte-exact download
         if (with6) {   // bf6 operand planes of the MX mat-mat kernel: 0.75 B / weight and digit (Q5_0, Q8_0: two digits)
             const size_t nf = q4 ? 1 : 2;
             off_6a = total; total += (size_t)nba * nf * w->Mpad * 16;
@@ -460,7 +460,7 @@ static int alloc_weight(DeviceCtx *c, int type, int64_t K, int64_t M, ggml_hip_w
         if (has_qh_plane(type)) w->qh = (uint32_t *)((uint8_t *)base + off_qh);
         w->gs = (uint32_t *)((uint8_t *)base + off_gs);
         if (with6) { w->q6a = (uint8_t *)base + off_6a; w->q6b = (uint8_t *)base + off_6b; }
-        if (q5k) w->khdr = (uint8_t *)base + off_kh;
+        if (kq) w->khdr = (uint8_t *)base + off_kh;
         if (type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1 || type == GGML_TYPE_Q4_2) w->i8p = (uint8_t *)base + off_i8;
         if (type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) w->mp3 = (uint8_t *)base + off_mp;
     }
@@ -476,8 +476,8 @@ int make_weight(DeviceCtx *c, int type, const void *rows, bool rows_on_host, int
     *out = nullptr;
     // Q5_K (unpinned extra, kquants.hip): super-blocks of 256 are re-laid-out as eight k-blocks of the planar Q5_1 form
     // (r4: Q4_K the same way -- its super-block is Q5_K's without the fifth-bit bytes; the fifth-bit plane stays zero)
-    const bool q5k = is_kquant(type);
-    if (q5k) {
+    const bool kq = is_kquant(type);
+    if (kq) {
         if (!rows || ne00 <= 0 || ne01 < 0 || row_begin < 0 || row_end < row_begin || row_end > ne01) return fail(GGML_HIP_ERR_ARG, "bad weight arguments");
         if (ne00 % 256 != 0) return fail(GGML_HIP_ERR_SHAPE, "Q5_K / Q4_K: ne00 %% 256 != 0 (QK_K)");
         if (nb01 < (uint64_t)(ne00 / 256) * kquant_bytes(type)) return fail(GGML_HIP_ERR_SHAPE, "nb01 smaller than a row");
@@ -715,11 +715,11 @@ void ggml_hip_debug_force_gemm(int which) { plan_set_force_gemm(which); }
 // the plan of mul_mat(type, M, K, N) as ggml_hip_mul_mat_dev will run it; no device is needed (tests/test_plan_cpu.py)
 int ggml_hip_mm_plan(int type, int64_t M, int64_t K, int64_t N, ggml_hip_mm_plan_t *out) {
     if (!out) return fail(GGML_HIP_ERR_ARG, "out is null");
-    const bool q5k = is_kquant(type);
-    const int t = q5k ? kquant_resident_type(type) : type;
+    const bool kq = is_kquant(type);
+    const int t = kq ? kquant_resident_type(type) : type;
     if (t < 0 || t >= GGML_TYPE_COUNT || !weight_type_ok(t)) return fail(GGML_HIP_ERR_TYPE, "type %d is not a supported weight type", type);
-    if (M <= 0 || K <= 0 || N <= 0 || K % BLCK[t] != 0 || (is_q(t) && K % QK != 0) || (q5k && K % 256 != 0)) return fail(GGML_HIP_ERR_SHAPE, "bad shape");
-    const mm_plan p = plan_mul_mat(t, q5k ? type : 0, M, K, N, true);
+    if (M <= 0 || K <= 0 || N <= 0 || K % BLCK[t] != 0 || (is_q(t) && K % QK != 0) || (kq && K % 256 != 0)) return fail(GGML_HIP_ERR_SHAPE, "bad shape");
+    const mm_plan p = plan_mul_mat(t, kq ? type : 0, M, K, N, true);
     out->family = p.family; out->image_kind = p.image | ((p.flags & MM_FLAG_MIN_PIECES) ? ACT_IMAGE_MIN_PIECES : 0); out->form = p.form; out->tree_id = plan_tree_id(p);
     out->ksplit = p.ksplit; out->kstyle = p.kstyle; out->kunit = p.kunit; out->arith = p.arith;
     out->tile_m = p.tile_m; out->tile_n = p.tile_n; out->waves = p.waves; out->tiles_per_wave = p.tiles_per_wave;
