@@ -116,6 +116,17 @@ static inline act_planes act_carve(void *base, int64_t K, int64_t Npad) {
 #ifdef __HIPCC__
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// K3s (gemm_qmx.hip / gemm_q8s.hip): workgroup -> (row tile, column tile), XCD-aware (speed only; a bijection whatever ntw and ncol are).
+// Workgroups b and b + 8 share an XCD and its L2: the ncol column tiles of one row tile sit 8 apart in launch order, so the weight tile they
+// all stream reaches that L2 once (with "row tile fastest" they were ntw launches apart and each fetched it again: what made the forms pay
+// by M above 32 src1 rows).  Row tiles in whole groups of eight; the last ntw % 8 keep the plain order.
+__device__ __forceinline__ void k3s_tile_of(int wg, int ntw, int ncol, int &rt, int &ct) {
+    const int full = ntw & ~7;
+    const int g = wg / (8 * ncol);
+    if (g * 8 < full) { const int idx = wg - g * 8 * ncol; rt = g * 8 + (idx & 7); ct = idx >> 3; }
+    else { const int w2 = wg - full * ncol, nt = ntw - full; rt = full + w2 % nt; ct = w2 / nt; }
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
 #define DPP_XOR1 0xB1        /* quad_perm:[1,0,3,2] */

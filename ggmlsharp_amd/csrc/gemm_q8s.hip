@@ -39,7 +39,9 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int m0 = (wg % ntw) * 32 * WMT, n0 = (wg / ntw) * 32;
+    int rt, ct;
+    k3s_tile_of(wg, ntw, (N + 31) / 32, rt, ct);
+    const int m0 = rt * 32 * WMT, n0 = ct * 32;
     const int kb0 = wave * nloc;
     // a slot past the wave's range or past the end of K (K1's image 0 does not write the k-blocks K is padded to) repeats a valid block:
     // its table row is zero, so it adds (sumi * 0) = +0

@@ -614,8 +614,10 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
     K3S_STAMP(0);
-    const int m0 = (wg % ntw) * 32 * WMT;                   // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
-    const int n0 = (wg / ntw) * 32;                         // ... and one 32-column slice of src1 (33..64 rows: two workgroups per tile group)
+    int rt, ct;
+    k3s_tile_of(wg, ntw, (N + 31) / 32, rt, ct);           // (XCD-aware: the column tiles of a row tile behind one L2, common.h)
+    const int m0 = rt * 32 * WMT;                           // WMT 32-row weight tiles per workgroup: one activation fragment serves them all
+    const int n0 = ct * 32;                                 // ... and one 32-column slice of src1 (33..64 rows: two workgroups per tile group)
     const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (nloc even; the planes are zero
     const int npair = nloc >> 1;                            // past the end of K, the descriptors' range check covers the rest)
     // ---- descriptors and per-lane offsets (planes [nbk][Mpad][16 | 8 | 4]; image per k-block [half][Npad][16] then [half][Npad][8]) ----

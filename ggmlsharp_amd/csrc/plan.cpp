@@ -53,8 +53,12 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool 
     // staged forms' K split is at its worst and M is small -- up to 128 rows there (staged | this form at 128 rows unless noted: 4096 x 11008
     // 43.0 | 26.7, 5120 x 13824 64.7 | 57.3, Q5_1 x 96 72.7 | 36.3, 8192 x 28672 151 | 120, Q5_0 132 | 119; the price is a square or tall matrix
     // with such a K: 11008 x 11008 78 | 93).  K = 8192 is mixed (8192 x 8192 41.6 | 38.1, 28672 x 8192 124 | 166) and stays at 64.
+    // Last, with the XCD-aware tile order (common.h k3s_tile_of: the column tiles of a row tile behind one L2) the price by M shrank -- staged | this
+    // form at 128 rows: 4096 x 4096 19.5 | 12.0 us, 8192 x 8192 42.4 | 37.5, 11008 x 4096 32.5 | 32.9, 28672 x 8192 134 | 136, Q5_1 11008 x 4096 x 96
+    // 49.1 | 35.7; still behind at 13824 x 5120 44.9 | 54.5 and 32000 x 4096 69.9 | 85.3 -- over the matrices of a decoder layer that is a gain at
+    // every model size looked at (the four attention projections and the down projection against gate / up): 128 rows whatever K.
     static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
-    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K >= 11008 ? 128 : 64;
+    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : 128;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
@@ -257,7 +261,9 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
             // Q4_1 49.5 | 28.3, 8192 x 28672 110 | 96.5; 11008 x 11008 66.4 | 83.5 is the price; behind a shorter K it pays by M: 4096 x 4096 16.1 | 13.1
             // but 11008 x 4096 29.0 | 37.3, 32000 x 4096 67.9 | 87.5)
             static const int ncmax_dev = dev_env_int("GGML_HIP_K3S_COLS", 0);   // developer A/B switch: 1 = K3s up to 32 rows only (0: the rule)
-            const int ncmax = ncmax_dev > 0 ? ncmax_dev : K >= 11008 ? 4 : 2;
+            // (with the XCD-aware tile order, staged | this form at 128 rows: Q4_1 4096 x 4096 20.2 | 12.8, 11008 x 4096 x 96 42.2 | 35.4 -- Q4_1 whatever K;
+            // Q4_0 4096 x 4096 16.0 | 13.1 but 11008 x 4096 28.8 | 34.0, 32000 x 4096 62.5 | 68.6, 28672 x 8192 106 | 112: its staged forms are better, K >= 11008 stays)
+            const int ncmax = ncmax_dev > 0 ? ncmax_dev : (K >= 11008 || !q40) ? 4 : 2;
             if (N <= 32 * ncmax && nbk >= 64 && var != 25 && var != 26 && plan_k3s_mx(p, type, M, Mpad, K, N)) return;
         }
         if (N <= 32 && var != 25) {

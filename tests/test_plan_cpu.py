@@ -95,13 +95,15 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q6_K, 4096, 4096, 1).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 1024, 4).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 33024, 1).family == FAM["gemv_rows"]
     assert plan(Q6_K, 4096, 4096, 5).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
     # (r4: the two-scale types -- Q4_2 and Q6_K in its form -- stay on the batched-decode form up to 256 rows: only the staged int8 kernel is behind it)
-    assert plan(Q6_K, 4096, 4096, 256).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 11008, 192).family == FAM["k3s_i8"] and plan(Q8_0, 4096, 4096, 65).family != FAM["k3s_i8"]
+    assert plan(Q6_K, 4096, 4096, 256).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 11008, 192).family == FAM["k3s_i8"] and plan(Q8_0, 4096, 4096, 129).family != FAM["k3s_i8"]
     assert plan(Q6_K, 4096, 4096, 257).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
     assert plan(Q6_K, 4096, 4096, 8).tree_id != plan(Q4_2, 4096, 4096, 32).tree_id              # (activations by the Q8_K rule: another tree)
     # r4: behind a long K (>= 11008, a down projection) the one-scale int8 types stay on the batched-decode form up to 128 rows
     assert plan(Q8_0, 4096, 11008, 128).family == FAM["k3s_i8"] and plan(Q5_1, 5120, 13824, 96).family == FAM["k3s_i8"] and plan(Q5_K, 4096, 11008, 128).family == FAM["k3s_i8"]
-    assert plan(Q8_0, 4096, 11008, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 8192, 128).family != FAM["k3s_i8"]
+    # (... and, with the XCD-aware tile order, whatever K for the int8 types and Q4_1; Q4_0 keeps the K rule: its staged forms are better)
+    assert plan(Q8_0, 4096, 11008, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 8192, 128).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 65).family == FAM["k3s_i8"]
     assert plan(Q4_0, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 8192, 28672, 96).family == FAM["k3s_mx"] and plan(Q4_0, 4096, 4096, 128).family == FAM["mx"]
+    assert plan(Q4_1, 4096, 4096, 128).family == FAM["k3s_mx"]
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
     assert plan(Q5_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 32).image_kind == 0
