@@ -30,6 +30,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "support"))     # ggml_mirror: the stand-in for the C# host (the drop-in side configs only)
 
 Q4_0 = 2
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -263,7 +264,7 @@ def seam1_host_config(M, K, N, iters):
     """The DROP-IN path: ggml_graph_compute of one mul_mat node with HOST tensors (Seam 1, host pointers in and out), as
     the C# host would run it -- the context pool registered for DMA (ggml_hip_register_host_pool, done by the mirror's
     ggml_init), src1 / dst moved in chunks of src1 rows that overlap the kernels.  PCIe-inclusive: never the headline."""
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     rows = make_weights_q4_0(M, K, 77).cpu().numpy()
     pool = (M * (K // 32) * 20) + 4 * K * N + 4 * M * N + (1 << 20)
     ctx = G.ggml_init(pool)
@@ -297,7 +298,7 @@ def dropin_decode_layer(N, iters, layers=1):
     tensors in the registered context pool.  What is timed is the wall clock of a whole graph compute (17 nodes): the seams,
     the launches, the device -> host copies that leave every node's data in host memory."""
     import ctypes as C
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     from ggmlsharp_amd._lib import lib
     D, F = 4096, 11008
     rng = np.random.default_rng(1)

@@ -1,7 +1,7 @@
 """ggmlsharp_amd -- MI355X-native quantized mul_mat path behind GGMLSharp's ggml_* surface.
 
-Layout:  csrc/   hand-written gfx950 kernels + the C-ABI (include/ggml_hip.h) + the host mirror (include/ggml.h)
-         _lib.py ctypes binding          ggml.py  ggml_* API mirror for Python callers
+Layout:  csrc/   hand-written gfx950 kernels + the C-ABI (include/ggml_hip.h, include/ggml_hip_ext.h)
+         _lib.py ctypes binding of libggml_hip.so (the product library alone; the host mirror is test support: tests/support/)
          device.py resident-weight / device-buffer helpers (torch is used for memory, streams and RCCL only)
          dist.py row-split across GPUs + all-gather
 """

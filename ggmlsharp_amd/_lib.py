@@ -1,8 +1,8 @@
-"""ctypes binding of libggml_hip.so (the product: the C-ABI declared in include/ggml_hip.h) and of
-libggml_hostmirror.so (TEST SUPPORT: the C++ stand-in for the reference's C# host, tests/support/ggml.h + ggml_host.cpp).
+"""ctypes binding of libggml_hip.so -- the product: the C-ABI declared in include/ggml_hip.h and include/ggml_hip_ext.h.
 
-The product is built in-tree (ggmlsharp_amd/lib/) by `make -C ggmlsharp_amd/csrc`, the mirror by `make -C tests/support`.
-Nothing here falls back to a CPU implementation: if the library is missing, loading raises.
+Built in-tree (ggmlsharp_amd/lib/) by `make -C ggmlsharp_amd/csrc`.  Nothing here falls back to a CPU implementation: if the
+library is missing, loading raises.  (The C++ stand-in for the reference's C# host and its Python face are TEST SUPPORT and live in
+tests/support/ -- ggml_host.cpp, ggml_mirror.py; this package neither needs nor loads them.)
 """
 import ctypes as C
 import os
@@ -11,8 +11,6 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("GGML_HIP_LIB") or os.path.join(PKG_DIR, "lib", "libggml_hip.so")   # env: developer ablation builds
-SUPPORT_DIR = os.path.join(os.path.dirname(PKG_DIR), "tests", "support")
-MIRROR_PATH = os.path.join(SUPPORT_DIR, "libggml_hostmirror.so")
 
 GGML_MAX_DIMS = 4
 GGML_MAX_OPT = 4
@@ -83,8 +81,7 @@ class ggml_hip_mm_plan_t(C.Structure):
                 ("workgroups", C.c_int64), ("flags", C.c_int32)]
 
 
-# every symbol include/ggml_hip.h declares (HIP_SYMBOLS, exported by libggml_hip.so) and include/ggml.h declares
-# (MIRROR_SYMBOLS, exported by libggml_hostmirror.so): name -> (restype, argtypes)
+# every symbol include/ggml_hip.h and include/ggml_hip_ext.h declare (exported by libggml_hip.so): name -> (restype, argtypes)
 _P = C.c_void_p
 _T = C.POINTER(ggml_tensor)
 _PP = C.POINTER(C.c_void_p)
@@ -181,43 +178,7 @@ HIP_SYMBOLS = {
     "ggml_hip_add_q_f32_rows_dev": (C.c_int, [C.c_int, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "ggml_hip_relayout_gathered_dev": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
 }
-MIRROR_SYMBOLS = {
-    "ggml_init": (_P, [C.POINTER(ggml_init_params)]),
-    "ggml_free": (None, [_P]),
-    "ggml_used_mem": (C.c_size_t, [_P]),
-    "ggml_new_tensor": (_T, [_P, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
-    "ggml_new_tensor_1d": (_T, [_P, C.c_int, C.c_int64]),
-    "ggml_new_tensor_2d": (_T, [_P, C.c_int, C.c_int64, C.c_int64]),
-    "ggml_new_tensor_3d": (_T, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
-    "ggml_new_tensor_4d": (_T, [_P, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
-    "ggml_nelements": (C.c_int64, [_T]),
-    "ggml_nrows": (C.c_int64, [_T]),
-    "ggml_nbytes": (C.c_size_t, [_T]),
-    "ggml_blck_size": (C.c_int, [C.c_int]),
-    "ggml_type_size": (C.c_size_t, [C.c_int]),
-    "ggml_is_quantized": (C.c_int, [C.c_int]),
-    "ggml_is_contiguous": (C.c_int, [_T]),
-    "ggml_can_mul_mat": (C.c_int, [_T, _T]),
-    "ggml_set_f32": (_T, [_T, C.c_float]),
-    "ggml_get_f32_1d": (C.c_float, [_T, C.c_int]),
-    "ggml_set_f32_1d": (None, [_T, C.c_int, C.c_float]),
-    "ggml_mul_mat": (_T, [_P, _T, _T]),
-    "ggml_view_tensor": (_T, [_P, _T]),
-    "ggml_dup_tensor": (_T, [_P, _T]),
-    "ggml_cpy": (_T, [_P, _T, _T]),
-    "ggml_add": (_T, [_P, _T, _T]),
-    "ggml_mul": (_T, [_P, _T, _T]),
-    "ggml_scale": (_T, [_P, _T, _T]),
-    "ggml_rms_norm": (_T, [_P, _T]),
-    "ggml_silu": (_T, [_P, _T]),
-    "ggml_silu_inplace": (_T, [_P, _T]),
-    "ggml_build_forward": (None, [C.POINTER(ggml_cgraph), _T]),
-    "ggml_build_forward_expand": (None, [C.POINTER(ggml_cgraph), _T]),
-    "ggml_graph_compute": (C.c_int, [_P, C.POINTER(ggml_cgraph)]),
-}
-
-
-SYMBOLS = dict(HIP_SYMBOLS, **MIRROR_SYMBOLS)
+SYMBOLS = HIP_SYMBOLS
 
 
 def build(force=False):
@@ -225,18 +186,7 @@ def build(force=False):
     if force:
         subprocess.check_call(["make", "-C", CSRC_DIR, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", CSRC_DIR, "-j4"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["make", "-C", SUPPORT_DIR], stdout=subprocess.DEVNULL)      # the host mirror (test support) links the product
     return LIB_PATH
-
-
-class _Libs:
-    """The product library and the host mirror behind one attribute namespace (ggml_hip_* / ggml_*)."""
-
-    def __init__(self, hip, mirror):
-        self.hip, self.mirror = hip, mirror
-
-    def __getattr__(self, name):
-        return getattr(self.hip if name.startswith("ggml_hip_") else self.mirror, name)
 
 
 _lib = None
@@ -245,7 +195,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not (os.path.exists(LIB_PATH) and os.path.exists(MIRROR_PATH)):
+        if not os.path.exists(LIB_PATH):
             if os.path.exists("/opt/rocm/bin/hipcc"):
                 build()
             else:
@@ -256,14 +206,12 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        hip = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)     # the mirror binds ggml_hip_* from it, as the C# host would
-        mirror = C.CDLL(MIRROR_PATH)
-        for L, table in ((hip, HIP_SYMBOLS), (mirror, MIRROR_SYMBOLS)):
-            for name, (res, args) in table.items():
-                fn = getattr(L, name)
-                fn.restype = res
-                fn.argtypes = args
-        _lib = _Libs(hip, mirror)
+        hip = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)     # (global: a host library that binds ggml_hip_* by name resolves against it)
+        for name, (res, args) in HIP_SYMBOLS.items():
+            fn = getattr(hip, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = hip
     return _lib
 
 

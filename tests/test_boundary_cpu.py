@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from ggmlsharp_amd import _lib
-from ggmlsharp_amd import ggml as G
+import ggml_mirror as G
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -49,11 +49,13 @@ def test_library_exports_every_declared_symbol():
     assert len(hip_decl) >= 59 and len(mirror_decl) >= 30
     assert all(n.startswith("ggml_hip_") for n in hip_decl)
     assert set(_exported(_lib.LIB_PATH)) == hip_decl, set(_exported(_lib.LIB_PATH)) ^ hip_decl
-    assert set(_exported(_lib.MIRROR_PATH)) == mirror_decl, set(_exported(_lib.MIRROR_PATH)) ^ mirror_decl
-    for name in hip_decl | mirror_decl:
+    assert set(_exported(G.MIRROR_PATH)) == mirror_decl, set(_exported(G.MIRROR_PATH)) ^ mirror_decl
+    for name in hip_decl:
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
+    for name in mirror_decl:
+        assert hasattr(G.mirror(), name), f"{name} declared in tests/support/ggml.h but not exported"
     assert hip_decl == set(_lib.HIP_SYMBOLS), hip_decl ^ set(_lib.HIP_SYMBOLS)
-    assert mirror_decl == set(_lib.MIRROR_SYMBOLS), mirror_decl ^ set(_lib.MIRROR_SYMBOLS)
+    assert mirror_decl == set(G.MIRROR_SYMBOLS), mirror_decl ^ set(G.MIRROR_SYMBOLS)
 
 
 def test_product_library_reads_no_environment_variable():
@@ -75,14 +77,14 @@ def test_struct_sizes_match_reference_layout():
 
 
 def test_type_tables():
-    L = _lib.lib()
+    L, Mi = _lib.lib(), G.mirror()
     for t, s in _lib.TYPE_SIZE.items():
         assert L.ggml_hip_type_size(t) == s and L.ggml_hip_blck_size(t) == _lib.BLCK_SIZE[t]
         if t in (_lib.Q5_K, _lib.Q4_K, _lib.Q6_K):       # the k-quant extension is a device-level type only: the reference (and its mirror) cannot express it
-            assert L.ggml_type_size(t) == 0 and L.ggml_blck_size(t) == 0
+            assert Mi.ggml_type_size(t) == 0 and Mi.ggml_blck_size(t) == 0
             continue
-        assert L.ggml_type_size(t) == s and L.ggml_blck_size(t) == _lib.BLCK_SIZE[t]
-    assert [L.ggml_is_quantized(t) for t in range(13)] == [0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0]
+        assert Mi.ggml_type_size(t) == s and Mi.ggml_blck_size(t) == _lib.BLCK_SIZE[t]
+    assert [Mi.ggml_is_quantized(t) for t in range(13)] == [0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0]
 
 
 def test_test0_tensor_layout():
@@ -110,12 +112,12 @@ def test_quantized_tensor_strides_and_pool_arithmetic():
         assert G.ggml_nbytes(w) == 8 * 128 * 20
         assert wc.data % 16 == 0                                                          # GGML_MEM_ALIGN
         assert wc.data == C.addressof(wc) + 176                                           # data = result + 1, Ggml.cs:7839
-        used0 = _lib.lib().ggml_used_mem(ctx)
+        used0 = G.mirror().ggml_used_mem(ctx)
         assert used0 == 32 + 176 + 8 * 128 * 20                                           # object header + tensor + data
         q5 = G.ggml_new_tensor_2d(ctx, G.Q5_0, 64, 3).contents
         assert q5.nb[1] == 44 and C.addressof(q5) == C.addressof(wc) - 32 + used0 + 32    # next object follows
         # data size is rounded up to 16: 3 rows * 44 B = 132 -> 144
-        assert _lib.lib().ggml_used_mem(ctx) == used0 + 32 + 176 + 144
+        assert G.mirror().ggml_used_mem(ctx) == used0 + 32 + 176 + 144
     finally:
         G.ggml_free(ctx)
 
@@ -151,14 +153,14 @@ def test_mul_mat_node_construction_and_graph():
         yc = y.contents
         assert yc.type == G.F32 and (yc.ne[0], yc.ne[1], yc.ne[2], yc.ne[3]) == (5, 7, 2, 1)   # Ggml.cs:8237
         assert yc.op == _lib.GGML_OP_MUL_MAT and C.addressof(yc.src0.contents) == C.addressof(a.contents)
-        assert _lib.lib().ggml_can_mul_mat(a, b) == 1
+        assert G.mirror().ggml_can_mul_mat(a, b) == 1
         assert not G.ggml_mul_mat(ctx, a, G.ggml_new_tensor_2d(ctx, G.F32, 64, 7))            # ne2 differs
         z = G.ggml_mul_mat(ctx, G.ggml_new_tensor_2d(ctx, G.F32, 5, 3), G.ggml_new_tensor_2d(ctx, G.F32, 5, 7))
         gf = G.ggml_build_forward(y)
         assert (gf.n_nodes, gf.n_leafs, gf.n_threads) == (1, 2, 4)                             # Ggml.cs:7659
-        _lib.lib().ggml_build_forward_expand(C.byref(gf), z)
+        G.mirror().ggml_build_forward_expand(C.byref(gf), z)
         assert (gf.n_nodes, gf.n_leafs) == (2, 4)
-        _lib.lib().ggml_build_forward_expand(C.byref(gf), z)                                   # already visited
+        G.mirror().ggml_build_forward_expand(C.byref(gf), z)                                   # already visited
         assert (gf.n_nodes, gf.n_leafs) == (2, 4)
     finally:
         G.ggml_free(ctx)
@@ -236,3 +238,17 @@ def test_reference_style_c_program_compiles_links_and_fails_loudly_without_gpu(t
         assert out.stdout.strip() == "no-device"
     else:
         assert out.stdout.startswith("ok ")
+
+
+def test_product_package_loads_without_the_test_support_mirror(tmp_path):
+    """the product's Python binding may not depend on tests/support -- a fresh interpreter with the mirror
+    library hidden imports ggmlsharp_amd, loads libggml_hip.so and resolves every declared symbol."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import ggmlsharp_amd as g; L = g.lib(); "
+            "[getattr(L, n) for n in g._lib.SYMBOLS]; "
+            "import ctypes; "
+            "maps = open('/proc/self/maps').read(); assert 'libggml_hip.so' in maps and 'hostmirror' not in maps; "
+            "assert not hasattr(g._lib, 'MIRROR_SYMBOLS') and not os.path.exists(os.path.join(os.path.dirname(g.__file__), 'ggml.py')); print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

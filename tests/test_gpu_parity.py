@@ -414,7 +414,7 @@ def test_row_functions_host_forms(dev):
 
 # ---------------------------------------------------------------- Seam 1 through the ggml_* mirror (Test3-style program)
 def test_ggml_api_program_quantized_and_batched(dev):
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     K, M, N = 256, 48, 12
     ctx = G.ggml_init(64 * 1024 * 1024)
     assert ctx
@@ -448,7 +448,7 @@ def test_ggml_api_program_quantized_and_batched(dev):
 def test_graph_residency_chained_mul_mats(dev):
     """Y2 = W2 * (W1 * X) in one graph.  The intermediate is consumed from HBM (no second host ->
     device copy), both node results are in host memory when ggml_graph_compute returns, values match the oracle chain."""
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     from ggmlsharp_amd._lib import lib
     K, M1, M2, N = 256, 96, 40, 24
     ctx = G.ggml_init(64 * 1024 * 1024)
@@ -487,7 +487,7 @@ def test_graph_residency_chained_mul_mats(dev):
 
 
 def test_seam1_ignores_non_compute_phases_and_other_threads(dev):
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     from ggmlsharp_amd._lib import lib, ggml_compute_params
     ctx = G.ggml_init(4 * 1024 * 1024)
     try:

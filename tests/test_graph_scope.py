@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from ggmlsharp_amd import ggml as G
+import ggml_mirror as G
 from ggmlsharp_amd import _lib
 
 pytestmark = pytest.mark.gpu

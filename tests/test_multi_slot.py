@@ -69,7 +69,7 @@ def _program(G, t, wraw, x, K, M, N, graph_chain=False, w2raw=None, M2=0):
 
 @pytest.mark.parametrize("t", [O.Q4_0, O.Q8_0, O.Q5_1, O.F16, O.F32])
 def test_seam1_row_split_over_slots_is_bitwise_the_single_slot_result(slots, t):
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     for (M, K, N) in ((515, 256, 40), (96, 512, 1), (992, 1024, 300)):      # (300 src1 rows: F32 runs the split-bf16 matrix-core kernel)
         w = _rand((M, K))
         x = _rand((N, K))
@@ -152,7 +152,7 @@ def test_rccl_exchange_form_one_rank_selftest(slots):
 def test_bound_threads_run_on_their_own_slot_concurrently(slots):
     """SURVEY 8(b) threading: two host threads bound to two slots run graphs at the same time; an unbound thread splits."""
     import threading
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     from ggmlsharp_amd._lib import lib, check
     slots([0, 0])
     M, K, N = 256, 256, 33
@@ -183,7 +183,7 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
     """ggml_hip_register_host_pool (the mirror's ggml_init does it): src1 / dst move by asynchronous DMA in chunks of src1
     rows that overlap the kernels.  Same values (within the mul_mat tolerance; chunks are whole calls of their own N) and
     exactly the same PCIe byte counts as the unchunked path."""
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     from ggmlsharp_amd._lib import lib
     slots([0])
     M, K, N = 512, 4096, 600            # 9.8 MB of activations: two chunks
@@ -245,7 +245,7 @@ def test_pinned_pool_pipeline_matches_the_oracle_and_counts_bytes(slots):
 def test_weight_cache_is_invalidated_by_writers_and_not_used_for_computed_src0(slots):
     """(1) a leaf rewritten between two computes (the reference's Test1 / Test2 pattern: set_f32, compute
     again) must not be served from the cache; (2) a src0 that a node of the graph computes must be rebuilt each time."""
-    from ggmlsharp_amd import ggml as G
+    import ggml_mirror as G
     slots([0])
     ctx = G.ggml_init(64 * 1024 * 1024)
     try:

@@ -8,7 +8,7 @@ import pytest
 
 import oracle_lib as O
 from ggmlsharp_amd import _lib
-from ggmlsharp_amd import ggml as G
+import ggml_mirror as G
 
 RNG = np.random.default_rng(77)
 QT = [O.Q4_0, O.Q4_1, O.Q5_0, O.Q8_0, O.Q4_2, O.Q5_1]

@@ -6,7 +6,9 @@ usage: python tools/experiments/node_cost.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from ggmlsharp_amd import device, ggml as G
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "support"))
+import ggml_mirror as G  # noqa: E402  (test support: the host mirror)
+from ggmlsharp_amd import device
 device.init(0)
 res = []
 for n in (4, 12, 20, 40):

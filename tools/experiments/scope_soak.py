@@ -9,7 +9,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import test_graph_scope as T  # noqa: E402
-from ggmlsharp_amd import device, ggml as G  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "support"))
+import ggml_mirror as G  # noqa: E402  (test support: the host mirror)
+from ggmlsharp_amd import device  # noqa: E402
 
 device.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000

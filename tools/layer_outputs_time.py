@@ -10,7 +10,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ggmlsharp_amd import device, ggml as G, _lib  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "support"))
+import ggml_mirror as G  # noqa: E402  (test support: the host mirror)
+from ggmlsharp_amd import device, _lib  # noqa: E402
 
 device.init(0)
 L = _lib.lib()
