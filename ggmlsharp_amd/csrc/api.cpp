@@ -899,8 +899,12 @@ int ggml_hip_mul_mat_push_dev(const ggml_hip_weight *w, const float *d_src1, int
         const act_planes pl = act_carve(d_work, w->K, pad_act(N));
         const hipError_t e = plan.family == MMF_K3P_I8 ? launch_gemm_q8_mid(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, ep)
                                                        : launch_gemm_qmx(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, &ep);
-        HIP_TRY(e);
-        return GGML_HIP_OK;
+        if (e == hipSuccess) return GGML_HIP_OK;
+        // not supported = ld_total beyond what the store phase addresses (a tile's rows past the 32-bit buffer offsets of the staged MX forms,
+        // a row stride past K3p's int): the product itself still runs, as ggml_hip_mul_mat_epilogue_dev's unfused path does -- the plain
+        // product (the one-call entry routes such a dst to a kernel that can address it) and the column-push kernel behind it
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+        (void)hipGetLastError();
     }
     int rc = ggml_hip_mul_mat_dev(w, d_src1, N, ld1, mine, ld_total, d_work, work_bytes, stream);
     if (rc) return rc;

@@ -607,6 +607,7 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
     const bool with_min = w->type == GGML_TYPE_Q5_1 || w->type == GGML_TYPE_Q4_1;
     const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : (w->type == GGML_TYPE_Q5_0 || with_min) ? w->i8p : nullptr;
     if (pl.family != MMF_K3P_I8 || !planes || !w->d || (with_min && (!w->m || !w->mp3 || !p.sp3))) return hipErrorInvalidValue;
+    if (ldd > 0x7FFFFFFF) return hipErrorNotSupported;     // (the kernel carries the row stride as an int: callers with an unfused form fall back)
     // applicability (at least 8 k-blocks per wave, the eight scale tables within 160 KB of LDS, every offset within 32 bits) and the
     // k-blocks per wave were decided by plan.cpp (plan_k3p_i8); the checks below only guard the kernel's assumptions
     const int nbkp = (int)pad_kblocks(w->nbk);
@@ -643,6 +644,7 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
 // Q4_0 (plan.cpp plan_k3p_mx: at least 8 k-blocks per wave, tables within LDS, offsets within 32 bits)
 hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     if (pl.family != MMF_K3P_MX || w->type != GGML_TYPE_Q4_0 || !w->q6a || !w->q6b) return hipErrorInvalidValue;
+    if (ldd > 0x7FFFFFFF) return hipErrorNotSupported;     // (see launch_gemm_q8_mid)
     const int nbkp = (int)pad_kblocks(w->nbk);
     const int nloc = pl.nloc;
     if (nloc < 8 || KS * nloc < nbkp) return hipErrorInvalidValue;

@@ -179,6 +179,10 @@ struct ggml_hip_split_weight {
     int G = 0;
     std::vector<ggml_hip_weight *> shard;
     std::vector<int64_t> r0, r1;
+    // can every slot's device store into every other slot's memory (exchange mode 2)?  -1: not asked yet.  Asked ONCE per slot set, at the
+    // first mode-2 product (the slots of a split weight never change: G == n_slots() is checked per call) -- it is O(G^2) runtime calls
+    // (hipDeviceCanAccessPeer + hipSetDevice + hipDeviceEnablePeerAccess, ~170 at G = 8) that have no place on the hot path.
+    mutable std::atomic<int> reach{-1};
 };
 
 extern "C" {
@@ -274,32 +278,48 @@ int ggml_hip_mul_mat_split_dev(const ggml_hip_split_weight *w, const float *cons
     // r4, exchange mode 2: every slot's GEMM stores its rows, as they leave the accumulators, into EVERY slot's dst (mm_epilogue mode 3
     // through ggml_hip_mul_mat_push_dev: up to eight destinations; kernel forms without the store phase push their columns with the
     // column kernel behind the product) -- no exchange pass at all.  Needs every slot's device to reach every other's memory.
-    if (g_exchange_mode.load() == 2 && G > 1 && G <= 16 && slots_reach_each_other(G, ctxs.data())) {
+    bool reach = false;
+    if (g_exchange_mode.load() == 2 && G > 1 && G <= 16) {
+        int r = w->reach.load(std::memory_order_acquire);
+        if (r < 0) {
+            r = slots_reach_each_other(G, ctxs.data()) ? 1 : 0;       // (leaves another device current: every use below makes its own current)
+            w->reach.store(r, std::memory_order_release);
+        }
+        reach = r == 1;
+    }
+    if (reach) {
+        // An error on one slot must not leave the others' streams unordered against stores already in flight: the first error is
+        // kept, every ev_xchg is still recorded and every wait still issued, and only then is the error returned.
+        int first = GGML_HIP_OK;
+        auto keep = [&](int rc) { if (rc && !first) first = rc; return rc; };
+        auto keep_hip = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess) { (void)hipGetLastError(); if (!first) first = fail(GGML_HIP_ERR_RUNTIME, "%s: %s", what, hipGetErrorString(e)); }
+            return e;
+        };
         for (int g = 0; g < G; ++g) {                        // "everything issued so far on my stream is done": peers may write into my dst
-            int rc = ctxs[(size_t)g]->make_current();
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(ctxs[(size_t)g]->ev_ready, ctxs[(size_t)g]->stream));
+            if (keep(ctxs[(size_t)g]->make_current())) continue;
+            keep_hip(hipEventRecord(ctxs[(size_t)g]->ev_ready, ctxs[(size_t)g]->stream), "hipEventRecord(ready)");
         }
         for (int g = 0; g < G; ++g) {
             DeviceCtx *c = ctxs[(size_t)g];
-            int rc = c->make_current();
-            if (rc) return rc;
-            if (w->r1[(size_t)g] > w->r0[(size_t)g]) {
-                if (c->work.ensure(wb ? wb : 16)) return fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch");
-                for (int p = 0; p < G; ++p)
-                    if (p != g) HIP_TRY(hipStreamWaitEvent(c->stream, ctxs[(size_t)p]->ev_ready, 0));
-                rc = ggml_hip_mul_mat_push_dev(w->shard[(size_t)g], d_src1[g], N, ld1, d_dst, G, g, ldd, w->r0[(size_t)g], c->work.p, c->work.cap, c->stream);
-                if (rc) return rc;
+            if (keep(c->make_current())) continue;
+            if (!first && w->r1[(size_t)g] > w->r0[(size_t)g]) {
+                if (c->work.ensure(wb ? wb : 16)) keep(fail(GGML_HIP_ERR_RUNTIME, "hipMalloc failed for scratch"));
+                else {
+                    for (int p = 0; p < G; ++p)
+                        if (p != g) keep_hip(hipStreamWaitEvent(c->stream, ctxs[(size_t)p]->ev_ready, 0), "hipStreamWaitEvent(ready)");
+                    if (!first)
+                        keep(ggml_hip_mul_mat_push_dev(w->shard[(size_t)g], d_src1[g], N, ld1, d_dst, G, g, ldd, w->r0[(size_t)g], c->work.p, c->work.cap, c->stream));
+                }
             }
-            HIP_TRY(hipEventRecord(c->ev_xchg, c->stream));
+            keep_hip(hipEventRecord(c->ev_xchg, c->stream), "hipEventRecord(xchg)");
         }
         for (int p = 0; p < G; ++p) {                        // a slot's stream continues only when every slot's stores into its dst have landed
-            int rc = ctxs[(size_t)p]->make_current();
-            if (rc) return rc;
+            if (keep(ctxs[(size_t)p]->make_current())) continue;
             for (int g = 0; g < G; ++g)
-                if (g != p) HIP_TRY(hipStreamWaitEvent(ctxs[(size_t)p]->stream, ctxs[(size_t)g]->ev_xchg, 0));
+                if (g != p) keep_hip(hipStreamWaitEvent(ctxs[(size_t)p]->stream, ctxs[(size_t)g]->ev_xchg, 0), "hipStreamWaitEvent(xchg)");
         }
-        return GGML_HIP_OK;
+        return first;
     }
     for (int g = 0; g < G; ++g) {
         DeviceCtx *c = ctxs[(size_t)g];

@@ -120,6 +120,13 @@ CONFIGS = [  # BASELINE.json configs (M, K, N), Q5_0 standing in for the absent 
     ("q5_0 700 rows", Q5_0, 4096, 4096, 700),
     ("q5_1 1024 rows", 7, 4096, 4096, 1024),
     ("q8_0 4096^3", Q8_0, 4096, 4096, 4096),
+    # r5: the min-term types at LONG K against the oracle.  K3p adds the block terms and the min terms apart and they
+    # nearly cancel, so the reordering error grows with sqrt(K) -- K = 20480 is the last K on one scale table, 28672 runs the sliced
+    # tables + the min-term product over 112 chunks (a 70B model's down projection at prompt size)
+    ("q5_1 K=28672 prompt-512 (sliced K3p + min-term product)", 7, 4096, 28672, 512),
+    ("q4_1 K=28672 prompt-512", 3, 4096, 28672, 512),
+    ("q5_1 K=20480 prompt-512", 7, 2048, 20480, 512),
+    ("q5_1 K=28672 batch of 32 (K3s + min-term product)", 7, 4096, 28672, 32),
 ]
 
 

@@ -445,6 +445,65 @@ def test_ggml_api_program_quantized_and_batched(dev):
         G.ggml_free(ctx)
 
 
+def _test3_data():
+    """Test3's design matrix and labels (Test3/Program.cs:22-42): F f32 [ne0 = NF = 256, ne1 = NP = 4096] from the LCG of :98-107
+    (seeded 0; the stream itself is pinned in test_oracle.py against the five values SURVEY 8(c) lists), generated by the build's own
+    oracle_xrand, in f32 arithmetic as the C# writes it."""
+    NP, NF = 1 << 12, 1 << 8
+    L = O.lib()
+    L.oracle_xsrand(0)
+    r = np.array([L.oracle_xrand() for _ in range(NP * NF)], dtype=np.float32).reshape(NP, NF)
+    ll = np.where(np.arange(NP) < NP // 2, np.float32(1.0), np.float32(-1.0)).astype(np.float32)
+    i = np.arange(NF)[None, :]
+    ind = np.where((ll[:, None] > 0) & (i < NF // 2), np.float32(1.0), np.where((ll[:, None] < 0) & (i >= NF // 2), np.float32(1.0), np.float32(0.0))).astype(np.float32)
+    noise = ((r / np.float32(32767.0) - np.float32(0.5)) * np.float32(0.1)).astype(np.float32)
+    F = ((ind + noise) / np.float32(0.5 * NF)).astype(np.float32)
+    return F, ll, NP, NF
+
+
+def test_the_references_own_caller_test3_product_through_seam_1(dev):
+    """The ONE workload the reference itself defines on this path: Test3/Program.cs:57 `ggml_mul_mat(ctx0, F, x)` --
+    F f32 [256, 4096] from the LCG, x f32 [256]: M = 4096, K = 256, N = 1 -- built with the ggml_* API of the host mirror, run by
+    ggml_graph_compute through Seam 1 (ggml_hip_compute_forward_mul_mat) and compared with the oracle's
+    ggml_compute_forward_mul_mat_f32 (Ggml.cs:5969-6178, f64 running sum) under THE tolerance.  x is taken at three points of the
+    optimizer's path: its start (all zeros, :46), the solution the test asserts (+1 / -1, :82-88) and a point in between.  Then the
+    product of its backward graph, mul_mat(cont(transpose(F)), grad) -- M = 256, K = 4096, N = 1 -- as a plain product on F^T."""
+    import ggml_mirror as G
+    F, ll, NP, NF = _test3_data()
+    ctx = G.ggml_init(64 * 1024 * 1024)
+    assert ctx
+    try:
+        Ft = G.ggml_new_tensor_2d(ctx, G.F32, NF, NP)
+        xt = G.ggml_new_tensor_1d(ctx, G.F32, NF)
+        G.tensor_f32(Ft)[:] = F.reshape(1, 1, NP, NF)
+        y = G.ggml_mul_mat(ctx, Ft, xt)
+        assert y and y.contents.ne[0] == NP and y.contents.ne[1] == 1          # Ggml.cs:7137-7151: {a.ne1, b.ne1}
+        gf = G.ggml_build_forward(y)
+        sol = np.where(np.arange(NF) < NF // 2, 1.0, -1.0).astype(np.float32)
+        for name, xv in (("start", np.zeros(NF, np.float32)), ("solution", sol), ("midway", (0.37 * sol + _rand(NF, 0.05)).astype(np.float32))):
+            G.tensor_f32(xt)[:] = xv.reshape(1, 1, 1, NF)
+            G.ggml_graph_compute(ctx, gf)
+            got = G.tensor_f32(y)[0, 0].copy()
+            ref = O.mul_mat(O.F32, F, xv.reshape(1, NF), NP, NF, 1, nth=4)[0, 0]
+            assert_close(got, ref, NF, f"Test3 F * x at the {name}")
+            if name == "solution":                        # what the optimizer converges to: F x = l up to the noise (sanity of the recipe itself)
+                assert np.max(np.abs(got - ll)) < 0.1
+        # the backward graph's product: F^T (contiguous) times the residual -- a 256 x 4096 x 1 mat-vec
+        FT = np.ascontiguousarray(F.T)
+        Tt = G.ggml_new_tensor_2d(ctx, G.F32, NP, NF)
+        gt = G.ggml_new_tensor_1d(ctx, G.F32, NP)
+        G.tensor_f32(Tt)[:] = FT.reshape(1, 1, NF, NP)
+        grad = (F @ (0.37 * sol) - ll).astype(np.float32)
+        G.tensor_f32(gt)[:] = grad.reshape(1, 1, 1, NP)
+        z = G.ggml_mul_mat(ctx, Tt, gt)
+        gz = G.ggml_build_forward(z)
+        G.ggml_graph_compute(ctx, gz)
+        ref = O.mul_mat(O.F32, FT, grad.reshape(1, NP), NF, NP, 1, nth=4)[0, 0]
+        assert_close(G.tensor_f32(z)[0, 0], ref, NP, "Test3 backward product F^T * grad")
+    finally:
+        G.ggml_free(ctx)
+
+
 def test_graph_residency_chained_mul_mats(dev):
     """Y2 = W2 * (W1 * X) in one graph.  The intermediate is consumed from HBM (no second host ->
     device copy), both node results are in host memory when ggml_graph_compute returns, values match the oracle chain."""
