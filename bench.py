@@ -760,6 +760,13 @@ def main():
                             "shard_bytes": S, "bytes_in_per_gpu": S * (world - 1),
                             "exchange_GBs_in_per_gpu": round(S * (world - 1) / t_xchg / 1e6, 1) if t_xchg > 0 else None,
                             "devices_shared_by_ranks": "GGML_BENCH_SHARE_DEVICES" in os.environ}
+        # the dominant kernel per GPU: one rank's row shard (INIT + COMPUTE, no exchange; max over ranks) against ONE GPU's matrix peak
+        Ms = gdist.shard_width(M, world)
+        tf_shard = 2.0 * Ms * K * N / (t_comp * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(tf_shard, 2), "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
+                           "frac": round(tf_shard / I8_MFMA_PEAK_TOPS, 4), "traffic": None, "algorithmic_bytes": algorithmic_bytes(Ms, K, N),
+                           "kernel": compute_kernel_name(Q4_0, Ms, K, N), "kernel_ms": round(t_comp, 5),
+                           "note": f"per GPU: INIT + COMPUTE of one rank's {Ms}-row shard (no exchange), max over ranks, vs one GPU's peak"}
         if hasattr(runner, "close"):
             torch.distributed.barrier()
             runner.close()

@@ -143,6 +143,8 @@ HIP_SYMBOLS = {
     "ggml_hip_debug_scope_counters": (None, [C.POINTER(C.c_uint64)] * 4),
     "ggml_hip_graph_end": (C.c_int, []),
     "ggml_hip_debug_transfer_counters": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ggml_hip_debug_weight_cache_budget": (None, [C.c_size_t]),
+    "ggml_hip_debug_weight_cache_stats": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ggml_hip_act_image_kind": (C.c_int, [C.c_int, C.c_int64, C.c_int64]),
     "ggml_hip_mm_plan": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
     "ggml_hip_debug_force_gemm": (None, [C.c_int]),

@@ -279,6 +279,7 @@ void DeviceCtx::invalidate(const void *host, size_t bytes) {
         if (x < b && a < y) {
             if (!synced) { (void)sync_all(); drop_captured(); synced = true; }     // kernels of an open graph scope may still read the entry
             for (ggml_hip_weight *w : it->second.slices) ggml_hip_weight_free(w);
+            cache_bytes -= it->second.dev_bytes < cache_bytes ? it->second.dev_bytes : cache_bytes;
             it = cache.erase(it);
         } else {
             ++it;
@@ -290,6 +291,28 @@ void DeviceCtx::free_cache() {
     for (auto &kv : cache)
         for (ggml_hip_weight *w : kv.second.slices) ggml_hip_weight_free(w);
     cache.clear();
+    cache_bytes = 0;
+}
+size_t DeviceCtx::evict_lru(size_t need, size_t budget, const CacheKey *keep) {
+    size_t freed = 0;
+    bool synced = false;
+    for (;;) {
+        const bool over = budget ? cache_bytes + need > budget : freed < need;
+        if (!over) break;
+        auto victim = cache.end();
+        for (auto it = cache.begin(); it != cache.end(); ++it) {
+            if (keep && it->first == *keep) continue;
+            if (victim == cache.end() || it->second.last_use < victim->second.last_use) victim = it;
+        }
+        if (victim == cache.end()) break;                   // nothing left that may go
+        if (!synced) { (void)sync_all(); drop_captured(); synced = true; }     // kernels in flight (an open graph scope) may still read the entry
+        for (ggml_hip_weight *w : victim->second.slices) ggml_hip_weight_free(w);
+        freed += victim->second.dev_bytes;
+        cache_bytes -= victim->second.dev_bytes < cache_bytes ? victim->second.dev_bytes : cache_bytes;
+        cache.erase(victim);
+        ++cache_evictions;
+    }
+    return freed;
 }
 
 int n_slots() { return g_nslots.load(std::memory_order_acquire); }

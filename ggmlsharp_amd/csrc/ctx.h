@@ -65,6 +65,8 @@ struct CachedWeight {
     size_t host_bytes = 0;                        // [host, host + host_bytes) is what the entry was built from
     std::vector<ggml_hip_weight *> slices;        // ne02 * ne03 entries (this slot's rows of each)
     int64_t row_begin = 0, row_end = 0;
+    uint64_t last_use = 0;                        // DeviceCtx::cache_clock at the entry's last hit (least recently used goes first)
+    size_t dev_bytes = 0;                         // resident bytes of the slices (the operand images are 1.5-2.6 x the file format)
 };
 using CacheKey = std::tuple<const void *, int, int64_t, int64_t, int64_t, int64_t, uint64_t, uint64_t, uint64_t, int64_t, int64_t>;
 
@@ -86,6 +88,13 @@ struct DeviceCtx {
     std::vector<Resident> pool;                    // device buffers free for reuse
     std::vector<ggml_hip_weight *> transient;      // weights built for one node from a computed src0, freed at graph end
     std::map<CacheKey, CachedWeight> cache;        // Seam-1 weight cache
+    uint64_t cache_clock = 0;                      // ticks once per cache hit / insertion
+    size_t cache_bytes = 0;                        // sum of the entries' dev_bytes
+    uint64_t cache_evictions = 0;                  // entries evicted so far (tests)
+    // Least-recently-used entries go until `need` bytes are free under `budget` (budget 0: until `need` bytes have been freed at all);
+    // the entry with key `keep` (the one the running call uses) stays.  Returns the bytes freed.  Waits for this slot's streams first and
+    // drops the captured graphs (their launches hold the entries' device pointers) -- only when something is evicted.
+    size_t evict_lru(size_t need, size_t budget, const CacheKey *keep);
     uint64_t h2d_bytes = 0, d2h_bytes = 0, resident_hits = 0;
     int graph_depth_ = 0;                          // ggml_hip_graph_begin / _end nesting on this slot
     // graph scope: results whose host copy is still owed.  A node of a graph scope costs the host ONE kernel launch; the

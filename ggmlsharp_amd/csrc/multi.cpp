@@ -294,7 +294,6 @@ int ggml_hip_mul_mat_split_dev(const ggml_hip_split_weight *w, const float *cons
         auto keep = [&](int rc) { if (rc && !first) first = rc; return rc; };
         auto keep_hip = [&](hipError_t e, const char *what) {
             if (e != hipSuccess) { (void)hipGetLastError(); if (!first) first = fail(GGML_HIP_ERR_RUNTIME, "%s: %s", what, hipGetErrorString(e)); }
-            return e;
         };
         for (int g = 0; g < G; ++g) {                        // "everything issued so far on my stream is done": peers may write into my dst
             if (keep(ctxs[(size_t)g]->make_current())) continue;

@@ -493,6 +493,21 @@ void ggml_hip_debug_scope_counters(uint64_t *observed, uint64_t *captured, uint6
     if (replayed) *replayed = v[2];
     if (refused) *refused = v[3];
 }
+/* The Seam-1 weight cache: a budget per slot in bytes (0 = the device's memory is the limit), and what the cache holds / has evicted so far. */
+static std::atomic<size_t> g_weight_cache_budget{0};
+static size_t weight_cache_budget() { return g_weight_cache_budget.load(std::memory_order_relaxed); }
+void ggml_hip_debug_weight_cache_budget(size_t bytes_per_slot) { g_weight_cache_budget.store(bytes_per_slot, std::memory_order_relaxed); }
+void ggml_hip_debug_weight_cache_stats(uint64_t *entries, uint64_t *bytes, uint64_t *evictions) {
+    uint64_t n = 0, b = 0, e = 0;
+    for (int i = 0; i < n_slots(); ++i) {
+        DeviceCtx *c = slot(i);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        n += c->cache.size(); b += c->cache_bytes; e += c->cache_evictions;
+    }
+    if (entries) *entries = n;
+    if (bytes) *bytes = b;
+    if (evictions) *evictions = e;
+}
 void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits) {
     uint64_t a = 0, b = 0, h = 0;
     for (int i = 0; i < n_slots(); ++i) {
@@ -606,6 +621,7 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
         auto it = cacheable ? c->cache.find(key) : c->cache.end();
         if (it != c->cache.end()) {
             W[(size_t)g] = it->second.slices;
+            it->second.last_use = ++c->cache_clock;
         } else {
             // the source rows: a device copy left by the node that computed them (graph scope), else host memory -- which an
             // earlier node's device -> host copy may still be filling, so wait for this slot's streams first
@@ -615,14 +631,28 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
             if (!dev_src && in_graph) { rc = c->pay_and_sync(); if (rc) return rc; }
             c->scope_dirty();                             // a weight upload (allocation, staging, a wait) is not replayable
             std::vector<ggml_hip_weight *> slices;
-            for (int64_t i03 = 0; i03 < ne03 && !rc; ++i03)
-                for (int64_t i02 = 0; i02 < ne02 && !rc; ++i02) {
-                    ggml_hip_weight *w = nullptr;
-                    const size_t off = (size_t)(i02 * src0->nb[2] + i03 * src0->nb[3]);
-                    rc = make_weight(c, type, (dev_src ? dev_src : (const uint8_t *)src0->data) + off, dev_src == nullptr, ne00, ne01,
-                                     src0->nb[1], r0[(size_t)g], r1[(size_t)g], c->stream, &w);
-                    if (!rc) slices.push_back(w);
-                }
+            // r5: the cache is bounded by the device's memory (and by the budget of ggml_hip_debug_weight_cache_budget, a test hook): when an
+            // upload cannot be allocated, the least recently used leaf entries go and the upload is tried ONCE more (it used
+            // to be an error return for good -- resident images are 1.5-2.6 x the file format)
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                rc = GGML_HIP_OK;
+                for (int64_t i03 = 0; i03 < ne03 && !rc; ++i03)
+                    for (int64_t i02 = 0; i02 < ne02 && !rc; ++i02) {
+                        ggml_hip_weight *w = nullptr;
+                        const size_t off = (size_t)(i02 * src0->nb[2] + i03 * src0->nb[3]);
+                        rc = make_weight(c, type, (dev_src ? dev_src : (const uint8_t *)src0->data) + off, dev_src == nullptr, ne00, ne01,
+                                         src0->nb[1], r0[(size_t)g], r1[(size_t)g], c->stream, &w);
+                        if (!rc) slices.push_back(w);
+                    }
+                if (rc != GGML_HIP_ERR_RUNTIME || attempt == 1 || c->cache.empty()) break;
+                size_t have = 0;
+                for (ggml_hip_weight *x : slices) { have += x->bytes; ggml_hip_weight_free(x); }
+                slices.clear();
+                (void)hipGetLastError();
+                // (how much the failed upload wanted is not known here: at least what its slices so far took, and no less than a quarter of the cache)
+                const size_t want = have > c->cache_bytes / 4 ? have : c->cache_bytes / 4;
+                if (c->evict_lru(want ? want : 1, 0, nullptr) == 0) break;
+            }
             if (rc) {
                 for (ggml_hip_weight *x : slices) ggml_hip_weight_free(x);
                 for (ggml_hip_weight *x : to_free) ggml_hip_weight_free(x);
@@ -633,7 +663,12 @@ static int seam1(const struct ggml_compute_params *params, const struct ggml_ten
                 CachedWeight cw;
                 cw.host = src0->data; cw.host_bytes = tensor_host_bytes(src0); cw.slices = slices;
                 cw.row_begin = r0[(size_t)g]; cw.row_end = r1[(size_t)g];
+                cw.last_use = ++c->cache_clock;
+                for (ggml_hip_weight *x : slices) cw.dev_bytes += x->bytes;
+                c->cache_bytes += cw.dev_bytes;
                 c->cache.emplace(key, std::move(cw));
+                const size_t budget = weight_cache_budget();
+                if (budget && c->cache_bytes > budget) c->evict_lru(0, budget, &key);   // (the entry this call runs on stays, whatever its size)
             } else if (in_graph) {
                 for (ggml_hip_weight *x : slices) c->transient.push_back(x);     // alive until graph end (kernels in flight)
             } else {

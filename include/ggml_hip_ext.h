@@ -63,6 +63,12 @@ int  ggml_hip_graph_begin_keyed(uint64_t key);
 void ggml_hip_debug_scope_counters(uint64_t *observed, uint64_t *captured, uint64_t *replayed, uint64_t *refused);
 /* Bytes moved over PCIe by seam 1 so far and the number of src1 operands served from a resident dst (tests, tuning). */
 void ggml_hip_debug_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *resident_hits);
+/* The Seam-1 weight cache (device forms of leaf src0 tensors, keyed by host pointer + shape; Ggml.cs:1545: tensor data is stable for the
+ * life of its context).  It is bounded by the device's memory: when an upload cannot be allocated, least-recently-used entries are evicted
+ * and the upload is tried once more.  _budget sets a smaller bound per slot in bytes (0 = none) so that a test can watch the eviction happen
+ * on a small problem -- the entry the running call uses always stays; _stats reports entries, resident bytes and evictions so far. */
+void ggml_hip_debug_weight_cache_budget(size_t bytes_per_slot);
+void ggml_hip_debug_weight_cache_stats(uint64_t *entries, uint64_t *bytes, uint64_t *evictions);
 
 
 /* Which layout step 1 writes into d_work for this weight type, K and N (introspection for tests and profiling tools):

@@ -504,6 +504,64 @@ def test_the_references_own_caller_test3_product_through_seam_1(dev):
         G.ggml_free(ctx)
 
 
+def test_seam1_weight_cache_evicts_least_recently_used_entries_under_a_budget(dev):
+    """the Seam-1 weight cache is bounded -- with a budget that holds two of three weights, the third upload evicts the
+    least recently used one, the entry a call runs on always stays, an evicted weight is uploaded again on its next use, and every
+    result stays the oracle's.  (Without a budget the bound is the device's memory: a failed hipMalloc evicts and retries once.)"""
+    import ggml_mirror as G
+    from ggmlsharp_amd._lib import lib
+    L = lib()
+    K, M, N = 512, 256, 8
+    ctx = G.ggml_init(32 * 1024 * 1024)
+
+    def stats():
+        v = [C.c_uint64(), C.c_uint64(), C.c_uint64()]
+        L.ggml_hip_debug_weight_cache_stats(*[C.byref(x) for x in v])
+        return [x.value for x in v]
+    try:
+        L.ggml_hip_invalidate_all()
+        Ws, graphs, refs = [], [], []
+        X = G.ggml_new_tensor_2d(ctx, G.F32, K, N)
+        x = _rand((N, K))
+        G.tensor_f32(X)[:] = x.reshape(1, 1, N, K)
+        for i in range(3):
+            W = G.ggml_new_tensor_2d(ctx, G.Q4_0, K, M)
+            wq = O.quantize_row(O.Q4_0, _rand((M, K)))
+            G.tensor_bytes(W)[:] = wq.reshape(-1)
+            Y = G.ggml_mul_mat(ctx, W, X)
+            Ws.append(W); graphs.append((G.ggml_build_forward(Y), Y)); refs.append(O.mul_mat(O.Q4_0, wq, x, M, K, N)[0, 0])
+
+        def run(i):
+            gf, Y = graphs[i]
+            G.ggml_graph_compute(ctx, gf)
+            assert_close(G.tensor_f32(Y)[0, 0], refs[i], K, f"weight {i} through the bounded cache")
+        run(0)
+        n0, b0, e0 = stats()
+        assert n0 == 1 and b0 > M * K // 2                         # one entry; its resident images are larger than the 20 B / 32 of the format
+        L.ggml_hip_debug_weight_cache_budget(2 * b0 + b0 // 2)      # room for two
+        run(1)
+        assert stats()[0] == 2 and stats()[2] == e0
+        run(0)                                                      # touch 0: now 1 is the least recently used
+        run(2)                                                      # third upload: 1 goes
+        n, b, e = stats()
+        assert n == 2 and e == e0 + 1 and b == 2 * b0
+        h0 = C.c_uint64()
+        L.ggml_hip_debug_transfer_counters(C.byref(h0), None, None)
+        run(0)                                                      # still cached: only src1 travels
+        h1 = C.c_uint64()
+        L.ggml_hip_debug_transfer_counters(C.byref(h1), None, None)
+        assert h1.value - h0.value == N * K * 4
+        run(1)                                                      # evicted: uploaded again (2 goes), same result
+        assert stats()[2] == e0 + 2 and stats()[0] == 2
+        L.ggml_hip_debug_weight_cache_budget(1)                     # a budget below any entry: the entry a call runs on still stays
+        run(2)
+        assert stats()[0] == 1
+        run(2)
+    finally:
+        L.ggml_hip_debug_weight_cache_budget(0)
+        G.ggml_free(ctx)
+
+
 def test_graph_residency_chained_mul_mats(dev):
     """Y2 = W2 * (W1 * X) in one graph.  The intermediate is consumed from HBM (no second host ->
     device copy), both node results are in host memory when ggml_graph_compute returns, values match the oracle chain."""
