@@ -243,6 +243,146 @@ void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restric
                                                                                                      w_bytes, a_bytes, (int)blockIdx.x, mp3, sp3, wm);
 }
 
+// ---- K3s-i8 on 16-ROW tiles (r5): the same form for matrices whose 32-row tiles do not fill the chip --------------------------------------
+// 4096 rows at up to 32 src1 rows are 128 workgroups of the form above on 256 CUs: half of the chip pulls the whole matrix through its
+// memory path, and a CU's path sustains about 10 B per cycle from HBM -- 4096 x 4096 x 32 measured a flat 8-10 us for every type where the
+// 19 MB of Q8_0 planes are 3 us of HBM time.  Here a workgroup owns a 16-row weight tile x NCT 16-column slices of src1 on
+// v_mfma_i32_16x16x32_i8 (K = 32: one quant block, so the block's integer sum comes out apart as the reference's sumi does): twice the
+// workgroups, every CU streaming (NCT = 1 or 2: up to 32 src1 rows; four slices at 33..64 rows measured slower than two 32-row workgroups).
+// THE SUMMATION TREE IS THE 32-ROW FORM'S: the same KS = 8 contiguous ranges of nloc k-blocks (wave w: w * nloc ..), a range's blocks in
+// ascending order with the same f32 statement per block, the eight partial sums added in wave order -- so the geometry may follow M and a
+// row shard computes the bits of the unsplit matrix whichever of the two forms either of them runs (tests/test_gpu_parity.py
+// test_k3s_16_row_tiles_are_bitwise_the_32_row_form).
+// Operands: the resident int8 planes [k-block][half h][row][16 B] (plane h byte j = element 2 j + h) and K1's image 0 of the same layout;
+// lane (row or column l % 16, group g = l / 16) takes bytes 8 (g & 1) .. + 7 of plane g >> 1 of its row -- 8-byte loads, the same element
+// permutation on both operands, 512 contiguous bytes per operand and k-block per wave instruction pair of planes.
+// D[i = src1 column][j = weight row]: lane holds weight row l % 16 and the columns 4 (l / 16) + 0..3 of the slice.
+using i32x4v = __attribute__((ext_vector_type(4))) int;
+template <int KS, int NB, bool ROT, int NCT, bool Q5>
+__device__ __forceinline__
+void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                          float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
+                          uint32_t w_bytes, uint32_t a_bytes, int wg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    constexpr int TN = 16 * NCT;                            // src1 columns of a workgroup
+    int rt, ct;
+    k3s_tile_of(wg, ntw, (N + TN - 1) / TN, rt, ct);
+    const int m0 = rt * 16, n0 = ct * TN;
+    const int kb0 = wave * nloc;
+    // (a slot past the wave's range or past the end of K repeats a valid block: its table row is zero, so it adds (sumi * 0) = +0)
+    auto blk = [&](int i) { const int kb = kb0 + (i < nloc ? i : nloc - 1); return kb < nbk ? kb : nbk - 1; };
+
+    struct WB { long q; float d; };
+    WB wb[NB];
+    long ab[NB][NCT];
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(qs), 0, (int)w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wd), 0, (int)(w_bytes / 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a8), 0, (int)a_bytes, 0x00020000);
+    const int hpl = g4 >> 1, sub = g4 & 1;                  // plane and 8-byte piece of this lane's group
+    const uint32_t offW = (uint32_t)((hpl * Mpad + m0 + l15) * 16 + 8 * sub), offD = (uint32_t)((m0 + l15) * 4);
+    const uint32_t offA = (uint32_t)((hpl * Npad + n0 + l15) * 16 + 8 * sub);
+    const uint32_t w_blk = (uint32_t)(2 * Mpad * 16), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)(2 * Npad * 16);
+    auto load_blk = [&](WB &f, long (&a)[NCT], int i) {
+        const uint32_t kb = (uint32_t)blk(i);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+            a[c] = __builtin_bit_cast(long, __builtin_amdgcn_raw_buffer_load_b64(rA, (int)(offA + 256u * c), (int)(kb * a_blk), 0));
+        f.q = __builtin_bit_cast(long, __builtin_amdgcn_raw_buffer_load_b64(rW, (int)offW, (int)(kb * w_blk), 0));
+        f.d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)offD, (int)(kb * d_blk), 0));
+    };
+
+    // ---- this wave's slice of the row scales: rows x TN floats into its own LDS slice (rows past its range: zero) ----
+    const int trows = (nloc + NB - 1) / NB * NB;
+    float *const tabD = (float *)smem8 + (size_t)wave * trows * TN;
+    constexpr int PPR = TN / 4;                             // float4 pieces per table row
+    constexpr int TP = 8;                                   // pieces per lane and round: 64 * TP / PPR rows (>= 64)
+    for (int base = 0; base < trows * PPR; base += 64 * TP) {
+        f32x4 td[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = base + lane + 64 * j, b = idx / PPR, c4 = idx % PPR;
+            const bool ok = b < nloc && kb0 + b < nbk;
+            td[j] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        if (base == 0) static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; load_blk(wb[u], ab[u], u); });
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = base + lane + 64 * j;
+            if (idx < trows * PPR) *(f32x4 *)(tabD + 4 * idx) = td[j];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    float acc[NCT][4];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[c][r] = 0.0f;
+    const i32x4v zero = {0, 0, 0, 0};
+    auto block = [&](int i, auto uc) {                      // block i of the wave out of slot u
+        constexpr int u = decltype(uc)::value;
+        const float dw = wb[u].d;
+        const float *dp = tabD + i * TN + 4 * g4;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const i32x4v t = __builtin_amdgcn_mfma_i32_16x16x32_i8(ab[u][c], wb[u].q, zero, 0, 0, 0);
+            const f32x4 da = *(const f32x4 *)(dp + 16 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if constexpr (Q5) acc[c][e] = fmaf(dw * (float)t[e], da[e], acc[c][e]);      // (d * sxy) * y.d, Ggml.cs:1296-1298
+                else acc[c][e] = fmaf((float)t[e], da[e] * dw, acc[c][e]);                    // Ggml.cs:1377-1378
+        }
+    };
+    static_for<NB>([&](auto uc) { block(decltype(uc)::value, uc); });
+    if constexpr (ROT) {
+        for (int base = NB; base < nloc; base += NB) {
+            __builtin_amdgcn_sched_barrier(0);              // (hoisted above the arithmetic, the loads would double the live slots)
+            static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; load_blk(wb[u], ab[u], base + u); });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NB>([&](auto uc) { block(base + decltype(uc)::value, uc); });
+        }
+    }
+
+    // ---- the waves' sums in wave order (the 32-row form's tree), the NCT * 4 result registers dealt over the waves ----
+    __syncthreads();
+    float *xch = (float *)smem8 + lane;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[(size_t)((wave * NCT + c) * 4 + r) * 64] = acc[c][r];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < NCT * 4; ++rr) {
+        if (rr % KS != wave) continue;                      // (uniform)
+        const int c = rr / 4, r = rr % 4;
+        float v = xch[(size_t)(c * 4 + r) * 64];
+#pragma unroll
+        for (int g = 1; g < KS; ++g) v += xch[(size_t)((g * NCT + c) * 4 + r) * 64];
+        const int n = n0 + 16 * c + 4 * g4 + r, m = m0 + l15;
+        if (n < N && m < M) {
+            if (ep.mode == 2) {
+                dst[(size_t)n * ldd + m] = v * ep.scale;
+            } else {
+                dst[(size_t)n * ldd + m] = v;
+                if (ep.mode == 1) ep.dst2[(size_t)n * ep.ld2 + m] = v + ep.addend[(size_t)n * ep.ld_add + m];
+            }
+        }
+    }
+}
+
+template <int KS, int NB, bool ROT, int NCT, bool Q5>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_q8_small16_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
+                            float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
+                            uint32_t w_bytes, uint32_t a_bytes) {
+    gemm_q8_small16_body<KS, NB, ROT, NCT, Q5>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
+}
+
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
 struct q8s_set {
     int n; int wg_end[4];
@@ -328,6 +468,34 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    if (pl.tile_m == 16) {
+        // r5: 16-row tiles (plan_k3s_i8: Q8_0 / Q5_0 where the 32-row tiles leave CUs idle) -- the same tree, NCT 16-column slices per workgroup
+        if (!(w->type == GGML_TYPE_Q8_0 || w->type == GGML_TYPE_Q5_0)) return hipErrorInvalidValue;
+        const int nct = pl.tile_n / 16;
+        const int ncg = (int)((N + pl.tile_n - 1) / pl.tile_n);
+        if (p.Npad < (int64_t)pl.tile_n * ncg || w->Mpad % 16 != 0) return hipErrorInvalidValue;
+        const int ntw16 = (int)((w->M + 15) / 16);
+        if (nct != 1 && nct != 2) return hipErrorInvalidValue;       // (four slices per workgroup were built and measured: slower than two 32-row workgroups, plan.cpp)
+        const int nb16 = nloc <= 8 ? 8 : 16, rows16 = (nloc + nb16 - 1) / nb16 * nb16;
+        const int tab16 = KS * rows16 * pl.tile_n * 4, xch16 = KS * nct * 4 * 64 * 4;
+        const int lds16 = tab16 > xch16 ? tab16 : xch16;
+        if (lds16 > 160 * 1024) return hipErrorInvalidValue;
+        dim3 grid16((unsigned)(ntw16 * ncg));
+        (void)hipGetLastError();
+#define Q8S16_GO1(NB, ROT, NCT, Q5F) do { \
+        auto kern = gemm_q8_small16_kernel<KS, NB, ROT, NCT, Q5F>; \
+        static PerDeviceOnce once; \
+        const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
+        if (attr != hipSuccess) return attr; \
+        kern<<<grid16, KS * 64, lds16, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw16, \
+                                          (uint32_t)wq_bytes, (uint32_t)aq_bytes); } while (0)
+#define Q8S16_GO(NB, ROT, NCT) do { if (q5) Q8S16_GO1(NB, ROT, NCT, true); else Q8S16_GO1(NB, ROT, NCT, false); } while (0)
+        if (nct == 2) { if (nloc <= 8) Q8S16_GO(8, false, 2); else if (nloc <= 16) Q8S16_GO(16, false, 2); else Q8S16_GO(16, true, 2); }
+        else { if (nloc <= 8) Q8S16_GO(8, false, 1); else if (nloc <= 16) Q8S16_GO(16, false, 1); else Q8S16_GO(16, true, 1); }
+#undef Q8S16_GO
+#undef Q8S16_GO1
+        return hipGetLastError();
+    }
     const int ntw = (int)((w->M + 32 * wmt - 1) / (32 * wmt));
     const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;   // (table rows: whole rounds of the form's slots)
     const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;

@@ -865,6 +865,165 @@ void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__res
                                                 ad_bytes, ep, (int)blockIdx.x, ntw);
 }
 
+// ---- K3s on 16-ROW tiles (r5, Q4_0): the form above for matrices whose 32-row tiles do not fill the chip ------------------------------------
+// 4096 rows at up to 32 src1 rows are 128 workgroups on 256 CUs: half of the chip pulls the whole matrix through its memory path (a flat
+// 8 us at 4096 x 4096 for 1 .. 32 rows where the planes are 2.5 us of HBM time).  Here a workgroup owns a 16-row weight tile x NCT 16-column
+// slices of src1 on v_mfma_scale_f32_16x16x128_f8f6f4.  That instruction sums over FOUR 32-element K groups (lane l: row / column l & 15,
+// K group l >> 4) where a quant block fills two (the ah digits with E8M0 scale 2^4, the al digits), and the reference wants every block's
+// integer sum apart -- so a PAIR of blocks rides in one operand set: K groups 0 / 1 = block i, 2 / 3 = block i + 1, and the pair takes two
+// MFMAs whose WEIGHT operand is zero in the other block's lanes (masked once per pair, whatever the number of column slices): exact zeros,
+// exact integer sums, the statement of the 32-row form per block.
+// THE SUMMATION TREE IS THE 32-ROW FORM'S (KS = 8 contiguous ranges of nloc k-blocks, pairs in ascending order, block i before block i + 1,
+// acc += (sumi * d1) * d0 per block, the eight partial sums added in wave order): geometry that may follow M
+// (tests/test_gpu_fullsize.py test_k3s_16_row_tiles_are_bitwise_the_32_row_form).
+template <int KS, int NP, bool ROT, int NCT>
+__device__ __forceinline__
+void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                           const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
+                           int nbkp, int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, const mm_epilogue &ep, int wg, int ntw) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;              // K group: 0 / 1 = the pair's first block (ah / al digits), 2 / 3 = its second
+    constexpr int TN = 16 * NCT;
+    int rt, ct;
+    k3s_tile_of(wg, ntw, (N + TN - 1) / TN, rt, ct);
+    const int m0 = rt * 16, n0 = ct * TN;
+    const int kb0 = wave * nloc, npair = nloc >> 1;
+    const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
+    const rsrc_t rA = make_rsrc(a6, a_bytes);
+    const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)Npad * 48u;
+    const uint32_t second = (uint32_t)(kg >> 1), half = (uint32_t)(kg & 1);
+    const int mrow = m0 + l15;
+    const uint32_t offA = (uint32_t)(mrow * 16) + second * wa_blk, offB = (uint32_t)(mrow * 8) + second * wb_blk, offD = (uint32_t)(mrow * 4);
+    const uint32_t voff16 = (uint32_t)((half * Npad + n0 + l15) * 16) + second * a_blk;
+    const uint32_t voff8 = (uint32_t)(32 * Npad + (half * Npad + n0 + l15) * 8) + second * a_blk;
+
+    struct WP { u32x4 lo; u32x2 hi; float d0, d1; };        // lanes of K groups 0 / 1: the pair's first block, 2 / 3: its second; both blocks' row scales in every lane
+    struct AF { u32x4 lo; u32x2 hi; };
+    WP wp[NP];
+    AF af[NP][NCT];
+    auto load_pair = [&](WP &f, AF (&a)[NCT], int pr) {     // pair pr of this wave (clamped to its last: its table rows past the range are zero)
+        const int kb = kb0 + 2 * (pr < npair ? pr : npair - 1);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            a[c].lo = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(voff16 + 256u * c), (int)((uint32_t)kb * a_blk), 0);
+            a[c].hi = __builtin_amdgcn_raw_buffer_load_b64(rA, (int)(voff8 + 128u * c), (int)((uint32_t)kb * a_blk), 0);
+        }
+        f.lo = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)offA, (int)((uint32_t)kb * wa_blk), 0);
+        f.hi = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)offB, (int)((uint32_t)kb * wb_blk), 0);
+        // (every lane needs the row scale of BOTH blocks: two 4-byte loads.  One load per lane group + v_permlane32_swap, the 32-row form's idiom,
+        // came out of hipcc with the swap's second result dropped and block i's scale on both blocks: tools/experiments/dbg_tile16.py)
+        f.d0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)offD, (int)((uint32_t)kb * d_blk), 0));
+        f.d1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)offD, (int)((uint32_t)(kb + 1) * d_blk), 0));
+    };
+
+    // ---- this wave's slice of the row scales: rows x TN floats into its own LDS slice; rows past the wave's range or past K are ZERO ----
+    const int trows = ROT ? nloc : 2 * NP;
+    float *const tabD = (float *)smem + (size_t)wave * trows * TN;
+    constexpr int PPR = TN / 4, TP = 8;
+    for (int base = 0; base < trows * PPR; base += 64 * TP) {
+        f32x4 td[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = base + lane + 64 * j, b = idx / PPR, c4 = idx % PPR;
+            const bool ok = b < nloc && kb0 + b < nbkp;
+            td[j] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        if (base == 0) static_for<NP>([&](auto uc) { constexpr int u = decltype(uc)::value; load_pair(wp[u], af[u], u); });
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int idx = base + lane + 64 * j;
+            if (idx < trows * PPR) *(f32x4 *)(tabD + 4 * idx) = td[j];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int scale_a = half ? 127 : 131;                   // E8M0: the ah digits carry 2^4
+    const bool first_blk = kg < 2;
+    auto pair = [&](int pr, auto uc) {
+        constexpr int u = decltype(uc)::value;
+        WP &w = wp[u];
+        const uint32_t wr[6] = {w.lo[0], w.lo[1], w.lo[2], w.lo[3], w.hi[0], w.hi[1]};
+        i32x8 B0, B1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { B0[k] = first_blk ? (int)wr[k] : 0; B1[k] = first_blk ? 0 : (int)wr[k]; }
+        B0[6] = B0[7] = B1[6] = B1[7] = 0;
+        const float d0 = w.d0, d1 = w.d1;
+        const int i = 2 * pr;
+        const float *dp0 = tabD + i * TN + 4 * kg, *dp1 = dp0 + TN;
+        f32x4 t0[NCT], t1[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const i32x8 A = {(int)af[u][c].lo[0], (int)af[u][c].lo[1], (int)af[u][c].lo[2], (int)af[u][c].lo[3], (int)af[u][c].hi[0], (int)af[u][c].hi[1], 0, 0};
+            t0[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B0, zero4, 3, 3, 0, scale_a, 0, 127);
+            t1[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B1, zero4, 3, 3, 0, scale_a, 0, 127);
+        }
+        if constexpr (ROT) load_pair(w, af[u], pr + NP);     // the fragments are in the MFMAs' hands: the slot takes the pair NP further on
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const f32x4 da = *(const f32x4 *)(dp0 + 16 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float x = t0[c][e] * da[e]; acc[c][e] = __builtin_fmaf(x, d0, acc[c][e]); }   // (sumi * d1) * d0, Ggml.cs:1158
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const f32x4 da = *(const f32x4 *)(dp1 + 16 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float x = t1[c][e] * da[e]; acc[c][e] = __builtin_fmaf(x, d1, acc[c][e]); }
+        }
+    };
+    if constexpr (!ROT) {
+        static_for<NP>([&](auto pc) { pair(decltype(pc)::value, pc); });
+    } else {
+        int base = 0;
+        for (; base + NP <= npair; base += NP)
+            static_for<NP>([&](auto pc) { pair(base + decltype(pc)::value, pc); });
+        static_for<NP>([&](auto pc) { if (base + decltype(pc)::value < npair) pair(base + decltype(pc)::value, pc); });
+    }
+
+    // ---- the waves' sums in wave order (the 32-row form's tree), the NCT * 4 result registers dealt over the waves ----
+    __syncthreads();
+    float *xch = (float *)smem + lane;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[(size_t)((wave * NCT + c) * 4 + r) * 64] = acc[c][r];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < NCT * 4; ++rr) {
+        if (rr % KS != wave) continue;                      // (uniform)
+        const int c = rr / 4, r = rr % 4;
+        float v = xch[(size_t)(c * 4 + r) * 64];
+#pragma unroll
+        for (int g = 1; g < KS; ++g) v += xch[(size_t)((g * NCT + c) * 4 + r) * 64];
+        const int n = n0 + 16 * c + 4 * kg + r, m = m0 + l15;
+        if (n < N && m < M) {
+            if (ep.mode == 2) {
+                dst[(size_t)n * ldd + m] = v * ep.scale;
+            } else {
+                dst[(size_t)n * ldd + m] = v;
+                if (ep.mode == 1) ep.dst2[(size_t)n * ep.ld2 + m] = v + ep.addend[(size_t)n * ep.ld_add + m];
+            }
+        }
+    }
+}
+
+template <int KS, int NP, bool ROT, int NCT>
+__global__ __launch_bounds__(KS * 64, 1)
+void gemm_qmx_small16_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
+                             const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
+                             int nbkp, int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, const mm_epilogue ep, int ntw) {
+    gemm_qmx_small16_body<KS, NP, ROT, NCT>(w6a, w6b, wd, a6, ad, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, w6a_bytes, wd_bytes, a_bytes, ep,
+                                            (int)blockIdx.x, ntw);
+}
+
 // Several weight matrices behind ONE activation image (q / k / v, gate / up of a batched decoder's step): the workgroups of all of
 // them in one launch -- 4096 rows are 128 tiles, half of the chip; three such matrices fill it.  A workgroup picks its matrix from
 // its index (uniform, once); everything after that is the single-matrix kernel, so every matrix gets the bits of its own call.
@@ -931,6 +1090,35 @@ hipError_t launch_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes 
     const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)w->Mpad * 4;
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
     if (nloc > 128 || wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;    // (the plan never sends such a shape here)
+    if (pl.tile_m == 16) {
+        // r5: 16-row tiles (plan_k3s_mx: Q4_0 where the 32-row tiles leave CUs idle) -- the same tree, NCT 16-column slices per workgroup
+        if constexpr (TYPE == GGML_TYPE_Q4_0) {
+            const int nct = pl.tile_n / 16, ncg = (int)((N + pl.tile_n - 1) / pl.tile_n);
+            if (p.Npad < (int64_t)pl.tile_n * ncg || w->Mpad % 16 != 0 || (nloc & 1)) return hipErrorInvalidValue;
+            if (nct != 1 && nct != 2) return hipErrorInvalidValue;
+            const int np16 = nloc <= 8 ? 4 : 8;                          // pairs in flight per wave (the slots)
+            const bool rot16 = nloc > 2 * np16;
+            const int rows16 = rot16 ? nloc : 2 * np16;
+            const int tab16 = KS * rows16 * pl.tile_n * 4, xch16 = KS * nct * 4 * 64 * 4;
+            const int lds16 = tab16 > xch16 ? tab16 : xch16;
+            if (lds16 > 160 * 1024) return hipErrorInvalidValue;
+            const int ntw16 = (int)((w->M + 15) / 16);
+            dim3 grid16((unsigned)(ntw16 * ncg));
+#define K3S16_GO(NP, ROT, NCT) do { \
+            auto kern = gemm_qmx_small16_kernel<KS, NP, ROT, NCT>; \
+            static PerDeviceOnce once; \
+            const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
+            if (attr != hipSuccess) return attr; \
+            kern<<<grid16, KS * 64, lds16, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
+                                              nbkp, nloc, (int)ldd, (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, t_epilogue, ntw16); } while (0)
+            if (nct == 2) { if (nloc <= 8) K3S16_GO(4, false, 2); else if (nloc <= 16) K3S16_GO(8, false, 2); else K3S16_GO(8, true, 2); }
+            else { if (nloc <= 8) K3S16_GO(4, false, 1); else if (nloc <= 16) K3S16_GO(8, false, 1); else K3S16_GO(8, true, 1); }
+#undef K3S16_GO
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;
     const int ncol = (int)((N + 31) / 32);                  // 32-column slices of src1: one workgroup per tile group and slice
     if (p.Npad < 32 * ncol) return hipErrorInvalidValue;

@@ -168,6 +168,24 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
     p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    // r5: 16-row tiles on v_mfma_i32_16x16x32_i8 where the 32-row tiles leave CUs idle (gemm_q8s.hip gemm_q8_small16_kernel; Q8_0 / Q5_0 -- the
+    // min-term and two-scale types keep the 32-row form).  GEOMETRY ONLY: the same eight K ranges, the same block order and statement, the same
+    // wave-order sum -- tree_id does not move, so this choice MAY look at M.  A workgroup takes 16 rows x the (up to 32) src1 rows in one or two
+    // 16-column slices: 4096 x 4096 x 32 is 256 workgroups instead of 128.  Measured (replayed graphs of 64 launches, 24 .. 32 weight copies in
+    // turn, 32-row | 16-row tiles, us per COMPUTE launch): Q8_0 4096 x 4096 x 32 11.5 | 9.1, x 8 11.4 | 7.3, Q5_0 x 32 11.6 | 9.1.  Up to 32 rows and
+    // one round of the chip only: four slices per workgroup at 33..64 rows lost to two 32-row workgroups sharing a weight tile through L2
+    // (Q8_0 4096 x 4096 x 64 11.3 | 13.1, 4096 x 11008 x 64 25.9 | 30.5), more than 256 of them lost too (Q4_0 8192 x 8192 x 32 23 | 33).
+    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N <= 32) {
+        const int tn16 = N <= 16 ? 16 : 32;
+        const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
+        const int nb16 = nloc <= 8 ? 8 : 16, rows16 = (int)cdiv(nloc, nb16) * nb16;   // (the launcher's slots: gemm_q8s.hip)
+        const bool fits = (int64_t)KS8 * rows16 * tn16 * 4 <= 160 * 1024;
+        static const int lim16 = dev_env_int("GGML_HIP_Q8S_16_WGS", 256);   // developer A/B switch: 16-row tiles up to this many workgroups (0: never)
+        if (fits && geo == 0 && wg16 <= lim16) {
+            p.form = 5 + (tn16 == 16 ? 0 : 1);
+            p.wmt = 1; p.tile_m = 16; p.tile_n = tn16; p.tiles_per_wave = tn16 / 16; p.wgs = wg16;
+        }
+    }
     return true;
 }
 
@@ -217,6 +235,22 @@ bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
     p.flags |= MM_FLAG_EPILOGUE_FUSED;
+    // r5: 16-row tiles on v_mfma_scale_f32_16x16x128_f8f6f4 where the 32-row tiles leave CUs idle (gemm_qmx.hip gemm_qmx_small16_kernel, Q4_0;
+    // Q4_1's min term keeps the 32-row form).  GEOMETRY ONLY, as in plan_k3s_i8: the same K ranges, pair and block order, statement and
+    // wave-order sum -- tree_id does not move, so the choice may look at M.  Up to 32 src1 rows and one round of the chip (plan_k3s_i8 has the
+    // reasons): Q4_0 4096 x 4096 x 32 10.6 | 8.6 us per COMPUTE launch (32-row | 16-row tiles, replayed graphs, 32 weight copies in turn), x 16 and
+    // x 5 10.6 | 7.1, 4096 x 11008 x 32 22.6 | 19.0, 2048 x 8192 x 32 19.1 | 16.5; the whole call at 16 rows 13.8 | 10.3.
+    if (type == GGML_TYPE_Q4_0 && N <= 32) {
+        const int tn16 = N <= 16 ? 16 : 32;
+        const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
+        const int np16 = nloc <= 8 ? 4 : 8, rows16 = nloc > 2 * np16 ? nloc : 2 * np16;   // (the launcher's slots: gemm_qmx.hip launch_small)
+        const bool fits = (int64_t)KS8 * rows16 * tn16 * 4 <= 160 * 1024;
+        static const int lim16 = dev_env_int("GGML_HIP_K3S_16_WGS", 256);   // developer A/B switch: 16-row tiles up to this many workgroups (0: never)
+        if (fits && geo == 0 && wg16 <= lim16) {
+            p.form = 5 + (tn16 == 16 ? 0 : 1);
+            p.wmt = 1; p.tile_m = 16; p.tile_n = tn16; p.tiles_per_wave = tn16 / 16; p.wgs = wg16;
+        }
+    }
     return true;
 }
 

@@ -211,6 +211,35 @@ def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
     W.free()
 
 
+@pytest.mark.parametrize("t", [Q8_0, Q5_0, Q4_0])
+@pytest.mark.parametrize("K,N", [(4096, 32), (4096, 16), (4096, 5), (2048, 24), (11008, 32), (6144, 31), (4096 + 64, 17), (28672, 9), (32768, 32)])
+def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
+    """r5: the batched-decode forms run 16-row tiles where 32-row tiles leave CUs idle -- GEOMETRY that follows M, on the
+    tree of the 32-row form (the same eight K ranges, block order, statement per block and wave-order sum).  So the plan's tree_id is the
+    same for both, a 16384-row matrix (32-row tiles, two per workgroup) and its 4096-row / ragged shards (16-row tiles) agree BIT FOR BIT --
+    and both meet the oracle sample and the fp64 evaluation.  Covers both slice counts (16 / 32 columns per workgroup), one table
+    round and several (K = 11008, 28672), ragged N, and a K whose last k-blocks fall short of a wave's range."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    M = 16384
+    pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 4096, K, N, C.byref(pb)) == 0
+    assert pa.tree_id == pb.tree_id and pa.family == pb.family and pa.family in (3, 4)
+    assert pa.tile_m >= 32 and pb.tile_m == 16, (pa.tile_m, pb.tile_m)          # the two geometries really are different kernels
+    rows, x, w = _make(dev, t, M, K, N, seed=K + N + t, keep_w=True)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((0, 4096), (4096, 8192), (12288, 12288 + 4000), (100, 100 + 1777), (16000, 16384)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        part = dev.mul_mat(Ws, x)
+        assert torch.equal(part, full[:, r0:r1]), (t, K, N, r0, r1)
+        if r0 == 0:
+            _check_fp64(dev, t, rows[r0:r1], x, part, K)
+            _check_oracle_sample(t, rows[r0:r1], w[r0:r1], x, part, K, seed=K + N)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("K", [512, 544, 1056, 2080])
 @pytest.mark.parametrize("N", [130, 256])
 def test_banked_four_way_tree_matches_the_real_split(dev, K, N):

@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggmlsharp_amd import device  # noqa: E402
 
+GRAPH = False
 TYPES = {"q4_0": 2, "q4_1": 3, "q4_2": 4, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q5_k": 113, "q4_k": 112, "q6_k": 114}   # (the k-quant extras: timing only, --no-check -- their activations follow the Q8_K rule)
 
 
@@ -105,6 +106,26 @@ def run(tname, M, K, N, iters, check=True, copies=1):
         ab1 = M * (K // 32) * {"q4_0": 20, "q4_1": 24, "q4_2": 20, "q5_0": 22, "q5_1": 24, "q8_0": 36, "q5_k": 22, "q4_k": 18, "q6_k": 26.25}[tname] + 4 * K * N + 4 * M * N
         print(f"   graph-replayed whole mul_mat (fused, {copies} rotating weight copies): {t_graph * 1e3:7.2f} us/call  "
               f"{ab1 / t_graph / 1e6:8.1f} GB/s algorithmic", flush=True)
+    if GRAPH:   # r5: GPU-side times -- the per-call figures above are host-bound below ~8 us per call (ctypes + launch); replay captured graphs of 64 launches
+        reps = max(copies, 64)
+
+        def cap(fn):
+            fn()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(reps):
+                    fn()
+            gr.replay()
+            torch.cuda.synchronize()
+            return min(ev_ms(gr.replay, 10) for _ in range(3)) / reps
+
+        def both():
+            init()
+            comp()
+        g_init, g_comp, g_both = cap(init), cap(comp), cap(both)
+        print(f"   graph-replayed ({copies} rotating weight copies, {reps} launches per graph): init {g_init * 1e3:6.2f} us  compute {g_comp * 1e3:6.2f} us  "
+              f"init + compute {g_both * 1e3:6.2f} us", flush=True)
     flops = 2.0 * M * K * N
     blk = {"q4_0": 20, "q4_1": 24, "q4_2": 20, "q5_0": 22, "q5_1": 24, "q8_0": 36, "q5_k": 22, "q4_k": 18, "q6_k": 26.25}[tname]   # bytes per 32 weights
     ab = M * (K // 32) * blk + 4 * K * N + 4 * M * N
@@ -120,7 +141,9 @@ if __name__ == "__main__":
                                                  "q8_0:4096:11008:512", "q5_0:4096:11008:512", "q4_0:32000:4096:512"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="also time INIT / COMPUTE / both as replayed hipGraphs of 64 launches (GPU-side time: small kernels are host-bound per call)")
     a = ap.parse_args()
+    GRAPH = a.graph
     device.init(0)
     for c in a.cfg:
         p = c.split(":")
