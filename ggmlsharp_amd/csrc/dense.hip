@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void dense_f32_big_kernel(const float *__restr
         }
 }
 
-// ---- F32 weights, 17 .. 256 src1 rows (r4): K split over the eight waves of a workgroup.  The tile kernels above give a workgroup the whole
+// ---- F32 weights, 5 .. 256 src1 rows (r4; the bounds are plan.cpp plan_dense's): K split over the eight waves of a workgroup.  The tile kernels above give a workgroup the whole
 //      K: at these sizes a 4096 x 4096 matrix is 64 .. 256 tiles of 64 x 64, every wave runs 2048 sixteen-pass MFMAs one after the other and the
 //      launch takes a flat 120 us whatever N is (the weights stream in 12).  Here a workgroup owns ONE 32 x 32 tile and each wave an eighth of
 //      K (a contiguous range of whole 32-k stages), staged through the wave's own LDS slice (no workgroup barrier in the K loop: a thread
@@ -349,7 +349,7 @@ hipError_t launch_dense(const ggml_hip_weight *w, const mm_plan &pl, const float
     dim3 grid((unsigned)((w->M + DT - 1) / DT), (unsigned)((N + DT - 1) / DT));
     // K % 32 == 0 keeps every 8-element piece of a stage inside the row
     const bool vec = w->K % DK == 0 && ld1 % 4 == 0 && ((uintptr_t)x & 15) == 0;
-    if (pl.form == DNF_KSPLIT) {                            // F32, 17 .. 256 rows, K % 256 == 0 (plan.cpp): a wave's range is K / 8, whole stages
+    if (pl.form == DNF_KSPLIT) {                            // F32, 5 .. 256 rows, K % 256 == 0 (plan.cpp): a wave's range is K / 8, whole stages
         if (f16 || w->K % 256 != 0) return hipErrorInvalidValue;
         const dim3 g2((unsigned)((w->M + 31) / 32), (unsigned)((N + 31) / 32));
         const int kr = (int)(w->K / 8);

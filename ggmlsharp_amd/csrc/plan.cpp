@@ -28,8 +28,9 @@ int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return
 // a hard limit at K = 20480) -- up to four slices of 78, K <= 79872 (the 32-bit offsets of the planes end earlier for wide matrices)
 bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 
-// Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 5..64 rows, 2048 <= K <= 16384: the stage-free batched-decode
-// form on the int8 matrix cores (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
+// Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 2048 <= K <= 32768, from 5 (Q5_1 / Q4_2: 9) src1 rows up to 128
+// (the two-scale types: 256) -- the bounds are the constants below: the stage-free batched-decode form on the int8 matrix cores
+// (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
@@ -103,7 +104,8 @@ void plan_set_force_gemm(int which) { t_force_gemm = which < 0 || which > 3 ? 0 
 //   gemm_q16.hip (f16 matrix cores, register-tile design) -- Q5_0 / Q5_1 / Q8_0 on prompt-sized batches (N <= 512, K split in the
 //                workgroup) and from 1024 rows up,
 //   gemm_q.hip   (int8 matrix cores, 64 x 64 / 128 x 128 tiles) -- Q4_2, and Q5_0 / Q5_1 / Q8_0 in between,
-//   gemm_qmp.hip / gemm_q8s.hip -- the stage-free forms (257..512 rows, the int8 types up to 2048; Q8_0 5..64 rows).
+//   gemm_qmp.hip / gemm_q8s.hip -- the stage-free forms (K3p: q8_mid_serves / plan_mx; batched decode: q8_small_serves / plan_mx -- the
+//                bounds live in those functions and nowhere else).
 // ggml_hip_debug_force_gemm forces one (test / developer switch; the product library reads no environment variable: GGML_HIP_GEMM is
 // honoured by -DGGML_HIP_DEV builds only).  Returns the K1 image kind: 0 = int8 planes, 1 / 2 = the f16 images, 3 = the bf6 image;
 // 0 + ACT_IMAGE_MIN_PIECES (64) = the int8 planes and the min-term piece planes (K3p-int8 behind a Q5_1 / Q4_1 / Q5_K weight).

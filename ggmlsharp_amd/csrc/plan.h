@@ -17,7 +17,7 @@ enum mm_family {
     MMF_GEMV_FUSED = 1,   // gemv.hip K2f / K2: INIT + COMPUTE in one launch, N <= 8
     MMF_GEMV_ROWS = 2,    // gemv.hip two-step form on K1's planes (Q4_2 at 9..16 rows where K < 2048; the COMPUTE-only entry for N <= 8)
     MMF_K3S_MX = 3,       // gemm_qmx.hip K3s: stage-free batched decode, MX
-    MMF_K3S_I8 = 4,       // gemm_q8s.hip: the same on the int8 cores (Q8_0)
+    MMF_K3S_I8 = 4,       // gemm_q8s.hip: the same on the int8 cores (Q8_0, Q5_0, Q5_1 / Q5_K, Q4_2 / Q6_K)
     MMF_K3P_MX = 5,       // gemm_qmp.hip K3p: prompt-sized batches, MX (Q4_0)
     MMF_K3P_I8 = 6,       // gemm_qmp.hip K3p on the int8 cores (Q8_0, Q5_0, Q5_1, Q4_1)
     MMF_MX = 7,           // gemm_qmx.hip staged forms
@@ -58,7 +58,7 @@ enum i8_form { I8F_64x64 = 0, I8F_128x128 };
 // dense16.hip F16 forms
 enum d16_form { D16F_S_256x128 = 0, D16F_S_128x128, D16F_256x128, D16F_S4_H128, D16F_S4_H32, D16F_V2_128x128, D16F_S2_128x128, D16F_S2_128x64, D16F_128x128 };
 // dense.hip
-enum dense_form { DNF_TILE = 0, DNF_BIG = 1, DNF_KSPLIT = 2 /* F32, 17..256 rows: 32 x 32 tiles, K over the workgroup's eight waves */ };
+enum dense_form { DNF_TILE = 0, DNF_BIG = 1, DNF_KSPLIT = 2 /* F32, 5..256 rows (plan.cpp plan_dense): 32 x 32 tiles, K over the workgroup's eight waves */ };
 
 // K3p (gemm_qmp.hip): k-blocks of a wave's scale table -- 80 fit whole (8 waves x 80 x 256 B = the 160 KB of LDS: K <= 20480); beyond that the
 // K loop refills slices of at most 78 rows (the int8 loop keeps one spare row behind the last wave's slice), four slices at most (K <= 79872)

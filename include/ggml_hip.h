@@ -206,11 +206,14 @@ int     ggml_hip_weight_type(const ggml_hip_weight *w);
  * For F32 / F16 weights it is ggml_compute_forward_mul_mat_f32 / _f16_f32 (Ggml.cs:5969-6178, 6180-6438).
  * d_src1: device f32 [N rows][K], row stride ld1 ELEMENTS; d_dst: device f32 [N][M], row stride ldd ELEMENTS
  * (the reference's dst layout: element (i01, ic) at ic*ne0 + i01, Ggml.cs:6692-6697).
- * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378; F32 weights: none in the
- *         reference, here 6 B per src1 element above 256 src1 rows -- src1 as three bf16 pieces for the matrix cores; without it, or
- *         with src1 not 16-byte aligned, the f32 matrix-instruction kernel runs instead: same contract, half the speed).
- * Alignment: for quantized weights d_src1 must be 16-byte aligned and ld1 a multiple of 4 (the INIT kernels read rows in
- * 16-byte pieces); GGML_HIP_ERR_SHAPE otherwise.  The device the weight lives on is made current for the launch. */
+ * d_work: device scratch of ggml_hip_mul_mat_work_size() bytes (the reference's wdata, Ggml.cs:3365-3378).  REQUIRED whenever
+ *         ggml_hip_mul_mat_work_size(type, K, N) is not 0 -- also for F32 weights above 256 src1 rows, where the reference needs no
+ *         wdata (Ggml.cs:3371-3373) and this library takes 6 B per src1 element: src1 as three bf16 pieces for the matrix cores.  A
+ *         missing or too small buffer is GGML_HIP_ERR_ARG; no other kernel is chosen in its place (the same product gives the same
+ *         bits whoever calls it).  The Seam-1 entry allocates its own scratch: a C# caller never sees this.
+ * Alignment: d_src1 must be 16-byte aligned and ld1 a multiple of 4 for quantized weights and for the matrix-core forms of dense
+ *         weights (F16 above 4 src1 rows, F32 above 256: the INIT kernels read rows in 16-byte pieces); GGML_HIP_ERR_SHAPE otherwise.
+ *         The device the weight lives on is made current for the launch. */
 size_t ggml_hip_mul_mat_work_size(int type, int64_t K, int64_t N);
 int    ggml_hip_mul_mat_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1,
                             float *d_dst, int64_t ldd, void *d_work, size_t work_bytes, void *stream);

@@ -35,8 +35,8 @@ extern "C" {
 #define GGML_HIP_TYPE_Q4_K 112
 /* r4: Q6_K of the same published format -- { u8 ql[128]; u8 qh[64]; i8 scales[16]; half d }, 210 bytes per 256 weights: sixteen sub-blocks
  * of 16 six-bit weights (q - 32) with a signed 8-bit scale each, no min.  Resident as eight k-blocks of the planar Q4_2 form (two scales per
- * k-block) on int8 operand planes; served by the int8 kernels that take two scales per k-block (the batched-decode form up to 64 src1 rows,
- * the staged int8 form elsewhere).  ggml_hip_quantize_rows_dev: quantize_row_q6_K_reference WITHOUT the least-squares refinement of the
+ * k-block) on int8 operand planes; served by the int8 kernels that take two scales per k-block (its own mat-vec, the batched-decode form and
+ * the staged int8 form: WHICH one serves a shape is ggml_hip_mm_plan's answer, the only authority -- no range is restated here).  ggml_hip_quantize_rows_dev: quantize_row_q6_K_reference WITHOUT the least-squares refinement of the
  * sub-block scales (make_qx_quants in its plain form) -- a valid encoder of the published structure.  Unpinned like the other two. */
 #define GGML_HIP_TYPE_Q6_K 114
 
@@ -116,8 +116,8 @@ void   ggml_hip_debug_force_gemm(int which);
  * the Q8_K rule of the k-quant extension instead (one scale per 256 elements; see GGML_HIP_TYPE_Q5_K).  image_kind + 64 (kind 0 only,
  * K >= 256): beside image 0, d * (float)sum(q) of every block -- the Q8_1 s0 + s1 of Ggml.cs:820-821 -- as three bf16 pieces that sum to it
  * exactly, in the half of the image region image 0 leaves free (same work size): what ggml_hip_act_image_kind returns for Q5_1 / Q4_1
- * weights from 129 src1 rows up (Q4_1: 257..1024) and for Q5_1 at 9..64, where the min terms run as a matrix product of their own
- * (gemm_qmp.hip, gemm_q8s.hip). */
+ * weights wherever the min terms run as a matrix product of their own (gemm_qmp.hip, gemm_q8s.hip; the row ranges are the plan's --
+ * ask ggml_hip_act_image_kind / ggml_hip_mm_plan, they are not restated here). */
 int    ggml_hip_quantize_act_dev(const float *d_src1, int64_t N, int64_t K, int64_t ld1, void *d_work, size_t work_bytes,
                                  int image_kind, void *stream);
 
@@ -164,9 +164,9 @@ int ggml_hip_compute_forward_silu(const struct ggml_compute_params *params, cons
  *   norm_mul_mat   the three (or, with an add node, four) nodes rms_norm, mul, mul_mat [, add] as ONE launch for N <= 4
  *   mul_mat_add    mm_dst = mul_mat(src0, src1), add_dst = mm_dst + addend        the add is applied to the accumulators in
  *   mul_mat_scale  mm_dst = scale_dst = mul_mat(src0, src1) * scalar (in place)   the store phase of the mat-mul kernels
- * (epilogue forms exist in the fused mat-vec, N <= 4, in the MX mat-mat of Q4_0 / Q4_1 -- N > 8, and 5..8 rows where K >= 2048 --
- * and in the batched-decode form of Q8_0, 5..64 rows with 2048 <= K <= 16384:
- * ggml_hip_mul_mat_epilogue_fused; elsewhere the node's own kernel runs behind the mat-mul inside the same call). */
+ * (epilogue forms exist in the fused mat-vec, the MX mat-mat forms, the batched-decode forms and K3p; whether the form that serves a
+ * given (weight, N) has one is ggml_hip_mul_mat_epilogue_fused's answer -- the plan's MM_FLAG_EPILOGUE_FUSED -- and elsewhere the node's
+ * own kernel runs behind the mat-mul inside the same call). */
 int ggml_hip_compute_forward_rms_norm_mul(const struct ggml_compute_params *params, const struct ggml_tensor *x,
                                           const struct ggml_tensor *g, struct ggml_tensor *norm_dst, struct ggml_tensor *mul_dst);
 int ggml_hip_compute_forward_silu_mul(const struct ggml_compute_params *params, const struct ggml_tensor *a,

@@ -384,6 +384,37 @@ def test_mul_mat_dense_matches_oracle(dev, t):
         assert_close(got, ref, K, f"dense type {t} M{M} K{K} N{N}")
 
 
+def test_dense_matrix_core_forms_require_scratch_and_aligned_src1(dev):
+    """the matrix-core forms of dense weights (F16 above 4 src1 rows; F32 above 256, where the reference needs no wdata,
+    Ggml.cs:3371-3373) REQUIRE the scratch of ggml_hip_mul_mat_work_size and a 16-byte aligned src1: a missing / short buffer is
+    GGML_HIP_ERR_ARG, a misaligned src1 GGML_HIP_ERR_SHAPE -- never a silent switch to another kernel (include/ggml_hip.h)."""
+    from ggmlsharp_amd._lib import lib, ERR_ARG, ERR_SHAPE
+    L = lib()
+    M, K = 128, 256
+    for t, N in ((O.F32, 300), (O.F16, 16)):
+        w = _rand((M, K))
+        wraw = w if t == O.F32 else w.astype(np.float16).view(np.uint16)
+        W = dev.Weight.from_host(t, wraw.view(np.uint8), K)
+        need = L.ggml_hip_mul_mat_work_size(t, K, N)
+        assert need > 0
+        x = torch.from_numpy(_rand((N, K + 4))).cuda()
+        out = torch.empty((N, M), device="cuda")
+        work = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        call = lambda xp, ld, wp, wb: L.ggml_hip_mul_mat_dev(W.handle, C.c_void_p(xp), N, ld, C.c_void_p(out.data_ptr()), M, wp, wb, st)  # noqa: E731
+        assert call(x.data_ptr(), K + 4, None, 0) == ERR_ARG                                     # no scratch
+        assert call(x.data_ptr(), K + 4, C.c_void_p(work.data_ptr()), need - 1) == ERR_ARG       # short scratch
+        assert call(x.data_ptr() + 4, K + 4, C.c_void_p(work.data_ptr()), need) == ERR_SHAPE     # base not 16-byte aligned
+        assert call(x.data_ptr(), K + 3, C.c_void_p(work.data_ptr()), need) == ERR_SHAPE         # row stride not a multiple of 4
+        assert call(x.data_ptr(), K + 4, C.c_void_p(work.data_ptr()), need) == 0                 # ... and the well-formed call runs
+        ref = O.mul_mat(t, wraw, x[:, :K].cpu().numpy().copy(), M, K, N, nth=4)[0, 0]
+        assert_close(out.cpu().numpy(), ref, K, f"dense type {t} with scratch")
+        # below the matrix-core range the reference's contract holds as it is: no scratch needed
+        n2 = 3
+        assert L.ggml_hip_mul_mat_work_size(t, K, n2) == 0 or t == O.F16
+        W.free()
+
+
 # ---------------------------------------------------------------- Seam 2 host forms
 def test_row_functions_host_forms(dev):
     from ggmlsharp_amd._lib import lib

@@ -1,6 +1,14 @@
 #!/usr/bin/env python3
-"""The types x batch-sizes grid of profiles/r04_grid_quant.txt: COMPUTE launch time of every quantized type over batch sizes under the plan as
-built (tools/kbench.py's event timing, 30 back-to-back launches).  Developer tool, GPU box: python tools/grid_quant.py > gpurun_out/grid.txt"""
+"""The types x batch-sizes grid behind the plan's thresholds (csrc/plan.cpp): GPU-side COMPUTE time of every quantized type over batch sizes
+under the plan as built.  r5: timed as REPLAYED hipGraphs of 64 launches (tools/kbench.py --graph) -- round 4's table used per-call events,
+which are host-bound near 8 us per call and read flat below that -- and re-checkable:
+
+    python tools/grid_quant.py > gpurun_out/grid.txt                          # measure (GPU box)
+    python tools/grid_quant.py --check profiles/r05_grid_quant.txt --tolerance 8%   # re-measure every cell of a committed table, list the
+                                                                              # cells that moved by more than the tolerance, exit 1 if any got SLOWER
+
+A cell that got slower beyond the tolerance is a regression of the plan or of a kernel; boxes of one day differ by +-4 %, hence 8 %."""
+import argparse
 import io
 import os
 import re
@@ -10,22 +18,55 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import kbench  # noqa: E402
 from ggmlsharp_amd import device  # noqa: E402
 
-device.init(0)
 TYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_2"]
 SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096)]
-NS = [1, 4, 5, 9, 16, 17, 32, 64, 65, 128, 256, 257, 512, 768, 1024, 2048, 3072, 4096]
-print("# COMPUTE launch time in us (tools/grid_quant.py = tools/kbench.py, HIP events over 30 back-to-back launches after 3 warm-up launches, real quantised data, one MI355X box,")
-print("# one gpurun call, the final plan of round 4) of every quantized type over batch sizes: which kernel form serves what is decided by csrc/plan.cpp from (type, K, N).")
-print("# Not a contract measurement (short runs on a chip that has not reached its steady clock read high, an isolated outlier is a one-off stall): the table is for")
-print("# spotting forms that are out of line with their neighbours -- DESIGN.md 10.2d.  INIT (4-20 us) not included.")
-print("M     K      N   " + "".join(f"{t:>9}" for t in TYPES), flush=True)
-for (M, K) in SHAPES:
-    for N in NS:
-        row = []
-        for t in TYPES:
-            buf = io.StringIO()
-            with redirect_stdout(buf):
-                kbench.run(t, M, K, N, 30, check=False)
-            m = re.search(r"compute\s+([0-9.]+) us", buf.getvalue())
-            row.append(float(m.group(1)) if m else float("nan"))
-        print(f"{M:5d} {K:5d} {N:5d}  " + "".join(f"{v:9.1f}" for v in row), flush=True)
+NS = [1, 4, 5, 9, 16, 17, 32, 64, 65, 128, 129, 256, 257, 512, 768, 1024, 2048, 4096]
+
+
+def measure(t, M, K, N):
+    copies = max(1, min(16, (300 << 20) // (M * K)))        # rotate weight copies past the Infinity Cache where the matrix is small
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        kbench.run(t, M, K, N, 5, check=False, copies=copies)
+    return kbench.RESULT.get("graph_compute_us", float("nan"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", help="a table written by this tool: re-measure its cells and compare")
+    ap.add_argument("--tolerance", default="8%")
+    ap.add_argument("--quick", action="store_true", help="--check only a spread of cells (every third row)")
+    a = ap.parse_args()
+    tol = float(a.tolerance.rstrip("%")) / 100.0
+    device.init(0)
+    kbench.GRAPH = True
+    if a.check:
+        rows = [ln.split() for ln in open(a.check) if ln.strip() and not ln.startswith(("#", "M "))]
+        worse = better = cells = 0
+        for i, r in enumerate(rows):
+            if a.quick and i % 3:
+                continue
+            M, K, N = int(r[0]), int(r[1]), int(r[2])
+            for t, old in zip(TYPES, r[3:]):
+                old = float(old)
+                new = measure(t, M, K, N)
+                cells += 1
+                if new > old * (1 + tol):
+                    worse += 1
+                    print(f"SLOWER  {t} {M} x {K} x {N}: {old:.1f} -> {new:.1f} us ({(new / old - 1) * 100:+.0f} %)", flush=True)
+                elif new < old * (1 - tol):
+                    better += 1
+                    print(f"faster  {t} {M} x {K} x {N}: {old:.1f} -> {new:.1f} us ({(new / old - 1) * 100:+.0f} %)", flush=True)
+        print(f"grid check: {cells} cells, {worse} slower and {better} faster beyond {a.tolerance}")
+        sys.exit(1 if worse else 0)
+    print("# COMPUTE time in us per launch, GPU side: replayed hipGraphs of 64 back-to-back COMPUTE launches rotating over weight copies (tools/grid_quant.py = tools/kbench.py --graph),")
+    print("# real quantised data, one MI355X box, one gpurun call, under the plan as built (csrc/plan.cpp).  INIT not included.  Re-check with --check FILE --tolerance 8%.")
+    print("M     K      N   " + "".join(f"{t:>9}" for t in TYPES), flush=True)
+    for (M, K) in SHAPES:
+        for N in NS:
+            row = [measure(t, M, K, N) for t in TYPES]
+            print(f"{M:5d} {K:5d} {N:5d}  " + "".join(f"{v:9.1f}" for v in row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggmlsharp_amd import device  # noqa: E402
 
 GRAPH = False
+RESULT = {}          # the last run()'s timings (tools/grid_quant.py reads graph_compute_us)
 TYPES = {"q4_0": 2, "q4_1": 3, "q4_2": 4, "q5_0": 6, "q5_1": 7, "q8_0": 8, "q5_k": 113, "q4_k": 112, "q6_k": 114}   # (the k-quant extras: timing only, --no-check -- their activations follow the Q8_K rule)
 
 
@@ -90,6 +91,8 @@ def run(tname, M, K, N, iters, check=True, copies=1):
 
     t_init = ev_ms(init, iters)
     t_comp = ev_ms(comp, iters)
+    RESULT.clear()
+    RESULT.update(init_us=t_init * 1e3, compute_us=t_comp * 1e3)
     if N <= 8:   # launch-bound from Python: replay a captured graph of `reps` whole mul_mat calls instead
         reps = max(copies, 32)
 
@@ -124,6 +127,7 @@ def run(tname, M, K, N, iters, check=True, copies=1):
             init()
             comp()
         g_init, g_comp, g_both = cap(init), cap(comp), cap(both)
+        RESULT.update(graph_init_us=g_init * 1e3, graph_compute_us=g_comp * 1e3, graph_both_us=g_both * 1e3)
         print(f"   graph-replayed ({copies} rotating weight copies, {reps} launches per graph): init {g_init * 1e3:6.2f} us  compute {g_comp * 1e3:6.2f} us  "
               f"init + compute {g_both * 1e3:6.2f} us", flush=True)
     flops = 2.0 * M * K * N
