@@ -340,6 +340,9 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
     };
     static_for<NB>([&](auto uc) { block(decltype(uc)::value, uc); });
     if constexpr (ROT) {
+        // longer K: rounds of NB blocks, a round's loads issued together behind the previous round's arithmetic (the 32-row form's structure).
+        // (r5, measured: refilling a slot as soon as its own product has issued, blocks pinned in program order -- NB - 1 blocks in flight across
+        // the whole range, what the MX form does -- was SLOWER here: Q8_0 4096 x 11008 x 16 13.5 -> 15.4 us, x 32 19.1 -> 19.4.)
         for (int base = NB; base < nloc; base += NB) {
             __builtin_amdgcn_sched_barrier(0);              // (hoisted above the arithmetic, the loads would double the live slots)
             static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; load_blk(wb[u], ab[u], base + u); });

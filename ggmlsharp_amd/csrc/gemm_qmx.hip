@@ -978,6 +978,11 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float x = t1[c][e] * da[e]; acc[c][e] = __builtin_fmaf(x, d1, acc[c][e]); }
         }
+        // Pairs in program order (longer K only): left alone hipcc gathers a round's sixteen MFMAs, then its eight refills, and waits for nearly
+        // all of them at the top of the next round (s_waitcnt vmcnt(9) five times: ONE pair in flight) -- with one 16-column slice a pair's
+        // arithmetic is too little to hold the schedule apart.  Pinned, the wait in front of a pair is for that pair alone and the seven
+        // others stay in flight (4096 x 11008 x 16: 17.9 -> see DESIGN.md section 11).
+        if constexpr (ROT) __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (!ROT) {
         static_for<NP>([&](auto pc) { pair(decltype(pc)::value, pc); });
