@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s a
 I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x BF16 per clock, ~5 PF dense.  The MX kernel issues bf6 MFMAs
                             # (4x BF16 per clock, ~10 PF) over twice the algorithmic K (two digits per Q8 activation): the same
                             # 5 PF ceiling in algorithmic FLOPs.
-PROFILE_TRAFFIC = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
+PROFILE_TRAFFIC = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # HBM bytes per launch from the committed rocprofv3 PMC passes
 
 
 def algorithmic_bytes(M, K, N, blk=20):

@@ -240,6 +240,32 @@ def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     W.free()
 
 
+@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 64), (Q8_0, 24), (Q5_0, 64), (3, 32), (7, 48), (4, 200)])
+def test_every_batched_decode_geometry_computes_the_same_bits(dev, t, N):
+    """the batched-decode forms pick their geometry from M -- 16-row tiles (r5), one, two or four 32-row tiles per workgroup -- and the
+    CPU plan test can only see that the LABELS agree.  Here every geometry really runs: a 33000-row matrix (four tiles per workgroup for Q4_0, two
+    for the others) and shards of 12000 rows (two), 6000 rows (one) and 4096 / 1000 rows (16-row tiles where the type has them) must agree bit
+    for bit, in the product build, with no developer switch."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    M, K = 33000, 4096
+    rows, x = _make(dev, t, M, K, N, seed=5 * N + t)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    seen = set()
+    for (r0, r1) in ((0, 33000), (0, 12000), (12000, 18000), (18000, 22096), (32000, 33000), (22096, 22096 + 257)):
+        pl = _lib.ggml_hip_mm_plan_t()
+        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family in (3, 4), (t, N, pl.family)
+        seen.add((pl.tile_m, pl.tile_n))
+        if (r0, r1) == (0, 33000):
+            continue
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x), full[:, r0:r1]), (t, N, r0, r1, pl.tile_m, pl.tile_n)
+        Ws.free()
+    assert len(seen) >= 2, seen                             # (the geometries really differed)
+    W.free()
+
+
 @pytest.mark.parametrize("K", [512, 544, 1056, 2080])
 @pytest.mark.parametrize("N", [130, 256])
 def test_banked_four_way_tree_matches_the_real_split(dev, K, N):
