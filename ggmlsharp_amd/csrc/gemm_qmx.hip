@@ -876,10 +876,10 @@ void gemm_qmx_small_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__res
 // THE SUMMATION TREE IS THE 32-ROW FORM'S (KS = 8 contiguous ranges of nloc k-blocks, pairs in ascending order, block i before block i + 1,
 // acc += (sumi * d1) * d0 per block, the eight partial sums added in wave order): geometry that may follow M
 // (tests/test_gpu_fullsize.py test_k3s_16_row_tiles_are_bitwise_the_32_row_form).
-template <int KS, int NP, bool ROT, int NCT>
+template <int KS, int NP, bool ROT, int NCT, bool Q41>
 __device__ __forceinline__
-void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
-                           const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
+void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd, const float *__restrict__ wm,
+                           const uint8_t *__restrict__ a6, const float *__restrict__ ad, const float *__restrict__ asd, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
                            int nbkp, int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, const mm_epilogue &ep, int wg, int ntw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
@@ -892,15 +892,17 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
     const int kb0 = wave * nloc, npair = nloc >> 1;
     const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
     const rsrc_t rA = make_rsrc(a6, a_bytes);
+    const rsrc_t rWm = make_rsrc(Q41 ? (const void *)wm : (const void *)wd, wd_bytes), rAs = make_rsrc(Q41 ? asd : ad, (uint32_t)nbkp * (uint32_t)Npad * 4u);
     const uint32_t wa_blk = (uint32_t)(Mpad * 16), wb_blk = (uint32_t)(Mpad * 8), d_blk = (uint32_t)(Mpad * 4), a_blk = (uint32_t)Npad * 48u;
     const uint32_t second = (uint32_t)(kg >> 1), half = (uint32_t)(kg & 1);
     const int mrow = m0 + l15;
     const uint32_t offA = (uint32_t)(mrow * 16) + second * wa_blk, offB = (uint32_t)(mrow * 8) + second * wb_blk, offD = (uint32_t)(mrow * 4);
     const uint32_t voff16 = (uint32_t)((half * Npad + n0 + l15) * 16) + second * a_blk;
     const uint32_t voff8 = (uint32_t)(32 * Npad + (half * Npad + n0 + l15) * 8) + second * a_blk;
+    const uint32_t voffS = (uint32_t)((n0 + l15) * 4) + second * (uint32_t)(Npad * 4), offDm = offD + second * d_blk;   // (Q4_1: the lane's own block of the pair)
 
-    struct WP { u32x4 lo; u32x2 hi; float d0, d1; };        // lanes of K groups 0 / 1: the pair's first block, 2 / 3: its second; both blocks' row scales in every lane
-    struct AF { u32x4 lo; u32x2 hi; };
+    struct WP { u32x4 lo; u32x2 hi; float d0, d1; float mn; };   // lanes of K groups 0 / 1: the pair's first block, 2 / 3: its second; both blocks' row scales in every lane (Q4_1: + the min of the lane's own block)
+    struct AF { u32x4 lo; u32x2 hi; float s; };             // (Q4_1: d1 * sum(a) of the lane's column and block -- K1's second plane)
     WP wp[NP];
     AF af[NP][NCT];
     auto load_pair = [&](WP &f, AF (&a)[NCT], int pr) {     // pair pr of this wave (clamped to its last: its table rows past the range are zero)
@@ -909,6 +911,8 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
         for (int c = 0; c < NCT; ++c) {
             a[c].lo = __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(voff16 + 256u * c), (int)((uint32_t)kb * a_blk), 0);
             a[c].hi = __builtin_amdgcn_raw_buffer_load_b64(rA, (int)(voff8 + 128u * c), (int)((uint32_t)kb * a_blk), 0);
+            // (Q4_1) a slot that repeats the wave's last pair must add nothing: its offset points past the plane, the range check returns 0
+            if constexpr (Q41) a[c].s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAs, (int)(voffS + 64u * c), pr < npair ? (int)((uint32_t)kb * (uint32_t)(Npad * 4)) : 0x7FFFFFF0, 0));
         }
         f.lo = __builtin_amdgcn_raw_buffer_load_b128(rWa, (int)offA, (int)((uint32_t)kb * wa_blk), 0);
         f.hi = __builtin_amdgcn_raw_buffer_load_b64(rWb, (int)offB, (int)((uint32_t)kb * wb_blk), 0);
@@ -916,6 +920,7 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
         // came out of hipcc with the swap's second result dropped and block i's scale on both blocks: tools/experiments/dbg_tile16.py)
         f.d0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)offD, (int)((uint32_t)kb * d_blk), 0));
         f.d1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWd, (int)offD, (int)((uint32_t)(kb + 1) * d_blk), 0));
+        if constexpr (Q41) f.mn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rWm, (int)offDm, (int)((uint32_t)kb * d_blk), 0));
     };
 
     // ---- this wave's slice of the row scales: rows x TN floats into its own LDS slice; rows past the wave's range or past K are ZERO ----
@@ -964,6 +969,16 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
             const i32x8 A = {(int)af[u][c].lo[0], (int)af[u][c].lo[1], (int)af[u][c].lo[2], (int)af[u][c].lo[3], (int)af[u][c].hi[0], (int)af[u][c].hi[1], 0, 0};
             t0[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B0, zero4, 3, 3, 0, scale_a, 0, 127);
             t1[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B1, zero4, 3, 3, 0, scale_a, 0, 127);
+        }
+        if constexpr (Q41) {
+            // + (m0 + 8 d0) * (d1 * sum(a)) per block (Ggml.cs:1190-1196 factorised; nib = (nib - 8) + 8), IN FRONT of the pair's block terms as in
+            // the 32-row form: there the pair's two blocks are the K = 2 of one v_mfma_f32_32x32x2_f32, here k = 0 and k = 2 of one
+            // v_mfma_f32_16x16x4_f32 (lane group kg supplies k = kg: the ah-digit groups 0 / 2 carry the blocks, the al-digit groups 1 / 3 zeros).
+            // The instruction is a k-ordered fmaf chain (cdna_hip_programming.md), and fma(0, 0, x) = x for every x the accumulators can hold
+            // (they start at +0 and never become -0): the same two fmaf in the same order, the same bits.
+            const float m8 = half ? 0.0f : fmaf(8.0f, second ? d1 : d0, w.mn);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(half ? 0.0f : af[u][c].s, m8, acc[c], 0, 0, 0);
         }
         if constexpr (ROT) load_pair(w, af[u], pr + NP);     // the fragments are in the MFMAs' hands: the slot takes the pair NP further on
 #pragma unroll
@@ -1020,13 +1035,13 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
     }
 }
 
-template <int KS, int NP, bool ROT, int NCT>
+template <int KS, int NP, bool ROT, int NCT, bool Q41>
 __global__ __launch_bounds__(KS * 64, 1)
-void gemm_qmx_small16_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
-                             const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
-                             int nbkp, int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, const mm_epilogue ep, int ntw) {
-    gemm_qmx_small16_body<KS, NP, ROT, NCT>(w6a, w6b, wd, a6, ad, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, w6a_bytes, wd_bytes, a_bytes, ep,
-                                            (int)blockIdx.x, ntw);
+void gemm_qmx_small16_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd, const float *__restrict__ wm,
+                             const uint8_t *__restrict__ a6, const float *__restrict__ ad, const float *__restrict__ asd, float *__restrict__ dst, int M, int N,
+                             int Mpad, int Npad, int nbkp, int nloc, int ldd, uint32_t w6a_bytes, uint32_t wd_bytes, uint32_t a_bytes, const mm_epilogue ep, int ntw) {
+    gemm_qmx_small16_body<KS, NP, ROT, NCT, Q41>(w6a, w6b, wd, wm, a6, ad, asd, dst, M, N, Mpad, Npad, nbkp, nloc, ldd, w6a_bytes, wd_bytes, a_bytes, ep,
+                                                 (int)blockIdx.x, ntw);
 }
 
 // Several weight matrices behind ONE activation image (q / k / v, gate / up of a batched decoder's step): the workgroups of all of
@@ -1096,12 +1111,14 @@ hipError_t launch_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes 
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad, ad_bytes = nba * (uint64_t)p.Npad * 4;
     if (nloc > 128 || wq_bytes > 0xFFFFFFFFull || a_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;    // (the plan never sends such a shape here)
     if (pl.tile_m == 16) {
-        // r5: 16-row tiles (plan_k3s_mx: Q4_0 where the 32-row tiles leave CUs idle) -- the same tree, NCT 16-column slices per workgroup
-        if constexpr (TYPE == GGML_TYPE_Q4_0) {
+        // r5: 16-row tiles (plan_k3s_mx: where the 32-row tiles leave CUs idle) -- the same tree, NCT 16-column slices per workgroup
+        {
+            constexpr bool Q41 = TYPE == GGML_TYPE_Q4_1;
             const int nct = pl.tile_n / 16, ncg = (int)((N + pl.tile_n - 1) / pl.tile_n);
             if (p.Npad < (int64_t)pl.tile_n * ncg || w->Mpad % 16 != 0 || (nloc & 1)) return hipErrorInvalidValue;
             if (nct != 1 && nct != 2) return hipErrorInvalidValue;
-            const int np16 = nloc <= 8 ? 4 : 8;                          // pairs in flight per wave (the slots)
+            if (Q41 && (!w->m || !p.as)) return hipErrorInvalidValue;
+            const int np16 = nloc <= 8 ? 4 : 8;                          // pairs in flight per wave (the slots; beyond 16 k-blocks per wave: in turn)
             const bool rot16 = nloc > 2 * np16;
             const int rows16 = rot16 ? nloc : 2 * np16;
             const int tab16 = KS * rows16 * pl.tile_n * 4, xch16 = KS * nct * 4 * 64 * 4;
@@ -1110,18 +1127,20 @@ hipError_t launch_small(const ggml_hip_weight *w, const mm_plan &pl, act_planes 
             const int ntw16 = (int)((w->M + 15) / 16);
             dim3 grid16((unsigned)(ntw16 * ncg));
 #define K3S16_GO(NP, ROT, NCT) do { \
-            auto kern = gemm_qmx_small16_kernel<KS, NP, ROT, NCT>; \
+            auto kern = gemm_qmx_small16_kernel<KS, NP, ROT, NCT, Q41>; \
             static PerDeviceOnce once; \
             const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
             if (attr != hipSuccess) return attr; \
-            kern<<<grid16, KS * 64, lds16, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
-                                              nbkp, nloc, (int)ldd, (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, t_epilogue, ntw16); } while (0)
-            if (nct == 2) { if (nloc <= 8) K3S16_GO(4, false, 2); else if (nloc <= 16) K3S16_GO(8, false, 2); else K3S16_GO(8, true, 2); }
+            kern<<<grid16, KS * 64, lds16, st>>>(w->q6a, w->q6b, w->d, w->m, (const uint8_t *)p.a8, p.ad, (const float *)p.as, dst, (int)w->M, (int)N, (int)w->Mpad, \
+                                              (int)p.Npad, nbkp, nloc, (int)ldd, (uint32_t)wq_bytes, (uint32_t)wd_bytes, (uint32_t)a_bytes, t_epilogue, ntw16); } while (0)
+            if (nct == 2) {
+                if (nloc <= 8) K3S16_GO(4, false, 2); else if (nloc <= 16) K3S16_GO(8, false, 2);
+                else if constexpr (Q41) K3S16_GO(6, true, 2);            // (Q4_1 carries the min and d1 * sum(a) per slot: eight slots of two slices spill)
+                else K3S16_GO(8, true, 2);
+            }
             else { if (nloc <= 8) K3S16_GO(4, false, 1); else if (nloc <= 16) K3S16_GO(8, false, 1); else K3S16_GO(8, true, 1); }
 #undef K3S16_GO
             return hipGetLastError();
-        } else {
-            return hipErrorInvalidValue;
         }
     }
     const int rows = nloc <= 8 ? 8 : nloc <= 16 ? 16 : nloc;

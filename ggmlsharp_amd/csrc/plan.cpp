@@ -242,7 +242,8 @@ bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // wave-order sum -- tree_id does not move, so the choice may look at M.  Up to 32 src1 rows and one round of the chip (plan_k3s_i8 has the
     // reasons): Q4_0 4096 x 4096 x 32 10.6 | 8.6 us per COMPUTE launch (32-row | 16-row tiles, replayed graphs, 32 weight copies in turn), x 16 and
     // x 5 10.6 | 7.1, 4096 x 11008 x 32 22.6 | 19.0, 2048 x 8192 x 32 19.1 | 16.5; the whole call at 16 rows 13.8 | 10.3.
-    if (type == GGML_TYPE_Q4_0 && N <= 32) {
+    // (Q4_1 too: its min term as k = 0 / 2 of one v_mfma_f32_16x16x4_f32 per pair -- the 32-row form's two fmaf in the same order)
+    if ((type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && N <= 32) {
         const int tn16 = N <= 16 ? 16 : 32;
         const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
         const int np16 = nloc <= 8 ? 4 : 8, rows16 = nloc > 2 * np16 ? nloc : 2 * np16;   // (the launcher's slots: gemm_qmx.hip launch_small)
