@@ -258,11 +258,11 @@ void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restric
 // permutation on both operands, 512 contiguous bytes per operand and k-block per wave instruction pair of planes.
 // D[i = src1 column][j = weight row]: lane holds weight row l % 16 and the columns 4 (l / 16) + 0..3 of the slice.
 using i32x4v = __attribute__((ext_vector_type(4))) int;
-template <int KS, int NB, bool ROT, int NCT, bool Q5>
+template <int KS, int NB, bool ROT, int NCT, bool Q5, bool Q42 = false>     // Q42: two 16-element blocks per k-block, a scale each (Q4_2, and Q6_K in its form)
 __device__ __forceinline__
 void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                           float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
-                          uint32_t w_bytes, uint32_t a_bytes, int wg) {
+                          uint32_t w_bytes, uint32_t a_bytes, int wg, const float *__restrict__ wm = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -275,12 +275,13 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
     // (a slot past the wave's range or past the end of K repeats a valid block: its table row is zero, so it adds (sumi * 0) = +0)
     auto blk = [&](int i) { const int kb = kb0 + (i < nloc ? i : nloc - 1); return kb < nbk ? kb : nbk - 1; };
 
-    struct WB { long q; float d; };
+    struct WB { long q; float d; float m; };               // (Q4_2: m = the scale of the k-block's second 16-element block)
     WB wb[NB];
     long ab[NB][NCT];
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(qs), 0, (int)w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wd), 0, (int)(w_bytes / 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a8), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q42 ? wm : wd), 0, (int)(w_bytes / 8), 0x00020000);
     const int hpl = g4 >> 1, sub = g4 & 1;                  // plane and 8-byte piece of this lane's group
     const uint32_t offW = (uint32_t)((hpl * Mpad + m0 + l15) * 16 + 8 * sub), offD = (uint32_t)((m0 + l15) * 4);
     const uint32_t offA = (uint32_t)((hpl * Npad + n0 + l15) * 16 + 8 * sub);
@@ -292,6 +293,7 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
             a[c] = __builtin_bit_cast(long, __builtin_amdgcn_raw_buffer_load_b64(rA, (int)(offA + 256u * c), (int)(kb * a_blk), 0));
         f.q = __builtin_bit_cast(long, __builtin_amdgcn_raw_buffer_load_b64(rW, (int)offW, (int)(kb * w_blk), 0));
         f.d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)offD, (int)(kb * d_blk), 0));
+        if constexpr (Q42) f.m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, (int)offD, (int)(kb * d_blk), 0));
     };
 
     // ---- this wave's slice of the row scales: rows x TN floats into its own LDS slice (rows past its range: zero) ----
@@ -328,6 +330,25 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
         constexpr int u = decltype(uc)::value;
         const float dw = wb[u].d;
         const float *dp = tabD + i * TN + 4 * g4;
+        if constexpr (Q42) {
+            // Q4_2: the lane groups with piece 0 (bytes 0..7 of a plane) hold the k-block's first 16-element block, those with piece 1 its second
+            // (Ggml.cs:1217-1252): one product per half with the weight operand zero in the other half's lanes -- sumi_0 and sumi_1 apart, each
+            // under its own scale; the 32-row form's two statements in its order
+            const long q0 = sub ? 0l : wb[u].q, q1 = sub ? wb[u].q : 0l;
+            const float dm = wb[u].m;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const i32x4v t = __builtin_amdgcn_mfma_i32_16x16x32_i8(ab[u][c], q0, zero, 0, 0, 0);
+                const i32x4v t2 = __builtin_amdgcn_mfma_i32_16x16x32_i8(ab[u][c], q1, zero, 0, 0, 0);
+                const f32x4 da = *(const f32x4 *)(dp + 16 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[c][e] = fmaf(dw * da[e], (float)t[e], acc[c][e]);
+                    acc[c][e] = fmaf(dm * da[e], (float)t2[e], acc[c][e]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
             const i32x4v t = __builtin_amdgcn_mfma_i32_16x16x32_i8(ab[u][c], wb[u].q, zero, 0, 0, 0);
@@ -378,12 +399,12 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
     }
 }
 
-template <int KS, int NB, bool ROT, int NCT, bool Q5>
+template <int KS, int NB, bool ROT, int NCT, int TY>         // TY: 0 Q8_0, 1 Q5_0, 4 Q4_2 (the 32-row kernel's numbering)
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_q8_small16_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                             float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
-                            uint32_t w_bytes, uint32_t a_bytes) {
-    gemm_q8_small16_body<KS, NB, ROT, NCT, Q5>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x);
+                            uint32_t w_bytes, uint32_t a_bytes, const float *__restrict__ wm) {
+    gemm_q8_small16_body<KS, NB, ROT, NCT, TY == 1, TY == 4>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x, wm);
 }
 
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
@@ -473,7 +494,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (pl.tile_m == 16) {
         // r5: 16-row tiles (plan_k3s_i8: Q8_0 / Q5_0 where the 32-row tiles leave CUs idle) -- the same tree, NCT 16-column slices per workgroup
-        if (!(w->type == GGML_TYPE_Q8_0 || w->type == GGML_TYPE_Q5_0)) return hipErrorInvalidValue;
+        if (!(w->type == GGML_TYPE_Q8_0 || w->type == GGML_TYPE_Q5_0 || q42)) return hipErrorInvalidValue;
         const int nct = pl.tile_n / 16;
         const int ncg = (int)((N + pl.tile_n - 1) / pl.tile_n);
         if (p.Npad < (int64_t)pl.tile_n * ncg || w->Mpad % 16 != 0) return hipErrorInvalidValue;
@@ -485,14 +506,14 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
         if (lds16 > 160 * 1024) return hipErrorInvalidValue;
         dim3 grid16((unsigned)(ntw16 * ncg));
         (void)hipGetLastError();
-#define Q8S16_GO1(NB, ROT, NCT, Q5F) do { \
-        auto kern = gemm_q8_small16_kernel<KS, NB, ROT, NCT, Q5F>; \
+#define Q8S16_GO1(NB, ROT, NCT, TY) do { \
+        auto kern = gemm_q8_small16_kernel<KS, NB, ROT, NCT, TY>; \
         static PerDeviceOnce once; \
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<grid16, KS * 64, lds16, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw16, \
-                                          (uint32_t)wq_bytes, (uint32_t)aq_bytes); } while (0)
-#define Q8S16_GO(NB, ROT, NCT) do { if (q5) Q8S16_GO1(NB, ROT, NCT, true); else Q8S16_GO1(NB, ROT, NCT, false); } while (0)
+                                          (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->m); } while (0)
+#define Q8S16_GO(NB, ROT, NCT) do { if (q42) Q8S16_GO1(NB, ROT, NCT, 4); else if (q5) Q8S16_GO1(NB, ROT, NCT, 1); else Q8S16_GO1(NB, ROT, NCT, 0); } while (0)
         if (nct == 2) { if (nloc <= 8) Q8S16_GO(8, false, 2); else if (nloc <= 16) Q8S16_GO(16, false, 2); else Q8S16_GO(16, true, 2); }
         else { if (nloc <= 8) Q8S16_GO(8, false, 1); else if (nloc <= 16) Q8S16_GO(16, false, 1); else Q8S16_GO(16, true, 1); }
 #undef Q8S16_GO

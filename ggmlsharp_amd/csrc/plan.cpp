@@ -177,7 +177,8 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // turn, 32-row | 16-row tiles, us per COMPUTE launch): Q8_0 4096 x 4096 x 32 11.5 | 9.1, x 8 11.4 | 7.3, Q5_0 x 32 11.6 | 9.1.  Up to 32 rows and
     // one round of the chip only: four slices per workgroup at 33..64 rows lost to two 32-row workgroups sharing a weight tile through L2
     // (Q8_0 4096 x 4096 x 64 11.3 | 13.1, 4096 x 11008 x 64 25.9 | 30.5), more than 256 of them lost too (Q4_0 8192 x 8192 x 32 23 | 33).
-    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N <= 32) {
+    // (Q4_2 too, and Q6_K in its form: a product per 16-element half with the weight operand zero in the other half's lanes)
+    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q4_2) && N <= 32) {
         const int tn16 = N <= 16 ? 16 : 32;
         const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
         const int nb16 = nloc <= 8 ? 8 : 16, rows16 = (int)cdiv(nloc, nb16) * nb16;   // (the launcher's slots: gemm_q8s.hip)

@@ -211,7 +211,7 @@ def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
     W.free()
 
 
-@pytest.mark.parametrize("t", [Q8_0, Q5_0, Q4_0, 3])
+@pytest.mark.parametrize("t", [Q8_0, Q5_0, Q4_0, 3, 4])
 @pytest.mark.parametrize("K,N", [(4096, 32), (4096, 16), (4096, 5), (2048, 24), (11008, 32), (6144, 31), (4096 + 64, 17), (28672, 9), (32768, 32)])
 def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     """r5: the batched-decode forms run 16-row tiles where 32-row tiles leave CUs idle -- GEOMETRY that follows M, on the
@@ -224,7 +224,9 @@ def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     M = 16384
     pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
     assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 4096, K, N, C.byref(pb)) == 0
-    assert pa.tree_id == pb.tree_id and pa.family == pb.family and pa.family in (3, 4)
+    assert pa.tree_id == pb.tree_id and pa.family == pb.family
+    if pa.family not in (3, 4):
+        pytest.skip("this type's mat-vec serves the shape (Q4_2 up to 8 rows)")
     assert pa.tile_m >= 32 and pb.tile_m == 16, (pa.tile_m, pb.tile_m)          # the two geometries really are different kernels
     rows, x, w = _make(dev, t, M, K, N, seed=K + N + t, keep_w=True)
     W = dev.Weight.from_device(t, rows, K)

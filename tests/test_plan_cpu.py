@@ -143,14 +143,14 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     assert (a.tile_m, a.tile_n, a.workgroups, b.tile_m, c.tile_m) == (16, 32, 256, 64, 32) and a.tree_id == b.tree_id == c.tree_id
     # r5: the batched-decode forms on 16-row tiles (Q4_0 on the MX cores, Q8_0 / Q5_0 on the int8 cores): 16 / 32 / 64 columns per workgroup by N,
     # the tree of the 32-row form; the min-term and two-scale types keep 32 rows
-    for t in (Q4_0, Q4_1, Q8_0, Q5_0):
-        for N, tn in ((5, 16), (16, 16), (17, 32), (32, 32)):
+    for t in (Q4_0, Q4_1, Q8_0, Q5_0, Q4_2):
+        for N, tn in ((9, 16), (16, 16), (17, 32), (32, 32)):
             a, b = plan(t, 4096, 4096, N), plan(t, 16384, 4096, N)
             assert (a.tile_m, a.tile_n, a.workgroups) == (16, tn, 256) and b.tile_m >= 32 and a.tree_id == b.tree_id and a.family == b.family, (t, N)
         assert plan(t, 4096, 4096, 33).tile_m == 32 and plan(t, 4096, 4096, 64).tile_m == 32       # (33..64 rows: two 32-row workgroups per weight tile measured faster)
         assert plan(t, 4112, 4096, 32).tile_m == 32                                                   # (more than one round of 16-row tiles: the 32-row form)
-    assert plan(Q5_1, 4096, 4096, 32).tile_m == 32 and plan(Q4_2, 4096, 4096, 32).tile_m == 32          # (the bf16-piece min term and the two-scale types keep 32 rows)
-    assert plan(Q5_K, 4096, 4096, 32).tile_m == 32 and plan(Q6_K, 4096, 4096, 32).tile_m == 32
+    assert plan(Q5_1, 4096, 4096, 32).tile_m == 32 and plan(Q5_K, 4096, 4096, 32).tile_m == 32          # (the bf16-piece min term is not exact: it keeps the 32-row form's MFMA shape)
+    assert plan(Q6_K, 4096, 4096, 32).tile_m == 16 and plan(Q6_K, 4096, 4096, 5).tile_m == 16              # (Q6_K lives in Q4_2's form)
     # and trees DO differ where they should: across N classes and across types
     assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_0, 4096, 4096, 513).tree_id
     assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_1, 4096, 4096, 512).tree_id
