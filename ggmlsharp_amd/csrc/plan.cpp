@@ -143,7 +143,8 @@ void plan_gemv(mm_plan &p, int type, int64_t M, int64_t K, int64_t N, bool fused
     // 16 rows per workgroup for every M (gemv.hip launch_typed: a choice by M would change the tree); 8 waves x 4 k-lanes = 32 k-workers,
     // worker u takes k-blocks u, u + 32, ...; two xor-shuffles + one LDS pass join them in a fixed order
     p.form = N <= 1 ? 1 : N <= 2 ? 2 : N <= 4 ? 4 : N <= 8 ? 8 : 16;                    // columns per pass (NC)
-    p.arith = 100 + (fused && N <= 4 ? 1 : 0);                                           // the wave-private fused form (N <= 4) is its own kernel
+    p.arith = 100;   // (the wave-private fused form, N <= 4, is its own kernel with the SAME quants and tree as INIT + the mat-vec: bitwise equal,
+                     //  tests/test_gpu_parity.py test_small_n_fused_path_equals_two_step_path -- so one label: ggml_hip_mm_plan's tree_id is what the COMPUTE-only entry runs too)
     p.ksplit = 32; p.kstyle = MMK_WORKERS; p.kunit = 1;
     p.tile_m = 16; p.tile_n = p.form; p.waves = 8; p.tiles_per_wave = 1;
     const int64_t ntiles = cdiv(M, 16);
