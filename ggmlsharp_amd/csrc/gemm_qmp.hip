@@ -60,11 +60,12 @@ constexpr int WNT = 2;         // 32-column tiles of src1 per wave
 // list ordered "n fastest", so the workgroups that stream the same weight rows sit behind one L2.
 // (tile = blockIdx.x + r * gridDim.x for the r-th tile of a persistent workgroup; the grid is a multiple of 8 whenever r > 0, so a
 // workgroup stays in its XCD's run of the list)
+template <int WM = WMT>      // WM: 32-row weight tiles per wave (4; r5: 2 where a grid of 128-row tiles leaves CUs idle -- the int8 kernel)
 __device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, int &m0, int &n0) {
     const int nwg = tiles_m * tiles_n;
     const int bid = tile, xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t_lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    m0 = (t_lin / tiles_n) * (32 * WMT);
+    m0 = (t_lin / tiles_n) * (32 * WM);
     n0 = (t_lin % tiles_n) * (32 * WNT);
 }
 
@@ -92,13 +93,15 @@ __device__ __forceinline__ void load_scale_table(float *tabD, const float *__res
 
 // The waves' sums, added in wave order, four of the eight tiles per round (128 KB of LDS in 16-byte pieces); every wave takes its
 // share of the pieces, so the additions of one element are the same, in the same order, whoever makes them.
-__device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[WMT][WNT], uint8_t *smem, float *__restrict__ dst, int M, int N, int ldd, int m0, int n0,
+template <int WM>
+__device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[WM][WNT], uint8_t *smem, float *__restrict__ dst, int M, int N, int ldd, int m0, int n0,
                                                  int wave, int lane, const mm_epilogue &ep) {
+    constexpr int WMT = WM;                                  // (shadows the file's default: the index arithmetic below is the wave tile's)
     const int l31 = lane & 31, hh = lane >> 5;
     const int lda = (int)ep.ld_add, ld2 = (int)ep.ld2;
     f32x4 *xch = (f32x4 *)smem + lane;                       // [wave][tile of the round][q][lane] pieces of four accumulator registers
 #pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
+    for (int rnd = 0; rnd < WMT * WNT / 4; ++rnd) {          // (four tiles per round: two rounds for the 128-row wave tile, one for the 64-row one)
         __syncthreads();                                     // (round 0: every wave is past its scale table; round 1: past its reads)
         if (rnd == 0) K3P_STAMP(3); else K3P_STAMP(4);
 #pragma unroll
@@ -140,16 +143,18 @@ __device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[WMT][WNT], uint8_
     }
 }
 
-struct WFrag { u32x4 lo[WMT / 2]; u32x2 hi[WMT / 2]; float d[WMT / 2]; };   // lanes 0..31: m-tile 2p, lanes 32..63: m-tile 2p + 1
+template <int WM> struct WFragT { u32x4 lo[WM / 2]; u32x2 hi[WM / 2]; float d[WM / 2]; };   // lanes 0..31: m-tile 2p, lanes 32..63: m-tile 2p + 1
 struct AFrag { u32x4 lo[WNT]; u32x2 hi[WNT]; };
 
-template <bool SLICED>   // (SLICED: the scale tables are refilled inside the K loop -- K > 19968; the one-table form compiles without the test)
+template <bool SLICED, int WM = 4>   // (SLICED: the scale tables are refilled inside the K loop -- K > 19968; the one-table form compiles without the test.  WM: 32-row m-tiles per wave -- 4, or r5 2 where a grid of 128-row tiles leaves CUs idle)
 __global__ __launch_bounds__(KS * 64, 2)
 void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restrict__ w6b, const float *__restrict__ wd,
                          const uint8_t *__restrict__ a6, const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad,
                          int Npad, int nbkp, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w6a_bytes, uint32_t wd_bytes,
                          uint32_t a_bytes, const mm_epilogue ep, int ch_arg) {
     const int ch = SLICED ? ch_arg : nloc;
+    constexpr int WMT = WM;                                  // (shadows the file's default)
+    using WFrag = WFragT<WMT>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -161,7 +166,7 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     const int nwg = tiles_m * tiles_n;
     int tile = blockIdx.x;
     int m0, n0;
-    tile_origin(tile, tiles_m, tiles_n, m0, n0);
+    tile_origin<WMT>(tile, tiles_m, tiles_n, m0, n0);
     const int kb0 = wave * nloc;                            // this wave's k-blocks: kb0 .. kb0 + nloc - 1 (planes and image read 0 past their end)
 
     const rsrc_t rWa = make_rsrc(w6a, w6a_bytes), rWb = make_rsrc(w6b, w6a_bytes / 2), rWd = make_rsrc(wd, wd_bytes);
@@ -303,12 +308,12 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
     const int m0c = m0, n0c = n0;
     tile += (int)gridDim.x;
     if (tile < nwg) {                                       // the next tile's first operands travel while this one is reduced and stored
-        tile_origin(tile, tiles_m, tiles_n, m0, n0);
+        tile_origin<WMT>(tile, tiles_m, tiles_n, m0, n0);
         set_offsets(m0, n0);
         load_w(wl, kb0);
         load_a(af, kb0);
     }
-    reduce_and_store(acc, smem, dst, M, N, ldd, m0c, n0c, wave, lane, ep);
+    reduce_and_store<WMT>(acc, smem, dst, M, N, ldd, m0c, n0c, wave, lane, ep);
     if (tile >= nwg) break;
   }
     K3P_STAMP(5);
@@ -333,15 +338,17 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 // 85.5 us where this one takes 77 at 4096 x 11008 x 512.)
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
-struct WI8 { i32x4 q[WMT]; float d[WMT]; };
+template <int WM> struct WI8T { i32x4 q[WM]; float d[WM]; };
 
-template <int TYPE, bool M3 = false, bool SLICED = false>
+template <int TYPE, bool M3 = false, bool SLICED = false, int WM = 4>
 __global__ __launch_bounds__(KS * 64, 2)
 void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8,
                         const float *__restrict__ ad, float *__restrict__ dst, int M, int N, int Mpad, int Npad,
                         int nbk, int nloc, int ldd, int tiles_m, int tiles_n, uint32_t w_bytes, uint32_t a_bytes, const mm_epilogue ep,
                         const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3, int ch_arg) {
     const int ch = SLICED ? ch_arg : nloc;
+    constexpr int WMT = WM;                                  // (r5: the wave tile's height is a parameter here -- 4 or 2 m-tiles; shadows the file's default)
+    using WI8 = WI8T<WMT>;
     constexpr bool MIN = TYPE == GGML_TYPE_Q5_1, MINP = MIN;   // (Q4_1 runs this instantiation: its int8 planes hold 0..15)
 #ifndef K3P_DA_INPLACE
 #define K3P_DA_INPLACE (MIN || SLICED)   // (the sliced forms: their extra live state took the scale look-ahead registers to scratch -- Q8_0 4096 x 28672 x 512 197 us)
@@ -355,7 +362,7 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const int nwg = tiles_m * tiles_n;                      // (persistent workgroups: see the MX kernel)
     int tile = blockIdx.x;
     int m0, n0;
-    tile_origin(tile, tiles_m, tiles_n, m0, n0);
+    tile_origin<WMT>(tile, tiles_m, tiles_n, m0, n0);
     const int kb0 = wave * nloc;
 
     const rsrc_t rW = make_rsrc(qs, w_bytes), rD = make_rsrc(wd, w_bytes / 8), rA = make_rsrc(a8, a_bytes);
@@ -573,11 +580,11 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const int m0c = m0, n0c = n0;
     tile += (int)gridDim.x;
     if (tile < nwg) {                                       // the next tile's first operands travel while this one is reduced and stored
-        tile_origin(tile, tiles_m, tiles_n, m0, n0);
+        tile_origin<WMT>(tile, tiles_m, tiles_n, m0, n0);
         set_offsets(m0, n0);
         load_first();
     }
-    reduce_and_store(acc, smem, dst, M, N, ldd, m0c, n0c, wave, lane, ep);
+    reduce_and_store<WMT>(acc, smem, dst, M, N, ldd, m0c, n0c, wave, lane, ep);
     if (tile >= nwg) break;
   }
     K3P_STAMP(5);
@@ -615,8 +622,9 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (nloc < 8 || (nloc & 1) || KS * nloc < nbkp) return hipErrorInvalidValue;
     if ((uint64_t)(KS * nloc + 2) * 2 * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 2 * (uint64_t)p.Npad * 16 > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
-    const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
+    const int wmt = pl.tile_m / 32;                         // (r5: 128-row wave tiles, or 64-row ones where those leave CUs idle: plan_k3p_i8 -- the same tree)
+    if ((wmt != 4 && wmt != 2) || w->Mpad % (32 * wmt) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
+    const int tiles_m = (int)((w->M + 32 * wmt - 1) / (32 * wmt)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
     // (K > 20480: table slices of `ch` k-blocks per wave, + one row behind the last slice for the loop's look-ahead of the next row's scales)
     const bool sliced = nloc > K3P_TABLE_ROWS;
     const int nch = (nloc + K3P_SLICE_ROWS - 1) / K3P_SLICE_ROWS, ch = sliced ? ((nloc + nch - 1) / nch + 1) & ~1 : nloc;
@@ -624,7 +632,8 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
     const size_t lds = tab > xch ? tab : xch;
     if (lds > 160 * 1024 || ch > nloc) return hipErrorInvalidValue;
     (void)hipGetLastError();
-#define Q8MID_GO(...) do { if (sliced) Q8MID_GO1(__VA_ARGS__, true); else Q8MID_GO1(__VA_ARGS__, false); } while (0)
+#define Q8MID_GO(...) do { if (wmt == 2) { if (sliced) Q8MID_GO1(__VA_ARGS__, true, 2); else Q8MID_GO1(__VA_ARGS__, false, 2); } \
+                           else { if (sliced) Q8MID_GO1(__VA_ARGS__, true, 4); else Q8MID_GO1(__VA_ARGS__, false, 4); } } while (0)
 #define Q8MID_GO1(...) do { \
         auto kern = gemm_q8_mid_kernel<__VA_ARGS__>; \
         static PerDeviceOnce once; \
@@ -653,16 +662,17 @@ hipError_t launch_gemm_qmx_mid(const ggml_hip_weight *w, const mm_plan &pl, act_
     const uint64_t a_bytes = nba * 48 * (uint64_t)p.Npad;
     // (32-bit buffer offsets, the look-ahead past a wave's range included)
     if ((uint64_t)(KS * nloc + 2) * (uint64_t)w->Mpad * 16 > 0xFFFFFFFFull || (uint64_t)(KS * nloc + 2) * 48 * (uint64_t)p.Npad > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    if (w->Mpad % (32 * WMT) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
-    const int tiles_m = (int)((w->M + 32 * WMT - 1) / (32 * WMT)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
+    const int wmt = pl.tile_m / 32;                         // (r5: 128-row wave tiles, or 64-row ones where those leave CUs idle: plan_k3p_mx -- the same tree)
+    if ((wmt != 4 && wmt != 2) || w->Mpad % (32 * wmt) != 0 || p.Npad % (32 * WNT) != 0) return hipErrorInvalidValue;
+    const int tiles_m = (int)((w->M + 32 * wmt - 1) / (32 * wmt)), tiles_n = (int)((N + 32 * WNT - 1) / (32 * WNT));
     const bool sliced = nloc > K3P_TABLE_ROWS;
     const int nch = (nloc + K3P_TABLE_ROWS - 1) / K3P_TABLE_ROWS, ch = (nloc + nch - 1) / nch;
     const size_t tab = (size_t)KS * ch * (32 * WNT) * 4, xch = (size_t)KS * 4 * 16 * 64 * 4;
     const size_t lds = tab > xch ? tab : xch;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    auto kern = sliced ? gemm_qmx_mid_kernel<true> : gemm_qmx_mid_kernel<false>;
-    static PerDeviceOnce once[2];
-    const hipError_t attr = once[sliced].max_dynamic_lds((const void *)kern, 160 * 1024);
+    auto kern = wmt == 2 ? (sliced ? gemm_qmx_mid_kernel<true, 2> : gemm_qmx_mid_kernel<false, 2>) : (sliced ? gemm_qmx_mid_kernel<true, 4> : gemm_qmx_mid_kernel<false, 4>);
+    static PerDeviceOnce once[4];
+    const hipError_t attr = once[(wmt == 2 ? 2 : 0) + (sliced ? 1 : 0)].max_dynamic_lds((const void *)kern, 160 * 1024);
     if (attr != hipSuccess) return attr;
     (void)hipGetLastError();
     kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(w->q6a, w->q6b, w->d, (const uint8_t *)p.a8, p.ad, dst, (int)w->M, (int)N,

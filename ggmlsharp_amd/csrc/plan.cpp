@@ -205,6 +205,14 @@ bool plan_k3p_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
     p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
     p.wgs = cdiv(M, 128) * cdiv(N, 64);
+    // r5: 64-row wave tiles (two m-tiles instead of four) where the 128-row tiles leave half of the chip idle -- 4096 rows at 129..256 src1 rows are
+    // 96..128 workgroups on 256 CUs.  GEOMETRY ONLY: the same eight K ranges, block order, statement and wave-order sum per element, so the choice
+    // may look at M (gemm_qmp.hip gemm_q8_mid_kernel<..., WM = 2>).
+    static const int k3p_wmt = dev_env_int("GGML_HIP_K3P_WMT", 0);   // developer A/B switch: 2 / 4 = that wave tile whatever the grid
+    const int64_t wg64 = cdiv(M, 64) * cdiv(N, 64);
+    if (k3p_wmt == 2 || (k3p_wmt == 0 && wg64 <= 256)) {
+        p.wmt = 2; p.tile_m = 64; p.tiles_per_wave = 4; p.wgs = wg64;
+    }
     p.flags |= MM_FLAG_EPILOGUE_FUSED;
     return true;
 }
@@ -217,6 +225,13 @@ bool plan_k3p_mx(mm_plan &p, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
     p.arith = 310; p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
     p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
     p.wgs = cdiv(M, 128) * cdiv(N, 64);
+    // r5: 64-row wave tiles where the 128-row tiles leave half of the chip idle (2048 rows at 512 src1 rows are 128 workgroups) -- geometry only, as in
+    // plan_k3p_i8 (same switch)
+    static const int k3p_wmt = dev_env_int("GGML_HIP_K3P_WMT", 0);
+    const int64_t wg64 = cdiv(M, 64) * cdiv(N, 64);
+    if (k3p_wmt == 2 || (k3p_wmt == 0 && wg64 <= 256)) {
+        p.wmt = 2; p.tile_m = 64; p.tiles_per_wave = 4; p.wgs = wg64;
+    }
     p.flags |= MM_FLAG_EPILOGUE_FUSED;
     return true;
 }

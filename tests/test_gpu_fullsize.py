@@ -399,6 +399,33 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     W.free()
 
 
+@pytest.mark.parametrize("t,N,K", [(Q8_0, 192, 4096), (Q5_0, 129, 4096), (7, 256, 4096), (3, 300, 2048), (Q8_0, 512, 11008), (7, 200, 22016), (Q5_0, 160, 2048 + 64),
+                                   (Q4_0, 512, 4096), (Q4_0, 257, 2048 + 64), (Q4_0, 400, 22016)])
+def test_k3p_64_row_wave_tiles_are_bitwise_the_128_row_form(dev, t, N, K):
+    """r5: K3p (both kernels: MX for Q4_0, int8 for the others) runs 64-row wave tiles (two m-tiles per wave) where a grid of 128-row tiles leaves CUs idle -- 4096 rows at 129..256
+    src1 rows were 96..128 workgroups.  Geometry on K3p's tree (the same eight K ranges, block order, statement, wave-order sum; the min-term
+    chunks go to the same waves): an 8192-row matrix (128-row tiles) and its shards of 4096 / 2048 / ragged rows (64-row tiles) agree bit for
+    bit; the plan's tree_id is one; fp64 and the oracle sample hold for the 64-row form.  One scale table and sliced ones (K = 22016)."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    M = 8192 if N <= 256 else 16384
+    pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 2048, K, N, C.byref(pb)) == 0
+    assert pa.family == pb.family and pa.family in (5, 6) and pa.tree_id == pb.tree_id and (pa.tile_m, pb.tile_m) == (128, 64), (pa.family, pa.tile_m, pb.tile_m)
+    rows, x, w = _make(dev, t, M, K, N, seed=K + N + t, keep_w=True)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((0, 2048), (2048, 2048 + 4096 if N <= 256 else 2048 + 2000), (M - 1000, M), (777, 777 + 333)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        part = dev.mul_mat(Ws, x)
+        assert torch.equal(part, full[:, r0:r1]), (t, N, K, r0, r1)
+        if r0 == 0:
+            _check_fp64(dev, t, rows[r0:r1], x, part, K)
+            _check_oracle_sample(t, rows[r0:r1], w[r0:r1], x, part, K, seed=K + N)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("t", [Q4_0, 3, Q5_0, 7, Q8_0])
 @pytest.mark.parametrize("K", [20512, 28672, 60000 // 32 * 32])
 def test_k3p_beyond_one_scale_table_slices_refill_inside_the_K_loop(dev, t, K):

@@ -151,6 +151,11 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
         assert plan(t, 4112, 4096, 32).tile_m == 32                                                   # (more than one round of 16-row tiles: the 32-row form)
     assert plan(Q5_1, 4096, 4096, 32).tile_m == 32 and plan(Q5_K, 4096, 4096, 32).tile_m == 32          # (the bf16-piece min term is not exact: it keeps the 32-row form's MFMA shape)
     assert plan(Q6_K, 4096, 4096, 32).tile_m == 16 and plan(Q6_K, 4096, 4096, 5).tile_m == 16              # (Q6_K lives in Q4_2's form)
+    # r5: K3p (both kernels) on 64-row wave tiles where a grid of 128-row tiles leaves CUs idle (<= 256 workgroups of 64 rows): the tree of the 128-row form
+    for t, N in ((Q8_0, 192), (Q5_0, 129), (Q5_1, 256), (Q4_1, 300), (Q4_0, 512), (Q5_K, 256)):
+        a, b = plan(t, 2048, 4096, N), plan(t, 16384, 4096, N)
+        assert (a.tile_m, b.tile_m) == (64, 128) and a.tree_id == b.tree_id and a.family == b.family and a.family in (FAM["k3p_mx"], FAM["k3p_i8"]), (t, N)
+    assert plan(Q8_0, 4096, 4096, 256).tile_m == 64 and plan(Q8_0, 4096, 4096, 257).tile_m == 128       # (256 workgroups of 64 rows fit one round, 320 do not)
     # and trees DO differ where they should: across N classes and across types
     assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_0, 4096, 4096, 513).tree_id
     assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_1, 4096, 4096, 512).tree_id
