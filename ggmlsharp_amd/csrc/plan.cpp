@@ -209,8 +209,15 @@ bool plan_k3p_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // 96..128 workgroups on 256 CUs.  GEOMETRY ONLY: the same eight K ranges, block order, statement and wave-order sum per element, so the choice
     // may look at M (gemm_qmp.hip gemm_q8_mid_kernel<..., WM = 2>).
     static const int k3p_wmt = dev_env_int("GGML_HIP_K3P_WMT", 0);   // developer A/B switch: 2 / 4 = that wave tile whatever the grid
-    const int64_t wg64 = cdiv(M, 64) * cdiv(N, 64);
-    if (k3p_wmt == 2 || (k3p_wmt == 0 && wg64 <= 256)) {
+    const int64_t wg64 = cdiv(M, 64) * cdiv(N, 64), wg128 = p.wgs;
+    // ... and on grids of a fractional number of rounds: a launch takes as long as its fullest CU, i.e. ceil(workgroups / 256) rounds (the hardware
+    // hands a free CU the next workgroup; from four rounds on the kernel deals the tiles itself), and a 64-row workgroup costs 0.545 of a 128-row one
+    // (config 4 forced onto 64-row tiles: 64.1 -> 69.7 us for exactly two rounds).  So 258 workgroups of 128 rows -- two rounds for two tiles -- are
+    // three rounds of half the size.  Measured, 128 | 64 rows, us: Q8_0 11008 x 4096 x 192 (258 | 516 workgroups) 49.3 | 42.3, x 256 (344 | 688) 52.1 | 45.8,
+    // x 384 (516 | 1032) 77.2 | 68.2, 5504 x 4096 x 512 48.8 | 43.3, 9000 x 4096 x 256 51.2 | 45.2; and where the model says no: 8192 x 8192 x 192 (192 | 384)
+    // 45.8 | 53.1, 14336 x 4096 x 256 (448 | 896) 55.4 | 61.0 (tools/experiments/ab_k3p_wmt_frac.sh).  7 % of margin; the contract configs keep 128 rows.
+    const double r128 = (double)cdiv(wg128, 256), r64 = (double)cdiv(wg64, 256) * 0.545;
+    if (k3p_wmt == 2 || (k3p_wmt == 0 && (wg64 <= 256 || r64 <= 0.93 * r128))) {
         p.wmt = 2; p.tile_m = 64; p.tiles_per_wave = 4; p.wgs = wg64;
     }
     p.flags |= MM_FLAG_EPILOGUE_FUSED;
@@ -226,7 +233,8 @@ bool plan_k3p_mx(mm_plan &p, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
     p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
     p.wgs = cdiv(M, 128) * cdiv(N, 64);
     // r5: 64-row wave tiles where the 128-row tiles leave half of the chip idle (2048 rows at 512 src1 rows are 128 workgroups) -- geometry only, as in
-    // plan_k3p_i8 (same switch)
+    // plan_k3p_i8 (same switch).  One round only: a 64-row workgroup of the MX kernel costs 0.63 of a 128-row one (Q4_0 11008 x 4096 x 320, 430 | 860
+    // workgroups: 50.8 | 64.4 us), too much for the fractional-round rule of the int8 kernel to pay.
     static const int k3p_wmt = dev_env_int("GGML_HIP_K3P_WMT", 0);
     const int64_t wg64 = cdiv(M, 64) * cdiv(N, 64);
     if (k3p_wmt == 2 || (k3p_wmt == 0 && wg64 <= 256)) {

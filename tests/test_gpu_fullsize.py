@@ -408,14 +408,17 @@ def test_k3p_64_row_wave_tiles_are_bitwise_the_128_row_form(dev, t, N, K):
     bit; the plan's tree_id is one; fp64 and the oracle sample hold for the 64-row form.  One scale table and sliced ones (K = 22016)."""
     from ggmlsharp_amd import _lib
     import ctypes as C
-    M = 8192 if N <= 256 else 16384
     pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
-    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 2048, K, N, C.byref(pb)) == 0
+    for M in (8192, 12288, 16384, 32768):                    # the smallest matrix of the list whose grid the plan gives 128-row tiles
+        assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0
+        if pa.tile_m == 128:
+            break
+    assert _lib.lib().ggml_hip_mm_plan(t, 2048, K, N, C.byref(pb)) == 0
     assert pa.family == pb.family and pa.family in (5, 6) and pa.tree_id == pb.tree_id and (pa.tile_m, pb.tile_m) == (128, 64), (pa.family, pa.tile_m, pb.tile_m)
     rows, x, w = _make(dev, t, M, K, N, seed=K + N + t, keep_w=True)
     W = dev.Weight.from_device(t, rows, K)
     full = dev.mul_mat(W, x)
-    for (r0, r1) in ((0, 2048), (2048, 2048 + 4096 if N <= 256 else 2048 + 2000), (M - 1000, M), (777, 777 + 333)):
+    for (r0, r1) in ((0, 2048), (2048, 2048 + 2000), (M - 1000, M), (777, 777 + 333)):
         Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
         part = dev.mul_mat(Ws, x)
         assert torch.equal(part, full[:, r0:r1]), (t, N, K, r0, r1)

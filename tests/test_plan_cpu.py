@@ -153,9 +153,15 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     assert plan(Q6_K, 4096, 4096, 32).tile_m == 16 and plan(Q6_K, 4096, 4096, 5).tile_m == 16              # (Q6_K lives in Q4_2's form)
     # r5: K3p (both kernels) on 64-row wave tiles where a grid of 128-row tiles leaves CUs idle (<= 256 workgroups of 64 rows): the tree of the 128-row form
     for t, N in ((Q8_0, 192), (Q5_0, 129), (Q5_1, 256), (Q4_1, 300), (Q4_0, 512), (Q5_K, 256)):
-        a, b = plan(t, 2048, 4096, N), plan(t, 16384, 4096, N)
+        a, b = plan(t, 2048, 4096, N), plan(t, 32768, 4096, N)
         assert (a.tile_m, b.tile_m) == (64, 128) and a.tree_id == b.tree_id and a.family == b.family and a.family in (FAM["k3p_mx"], FAM["k3p_i8"]), (t, N)
     assert plan(Q8_0, 4096, 4096, 256).tile_m == 64 and plan(Q8_0, 4096, 4096, 257).tile_m == 128       # (256 workgroups of 64 rows fit one round, 320 do not)
+    # ... and, int8 kernel, on grids of a fractional number of rounds: 258 workgroups of 128 rows (two rounds for two tiles) run as 516 of 64 (three half-size rounds)
+    assert plan(Q8_0, 11008, 4096, 192).tile_m == 64 and plan(Q8_0, 11008, 4096, 256).tile_m == 64 and plan(Q8_0, 8192, 8192, 192).tile_m == 128
+    assert plan(Q8_0, 14336, 4096, 256).tile_m == 128 and plan(Q4_0, 11008, 4096, 320).tile_m == 128                                 # (the MX kernel: one round only)
+    for t, M in ((Q4_0, 4096), (Q4_0, 4000), (Q4_0, 32000), (Q8_0, 4096), (Q5_0, 4096), (Q5_K, 4096)):                              # the contract configs keep their 128-row tiles
+        assert plan(t, M, 4096 if t == Q4_0 else 11008, 512).tile_m == 128, (t, M)
+    assert plan(Q8_0, 11008, 4096, 512).tile_m == 128
     # and trees DO differ where they should: across N classes and across types
     assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_0, 4096, 4096, 513).tree_id
     assert plan(Q4_0, 4096, 4096, 512).tree_id != plan(Q4_1, 4096, 4096, 512).tree_id
