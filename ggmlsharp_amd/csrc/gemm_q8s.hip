@@ -521,7 +521,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
         return hipGetLastError();
     }
     const int ntw = (int)((w->M + 32 * wmt - 1) / (32 * wmt));
-    const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;   // (table rows: whole rounds of the form's slots)
+    const int nb = wmt == 4 ? 4 : wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;   // (table rows: whole rounds of the form's slots)
     const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
     const int lds = tab > xch ? tab : xch;
     dim3 grid((unsigned)(ntw * ncol));
@@ -536,7 +536,12 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
 #define Q8S_GO(NB, ROT, WMT) do { if (q42) Q8S_GO1(NB, ROT, WMT, 4); else if (q5k) Q8S_GO1(NB, ROT, WMT, 3); else if (q51) Q8S_GO1(NB, ROT, WMT, 2); else if (q5) Q8S_GO1(NB, ROT, WMT, 1); else Q8S_GO1(NB, ROT, WMT, 0); } while (0)
     // one tile per workgroup: a wave's range in 8 / 16 slots, longer K in rounds of 16; two tiles (more than 256 tile groups): 8 slots,
     // in rounds beyond K = 2048
-    if (wmt == 2) { if (nloc <= 8) Q8S_GO(8, false, 2); else Q8S_GO(8, true, 2); }
+    if (wmt == 4) {                                         // (r5: four tiles per workgroup, more than 512 tile groups -- Q8_0 / Q5_0: four slots in turn)
+        if (q42 || q51) return hipErrorInvalidValue;
+        if (q5) { if (nloc <= 4) Q8S_GO1(4, false, 4, 1); else Q8S_GO1(4, true, 4, 1); }
+        else { if (nloc <= 4) Q8S_GO1(4, false, 4, 0); else Q8S_GO1(4, true, 4, 0); }
+    }
+    else if (wmt == 2) { if (nloc <= 8) Q8S_GO(8, false, 2); else Q8S_GO(8, true, 2); }
     else if (nloc <= 8) Q8S_GO(8, false, 1);
     else if (nloc <= 16) Q8S_GO(16, false, 1);
     else Q8S_GO(16, true, 1);

@@ -162,10 +162,13 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     if ((uint64_t)nbkp * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)nbkp * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
     static const int geo = dev_env_int("GGML_HIP_Q8S_TILES", 0);   // developer A/B switch: 1 / 2 tiles per workgroup whatever M
     const int64_t t32 = cdiv(M, 32) * ncol;
-    const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : t32 <= 256 ? 1 : 2;
+    // (r5: four tiles per workgroup beyond 512 tile groups for Q8_0 / Q5_0, as the MX form has for Q4_0 -- 11008 x 4096 x 64 is 688 tile groups: 344
+    // workgroups of two tiles ran a second, 34 %-full round (24.2 us where Q4_0's 172 workgroups of four took 17.0); the min-term and two-scale types keep two)
+    const bool four_ok = (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && nloc <= 128;
+    const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : geo == 4 && four_ok ? 4 : t32 <= 256 ? 1 : (t32 <= 512 || !four_ok) ? 2 : 4;
     p.family = MMF_K3S_I8; p.image = 0;
     if (type == GGML_TYPE_Q5_1) p.flags |= MM_FLAG_MIN_PIECES;
-    p.form = wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
+    p.form = wmt == 4 ? 7 : wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
     p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : type == GGML_TYPE_Q5_1 ? 2 : type == GGML_TYPE_Q4_2 ? 3 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
     p.nloc = nloc; p.wmt = wmt;
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;

@@ -140,7 +140,9 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     a, b = plan(Q4_0, 512, 4096, 4096), plan(Q4_0, 4096, 4096, 4096)          # a row shard of the headline: 64 x 64 tiles, the whole: 256 x 128
     assert (a.tile_m, a.tile_n, b.tile_m, b.tile_n) == (64, 64, 256, 128) and a.tree_id == b.tree_id
     a, b, c = plan(Q8_0, 4096, 4096, 32), plan(Q8_0, 32000, 4096, 32), plan(Q8_0, 8192, 4096, 32)   # K3s on the int8 cores: r5 16-row tiles while they fit one round of the chip, else one / two 32-row tiles per workgroup
-    assert (a.tile_m, a.tile_n, a.workgroups, b.tile_m, c.tile_m) == (16, 32, 256, 64, 32) and a.tree_id == b.tree_id == c.tree_id
+    d = plan(Q8_0, 12000, 4096, 32)                                                                  # (r5: four 32-row tiles beyond 512 tile groups, two up to there)
+    assert (a.tile_m, a.tile_n, a.workgroups, b.tile_m, c.tile_m, d.tile_m) == (16, 32, 256, 128, 32, 64) and a.tree_id == b.tree_id == c.tree_id == d.tree_id
+    assert plan(Q5_1, 32000, 4096, 32).tile_m == 64 and plan(Q4_2, 32000, 4096, 32).tile_m == 64         # (the min-term and two-scale types: two at most)
     # r5: the batched-decode forms on 16-row tiles (Q4_0 on the MX cores, Q8_0 / Q5_0 on the int8 cores): 16 / 32 / 64 columns per workgroup by N,
     # the tree of the 32-row form; the min-term and two-scale types keep 32 rows
     for t in (Q4_0, Q4_1, Q8_0, Q5_0, Q4_2):
