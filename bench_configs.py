@@ -315,6 +315,9 @@ def single_gpu_side_configs(device):
         "q6_k_batch1_unpinned_extra": side_config(device, 4096, 4096, 1, copies=32, iters=100, qtype=B.Q6_K),    #     ... and its decode step (its own mat-vec on the int8 planes, the Q8_K rule fused)
         "q5_k_batch1_unpinned_extra": side_config(device, 4096, 4096, 1, copies=32, iters=100, qtype=B.Q5_K),    # (r4: the k-quants' fused mat-vec -- the Q8_K rule inside the kernel)
         "q5_0_batch32": side_config(device, 4096, 4096, 32, copies=32, iters=100, qtype=B.Q5_0),
+        # r5: prompt chunks whose grid of 128-row K3p tiles left CUs idle -- 64-row wave tiles on K3p's tree
+        "q8_0_prompt192": side_config(device, 4096, 4096, 192, copies=16, iters=60, qtype=B.Q8_0),
+        "q8_0_ffn_down256": side_config(device, 4096, 11008, 256, copies=6, iters=60, qtype=B.Q8_0),
         "vocab512": side_config(device, 32000, 4096, 512, copies=3, iters=30),
         "vocab512_shard_of_8": side_config(device, 4000, 4096, 512, copies=24, iters=100),      # what each rank of config 5's 8-GPU split computes
         # the dense case of the path (north_star: MFMA utilisation for the dense f16 / f32 mul_mat)
