@@ -63,7 +63,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool 
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (257..1024), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (129..1024; r5: it was 257), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
 // r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
 // one round of the chip (A/B in one gpurun call, staged | K3p): Q8_0 4096 x 11008 x 1024 165 | 131 us, x 2048 320 | 257, 8192 x 8192 x 1024
@@ -81,7 +81,10 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // 8192 x 8192 x 192 (Q5_0) 61.0 | 44.1, Q5_1 11008 x 4096 x 192 70.6 | 52.9; 4096 x 4096 x 129 / 192 / 256 20.0 | 23.0, 22.1 | 24.1, 23.7 | 24.6 (the price),
     // 4096 x 11008 x 192 / 256 48.9 | 51.2, 55.4 | 52.1.  Q4_1 keeps 257: its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6).
     static const int nmin_dev = dev_env_int("GGML_HIP_K3P_NMIN", 0);   // developer A/B switch
-    const int64_t nmin = nmin_dev > 0 ? nmin_dev : type == GGML_TYPE_Q4_1 ? 257 : 129;
+    // (r5: Q4_1 from 129 too -- it kept 257 because its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6 us then); with K3p's 64-row wave tiles
+    // and GPU-side timing, staged | K3p: 4096 x 4096 x 129 / 192 / 256 25.0 | 18.4, 24.8 | 18.4, 25.6 | 19.2, 4096 x 11008 x 192 59.3 | 40.4, 11008 x 4096 x 192 / 256 62.9 | 48.0,
+    // 71.3 | 52.5, 32000 x 4096 x 192 139 | 95.5, 8192 x 8192 x 160 78.0 | 51.4)
+    const int64_t nmin = nmin_dev > 0 ? nmin_dev : 129;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }

@@ -118,7 +118,7 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q4_1, 4096, 4096, 1024).family == FAM["k3p_i8"] and plan(Q4_1, 4096, 4096, 1025).family == FAM["mx"]
     assert plan(Q4_0, 4096, 4096, 513).family == FAM["mx"]
     assert plan(Q8_0, 4096, 4096, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 4096, 128).family != FAM["k3p_i8"]   # (from 129 rows: Q8_0 / Q5_0 / Q5_1)
-    assert plan(Q4_1, 4096, 4096, 256).family == FAM["mx"] and plan(Q4_1, 4096, 4096, 257).family == FAM["k3p_i8"]      # (Q4_1: from 257)
+    assert plan(Q4_1, 4096, 4096, 128).family == FAM["k3s_mx"] and plan(Q4_1, 4096, 4096, 129).family == FAM["k3p_i8"]  # (r5: Q4_1 from 129 too; it was 257)
     assert plan(Q5_1, 4096, 4096, 4096).family == FAM["k3p_i8"] and plan(Q5_K, 4096, 11008, 8192).family == FAM["k3p_i8"]   # (Q5_1 / Q5_K: no upper bound)
     # r4: K > 19968 -- the eight scale tables no longer fit LDS whole: K3p refills them in slices (up to four: K <= 79872), beyond that the staged forms
     assert plan(Q8_0, 4096, 22016, 512).family == FAM["k3p_i8"] and plan(Q4_0, 4096, 28672, 512).family == FAM["k3p_mx"]
