@@ -79,6 +79,28 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
         const bool ok = b < nloc && kb0 + b < nbk;
         td[j] = ok ? *(const f32x4 *)(ad + (size_t)(kb0 + b) * Npad + n0 + 4 * c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
+    // (min-term types) the wave's FIRST chunk of min-term pieces is requested here, in front of the blocks' loads: loads return in order, so the
+    // chunk's wait below is then for the chunk alone (r5: issued behind the blocks it waited for all of them, and every further chunk exposed a
+    // memory round trip with nothing else in flight -- Q5_1 4096 x 11008 x 16 29.4 us where Q5_0 took 13.6)
+    using f32x16m = __attribute__((ext_vector_type(16))) float;
+    using bf16x8m = __attribute__((ext_vector_type(8))) __bf16;
+    constexpr int MP = MINT ? MINT : 1;
+    const int nchunks = (nbk + 15) / 16;
+    const __amdgpu_buffer_rsrc_t rMP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(MINT ? mp3 : qs), 0, MINT ? (int)((uint32_t)(nchunks * 6) * (uint32_t)Mpad * 16u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(MINT ? sp3 : qs), 0, MINT ? (int)((uint32_t)(nchunks * 6) * (uint32_t)Npad * 16u) : 0, 0x00020000);
+    const uint32_t vM = (uint32_t)((3 * hh) * Mpad + m0 + l31) * 16u, vS = (uint32_t)((3 * hh) * Npad + n0 + l31) * 16u;
+    auto chunk_load = [&](int c, i32x4 (&sa_)[3], i32x4 (&mb_)[WMT][MP]) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            if (pc < MINT)
+#pragma unroll
+                for (int t = 0; t < WMT; ++t)
+                    mb_[t][pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rMP, (int)(vM + 512u * t), (int)((uint32_t)(6 * c + pc) * (uint32_t)Mpad * 16u), 0));
+            sa_[pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rSP, (int)vS, (int)((uint32_t)(6 * c + pc) * (uint32_t)Npad * 16u), 0));
+        }
+    };
+    i32x4 sa0[3], mb0[WMT][MP];
+    if constexpr (MINT) { if (wave < nchunks) chunk_load(wave, sa0, mb0); }
     static_for<NB>([&](auto uc) { constexpr int u = decltype(uc)::value; load_blk(wb[u], ab[u], u); });
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -113,35 +135,35 @@ void gemm_q8_small_body(const uint8_t *__restrict__ qs, const float *__restrict_
     // (ggml_hip_weight::mp3 from the upload, act_planes::sp3 = d1 * (float)sum(a) from K1), a Q5_1 min is an f16 value (two pieces, five
     // products); chunk c (k-blocks 16c .. 16c + 15, k-group 2c + lane half) is wave c % KS's, by K alone.
     if constexpr (MINT) {
-        using f32x16 = __attribute__((ext_vector_type(16))) float;
-        using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-        const int nchunks = (nbk + 15) / 16;
-        const __amdgpu_buffer_rsrc_t rMP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mp3), 0, (int)((uint32_t)(nchunks * 6) * (uint32_t)Mpad * 16u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sp3), 0, (int)((uint32_t)(nchunks * 6) * (uint32_t)Npad * 16u), 0x00020000);
-        const uint32_t vM = (uint32_t)((3 * hh) * Mpad + m0 + l31) * 16u, vS = (uint32_t)((3 * hh) * Npad + n0 + l31) * 16u;
-        for (int c = wave; c < nchunks; c += KS) {
-            i32x4 sa[3], mb[WMT][MINT ? MINT : 1];
+        // chunk c's products while chunk c + KS's pieces travel (two register sets, the second copied down): the ORDER of an element's additions is
+        // unchanged -- the wave's chunks in ascending order, six / five products each, smallest first, then its blocks
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first (activation piece x weight piece)
+        if (wave < nchunks) {
+            for (int c = wave;;) {
+                const int cn = c + KS;
+                i32x4 sa1[3], mb1[WMT][MP];
+                if (cn < nchunks) chunk_load(cn, sa1, mb1);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                if (pc < MINT)
+                for (int t = 0; t < WMT; ++t) {
+                    f32x16m a;
 #pragma unroll
-                    for (int t = 0; t < WMT; ++t)
-                        mb[t][pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rMP, (int)(vM + 512u * t), (int)((uint32_t)(6 * c + pc) * (uint32_t)Mpad * 16u), 0));
-                sa[pc] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rSP, (int)vS, (int)((uint32_t)(6 * c + pc) * (uint32_t)Npad * 16u), 0));
-            }
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first (activation piece x weight piece)
+                    for (int r = 0; r < 16; ++r) a[r] = acc[t][r];
+                    static_for<6>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (PB[k] < MINT)             // (a Q5_1 min is an f16 value: two pieces, five products; Q5_K's is an f32 product: three, six)
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8m, sa0[PA[k]]), __builtin_bit_cast(bf16x8m, mb0[t][PB[k]]), a, 0, 0, 0);
+                    });
 #pragma unroll
-            for (int t = 0; t < WMT; ++t) {
-                f32x16 a;
+                    for (int r = 0; r < 16; ++r) acc[t][r] = a[r];
+                }
+                if (cn >= nchunks) break;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = acc[t][r];
-                static_for<6>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    if constexpr (PB[k] < MINT)             // (a Q5_1 min is an f16 value: two pieces, five products; Q5_K's is an f32 product: three, six)
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sa[PA[k]]), __builtin_bit_cast(bf16x8, mb[t][PB[k]]), a, 0, 0, 0);
-                });
+                for (int pc = 0; pc < 3; ++pc) {
+                    sa0[pc] = sa1[pc];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = a[r];
+                    for (int t = 0; t < WMT; ++t) if (pc < MINT) mb0[t][pc] = mb1[t][pc];
+                }
+                c = cn;
             }
         }
     }
