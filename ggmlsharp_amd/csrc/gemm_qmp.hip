@@ -338,7 +338,7 @@ void gemm_qmx_mid_kernel(const uint8_t *__restrict__ w6a, const uint8_t *__restr
 // 85.5 us where this one takes 77 at 4096 x 11008 x 512.)
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x16 = __attribute__((ext_vector_type(16))) int;
-template <int WM> struct WI8T { i32x4 q[WM]; float d[WM]; };
+template <int WM, bool TWO = false> struct WI8T { i32x4 q[WM]; float d[WM]; float m[TWO ? WM : 1]; };   // (TWO: m = the scale of the k-block's second 16-element block)
 
 template <int TYPE, bool M3 = false, bool SLICED = false, int WM = 4>
 __global__ __launch_bounds__(KS * 64, 2)
@@ -348,10 +348,11 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
                         const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3, int ch_arg) {
     const int ch = SLICED ? ch_arg : nloc;
     constexpr int WMT = WM;                                  // (r5: the wave tile's height is a parameter here -- 4 or 2 m-tiles; shadows the file's default)
-    using WI8 = WI8T<WMT>;
+    constexpr bool TWO = TYPE == GGML_TYPE_Q4_2;            // (r5) two 16-element blocks per k-block, a scale each: Q4_2, and Q6_K in its planar form
+    using WI8 = WI8T<WMT, TWO>;
     constexpr bool MIN = TYPE == GGML_TYPE_Q5_1, MINP = MIN;   // (Q4_1 runs this instantiation: its int8 planes hold 0..15)
 #ifndef K3P_DA_INPLACE
-#define K3P_DA_INPLACE (MIN || SLICED)   // (the sliced forms: their extra live state took the scale look-ahead registers to scratch -- Q8_0 4096 x 28672 x 512 197 us)
+#define K3P_DA_INPLACE (MIN || SLICED || TWO)   // (the sliced forms: their extra live state took the scale look-ahead registers to scratch -- Q8_0 4096 x 28672 x 512 197 us)
 #endif
     constexpr bool DA_INPLACE = K3P_DA_INPLACE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -366,6 +367,7 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
     const int kb0 = wave * nloc;
 
     const rsrc_t rW = make_rsrc(qs, w_bytes), rD = make_rsrc(wd, w_bytes / 8), rA = make_rsrc(a8, a_bytes);
+    const rsrc_t rM2 = make_rsrc(TWO ? (const void *)mp3 : (const void *)wd, w_bytes / 8);   // (TWO: the second scales' plane rides in the mp3 argument)
     uint32_t offW, offD, offA;
     auto set_offsets = [&](int m0_, int n0_) {
         offW = (uint32_t)((hh * Mpad + m0_ + l31) * 16); offD = (uint32_t)((m0_ + l31) * 4); offA = (uint32_t)((hh * Npad + n0_ + l31) * 16);
@@ -377,6 +379,7 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
         for (int i = 0; i < WMT; ++i) {
             f.q[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(offW + 512u * i), (int)((uint32_t)kb * w_blk), 0));
             f.d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rD, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
+            if constexpr (TWO) f.m[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM2, (int)(offD + 128u * i), (int)((uint32_t)kb * d_blk), 0));
         }
     };
     float *const tabD = (float *)smem + (size_t)wave * ch * (32 * WNT);   // (`ch` k-blocks of the wave's range at a time: see the MX kernel)
@@ -553,11 +556,50 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
             }
         });
     };
+    // (r5) the two-scale types -- Q4_2 (Ggml.cs:1217-1252), and Q6_K in its planar form: a k-block is two 16-element blocks with a scale each.  Bytes 0..7
+    // of both operand planes are the first block's elements, bytes 8..15 the second's, so one v_mfma_i32_32x32x16_i8 per half gives the two integer sums
+    // apart; per element sumf += (d_lo * yd) * sumi_lo, then += (d_hi * yd) * sumi_hi -- the statement of the batched-decode form (gemm_q8s.hip).  The loop
+    // above with 2 x 8 steps per k-block: the product of step s + 1 is issued in front of step s's scale-accumulates.
+    auto half8 = [](const i32x4 &v, int h) -> long { return (long)(uint32_t)v[2 * h] | ((long)v[2 * h + 1] << 32); };
+    auto block2 = [&](int b, int tb, WI8 &w, WI8 &wn) {
+        if (wave >= KS / 2) { if (b & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        load_w(wn, kb0 + b + 1);
+        const float *dp = tabD + tb * (32 * WNT) + 4 * hh;
+        static_for<2 * WMT * WNT>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value, t = s / 2, h = s % 2, j = t / WMT, i = t % WMT;
+            if constexpr (s + 1 == 2 * WMT * WNT) {
+                constexpr int tp = (s - 1) / 2, jp = tp / WMT, ip = tp % WMT;
+                asm volatile("" : "+v"(wn.q[0]), "+v"(acc[ip][jp]));
+                x[0] = __builtin_amdgcn_mfma_i32_32x32x16_i8(half8(af[0], 0), half8(wn.q[0], 0), zero, 0, 0, 0);   // (the last block's: operands of the look-ahead, never used)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (s + 1 < 2 * WMT * WNT) {
+                constexpr int s1 = s + 1, t1 = s1 / 2, h1 = s1 % 2, j1 = t1 / WMT, i1 = t1 % WMT;
+                if constexpr (s >= 1) {
+                    constexpr int tp = (s - 1) / 2, jp = tp / WMT, ip = tp % WMT;
+                    asm volatile("" : "+v"(w.q[i1]), "+v"(acc[ip][jp]));
+                }
+                x[s1 & 1] = __builtin_amdgcn_mfma_i32_32x32x16_i8(half8(af[j1], h1), half8(w.q[i1], h1), zero, 0, 0, 0);
+                if constexpr (i1 == WMT - 1 && h1 == 1)
+                    af[j1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)(offA + 512u * j1), (int)((uint32_t)(kb0 + b + 1) * a_blk), 0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float sw = h ? w.m[TWO ? i : 0] : w.d[i];
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][4 * q + e] = __builtin_fmaf(sw * da[q][e], (float)x[s & 1][4 * q + e], acc[i][j][4 * q + e]);   // Ggml.cs:1217-1252
+                if constexpr (i == WMT - 1 && h == 1) da[q] = *(const f32x4 *)(dp + 32 * (j + 1) + 8 * q);
+            });
+        });
+    };
     K3P_STAMP(1);
 #ifdef K3P_TRACE
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
-    x[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], w0.q[0], zero, 0, 0, 0);
+    if constexpr (TWO) x[0] = __builtin_amdgcn_mfma_i32_32x32x16_i8(half8(af[0], 0), half8(w0.q[0], 0), zero, 0, 0, 0);
+    else x[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], w0.q[0], zero, 0, 0, 0);
     for (int b = 0, tb = 0; b < nloc; b += 2, tb += 2) {    // (the look-ahead of the last trip reads past the wave's range: never used)
         if (SLICED && tb == ch) {                           // (K beyond 19968: the next `ch` rows of every wave's table; `ch` is even.  The scales the last
             tb = 0;                                         // tile prefetched from the row behind the slice are replaced here)
@@ -568,8 +610,8 @@ void gemm_q8_mid_kernel(const uint8_t *__restrict__ qs, const float *__restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q) da[q] = *(const f32x4 *)(tabD + 4 * hh + 8 * q);
         }
-        block(b, SLICED ? tb : b, w0, w1);
-        block(b + 1, (SLICED ? tb : b) + 1, w1, w0);
+        if constexpr (TWO) { block2(b, SLICED ? tb : b, w0, w1); block2(b + 1, (SLICED ? tb : b) + 1, w1, w0); }
+        else { block(b, SLICED ? tb : b, w0, w1); block(b + 1, (SLICED ? tb : b) + 1, w1, w0); }
     }
 #ifdef K3P_TRACE
     asm volatile("" : "+v"(acc[0][0]));
@@ -612,8 +654,9 @@ static unsigned persistent_grid(int tiles) {
 
 hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_planes p, int64_t N, float *dst, int64_t ldd, hipStream_t st, const mm_epilogue &ep) {
     const bool with_min = w->type == GGML_TYPE_Q5_1 || w->type == GGML_TYPE_Q4_1;
-    const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : (w->type == GGML_TYPE_Q5_0 || with_min) ? w->i8p : nullptr;
-    if (pl.family != MMF_K3P_I8 || !planes || !w->d || (with_min && (!w->m || !w->mp3 || !p.sp3))) return hipErrorInvalidValue;
+    const bool two = w->type == GGML_TYPE_Q4_2;             // (and Q6_K in its planar form: int8 planes, the k-block's second scale in the m plane)
+    const uint8_t *planes = w->type == GGML_TYPE_Q8_0 ? w->qs : (w->type == GGML_TYPE_Q5_0 || with_min || two) ? w->i8p : nullptr;
+    if (pl.family != MMF_K3P_I8 || !planes || !w->d || (with_min && (!w->m || !w->mp3 || !p.sp3)) || (two && !w->m)) return hipErrorInvalidValue;
     if (ldd > 0x7FFFFFFF) return hipErrorNotSupported;     // (the kernel carries the row stride as an int: callers with an unfused form fall back)
     // applicability (at least 8 k-blocks per wave, the eight scale tables within 160 KB of LDS, every offset within 32 bits) and the
     // k-blocks per wave were decided by plan.cpp (plan_k3p_i8); the checks below only guard the kernel's assumptions
@@ -640,9 +683,10 @@ hipError_t launch_gemm_q8_mid(const ggml_hip_weight *w, const mm_plan &pl, act_p
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<dim3(persistent_grid(tiles_m * tiles_n)), KS * 64, lds, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, \
-                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep, w->mp3, p.sp3, ch); } while (0)
+                                                                        (int)w->nbk, nloc, (int)ldd, tiles_m, tiles_n, (uint32_t)wq_bytes, (uint32_t)aq_bytes, ep, two ? (const uint8_t *)w->m : w->mp3, p.sp3, ch); } while (0)
     // (Q4_1: the kernel of Q5_1 -- unsigned values 0..15 on the int8 planes, the same min term)
     if (w->type == GGML_TYPE_Q8_0) Q8MID_GO(GGML_TYPE_Q8_0, false); else if (w->type == GGML_TYPE_Q5_0) Q8MID_GO(GGML_TYPE_Q5_0, false);
+    else if (two) Q8MID_GO(GGML_TYPE_Q4_2, false);
     // (the min of a Q5_1 block is an f16 value: two bf16 pieces; Q4_1's is an f32, Q5_K's an f32 product: three)
     else if (w->ext_type != 0 || w->type == GGML_TYPE_Q4_1) Q8MID_GO(GGML_TYPE_Q5_1, true); else Q8MID_GO(GGML_TYPE_Q5_1, false);
 #undef Q8MID_GO

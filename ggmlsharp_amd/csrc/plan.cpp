@@ -29,7 +29,7 @@ int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return
 bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 2048 <= K <= 32768, from 5 (Q5_1 / Q4_2: 9) src1 rows up to 128
-// (the two-scale types: 256) -- the bounds are the constants below: the stage-free batched-decode form on the int8 matrix cores
+// (r4: the two-scale types 256; r5: 128 for them too) -- the bounds are the constants below: the stage-free batched-decode form on the int8 matrix cores
 // (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
@@ -49,7 +49,10 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool 
     // 4096 x 11008 x 128 / 192 122 | 39.4, 124 | 73.6, 11008 x 4096 x 128 / 192 58.6 | 51.1, 97.9 | 80.4; the price: 32000 x 4096 x 128 120 | 134).
     // The one-scale types keep 64: 4096 x 4096 x 128 19.0 | 11.6 and 4096 x 11008 x 128 43.0 | 26.7, but 11008 x 4096 x 128 32.4 | 41.9 and
     // 32000 x 4096 x 128 69 | 114 -- their staged K-split forms are good, and a choice by M would change the summation tree.
-    static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 256);  // developer A/B switch: the two-scale types' upper bound
+    // r5: K3p has a two-scale form (q8_mid_serves) and takes them from 129 rows like every other type -- this form | K3p: 4096 x 4096 x 129 / 192 / 256 27.1 | 19.9,
+    // 27.3 | 20.1, 27.4 | 20.9 us, 4096 x 11008 x 192 / 256 66.8 | 46.7, 67.4 | 50.2, 11008 x 4096 x 256 78.6 | 58.3, 32000 x 4096 x 192 166 | 136; the price:
+    // 11008 x 4096 x 129 52.6 | 56.6, 8192 x 8192 x 160 68.4 | 75.5, 2048 x 4096 x 256 14.8 | 19.9 (tools/experiments/ab_k3p_two_scale_129.sh).
+    static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 128);  // developer A/B switch: the two-scale types' upper bound (r4: 256)
     // ... except behind a LONG K (from 11008: a down projection's shape, more columns than rows in every model family looked at), where the
     // staged forms' K split is at its worst and M is small -- up to 128 rows there (staged | this form at 128 rows unless noted: 4096 x 11008
     // 43.0 | 26.7, 5120 x 13824 64.7 | 57.3, Q5_1 x 96 72.7 | 36.3, 8192 x 28672 151 | 120, Q5_0 132 | 119; the price is a square or tall matrix
@@ -63,7 +66,7 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool 
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
-// Q8_0 / Q5_0 (129..3072 rows), Q5_1 (129 rows and up) and Q4_1 (129..1024; r5: it was 257), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
+// Q8_0 / Q5_0 (129..3072 rows), Q5_1 and (r5) Q4_2 / Q6_K in its form (129 rows and up) and Q4_1 (129..1024; r5: it was 257), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
 // r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
 // one round of the chip (A/B in one gpurun call, staged | K3p): Q8_0 4096 x 11008 x 1024 165 | 131 us, x 2048 320 | 257, 8192 x 8192 x 1024
@@ -85,6 +88,14 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // and GPU-side timing, staged | K3p: 4096 x 4096 x 129 / 192 / 256 25.0 | 18.4, 24.8 | 18.4, 25.6 | 19.2, 4096 x 11008 x 192 59.3 | 40.4, 11008 x 4096 x 192 / 256 62.9 | 48.0,
     // 71.3 | 52.5, 32000 x 4096 x 192 139 | 95.5, 8192 x 8192 x 160 78.0 | 51.4)
     const int64_t nmin = nmin_dev > 0 ? nmin_dev : 129;
+    // (r5) the two-scale types -- Q4_2, and Q6_K in its form: gemm_q8_mid_kernel<Q4_2> (two K = 16 products and two scale-accumulates per tile and k-block)
+    // instead of the staged int8 kernel's stages -- staged | K3p: 4096 x 4096 x 512 / 1024 / 2048 / 4096 55.8 | 44.2, 111 | 87.9, 187 | 176, 390 | 348 us, 4096 x 11008 x 512
+    // 142 | 112, x 2048 486 | 442, 11008 x 4096 x 512 169 | 128, 32000 x 4096 x 512 401 | 348, Q6_K 4096 x 4096 x 512 54.5 | 44.8, 4096 x 11008 x 512 138 | 110
+    // (tools/experiments/ab_k3p_two_scale.sh): no upper bound, like Q5_1.  What is left of the factor 2 to the one-scale types is the format's (twice the
+    // conversions and scale-accumulates per weight).
+    static const int two_min = dev_env_int("GGML_HIP_K3P_2SC_NMIN", 129), two_max = dev_env_int("GGML_HIP_K3P_2SC_NMAX", 0);   // developer A/B switches (NMIN 100000: the staged kernel)
+    if (type == GGML_TYPE_Q4_2)
+        return N >= two_min && N <= (two_max > 0 ? two_max : INT64_MAX) && K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }
@@ -206,7 +217,7 @@ bool plan_k3p_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     if ((uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
     p.family = MMF_K3P_I8; p.image = 0; p.form = 0;
     // Q8_0: fma(sumi, d1 * d0); others: fma(d0 * sumi, d1); min types: + the min terms of 16 k-blocks as six bf16-piece MFMAs per tile
-    p.arith = 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0);
+    p.arith = 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0) + (type == GGML_TYPE_Q4_2 ? 4 : 0);   // (Q4_2 / Q6_K: two fma(d * yd, sumi) per k-block)
     if (min_type(type)) p.flags |= MM_FLAG_MIN_PIECES;
     p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
     p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;

@@ -19,7 +19,7 @@ enum mm_family {
     MMF_K3S_MX = 3,       // gemm_qmx.hip K3s: stage-free batched decode, MX
     MMF_K3S_I8 = 4,       // gemm_q8s.hip: the same on the int8 cores (Q8_0, Q5_0, Q5_1 / Q5_K, Q4_2 / Q6_K)
     MMF_K3P_MX = 5,       // gemm_qmp.hip K3p: prompt-sized batches, MX (Q4_0)
-    MMF_K3P_I8 = 6,       // gemm_qmp.hip K3p on the int8 cores (Q8_0, Q5_0, Q5_1, Q4_1)
+    MMF_K3P_I8 = 6,       // gemm_qmp.hip K3p on the int8 cores (Q8_0, Q5_0, Q5_1, Q4_1; r5: Q4_2 and Q6_K in its form)
     MMF_MX = 7,           // gemm_qmx.hip staged forms
     MMF_F16 = 8,          // gemm_q16.hip staged forms
     MMF_I8 = 9,           // gemm_q.hip staged forms

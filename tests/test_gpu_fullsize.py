@@ -242,7 +242,7 @@ def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     W.free()
 
 
-@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 64), (Q8_0, 24), (Q5_0, 64), (3, 32), (7, 48), (4, 200)])
+@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 64), (Q8_0, 24), (Q5_0, 64), (3, 32), (7, 48), (4, 100)])
 def test_every_batched_decode_geometry_computes_the_same_bits(dev, t, N):
     """the batched-decode forms pick their geometry from M -- 16-row tiles (r5), one, two or four 32-row tiles per workgroup -- and the
     CPU plan test can only see that the LABELS agree.  Here every geometry really runs: a 33000-row matrix (four tiles per workgroup for Q4_0, two
@@ -377,12 +377,13 @@ def test_min_term_types_tall_matrix_and_its_shards_add_in_one_order(dev, t, kern
         lib().ggml_hip_debug_force_gemm(0)
 
 
-@pytest.mark.parametrize("t", [Q4_0, 3, Q5_0, 7, Q8_0])
+@pytest.mark.parametrize("t", [Q4_0, 3, 4, Q5_0, 7, Q8_0])
 @pytest.mark.parametrize("N", [300, 512])
 def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     """257..512 src1 rows, K >= 2048 (gemm_qmp.hip): eight K ranges per workgroup whatever M -- a vocabulary-sized matrix (persistent
     workgroups: more than four rounds of tiles), a 4000-row shard (one dispatch round) and a ragged shard compute the same bits.
-    r4: Q5_1 (min term per pair of k-blocks on the matrix pipe) and Q4_1 run the form too."""
+    r4: Q5_1 (min term per pair of k-blocks on the matrix pipe) and Q4_1 run the form too; r5: Q4_2 (two K = 16 products and two
+    scale-accumulates per k-block)."""
     M, K = 26000, 2048
     g = torch.Generator(device="cuda")
     g.manual_seed(100 * t + N)
@@ -400,6 +401,7 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
 
 
 @pytest.mark.parametrize("t,N,K", [(Q8_0, 192, 4096), (Q5_0, 129, 4096), (7, 256, 4096), (3, 300, 2048), (Q8_0, 512, 11008), (7, 200, 22016), (Q5_0, 160, 2048 + 64),
+                                   (4, 129, 4096), (4, 512, 11008), (4, 200, 22016),
                                    (Q4_0, 512, 4096), (Q4_0, 257, 2048 + 64), (Q4_0, 400, 22016)])
 def test_k3p_64_row_wave_tiles_are_bitwise_the_128_row_form(dev, t, N, K):
     """r5: K3p (both kernels: MX for Q4_0, int8 for the others) runs 64-row wave tiles (two m-tiles per wave) where a grid of 128-row tiles leaves CUs idle -- 4096 rows at 129..256
@@ -429,7 +431,7 @@ def test_k3p_64_row_wave_tiles_are_bitwise_the_128_row_form(dev, t, N, K):
     W.free()
 
 
-@pytest.mark.parametrize("t", [Q4_0, 3, Q5_0, 7, Q8_0])
+@pytest.mark.parametrize("t", [Q4_0, 3, 4, Q5_0, 7, Q8_0])
 @pytest.mark.parametrize("K", [20512, 28672, 60000 // 32 * 32])
 def test_k3p_beyond_one_scale_table_slices_refill_inside_the_K_loop(dev, t, K):
     """K > 20480 (a 70B model's ffn-down at prompt sizes): the eight waves' scale tables no longer fit the 160 KB of LDS whole; the K loop
@@ -451,11 +453,11 @@ def test_k3p_beyond_one_scale_table_slices_refill_inside_the_K_loop(dev, t, K):
     W.free()
 
 
-@pytest.mark.parametrize("t,K,N", [(4, 4096, 9), (4, 4096, 16), (4, 2048, 200), (4, 4096, 256), (Q8_0, 11008, 100), (Q8_0, 11008, 128), (Q5_0, 13824, 96),
+@pytest.mark.parametrize("t,K,N", [(4, 4096, 9), (4, 4096, 16), (4, 2048, 128), (4, 4096, 100), (Q8_0, 11008, 100), (Q8_0, 11008, 128), (Q5_0, 13824, 96),
                                    (7, 11008, 128), (Q4_0, 11008, 128), (3, 11008, 96)])
 def test_batched_decode_forms_beyond_their_round_3_ranges(dev, t, K, N):
     """The stage-free batched-decode forms (gemm_q8s.hip, gemm_qmx.hip K3s) where the end of round 4 put them (plan.cpp q8_small_serves, plan_mx):
-    the two-scale type Q4_2 from 9 rows up to 256, every other type up to 128 rows behind K >= 11008 -- three and more column tiles per weight
+    the two-scale type Q4_2 from 9 rows (up to 256 in r4; r5: 128, K3p beyond), every other type up to 128 rows behind K >= 11008 -- three and more column tiles per weight
     tile.  fp64 evaluation of the block arithmetic; a row shard is the bitwise slice (the form is chosen by type, K and N alone)."""
     import ctypes as C
     from ggmlsharp_amd import _lib

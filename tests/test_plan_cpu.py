@@ -94,9 +94,15 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     # batched-decode form at 5..64 rows, the staged int8 form's two-scale instantiation elsewhere
     assert plan(Q6_K, 4096, 4096, 1).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 1024, 4).family == FAM["gemv_fused"] and plan(Q6_K, 4096, 33024, 1).family == FAM["gemv_rows"]
     assert plan(Q6_K, 4096, 4096, 5).family == FAM["k3s_i8"] and plan(Q6_K, 4096, 4096, 64).family == FAM["k3s_i8"]
-    # (r4: the two-scale types -- Q4_2 and Q6_K in its form -- stay on the batched-decode form up to 256 rows: only the staged int8 kernel is behind it)
-    assert plan(Q6_K, 4096, 4096, 256).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 11008, 192).family == FAM["k3s_i8"] and plan(Q8_0, 4096, 4096, 129).family != FAM["k3s_i8"]
-    assert plan(Q6_K, 4096, 4096, 257).family == FAM["i8"] and plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q6_K, 4096, 11008, 512).family == FAM["i8"]
+    # (r4: the two-scale types -- Q4_2 and Q6_K in its form -- stayed on the batched-decode form up to 256 rows with only the staged int8 kernel behind it;
+    # r5: K3p has a two-scale form and takes them from 129 rows at every size, like Q5_1)
+    assert plan(Q6_K, 4096, 4096, 128).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 11008, 128).family == FAM["k3s_i8"] and plan(Q8_0, 4096, 4096, 129).family != FAM["k3s_i8"]
+    for t in (Q6_K, Q4_2):
+        for (M, K, N) in ((4096, 4096, 129), (4096, 4096, 256), (4096, 11008, 512), (4096, 4096, 4096), (32000, 4096, 8192)):
+            assert plan(t, M, K, N).family == FAM["k3p_i8"], (t, M, K, N)
+        assert plan(t, 4096, 4096, 512).tree_id not in {plan(u, 4096, 4096, 512).tree_id for u in (Q8_0, Q5_0, Q5_1, Q4_1)}   # (two scale-accumulates per k-block: a tree of its own)
+    assert plan(Q6_K, 4096, 4096, 512).tree_id != plan(Q4_2, 4096, 4096, 512).tree_id              # (activations by the Q8_K rule)
+    assert plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q4_2, 4096, 1024, 512).family == FAM["i8"]   # (K < 2048: the staged int8 kernel)
     assert plan(Q6_K, 4096, 4096, 8).tree_id != plan(Q4_2, 4096, 4096, 32).tree_id              # (activations by the Q8_K rule: another tree)
     # r4: behind a long K (>= 11008, a down projection) the one-scale int8 types stay on the batched-decode form up to 128 rows
     assert plan(Q8_0, 4096, 11008, 128).family == FAM["k3s_i8"] and plan(Q5_1, 5120, 13824, 96).family == FAM["k3s_i8"] and plan(Q5_K, 4096, 11008, 128).family == FAM["k3s_i8"]

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggmlsharp_amd import device  # noqa: E402
 device.init(0)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-TYPES = {2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
+TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
 g = torch.Generator(device="cuda"); g.manual_seed(5)
 # a different kernel that fills LDS with other contents between the launches under test (staged MX form, 64 KB of stages per workgroup)
 wo = device.Weight.from_device(2, device.quantize_rows(2, torch.randn((2048, 1024), generator=g, device="cuda")), 1024)

@@ -16,7 +16,7 @@ from ggmlsharp_amd._lib import lib, check  # noqa: E402
 device.init(0)
 L = lib()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-TYPES = {2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
+TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
 nbad = ntot = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     t = int(rng.choice(list(TYPES)))

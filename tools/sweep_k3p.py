@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggmlsharp_amd import device  # noqa: E402
 device.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-TYPES = {2: "q4_0", 3: "q4_1", 6: "q5_0", 7: "q5_1", 8: "q8_0"}
+TYPES = {2: "q4_0", 3: "q4_1", 4: "q4_2", 6: "q5_0", 7: "q5_1", 8: "q8_0"}   # (r5: Q4_2 -- the two-scale form of K3p)
 KB = [64, 65, 66, 71, 79, 80, 81, 95, 96, 97, 127, 128, 129, 143, 144, 200, 257, 344, 400, 512, 513, 617, 623, 624, 625, 639, 640, 641, 688, 896, 1000, 1024, 1249, 1873, 2000]   # (from 625: the scale tables in two to four slices)
 nbad = ntot = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
@@ -44,7 +44,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     W.free()
 # r4: the batched-decode forms (K3s, 5..64 rows) over long K -- one and two rounds of table pieces (K <= 16384 | <= 32768), beyond: the staged forms
 for it in range(80):
-    t = int(rng.choice(list(TYPES) + [4, 4]))
+    t = int(rng.choice(list(TYPES) + [4]))
     K = 32 * int(rng.choice([344, 345, 432, 512, 513, 640, 896, 1000, 1024, 1025]))
     N = int(rng.choice([5, 9, 17, 31, 32, 33, 64, 65, 96, 100, 128, 129, 200, 256]))   # (r4: behind K >= 11008 the one-scale types stay on the form up to 128 rows, the two-scale ones up to 256 whatever K)
     M = int(rng.choice([100, 700, 3000]))
