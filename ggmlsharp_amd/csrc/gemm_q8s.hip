@@ -280,11 +280,12 @@ void gemm_q8_small_kernel(const uint8_t *__restrict__ qs, const float *__restric
 // permutation on both operands, 512 contiguous bytes per operand and k-block per wave instruction pair of planes.
 // D[i = src1 column][j = weight row]: lane holds weight row l % 16 and the columns 4 (l / 16) + 0..3 of the slice.
 using i32x4v = __attribute__((ext_vector_type(4))) int;
-template <int KS, int NB, bool ROT, int NCT, bool Q5, bool Q42 = false>     // Q42: two 16-element blocks per k-block, a scale each (Q4_2, and Q6_K in its form)
+template <int KS, int NB, bool ROT, int NCT, bool Q5, bool Q42 = false, int MINT = 0>     // Q42: two 16-element blocks per k-block, a scale each (Q4_2, and Q6_K in its form); MINT: bf16 pieces of the weight's min (2: Q5_1; 3: Q5_K / Q4_K)
 __device__ __forceinline__
 void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                           float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue &ep, int ntw,
-                          uint32_t w_bytes, uint32_t a_bytes, int wg, const float *__restrict__ wm = nullptr) {
+                          uint32_t w_bytes, uint32_t a_bytes, int wg, const float *__restrict__ wm = nullptr,
+                          const uint8_t *__restrict__ mp3 = nullptr, const uint8_t *__restrict__ sp3 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,6 +319,34 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
         if constexpr (Q42) f.m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, (int)offD, (int)(kb * d_blk), 0));
     };
 
+    // (min-term types, r5) the min terms m * (s0 + s1) of sixteen k-blocks as ONE K = 16 product on the bf16 cores in front of the wave's blocks -- the 32-row
+    // form's product, instruction for instruction (v_mfma_f32_32x32x16_bf16 on the same piece planes, chunk c = wave, wave + KS, .. in ascending order, five / six
+    // piece products each, smallest first), so an element's sum has the same bits: the weight operand carries this workgroup's 16 rows in lanes 0..15 of each
+    // half and zeros elsewhere, the activation operand the 32 columns at n0; an element of the product depends on its own row and column alone.  The result
+    // (lane = weight row, 16 registers x 2 halves = 32 columns) is then handed to the 16 x 16 tiles' lanes, once per wave.
+    using f32x16m = __attribute__((ext_vector_type(16))) float;
+    using bf16x8m = __attribute__((ext_vector_type(8))) __bf16;
+    constexpr int MP = MINT ? MINT : 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int nchunks = (nbk + 15) / 16;
+    const __amdgpu_buffer_rsrc_t rMP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(MINT ? mp3 : qs), 0, MINT ? (int)((uint32_t)(nchunks * 6) * (uint32_t)Mpad * 16u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(MINT ? sp3 : qs), 0, MINT ? (int)((uint32_t)(nchunks * 6) * (uint32_t)Npad * 16u) : 0, 0x00020000);
+    const uint32_t vM = (uint32_t)((3 * hh) * Mpad + m0 + (l31 & 15)) * 16u, vS = (uint32_t)((3 * hh) * Npad + n0 + (TN == 16 ? (l31 & 15) : l31)) * 16u;
+    const bool row_lane = l31 < 16, col_lane = TN == 32 || l31 < 16;
+    auto chunk_load = [&](int c, i32x4 (&sa_)[3], i32x4 (&mb_)[MP]) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            if (pc < MINT) {
+                const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rMP, (int)vM, (int)((uint32_t)(6 * c + pc) * (uint32_t)Mpad * 16u), 0));
+                mb_[pc] = row_lane ? v : i32x4{0, 0, 0, 0};
+            }
+            const i32x4 u = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rSP, (int)vS, (int)((uint32_t)(6 * c + pc) * (uint32_t)Npad * 16u), 0));
+            sa_[pc] = col_lane ? u : i32x4{0, 0, 0, 0};
+        }
+    };
+    i32x4 sa0[3], mb0[MP];
+    if constexpr (MINT) { if (wave < nchunks) chunk_load(wave, sa0, mb0); }   // (in front of the blocks' loads: its wait is then for the chunk alone)
+
     // ---- this wave's slice of the row scales: rows x TN floats into its own LDS slice (rows past its range: zero) ----
     const int trows = (nloc + NB - 1) / NB * NB;
     float *const tabD = (float *)smem8 + (size_t)wave * trows * TN;
@@ -347,6 +376,39 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[c][r] = 0.0f;
+    if constexpr (MINT) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest products first (activation piece x weight piece)
+        if (wave < nchunks) {
+            f32x16m a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = wave;;) {
+                const int cn = c + KS;
+                i32x4 sa1[3], mb1[MP];
+                if (cn < nchunks) chunk_load(cn, sa1, mb1);
+                static_for<6>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (PB[k] < MINT)
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8m, sa0[PA[k]]), __builtin_bit_cast(bf16x8m, mb0[PB[k]]), a, 0, 0, 0);
+                });
+                if (cn >= nchunks) break;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) { sa0[pc] = sa1[pc]; if (pc < MINT) mb0[pc] = mb1[pc]; }
+                c = cn;
+            }
+            // D[column (r & 3) + 8 (r >> 2) + 4 hh][weight row l31] -> the 16 x 16 tiles' lanes (row l15, group g4): column 16 c + 4 g4 + e of slice c sits in
+            // lane l15 + 32 (g4 & 1), register 4 (2 c + (g4 >> 1)) + e
+            const int src = 4 * (l15 + 32 * (g4 & 1));
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (through float temporaries: __builtin_bit_cast applied to an element of an ext_vector reads element 0 whatever the index -- hipcc 7.2)
+                    const float f0 = a[8 * c + e], f1 = a[8 * c + 4 + e];
+                    const int v0 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, f0));
+                    const int v1 = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, f1));
+                    acc[c][e] = __builtin_bit_cast(float, (g4 >> 1) ? v1 : v0);
+                }
+        }
+    }
     const i32x4v zero = {0, 0, 0, 0};
     auto block = [&](int i, auto uc) {                      // block i of the wave out of slot u
         constexpr int u = decltype(uc)::value;
@@ -421,12 +483,13 @@ void gemm_q8_small16_body(const uint8_t *__restrict__ qs, const float *__restric
     }
 }
 
-template <int KS, int NB, bool ROT, int NCT, int TY>         // TY: 0 Q8_0, 1 Q5_0, 4 Q4_2 (the 32-row kernel's numbering)
+template <int KS, int NB, bool ROT, int NCT, int TY>         // TY: 0 Q8_0, 1 Q5_0, 2 Q5_1, 3 Q5_K / Q4_K in the Q5_1 form, 4 Q4_2 (the 32-row kernel's numbering)
 __global__ __launch_bounds__(KS * 64, 1)
 void gemm_q8_small16_kernel(const uint8_t *__restrict__ qs, const float *__restrict__ wd, const int8_t *__restrict__ a8, const float *__restrict__ ad,
                             float *__restrict__ dst, int M, int N, int Mpad, int Npad, int nbk, int nloc, int64_t ldd, const mm_epilogue ep, int ntw,
-                            uint32_t w_bytes, uint32_t a_bytes, const float *__restrict__ wm) {
-    gemm_q8_small16_body<KS, NB, ROT, NCT, TY == 1, TY == 4>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes, a_bytes, (int)blockIdx.x, wm);
+                            uint32_t w_bytes, uint32_t a_bytes, const float *__restrict__ wm, const uint8_t *__restrict__ mp3, const uint8_t *__restrict__ sp3) {
+    gemm_q8_small16_body<KS, NB, ROT, NCT, TY == 1 || TY == 2 || TY == 3, TY == 4, (TY == 2 || TY == 3 ? TY : 0)>(qs, wd, a8, ad, dst, M, N, Mpad, Npad, nbk, nloc, ldd, ep, ntw, w_bytes,
+                                                                                                      a_bytes, (int)blockIdx.x, wm, mp3, sp3);
 }
 
 // several Q8_0 matrices behind one activation image in one launch (gemm_qmx.hip gemm_qmx_small_multi_kernel has the story)
@@ -516,7 +579,7 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;
     if (pl.tile_m == 16) {
         // r5: 16-row tiles (plan_k3s_i8: Q8_0 / Q5_0 where the 32-row tiles leave CUs idle) -- the same tree, NCT 16-column slices per workgroup
-        if (!(w->type == GGML_TYPE_Q8_0 || w->type == GGML_TYPE_Q5_0 || q42)) return hipErrorInvalidValue;
+        if (!(w->type == GGML_TYPE_Q8_0 || q5 || q42)) return hipErrorInvalidValue;
         const int nct = pl.tile_n / 16;
         const int ncg = (int)((N + pl.tile_n - 1) / pl.tile_n);
         if (p.Npad < (int64_t)pl.tile_n * ncg || w->Mpad % 16 != 0) return hipErrorInvalidValue;
@@ -534,8 +597,9 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<grid16, KS * 64, lds16, st>>>(planes, w->d, p.a8, p.ad, dst, (int)w->M, (int)N, (int)w->Mpad, (int)p.Npad, (int)w->nbk, nloc, ldd, ep, ntw16, \
-                                          (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->m); } while (0)
-#define Q8S16_GO(NB, ROT, NCT) do { if (q42) Q8S16_GO1(NB, ROT, NCT, 4); else if (q5) Q8S16_GO1(NB, ROT, NCT, 1); else Q8S16_GO1(NB, ROT, NCT, 0); } while (0)
+                                          (uint32_t)wq_bytes, (uint32_t)aq_bytes, w->m, w->mp3, p.sp3); } while (0)
+#define Q8S16_GO(NB, ROT, NCT) do { if (q42) Q8S16_GO1(NB, ROT, NCT, 4); else if (q5k) Q8S16_GO1(NB, ROT, NCT, 3); else if (q51) Q8S16_GO1(NB, ROT, NCT, 2); \
+                                    else if (q5) Q8S16_GO1(NB, ROT, NCT, 1); else Q8S16_GO1(NB, ROT, NCT, 0); } while (0)
         if (nct == 2) { if (nloc <= 8) Q8S16_GO(8, false, 2); else if (nloc <= 16) Q8S16_GO(16, false, 2); else Q8S16_GO(16, true, 2); }
         else { if (nloc <= 8) Q8S16_GO(8, false, 1); else if (nloc <= 16) Q8S16_GO(16, false, 1); else Q8S16_GO(16, true, 1); }
 #undef Q8S16_GO

@@ -188,15 +188,20 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
     p.flags |= MM_FLAG_EPILOGUE_FUSED;
-    // r5: 16-row tiles on v_mfma_i32_16x16x32_i8 where the 32-row tiles leave CUs idle (gemm_q8s.hip gemm_q8_small16_kernel; Q8_0 / Q5_0 -- the
-    // min-term and two-scale types keep the 32-row form).  GEOMETRY ONLY: the same eight K ranges, the same block order and statement, the same
+    // r5: 16-row tiles on v_mfma_i32_16x16x32_i8 where the 32-row tiles leave CUs idle (gemm_q8s.hip gemm_q8_small16_kernel; first Q8_0 / Q5_0, then
+    // the two-scale and the min-term types, see below).  GEOMETRY ONLY: the same eight K ranges, the same block order and statement, the same
     // wave-order sum -- tree_id does not move, so this choice MAY look at M.  A workgroup takes 16 rows x the (up to 32) src1 rows in one or two
     // 16-column slices: 4096 x 4096 x 32 is 256 workgroups instead of 128.  Measured (replayed graphs of 64 launches, 24 .. 32 weight copies in
     // turn, 32-row | 16-row tiles, us per COMPUTE launch): Q8_0 4096 x 4096 x 32 11.5 | 9.1, x 8 11.4 | 7.3, Q5_0 x 32 11.6 | 9.1.  Up to 32 rows and
     // one round of the chip only: four slices per workgroup at 33..64 rows lost to two 32-row workgroups sharing a weight tile through L2
     // (Q8_0 4096 x 4096 x 64 11.3 | 13.1, 4096 x 11008 x 64 25.9 | 30.5), more than 256 of them lost too (Q4_0 8192 x 8192 x 32 23 | 33).
     // (Q4_2 too, and Q6_K in its form: a product per 16-element half with the weight operand zero in the other half's lanes)
-    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q4_2) && N <= 32) {
+    // (Q5_1 too, and Q5_K / Q4_K in its form: the min-term product stays the 32-row form's instruction -- v_mfma_f32_32x32x16_bf16 with the workgroup's 16 rows in
+    // half of the weight operand's lanes -- and its result is handed to the 16 x 16 tiles' lanes once per wave, so the bits are the 32-row form's.  32-row | 16-row tiles:
+    // Q5_1 4096 x 4096 x 9 / 16 / 32 12.8 | 8.0, 12.9 | 8.0, 12.9 | 10.2 us, 4096 x 11008 x 16 / 32 27.7 | 16.2, 27.7 | 21.4, 2048 x 8192 x 32 16.7 | 13.1, 4096 x 28672 x 16 62.5 | 34.8,
+    // Q5_K 4096 x 4096 x 16 13.0 | 8.1, Q4_K x 32 13.2 | 10.4, 4096 x 11008 x 16 28.4 | 16.4 -- tools/experiments/ab_q8s_16_min.sh)
+    static const int min16 = dev_env_int("GGML_HIP_Q8S_16_MIN", 1);   // developer A/B switch: 0 = the min-term types keep the 32-row form
+    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q4_2 || (type == GGML_TYPE_Q5_1 && min16)) && N <= 32) {
         const int tn16 = N <= 16 ? 16 : 32;
         const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
         const int nb16 = nloc <= 8 ? 8 : 16, rows16 = (int)cdiv(nloc, nb16) * nb16;   // (the launcher's slots: gemm_q8s.hip)

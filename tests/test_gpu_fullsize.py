@@ -211,7 +211,7 @@ def test_row_shards_are_bitwise_slices_for_every_kernel_form(dev, t, N):
     W.free()
 
 
-@pytest.mark.parametrize("t", [Q8_0, Q5_0, Q4_0, 3, 4])
+@pytest.mark.parametrize("t", [Q8_0, Q5_0, Q4_0, 3, 4, 7])
 @pytest.mark.parametrize("K,N", [(4096, 32), (4096, 16), (4096, 5), (2048, 24), (11008, 32), (6144, 31), (4096 + 64, 17), (28672, 9), (32768, 32)])
 def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     """r5: the batched-decode forms run 16-row tiles where 32-row tiles leave CUs idle -- GEOMETRY that follows M, on the

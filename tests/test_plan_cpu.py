@@ -149,15 +149,17 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     d = plan(Q8_0, 12000, 4096, 32)                                                                  # (r5: four 32-row tiles beyond 512 tile groups, two up to there)
     assert (a.tile_m, a.tile_n, a.workgroups, b.tile_m, c.tile_m, d.tile_m) == (16, 32, 256, 128, 32, 64) and a.tree_id == b.tree_id == c.tree_id == d.tree_id
     assert plan(Q5_1, 32000, 4096, 32).tile_m == 64 and plan(Q4_2, 32000, 4096, 32).tile_m == 64         # (the min-term and two-scale types: two at most)
-    # r5: the batched-decode forms on 16-row tiles (Q4_0 on the MX cores, Q8_0 / Q5_0 on the int8 cores): 16 / 32 / 64 columns per workgroup by N,
-    # the tree of the 32-row form; the min-term and two-scale types keep 32 rows
-    for t in (Q4_0, Q4_1, Q8_0, Q5_0, Q4_2):
+    # r5: the batched-decode forms on 16-row tiles (Q4_0 / Q4_1 on the MX cores, every other type on the int8 cores): 16 / 32 columns per workgroup by N,
+    # the tree of the 32-row form (Q5_1 and Q5_K / Q4_K in its form: the min-term product stays the 32-row form's instruction, its result is handed to the 16 x 16 tiles' lanes)
+    for t in (Q4_0, Q4_1, Q8_0, Q5_0, Q4_2, Q5_1):
         for N, tn in ((9, 16), (16, 16), (17, 32), (32, 32)):
             a, b = plan(t, 4096, 4096, N), plan(t, 16384, 4096, N)
             assert (a.tile_m, a.tile_n, a.workgroups) == (16, tn, 256) and b.tile_m >= 32 and a.tree_id == b.tree_id and a.family == b.family, (t, N)
         assert plan(t, 4096, 4096, 33).tile_m == 32 and plan(t, 4096, 4096, 64).tile_m == 32       # (33..64 rows: two 32-row workgroups per weight tile measured faster)
         assert plan(t, 4112, 4096, 32).tile_m == 32                                                   # (more than one round of 16-row tiles: the 32-row form)
-    assert plan(Q5_1, 4096, 4096, 32).tile_m == 32 and plan(Q5_K, 4096, 4096, 32).tile_m == 32          # (the bf16-piece min term is not exact: it keeps the 32-row form's MFMA shape)
+    for t in (Q5_K, Q4_K, Q6_K):                                                                          # (the k-quants live in the Q5_1 / Q4_2 forms: the same geometry rule)
+        a, b = plan(t, 4096, 4096, 32), plan(t, 16384, 4096, 32)
+        assert a.tile_m == 16 and b.tile_m >= 32 and a.tree_id == b.tree_id and a.family == b.family, t
     assert plan(Q6_K, 4096, 4096, 32).tile_m == 16 and plan(Q6_K, 4096, 4096, 5).tile_m == 16              # (Q6_K lives in Q4_2's form)
     # r5: K3p (both kernels) on 64-row wave tiles where a grid of 128-row tiles leaves CUs idle (<= 256 workgroups of 64 rows): the tree of the 128-row form
     for t, N in ((Q8_0, 192), (Q5_0, 129), (Q5_1, 256), (Q4_1, 300), (Q4_0, 512), (Q5_K, 256)):
