@@ -515,7 +515,8 @@ void gemm_q8_small_multi_kernel(const q8s_set ws, const int8_t *__restrict__ a8,
 hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_planes p, int64_t N, float *const *dst, const int64_t *ldd, hipStream_t st) {
     constexpr int KS = 8;
     const int nbkp = (int)pad_kblocks(w[0]->nbk);
-    const int nloc = (nbkp + KS - 1) / KS;
+    int nloc = (nbkp + KS - 1) / KS;
+    nloc += nloc & 1;                                       // (plan.cpp k3p_i8_nloc: the single-matrix form's ranges -- a group computes its members' bits)
     const int ncol = (int)((N + 31) / 32);
     if (nloc > 128 || p.Npad < 32 * ncol) return hipErrorNotSupported;
     int64_t t32 = 0;

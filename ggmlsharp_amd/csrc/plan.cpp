@@ -31,6 +31,7 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 2048 <= K <= 32768, from 5 (Q5_1 / Q4_2: 9) src1 rows up to 128
 // (r4: the two-scale types 256; r5: 128 for them too) -- the bounds are the constants below: the stage-free batched-decode form on the int8 matrix cores
 // (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
+constexpr int64_t K3_DUAL_MIN = 65, K3_DUAL_MAX = 256;     // src1 rows between which K3s-int8 and K3p-int8 both serve (one tree: the family follows M)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
@@ -62,9 +63,10 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool 
     // 49.1 | 35.7; still behind at 13824 x 5120 44.9 | 54.5 and 32000 x 4096 69.9 | 85.3 -- over the matrices of a decoder layer that is a gain at
     // every model size looked at (the four attention projections and the down projection against gate / up): 128 rows whatever K.
     static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
-    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : 128;
+    // r5: ... and up to K3_DUAL_MAX rows wherever K3p-int8 serves too: there the two families are ONE tree and plan_mul_mat picks between them by M
+    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K3_DUAL_MAX;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+           N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 && k3s_nmax_2sc != 128 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
 // Q8_0 / Q5_0 (129..3072 rows), Q5_1 and (r5) Q4_2 / Q6_K in its form (129 rows and up) and Q4_1 (129..1024; r5: it was 257), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
 // N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
@@ -87,7 +89,9 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // (r5: Q4_1 from 129 too -- it kept 257 because its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6 us then); with K3p's 64-row wave tiles
     // and GPU-side timing, staged | K3p: 4096 x 4096 x 129 / 192 / 256 25.0 | 18.4, 24.8 | 18.4, 25.6 | 19.2, 4096 x 11008 x 192 59.3 | 40.4, 11008 x 4096 x 192 / 256 62.9 | 48.0,
     // 71.3 | 52.5, 32000 x 4096 x 192 139 | 95.5, 8192 x 8192 x 160 78.0 | 51.4)
-    const int64_t nmin = nmin_dev > 0 ? nmin_dev : 129;
+    // r5: from K3_DUAL_MIN rows where K3s-int8 serves too (K <= 32768; not Q4_1, whose batched-decode form is the MX kernel's): the same tree, the family by M
+    const bool dual = type != GGML_TYPE_Q4_1 && K / QK <= 1024;
+    const int64_t nmin = nmin_dev > 0 ? nmin_dev : dual ? K3_DUAL_MIN : 129;
     // (r5) the two-scale types -- Q4_2, and Q6_K in its form: gemm_q8_mid_kernel<Q4_2> (two K = 16 products and two scale-accumulates per tile and k-block)
     // instead of the staged int8 kernel's stages -- staged | K3p: 4096 x 4096 x 512 / 1024 / 2048 / 4096 55.8 | 44.2, 111 | 87.9, 187 | 176, 390 | 348 us, 4096 x 11008 x 512
     // 142 | 112, x 2048 486 | 442, 11008 x 4096 x 512 169 | 128, 32000 x 4096 x 512 401 | 348, Q6_K 4096 x 4096 x 512 54.5 | 44.8, 4096 x 11008 x 512 138 | 110
@@ -95,12 +99,16 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // conversions and scale-accumulates per weight).
     static const int two_min = dev_env_int("GGML_HIP_K3P_2SC_NMIN", 129), two_max = dev_env_int("GGML_HIP_K3P_2SC_NMAX", 0);   // developer A/B switches (NMIN 100000: the staged kernel)
     if (type == GGML_TYPE_Q4_2)
-        return N >= two_min && N <= (two_max > 0 ? two_max : INT64_MAX) && K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
+        return N >= (two_min != 129 ? two_min : nmin) && N <= (two_max > 0 ? two_max : INT64_MAX) && K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top &&
            K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
 }
 
 int f16_image_kind(int type) { return type == GGML_TYPE_Q8_0 ? 2 : 1; }
+
+// the arithmetic label of the stage-free int8 families (K3s-int8 and K3p-int8 share it, r5): Q8_0 fma(sumi, d1 * d0); the others fma(d0 * sumi, d1); min types:
+// + the min terms of 16 k-blocks as five / six bf16-piece MFMAs in front of a wave's blocks; Q4_2 / Q6_K: two fma(d * yd, sumi) per k-block
+int k3_i8_arith(int type) { return 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0) + (type == GGML_TYPE_Q4_2 ? 4 : 0); }
 
 }  // namespace
 
@@ -170,7 +178,9 @@ void plan_gemv(mm_plan &p, int type, int64_t M, int64_t K, int64_t N, bool fused
 
 bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N) {
     const int nbkp = (int)pad_kblocks(K / QK);
-    const int nloc = (int)cdiv(nbkp, KS8);
+    // r5: K3p-int8's rule (an even number of k-blocks per wave; it was cdiv(nbkp, 8)): with the same ranges, the same statement per block and the same wave-order
+    // sum the two families compute the SAME BITS per element -- one tree, see plan_mul_mat -- so between them the family may follow M
+    const int nloc = k3p_i8_nloc(K);
     const int ncol = (int)cdiv(N, 32);
     if (nloc > 128) return false;                           // (two rounds of table pieces: K <= 32768; r4 -- it was one round, K <= 16384)
     if ((uint64_t)nbkp * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)nbkp * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
@@ -183,7 +193,7 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     p.family = MMF_K3S_I8; p.image = 0;
     if (type == GGML_TYPE_Q5_1) p.flags |= MM_FLAG_MIN_PIECES;
     p.form = wmt == 4 ? 7 : wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
-    p.arith = 200 + (type == GGML_TYPE_Q5_0 ? 1 : type == GGML_TYPE_Q5_1 ? 2 : type == GGML_TYPE_Q4_2 ? 3 : 0); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1)
+    p.arith = k3_i8_arith(type); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1) -- K3p-int8's labels: the same arithmetic
     p.nloc = nloc; p.wmt = wmt;
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
@@ -222,7 +232,7 @@ bool plan_k3p_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     if ((uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)Mpad * 16 > LIM32 || (uint64_t)(KS8 * nloc + 2) * 2 * (uint64_t)pad_act(N) * 16 > LIM32) return false;
     p.family = MMF_K3P_I8; p.image = 0; p.form = 0;
     // Q8_0: fma(sumi, d1 * d0); others: fma(d0 * sumi, d1); min types: + the min terms of 16 k-blocks as six bf16-piece MFMAs per tile
-    p.arith = 300 + (min_type(type) ? 1 : 0) + (type == GGML_TYPE_Q8_0 ? 2 : 0) + (type == GGML_TYPE_Q4_2 ? 4 : 0);   // (Q4_2 / Q6_K: two fma(d * yd, sumi) per k-block)
+    p.arith = k3_i8_arith(type);
     if (min_type(type)) p.flags |= MM_FLAG_MIN_PIECES;
     p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = 4;
     p.tile_m = 128; p.tile_n = 64; p.waves = KS8; p.tiles_per_wave = 8;
@@ -525,13 +535,25 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     int kind = wide ? 0 : plan_image_kind(type, K, N);
     bool no_fused = false;
     const bool i8_only = ext_type != 0 && type == GGML_TYPE_Q4_2;   // (Q6_K: no nibble plane -- the int8 forms only)
-    if (q8_small_serves(type, K, N, i8_only, ext_type != 0)) {             // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
+    const bool small = q8_small_serves(type, K, N, i8_only, ext_type != 0), mid = q8_mid_serves(type, K, N);
+    // r5: K3s-int8 and K3p-int8 are ONE summation tree -- the same eight K ranges (k3p_i8_nloc), a range's min-term chunks and blocks in the
+    // same order with the same statement, the eight sums added in wave order: the same bits per element (tests/test_gpu_fullsize.py
+    // test_k3s_and_k3p_int8_compute_the_same_bits) and the same tree_id -- so where both serve (K3_DUAL_MIN .. K3_DUAL_MAX src1 rows) the FAMILY follows M: K3p once
+    // its grid of 64-row tiles has `dual` workgroups, K3s below.  K3s | K3p, us per COMPUTE launch (tools/experiments/ab_k3s_k3p_overlap.sh): Q8_0 4096 x 4096 x 128 13.3 | 15.6,
+    // 4096 x 11008 x 128 27.6 | 32.4, 1024 x 4096 x 256 7.8 | 13.8, 2048 x 4096 x 256 11.8 | 15.3, 1024 x 11008 x 256 16.9 | 29.2, 2048 x 8192 x 160 17.3 | 22.9 (128 workgroups
+    // or fewer: K3s) -- 8192 x 4096 x 128 20.4 | 17.9, 11008 x 4096 x 65 / 128 31.1 | 27.0, 35.2 | 27.5, 16384 x 4096 x 128 39.7 | 31.4, 32000 x 4096 x 128 75.2 | 60.0, 8192 x 8192 x 128 33.0 | 30.0,
+    // Q5_1 11008 x 4096 x 128 38.3 | 30.5, Q4_2 32000 x 4096 x 128 118 | 96.5, Q4_2 4096 x 4096 x 192 27.3 | 20.1 (192 workgroups and more: K3p).
+    static const int dual = dev_env_int("GGML_HIP_K3_DUAL_WGS", 192);   // developer A/B switch: K3p from this many 64-row workgroups (0: always K3s, 1: always K3p)
+    const bool mid_first = small && mid && cdiv(M, 64) * cdiv(N, 64) >= dual;
+    if (small && !mid_first) {                              // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
         if (plan_k3s_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
-        wide = true; kind = 0; no_fused = true;             // (its planes are beyond the form's offsets: the two-step forms below)
+        if (!mid) { wide = true; kind = 0; no_fused = true; }   // (its planes are beyond the form's offsets: the two-step forms below)
     }
-    if (q8_mid_serves(type, K, N)) {                        // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)
+    if (mid) {                                              // (Q5_K weights too: they live in the planar Q5_1 form, their activations in image 0 by the Q8_K rule)
         if (plan_k3p_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
-        wide = true; kind = 0;
+        p = mm_plan{}; p.ksplit = 1; if (ext_type != 0) p.flags |= MM_FLAG_Q8K;
+        if (mid_first && plan_k3s_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }
+        wide = true; kind = 0; if (small) no_fused = true;
     }
     if (wide) p.flags |= MM_FLAG_WIDE;
     if (kind == 0) {

@@ -242,7 +242,7 @@ def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     W.free()
 
 
-@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 64), (Q8_0, 24), (Q5_0, 64), (3, 32), (7, 48), (4, 100)])
+@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 64), (Q8_0, 24), (Q5_0, 64), (3, 32), (7, 48), (4, 64)])
 def test_every_batched_decode_geometry_computes_the_same_bits(dev, t, N):
     """the batched-decode forms pick their geometry from M -- 16-row tiles (r5), one, two or four 32-row tiles per workgroup -- and the
     CPU plan test can only see that the LABELS agree.  Here every geometry really runs: a 33000-row matrix (four tiles per workgroup for Q4_0, two
@@ -400,6 +400,36 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     W.free()
 
 
+@pytest.mark.parametrize("t", [Q8_0, Q5_0, 7, 4])
+@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 256), (4096, 200), (22016, 96)])
+def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):
+    """r5: between 65 and 256 src1 rows the plan picks K3s-int8 or K3p-int8 by M -- allowed because the two families are one
+    summation tree: the same eight K ranges (an even number of k-blocks per wave), a range's min-term chunks and blocks in the same order with the
+    same statement, the eight sums added in wave order.  Here both really run: a tall matrix (K3p) and its short shards (K3s) agree BIT FOR BIT; the
+    short form also meets fp64 and the oracle sample.  Q8_0, Q5_0, the min-term type Q5_1 and the two-scale type Q4_2; K with an odd number of
+    k-blocks per eighth (11008: 43 -> 44), a ragged last range (2112) and sliced scale tables on the K3p side (22016)."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    M = 16384 if K <= 11008 else 12288
+    pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 1024, K, N, C.byref(pb)) == 0
+    assert (pa.family, pb.family) == (6, 4) and pa.tree_id == pb.tree_id, (pa.family, pb.family)     # 6 = K3p-int8, 4 = K3s-int8
+    rows, x, w = _make(dev, t, M, K, N, seed=3 * K + N + t, keep_w=True)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((0, 1024), (5000, 5000 + 2000), (M - 700, M), (777, 777 + 333)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        pl = _lib.ggml_hip_mm_plan_t()
+        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family == 4
+        part = dev.mul_mat(Ws, x)
+        assert torch.equal(part, full[:, r0:r1]), (t, N, K, r0, r1)
+        if r0 == 0:
+            _check_fp64(dev, t, rows[r0:r1], x, part, K)
+            _check_oracle_sample(t, rows[r0:r1], w[r0:r1], x, part, K, seed=K + N)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("t,N,K", [(Q8_0, 192, 4096), (Q5_0, 129, 4096), (7, 256, 4096), (3, 300, 2048), (Q8_0, 512, 11008), (7, 200, 22016), (Q5_0, 160, 2048 + 64),
                                    (4, 129, 4096), (4, 512, 11008), (4, 200, 22016),
                                    (Q4_0, 512, 4096), (Q4_0, 257, 2048 + 64), (Q4_0, 400, 22016)])
@@ -415,12 +445,14 @@ def test_k3p_64_row_wave_tiles_are_bitwise_the_128_row_form(dev, t, N, K):
         assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0
         if pa.tile_m == 128:
             break
-    assert _lib.lib().ggml_hip_mm_plan(t, 2048, K, N, C.byref(pb)) == 0
+    # (the int8 types' short matrices run K3s up to 256 src1 rows -- the same tree, test_k3s_and_k3p_int8_compute_the_same_bits: there the 64-row K3p shard is 4096 rows)
+    Ms = 4096 if N <= 256 and t not in (Q4_0, 3) else 2048
+    assert _lib.lib().ggml_hip_mm_plan(t, Ms, K, N, C.byref(pb)) == 0
     assert pa.family == pb.family and pa.family in (5, 6) and pa.tree_id == pb.tree_id and (pa.tile_m, pb.tile_m) == (128, 64), (pa.family, pa.tile_m, pb.tile_m)
     rows, x, w = _make(dev, t, M, K, N, seed=K + N + t, keep_w=True)
     W = dev.Weight.from_device(t, rows, K)
     full = dev.mul_mat(W, x)
-    for (r0, r1) in ((0, 2048), (2048, 2048 + 2000), (M - 1000, M), (777, 777 + 333)):
+    for (r0, r1) in ((0, Ms), (Ms, Ms + 2000), (M - 1000, M), (777, 777 + 333)):
         Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
         part = dev.mul_mat(Ws, x)
         assert torch.equal(part, full[:, r0:r1]), (t, N, K, r0, r1)

@@ -163,7 +163,8 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     assert plan(Q6_K, 4096, 4096, 32).tile_m == 16 and plan(Q6_K, 4096, 4096, 5).tile_m == 16              # (Q6_K lives in Q4_2's form)
     # r5: K3p (both kernels) on 64-row wave tiles where a grid of 128-row tiles leaves CUs idle (<= 256 workgroups of 64 rows): the tree of the 128-row form
     for t, N in ((Q8_0, 192), (Q5_0, 129), (Q5_1, 256), (Q4_1, 300), (Q4_0, 512), (Q5_K, 256)):
-        a, b = plan(t, 2048, 4096, N), plan(t, 32768, 4096, N)
+        Ms = 4096 if N <= 256 and t not in (Q4_1, Q4_0) else 2048    # (up to 256 src1 rows the int8 types' SHORT matrices run K3s, see below: 4096 rows are 192+ workgroups of K3p)
+        a, b = plan(t, Ms, 4096, N), plan(t, 32768, 4096, N)
         assert (a.tile_m, b.tile_m) == (64, 128) and a.tree_id == b.tree_id and a.family == b.family and a.family in (FAM["k3p_mx"], FAM["k3p_i8"]), (t, N)
     assert plan(Q8_0, 4096, 4096, 256).tile_m == 64 and plan(Q8_0, 4096, 4096, 257).tile_m == 128       # (256 workgroups of 64 rows fit one round, 320 do not)
     # ... and, int8 kernel, on grids of a fractional number of rounds: 258 workgroups of 128 rows (two rounds for two tiles) run as 516 of 64 (three half-size rounds)
@@ -186,3 +187,28 @@ def test_bad_arguments_are_reported():
     assert L.ggml_hip_mm_plan(Q4_0, 4096, 4100, 16, C.byref(out)) == -3    # K % 32
     assert L.ggml_hip_mm_plan(Q5_K, 4096, 4128, 16, C.byref(out)) == -3    # K % 256
     assert L.ggml_hip_mm_plan(Q4_0, 0, 4096, 16, C.byref(out)) == -3
+
+
+def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
+    """r5: the stage-free int8 families -- batched decode K3s and prompt-sized K3p -- share their summation tree (the same eight K
+    ranges, statement, wave-order sum; GPU: test_k3s_and_k3p_int8_compute_the_same_bits), so between 65 and 256 src1 rows the plan picks the FAMILY by
+    M: K3p once its grid of 64-row tiles has 192 workgroups, K3s below.  tree_id may not move with that choice."""
+    for t in (Q8_0, Q5_0, Q5_1, Q4_2, Q5_K, Q6_K):
+        for K in (4096, 11008, 2048 + (256 if t in (Q5_K, Q6_K) else 64)):
+            for N in (65, 100, 128, 129, 200, 256):
+                ids, fams = set(), set()
+                for M in (512, 1024, 2048, 4096, 8192, 11008, 32000):
+                    p = plan(t, M, K, N)
+                    assert p.family in (FAM["k3s_i8"], FAM["k3p_i8"]), (t, M, K, N, p.family)
+                    want = FAM["k3p_i8"] if -(-M // 64) * -(-N // 64) >= 192 else FAM["k3s_i8"]
+                    assert p.family == want, (t, M, K, N)
+                    ids.add(p.tree_id); fams.add(p.family)
+                assert len(ids) == 1 and len(fams) == 2, (t, K, N)
+    # outside the shared range nothing moved: up to 64 rows K3s whatever M, from 257 K3p whatever M
+    for M in (512, 4096, 32000):
+        assert plan(Q8_0, M, 4096, 64).family == FAM["k3s_i8"] and plan(Q8_0, M, 4096, 257).family == FAM["k3p_i8"]
+    # ... and the two families label the same arithmetic the same way below and above it too (one K range rule: an even number of k-blocks per wave)
+    assert plan(Q8_0, 4096, 11008, 32).kunit == plan(Q8_0, 4096, 11008, 512).kunit == 44
+    assert plan(Q8_0, 4096, 11008, 32).tree_id == plan(Q8_0, 4096, 11008, 512).tree_id
+    # Q4_1's batched-decode form is the MX kernel's (another arithmetic): its K3p keeps 129 rows as the lower bound, no shared range
+    assert plan(Q4_1, 32000, 4096, 128).family == FAM["k3s_mx"] and plan(Q4_1, 512, 4096, 129).family == FAM["k3p_i8"]
