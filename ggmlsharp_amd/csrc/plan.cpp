@@ -22,7 +22,7 @@ int64_t gemv_rows_max(int t) { return t == GGML_TYPE_Q4_2 ? GEMV_WIDE_MAX_N : GE
 
 // ---- K3p / K3s / q8s geometry of K: contiguous ranges of k-blocks, one per wave (KS = 8 waves) ----
 constexpr int KS8 = 8;
-int k3p_mx_nloc(int64_t K) { return (int)cdiv(pad_kblocks(K / QK), KS8); }
+int k3p_mx_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return n + (n & 1); }   // (r5: even, K3s-MX's rule -- pairs of blocks stay inside one wave: the two families are one tree)
 int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return n + (n & 1); }      // two k-blocks per trip (and the min term goes by pairs)
 // the waves' row-scale tables: the whole range of a wave up to 80 k-blocks (K <= 20480), beyond that in refills inside the K loop (r4; it was
 // a hard limit at K = 20480) -- up to four slices of 78, K <= 79872 (the 32-bit offsets of the planes end earlier for wide matrices)
@@ -289,7 +289,7 @@ bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // (four tiles: Q4_0 only -- Q4_1's min-term registers do not fit beside four accumulator tiles)
     const int wmt = geo == 1 ? 1 : geo == 2 || type == GGML_TYPE_Q4_1 ? (geo == 2 || geo == 4 || t32 > 256 ? 2 : 1) : geo == 4 ? 4 : (t32 <= 256 ? 1 : t32 <= 512 ? 2 : 4);
     p.family = MMF_K3S_MX; p.image = 3; p.form = 0;
-    p.arith = 210 + (type == GGML_TYPE_Q4_1 ? 1 : 0);
+    p.arith = type == GGML_TYPE_Q4_1 ? 211 : 310;           // (Q4_0: K3p-MX's label -- the same arithmetic on the same ranges, r5)
     p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc; p.nloc = nloc; p.wmt = wmt;
     p.tile_m = 32 * wmt; p.tile_n = 32; p.waves = KS8; p.tiles_per_wave = wmt;
     p.wgs = cdiv(M, 32 * wmt) * ncol;
@@ -347,6 +347,24 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     if (q40 && (tm256 * tn128 >= t256 || var == 30) && N > 512) return take(var == 2 ? MXF_256x128_ALT : MXF_256x128);
     // Batches up to 128 rows (Q4_1: 256): 32-row weight tiles with K split four ways inside the workgroup; the same four-way tree on
     // taller tiles where those cover the chip.  The choice of the SPLIT depends on N and K only; the tile height follows the tile count.
+    // r5 (the MX side): Q4_0's stage-free forms K3s and K3p are ONE tree too -- the same eight K ranges (an even number of k-blocks per wave),
+    // acc += (sumi * d1) * d0 block by block, the eight sums in wave order: the same bits (test_k3s_and_k3p_mx_compute_the_same_bits) -- so between 65 and 256 src1
+    // rows the family follows M whatever K: K3p once its grid of 64-row tiles has 192 workgroups, K3s below; the staged four-way forms that served K < 11008 there lose to
+    // one or the other at every size measured.  The r4 plan | K3s | K3p, us per COMPUTE launch (tools/experiments/ab_mx_dual.sh): 2048 x 4096 x 128 15.7 | 9.2 | 17.3,
+    // 4096 x 4096 x 96 / 128 17.2 | 13.8 | 17.6, 17.2 | 13.7 | 17.5, 4096 x 11008 x 128 26.2 | 26.0 | 39.6 (K3s: 128 workgroups or fewer) -- 8192 x 4096 x 128 20.8 | 19.9 | 19.1,
+    // 11008 x 4096 x 65 / 128 31.8 | 31.3 | 24.8, 31.9 | 35.3 | 25.3, 16384 x 4096 x 128 35.8 | 37.2 | 28.5, 32000 x 4096 x 96 / 128 69.1 | 57.3 | 54.9, 69.7 | 71.8 | 55.8,
+    // 8192 x 8192 x 128 36.3 | 30.9 | 31.8, 11008 x 11008 x 128 71.8 | 72.0 | 53.6 (K3p: 256 and more).
+    static const int mxdual = dev_env_int("GGML_HIP_MX_DUAL_WGS", 192);     // developer A/B switch: K3p from this many 64-row workgroups (1: always, 1000000: never, 0: the r4 plan)
+    // ... and up to 256 rows (the staged two-/four-way forms served 129..256): the r4 plan | the family by M -- 1024 x 4096 x 256 15.3 | 8.0, 2048 x 4096 x 192 / 256 18.0 | 12.8, 17.5 | 12.6,
+    // 4096 x 4096 x 129 / 192 / 256 19.1 | 17.6, 19.1 | 17.7, 19.5 | 17.8, 8192 x 4096 x 192 31.6 | 25.2, 32000 x 4096 x 192 / 256 85.5 | 79.7, 118 | 105, 4096 x 11008 x 192 / 256 45.2 | 40.0, 46.5 | 40.4,
+    // 8192 x 8192 x 192 57.3 | 42.1, 1024 x 11008 x 256 35.2 | 17.1; the price is a grid just past a whole round -- 11008 x 4096 x 192 / 256 (258 / 344 workgroups of 128 rows) 37.7 | 46.5, 42.6 | 48.4
+    // (tools/experiments/ab_mx_dual_256.sh)
+    static const int mxdual_nmax = dev_env_int("GGML_HIP_MX_DUAL_NMAX", 256);
+    if (mxdual > 0 && q40 && N > 64 && N <= mxdual_nmax && nbk >= 64 && var == 0) {
+        if (cdiv(M, 64) * cdiv(N, 64) >= mxdual && plan_k3p_mx(p, M, Mpad, K, N)) return;
+        if (plan_k3s_mx(p, type, M, Mpad, K, N)) return;
+        if (plan_k3p_mx(p, M, Mpad, K, N)) return;
+    }
     if (N <= (q40 || var == 20 ? 128 : 256) && nbk >= 16 && var != 3 && var != 9) {
         const int64_t t64 = cdiv(M, 64) * cdiv(N, 64);
         if (q4) {

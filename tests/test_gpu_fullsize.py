@@ -400,6 +400,35 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     W.free()
 
 
+@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 128), (2048, 96), (22016, 96), (4096, 256), (11008, 200)])
+def test_k3s_and_k3p_mx_compute_the_same_bits(dev, K, N):
+    """r5: Q4_0's stage-free forms on the MX cores -- K3s (pairs of k-blocks per operand set) and K3p (one k-block per trip) -- are one tree as well: the same
+    eight K ranges of an even number of k-blocks, acc += (sumi * d1) * d0 block by block, the eight sums in wave order.  Between 65 and 256 src1 rows the
+    plan picks by M; a tall matrix (K3p) and its short shards (K3s) agree BIT FOR BIT, the short form meets fp64 and the oracle sample.  K with an odd
+    number of k-blocks per eighth (11008), a ragged last range (2112), the smallest K of the forms (2048), sliced scale tables on the K3p side (22016)."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    t = Q4_0
+    M = 16384 if K <= 11008 else 12288
+    pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 1024, K, N, C.byref(pb)) == 0
+    assert (pa.family, pb.family) == (5, 3) and pa.tree_id == pb.tree_id, (pa.family, pb.family)     # 5 = K3p-MX, 3 = K3s-MX
+    rows, x, w = _make(dev, t, M, K, N, seed=3 * K + N + t, keep_w=True)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((0, 1024), (5000, 5000 + 2000), (M - 700, M), (777, 777 + 333)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        pl = _lib.ggml_hip_mm_plan_t()
+        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family == 3
+        part = dev.mul_mat(Ws, x)
+        assert torch.equal(part, full[:, r0:r1]), (N, K, r0, r1)
+        if r0 == 0:
+            _check_fp64(dev, t, rows[r0:r1], x, part, K)
+            _check_oracle_sample(t, rows[r0:r1], w[r0:r1], x, part, K, seed=K + N)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("t", [Q8_0, Q5_0, 7, 4])
 @pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 256), (4096, 200), (22016, 96)])
 def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):

@@ -108,7 +108,8 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q8_0, 4096, 11008, 128).family == FAM["k3s_i8"] and plan(Q5_1, 5120, 13824, 96).family == FAM["k3s_i8"] and plan(Q5_K, 4096, 11008, 128).family == FAM["k3s_i8"]
     # (... and, with the XCD-aware tile order, whatever K for the int8 types and Q4_1; Q4_0 keeps the K rule: its staged forms are better)
     assert plan(Q8_0, 4096, 11008, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 8192, 128).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 65).family == FAM["k3s_i8"]
-    assert plan(Q4_0, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 8192, 28672, 96).family == FAM["k3s_mx"] and plan(Q4_0, 4096, 4096, 128).family == FAM["mx"]
+    # (r5: Q4_0 at 65..128 rows runs its stage-free forms whatever K -- K3s and K3p are one tree, the family follows M: test_k3s_and_k3p_mx_are_one_tree...)
+    assert plan(Q4_0, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 8192, 28672, 96).family == FAM["k3s_mx"] and plan(Q4_0, 4096, 4096, 128).family == FAM["k3s_mx"]
     assert plan(Q4_1, 4096, 4096, 128).family == FAM["k3s_mx"]
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
@@ -141,8 +142,10 @@ def test_baseline_configs_get_the_kernels_design_md_names():
 def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     """Not vacuous: the plan DOES change with M -- in the fields that are allowed to (tile height, tiles per workgroup, form, family
     between forms of one tree) -- while tree_id stays put; so an M-dependent tree would be seen just as well."""
-    a, b = plan(Q4_0, 4096, 4096, 100), plan(Q4_0, 32000, 4096, 100)          # four-way tree on 32-row / 128-row tiles
-    assert (a.tile_m, b.tile_m) == (32, 128) and a.tree_id == b.tree_id and a.ksplit == b.ksplit == 4
+    a, b = plan(Q4_1, 4096, 1024, 100), plan(Q4_1, 32000, 1024, 100)          # four-way tree of the staged MX forms (K < 2048) on 32-row / 64-row tiles
+    assert (a.tile_m, b.tile_m) == (32, 64) and a.tree_id == b.tree_id and a.ksplit == b.ksplit == 4
+    a, b = plan(Q4_0, 4096, 4096, 100), plan(Q4_0, 32000, 4096, 100)          # r5: one tree for Q4_0's stage-free forms -- K3s on a short matrix, K3p on a tall one
+    assert (a.family, b.family) == (FAM["k3s_mx"], FAM["k3p_mx"]) and a.tree_id == b.tree_id and a.ksplit == b.ksplit == 8
     a, b = plan(Q4_0, 512, 4096, 4096), plan(Q4_0, 4096, 4096, 4096)          # a row shard of the headline: 64 x 64 tiles, the whole: 256 x 128
     assert (a.tile_m, a.tile_n, b.tile_m, b.tile_n) == (64, 64, 256, 128) and a.tree_id == b.tree_id
     a, b, c = plan(Q8_0, 4096, 4096, 32), plan(Q8_0, 32000, 4096, 32), plan(Q8_0, 8192, 4096, 32)   # K3s on the int8 cores: r5 16-row tiles while they fit one round of the chip, else one / two 32-row tiles per workgroup
@@ -212,3 +215,19 @@ def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
     assert plan(Q8_0, 4096, 11008, 32).tree_id == plan(Q8_0, 4096, 11008, 512).tree_id
     # Q4_1's batched-decode form is the MX kernel's (another arithmetic): its K3p keeps 129 rows as the lower bound, no shared range
     assert plan(Q4_1, 32000, 4096, 128).family == FAM["k3s_mx"] and plan(Q4_1, 512, 4096, 129).family == FAM["k3p_i8"]
+
+
+def test_k3s_and_k3p_mx_are_one_tree_and_the_family_follows_M():
+    """r5: the same for Q4_0 on the MX cores between 65 and 256 src1 rows, whatever K (the staged K-split forms that served there are left with K < 2048)."""
+    for K in (2048, 4096, 11008, 2048 + 64):
+        for N in (65, 100, 128, 129, 200, 256):
+            ids, fams = set(), set()
+            for M in (512, 2048, 4096, 8192, 11008, 32000):
+                p = plan(Q4_0, M, K, N)
+                want = FAM["k3p_mx"] if -(-M // 64) * -(-N // 64) >= 192 else FAM["k3s_mx"]
+                assert p.family == want, (M, K, N, p.family)
+                ids.add(p.tree_id); fams.add(p.family)
+            assert len(ids) == 1 and len(fams) == 2, (K, N)
+    assert plan(Q4_0, 32000, 4096, 64).family == FAM["k3s_mx"] and plan(Q4_0, 512, 4096, 257).family == FAM["k3p_mx"] and plan(Q4_0, 4096, 1024, 129).family == FAM["mx"]      # outside the range nothing moved
+    assert plan(Q4_0, 4096, 11008, 32).kunit == plan(Q4_0, 4096, 11008, 512).kunit == 44 and plan(Q4_0, 4096, 11008, 32).tree_id == plan(Q4_0, 4096, 11008, 512).tree_id
+    assert plan(Q4_1, 32000, 4096, 128).family == FAM["k3s_mx"]                                                           # (Q4_1: its K3p is the int8 kernel -- another arithmetic)
