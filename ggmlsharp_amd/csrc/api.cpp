@@ -897,7 +897,7 @@ int ggml_hip_mul_mat_epilogue_dev(const ggml_hip_weight *w, const float *d_src1,
 static bool push_is_fused(const ggml_hip_weight *w, int64_t N, int n_peers) {
     if (!is_q(w->type) || n_peers - 1 > MM_PUSH_MAX) return false;
     const int f = weight_plan(w, N, true).family;
-    return f == MMF_MX || f == MMF_K3P_MX || f == MMF_K3P_I8;
+    return f == MMF_MX || f == MMF_K3P_MX || f == MMF_K3P_I8 || f == MMF_K3S_MX || f == MMF_K3S_I8;   // (r5: the batched-decode forms too -- a short shard at prompt sizes runs them)
 }
 int ggml_hip_mul_mat_push_fused(const ggml_hip_weight *w, int64_t N, int n_peers) { return w && push_is_fused(w, N, n_peers) ? 1 : 0; }
 
@@ -921,7 +921,8 @@ int ggml_hip_mul_mat_push_dev(const ggml_hip_weight *w, const float *d_src1, int
         const mm_plan plan = weight_plan(w, N, true);
         const act_planes pl = act_carve(d_work, w->K, pad_act(N));
         const hipError_t e = plan.family == MMF_K3P_I8 ? launch_gemm_q8_mid(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, ep)
-                                                       : launch_gemm_qmx(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, &ep);
+                             : plan.family == MMF_K3S_I8 ? launch_gemm_q8_small(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, &ep)
+                                                         : launch_gemm_qmx(w, plan, pl, N, mine, ld_total, (hipStream_t)stream, &ep);
         if (e == hipSuccess) return GGML_HIP_OK;
         // not supported = ld_total beyond what the store phase addresses (a tile's rows past the 32-bit buffer offsets of the staged MX forms,
         // a row stride past K3p's int): the product itself still runs, as ggml_hip_mul_mat_epilogue_dev's unfused path does -- the plain

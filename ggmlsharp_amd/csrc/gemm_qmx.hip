@@ -843,7 +843,10 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
         // ---- dst[n][m]: D[row = (r&3) + 8*(r>>2) + 4*hh][col = lane & 31] ----
         const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hh, m = m0 + 32 * t + l31;
         if (n < N && m < M) {
-            if (ep.mode == 2) {
+            if (ep.mode == 3) {                             // the row split's exchange: the same position in this rank's and every peer's [N][M] buffer (r5: the batched-decode forms too)
+                dst[(size_t)n * ldd + m] = v;
+                for (int pk = 0; pk < ep.npush; ++pk) ep.push[pk][(size_t)n * ldd + m] = v;
+            } else if (ep.mode == 2) {
                 dst[(size_t)n * ldd + m] = v * ep.scale;
             } else {
                 dst[(size_t)n * ldd + m] = v;
@@ -1025,7 +1028,10 @@ void gemm_qmx_small16_body(const uint8_t *__restrict__ w6a, const uint8_t *__res
         for (int g = 1; g < KS; ++g) v += xch[(size_t)((g * NCT + c) * 4 + r) * 64];
         const int n = n0 + 16 * c + 4 * kg + r, m = m0 + l15;
         if (n < N && m < M) {
-            if (ep.mode == 2) {
+            if (ep.mode == 3) {                             // the row split's exchange: the same position in this rank's and every peer's [N][M] buffer (r5: the batched-decode forms too)
+                dst[(size_t)n * ldd + m] = v;
+                for (int pk = 0; pk < ep.npush; ++pk) ep.push[pk][(size_t)n * ldd + m] = v;
+            } else if (ep.mode == 2) {
                 dst[(size_t)n * ldd + m] = v * ep.scale;
             } else {
                 dst[(size_t)n * ldd + m] = v;

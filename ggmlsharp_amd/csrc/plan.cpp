@@ -31,7 +31,10 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 2048 <= K <= 32768, from 5 (Q5_1 / Q4_2: 9) src1 rows up to 128
 // (r4: the two-scale types 256; r5: 128 for them too) -- the bounds are the constants below: the stage-free batched-decode form on the int8 matrix cores
 // (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
-constexpr int64_t K3_DUAL_MIN = 65, K3_DUAL_MAX = 256;     // src1 rows between which K3s-int8 and K3p-int8 both serve (one tree: the family follows M)
+// src1 rows between which K3s-int8 and K3p-int8 both serve (one tree: the family follows M).  512: a short matrix (a grouped-query model's k / v projection, 1024 x 4096) at
+// prompt sizes is 128 workgroups of K3p -- K3p | K3s: Q8_0 1024 x 4096 x 384 / 512 13.6 | 10.7, 13.7 | 11.4, 512 x 4096 x 512 13.5 | 7.8, 1024 x 11008 x 512 31.5 | 25.3, Q5_1 1024 x 4096 x 512 15.1 | 12.4,
+// Q4_0 (the MX pair) 14.9 | 11.9, 512 x 4096 x 512 14.3 | 8.0, 1024 x 11008 x 512 33.4 | 23.2 (tools/experiments/ab_dual_512.sh)
+constexpr int64_t K3_DUAL_MIN = 65, K3_DUAL_MAX = 512;
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
@@ -348,7 +351,7 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     // Batches up to 128 rows (Q4_1: 256): 32-row weight tiles with K split four ways inside the workgroup; the same four-way tree on
     // taller tiles where those cover the chip.  The choice of the SPLIT depends on N and K only; the tile height follows the tile count.
     // r5 (the MX side): Q4_0's stage-free forms K3s and K3p are ONE tree too -- the same eight K ranges (an even number of k-blocks per wave),
-    // acc += (sumi * d1) * d0 block by block, the eight sums in wave order: the same bits (test_k3s_and_k3p_mx_compute_the_same_bits) -- so between 65 and 256 src1
+    // acc += (sumi * d1) * d0 block by block, the eight sums in wave order: the same bits (test_k3s_and_k3p_mx_compute_the_same_bits) -- so between 65 and 512 src1
     // rows the family follows M whatever K: K3p once its grid of 64-row tiles has 192 workgroups, K3s below; the staged four-way forms that served K < 11008 there lose to
     // one or the other at every size measured.  The r4 plan | K3s | K3p, us per COMPUTE launch (tools/experiments/ab_mx_dual.sh): 2048 x 4096 x 128 15.7 | 9.2 | 17.3,
     // 4096 x 4096 x 96 / 128 17.2 | 13.8 | 17.6, 17.2 | 13.7 | 17.5, 4096 x 11008 x 128 26.2 | 26.0 | 39.6 (K3s: 128 workgroups or fewer) -- 8192 x 4096 x 128 20.8 | 19.9 | 19.1,
@@ -359,7 +362,7 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     // 4096 x 4096 x 129 / 192 / 256 19.1 | 17.6, 19.1 | 17.7, 19.5 | 17.8, 8192 x 4096 x 192 31.6 | 25.2, 32000 x 4096 x 192 / 256 85.5 | 79.7, 118 | 105, 4096 x 11008 x 192 / 256 45.2 | 40.0, 46.5 | 40.4,
     // 8192 x 8192 x 192 57.3 | 42.1, 1024 x 11008 x 256 35.2 | 17.1; the price is a grid just past a whole round -- 11008 x 4096 x 192 / 256 (258 / 344 workgroups of 128 rows) 37.7 | 46.5, 42.6 | 48.4
     // (tools/experiments/ab_mx_dual_256.sh)
-    static const int mxdual_nmax = dev_env_int("GGML_HIP_MX_DUAL_NMAX", 256);
+    static const int mxdual_nmax = dev_env_int("GGML_HIP_MX_DUAL_NMAX", (int)K3_DUAL_MAX);   // (r5: 512 -- short matrices at prompt sizes, see K3_DUAL_MAX)
     if (mxdual > 0 && q40 && N > 64 && N <= mxdual_nmax && nbk >= 64 && var == 0) {
         if (cdiv(M, 64) * cdiv(N, 64) >= mxdual && plan_k3p_mx(p, M, Mpad, K, N)) return;
         if (plan_k3s_mx(p, type, M, Mpad, K, N)) return;

@@ -400,10 +400,10 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     W.free()
 
 
-@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 128), (2048, 96), (22016, 96), (4096, 256), (11008, 200)])
+@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 128), (2048, 96), (22016, 96), (4096, 256), (11008, 200), (4096, 512)])
 def test_k3s_and_k3p_mx_compute_the_same_bits(dev, K, N):
     """r5: Q4_0's stage-free forms on the MX cores -- K3s (pairs of k-blocks per operand set) and K3p (one k-block per trip) -- are one tree as well: the same
-    eight K ranges of an even number of k-blocks, acc += (sumi * d1) * d0 block by block, the eight sums in wave order.  Between 65 and 256 src1 rows the
+    eight K ranges of an even number of k-blocks, acc += (sumi * d1) * d0 block by block, the eight sums in wave order.  Between 65 and 512 src1 rows the
     plan picks by M; a tall matrix (K3p) and its short shards (K3s) agree BIT FOR BIT, the short form meets fp64 and the oracle sample.  K with an odd
     number of k-blocks per eighth (11008), a ragged last range (2112), the smallest K of the forms (2048), sliced scale tables on the K3p side (22016)."""
     from ggmlsharp_amd import _lib
@@ -419,7 +419,7 @@ def test_k3s_and_k3p_mx_compute_the_same_bits(dev, K, N):
     for (r0, r1) in ((0, 1024), (5000, 5000 + 2000), (M - 700, M), (777, 777 + 333)):
         Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
         pl = _lib.ggml_hip_mm_plan_t()
-        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family == 3
+        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family in (3, 5) and (r0 != 0 or pl.family == 3)
         part = dev.mul_mat(Ws, x)
         assert torch.equal(part, full[:, r0:r1]), (N, K, r0, r1)
         if r0 == 0:
@@ -430,9 +430,9 @@ def test_k3s_and_k3p_mx_compute_the_same_bits(dev, K, N):
 
 
 @pytest.mark.parametrize("t", [Q8_0, Q5_0, 7, 4])
-@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 256), (4096, 200), (22016, 96)])
+@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 256), (4096, 200), (22016, 96), (4096, 512)])
 def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):
-    """r5: between 65 and 256 src1 rows the plan picks K3s-int8 or K3p-int8 by M -- allowed because the two families are one
+    """r5: between 65 and 512 src1 rows the plan picks K3s-int8 or K3p-int8 by M -- allowed because the two families are one
     summation tree: the same eight K ranges (an even number of k-blocks per wave), a range's min-term chunks and blocks in the same order with the
     same statement, the eight sums added in wave order.  Here both really run: a tall matrix (K3p) and its short shards (K3s) agree BIT FOR BIT; the
     short form also meets fp64 and the oracle sample.  Q8_0, Q5_0, the min-term type Q5_1 and the two-scale type Q4_2; K with an odd number of
@@ -449,7 +449,7 @@ def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):
     for (r0, r1) in ((0, 1024), (5000, 5000 + 2000), (M - 700, M), (777, 777 + 333)):
         Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
         pl = _lib.ggml_hip_mm_plan_t()
-        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family == 4
+        assert _lib.lib().ggml_hip_mm_plan(t, r1 - r0, K, N, C.byref(pl)) == 0 and pl.family in (4, 6) and (r0 != 0 or pl.family == 4)   # (a 2000-row shard at 512 src1 rows is K3p again)
         part = dev.mul_mat(Ws, x)
         assert torch.equal(part, full[:, r0:r1]), (t, N, K, r0, r1)
         if r0 == 0:
@@ -474,9 +474,11 @@ def test_k3p_64_row_wave_tiles_are_bitwise_the_128_row_form(dev, t, N, K):
         assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0
         if pa.tile_m == 128:
             break
-    # (the int8 types' short matrices run K3s up to 256 src1 rows -- the same tree, test_k3s_and_k3p_int8_compute_the_same_bits: there the 64-row K3p shard is 4096 rows)
-    Ms = 4096 if N <= 256 and t not in (Q4_0, 3) else 2048
-    assert _lib.lib().ggml_hip_mm_plan(t, Ms, K, N, C.byref(pb)) == 0
+    # (short matrices run K3s up to 512 src1 rows -- the same tree, test_k3s_and_k3p_*_compute_the_same_bits)
+    for Ms in (2048, 3072, 4096):                            # the smallest shard the plan gives K3p at all (192 workgroups of 64 rows; Q4_1 has no K3s on this arithmetic: 2048)
+        assert _lib.lib().ggml_hip_mm_plan(t, Ms, K, N, C.byref(pb)) == 0
+        if pb.family == pa.family:
+            break
     assert pa.family == pb.family and pa.family in (5, 6) and pa.tree_id == pb.tree_id and (pa.tile_m, pb.tile_m) == (128, 64), (pa.family, pa.tile_m, pb.tile_m)
     rows, x, w = _make(dev, t, M, K, N, seed=K + N + t, keep_w=True)
     W = dev.Weight.from_device(t, rows, K)

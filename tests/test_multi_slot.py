@@ -393,8 +393,9 @@ def test_both_exchange_forms_move_eight_ranks_shards_into_the_unsplit_result(nam
 
 
 FUSED_PUSH_CASES = [("config 5 (K3p-MX shards)", O.Q4_0, 32000, 4096, 512, True), ("headline 4096^3 (64 x 64 MX shards)", O.Q4_0, 4096, 4096, 4096, True),
-                    ("weak scaling (256 x 128 MX shards)", O.Q4_0, 32768, 2048, 1024, True), ("config 4's type (K3p-int8 shards)", O.Q8_0, 8192, 4096, 512, True),
-                    ("Q5_1, ragged last shard (K3p-int8 + min term)", 7, 4000, 2048, 300, True), ("Q4_1 above 512 rows (staged MX with the min-term MFMA)", 3, 4096, 1024, 640, True),
+                    ("weak scaling (256 x 128 MX shards)", O.Q4_0, 32768, 2048, 1024, True), ("config 4's type (1024-row shards: K3s-int8, r5 -- on K3p's tree, with the store-phase exchange too)", O.Q8_0, 8192, 4096, 512, True),
+                    ("Q5_1, ragged last shard (K3s-int8 + min term)", 7, 4000, 2048, 300, True), ("config 4's type, taller (K3p-int8 shards)", O.Q8_0, 16384, 4096, 512, True),
+                    ("batched decode (K3s-MX shards, 16-row tiles)", O.Q4_0, 4096, 4096, 32, True), ("batched decode, two-scale type (K3s-int8)", 4, 8192, 4096, 24, True), ("Q4_1 above 512 rows (staged MX with the min-term MFMA)", 3, 4096, 1024, 640, True),
                     ("Q8_0, 640 rows: a family without the store-phase exchange", O.Q8_0, 4096, 1024, 640, False),
                     ("decode batch: the mat-vec", O.Q4_0, 4096, 4096, 2, False)]
 
