@@ -575,12 +575,13 @@ hipError_t launch_q8_small(const ggml_hip_weight *w, const mm_plan &pl, act_plan
     // ... and Q4_2 (9 .. 256 rows -- it was 17 .. 64; plan.cpp q8_small_serves has the measurements): int8 planes of nib - 8 (built at upload, r4), two K = 16 MFMAs per block
     // (4096 x 4096 x 32 40.3 us on the staged int8 kernel).
     const bool q42 = w->type == GGML_TYPE_Q4_2;
-    const bool q51 = w->type == GGML_TYPE_Q5_1, q5 = w->type == GGML_TYPE_Q5_0 || q51;
+    const bool q41 = w->type == GGML_TYPE_Q4_1;             // (r5: from 65 rows -- unsigned values 0..15 on the int8 planes, an f32 min: Q5_K's instantiation, as in K3p)
+    const bool q51 = w->type == GGML_TYPE_Q5_1 || q41, q5 = w->type == GGML_TYPE_Q5_0 || q51;
     const uint8_t *planes = q5 || q42 ? w->i8p : w->qs;
     if (q42 && !w->m) return hipErrorInvalidValue;
     if (pl.family != MMF_K3S_I8 || !(q5 || q42 || w->type == GGML_TYPE_Q8_0) || !planes || !w->d || nloc > 128 || KS * nloc < nbkp || p.Npad < 32 * ncol) return hipErrorInvalidValue;
     if (q51 && (!w->mp3 || !p.sp3)) return hipErrorInvalidValue;
-    const bool q5k = q51 && w->ext_type != 0;               // (the Q5_K extension: activations by the Q8_K rule, three min pieces)
+    const bool q5k = (q51 && w->ext_type != 0) || q41;      // (the Q5_K extension: activations by the Q8_K rule, three min pieces; Q4_1: three pieces too)
     if (w->Mpad % (32 * wmt) != 0) return hipErrorInvalidValue;
     const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)w->Mpad * 16, aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (wq_bytes > 0xFFFFFFFFull || aq_bytes > 0xFFFFFFFFull) return hipErrorInvalidValue;

@@ -35,6 +35,7 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // prompt sizes is 128 workgroups of K3p -- K3p | K3s: Q8_0 1024 x 4096 x 384 / 512 13.6 | 10.7, 13.7 | 11.4, 512 x 4096 x 512 13.5 | 7.8, 1024 x 11008 x 512 31.5 | 25.3, Q5_1 1024 x 4096 x 512 15.1 | 12.4,
 // Q4_0 (the MX pair) 14.9 | 11.9, 512 x 4096 x 512 14.3 | 8.0, 1024 x 11008 x 512 33.4 | 23.2 (tools/experiments/ab_dual_512.sh)
 constexpr int64_t K3_DUAL_MIN = 65, K3_DUAL_MAX = 512;
+int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : K3_DUAL_MIN; }   // Q4_1: the first src1 row count served by the int8 pair (below: its MX batched-decode form)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
@@ -68,6 +69,10 @@ bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool 
     static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
     // r5: ... and up to K3_DUAL_MAX rows wherever K3p-int8 serves too: there the two families are ONE tree and plan_mul_mat picks between them by M
     const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K3_DUAL_MAX;
+    // (r5: Q4_1 from K3_DUAL_MIN rows -- Q5_K's instantiation on its unsigned int8 planes and three min pieces, the arithmetic of its K3p form: up to 64 rows its MX form
+    // stays.  MX K3s | this pair by M: 32000 x 4096 x 128 97.5 | 63.7 us, 11008 x 4096 x 128 36.1 | 30.3, 1024 x 4096 x 256 (it was K3p) 15.0 | 8.8; the price 4096 x 4096 x 128 13.7 | 14.7)
+    // Behind a long K (>= 11008: a down projection, more columns than rows) the MX form keeps 65..128 rows -- the min-term product's pieces grow with K: 4096 x 11008 x 128 26.6 | 32.5.
+    if (type == GGML_TYPE_Q4_1) return !kq && N >= q41_pair_min(K) && N <= k3s_nmax && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
            N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 && k3s_nmax_2sc != 128 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
 }
@@ -92,9 +97,9 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     // (r5: Q4_1 from 129 too -- it kept 257 because its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6 us then); with K3p's 64-row wave tiles
     // and GPU-side timing, staged | K3p: 4096 x 4096 x 129 / 192 / 256 25.0 | 18.4, 24.8 | 18.4, 25.6 | 19.2, 4096 x 11008 x 192 59.3 | 40.4, 11008 x 4096 x 192 / 256 62.9 | 48.0,
     // 71.3 | 52.5, 32000 x 4096 x 192 139 | 95.5, 8192 x 8192 x 160 78.0 | 51.4)
-    // r5: from K3_DUAL_MIN rows where K3s-int8 serves too (K <= 32768; not Q4_1, whose batched-decode form is the MX kernel's): the same tree, the family by M
-    const bool dual = type != GGML_TYPE_Q4_1 && K / QK <= 1024;
-    const int64_t nmin = nmin_dev > 0 ? nmin_dev : dual ? K3_DUAL_MIN : 129;
+    // r5: from K3_DUAL_MIN rows where K3s-int8 serves too (K <= 32768): the same tree, the family by M
+    const bool dual = K / QK <= 1024;
+    const int64_t nmin = nmin_dev > 0 ? nmin_dev : !dual ? 129 : type == GGML_TYPE_Q4_1 ? q41_pair_min(K) : K3_DUAL_MIN;
     // (r5) the two-scale types -- Q4_2, and Q6_K in its form: gemm_q8_mid_kernel<Q4_2> (two K = 16 products and two scale-accumulates per tile and k-block)
     // instead of the staged int8 kernel's stages -- staged | K3p: 4096 x 4096 x 512 / 1024 / 2048 / 4096 55.8 | 44.2, 111 | 87.9, 187 | 176, 390 | 348 us, 4096 x 11008 x 512
     // 142 | 112, x 2048 486 | 442, 11008 x 4096 x 512 169 | 128, 32000 x 4096 x 512 401 | 348, Q6_K 4096 x 4096 x 512 54.5 | 44.8, 4096 x 11008 x 512 138 | 110
@@ -194,7 +199,7 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     const bool four_ok = (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && nloc <= 128;
     const int wmt = geo == 1 ? 1 : geo == 2 ? 2 : geo == 4 && four_ok ? 4 : t32 <= 256 ? 1 : (t32 <= 512 || !four_ok) ? 2 : 4;
     p.family = MMF_K3S_I8; p.image = 0;
-    if (type == GGML_TYPE_Q5_1) p.flags |= MM_FLAG_MIN_PIECES;
+    if (min_type(type)) p.flags |= MM_FLAG_MIN_PIECES;
     p.form = wmt == 4 ? 7 : wmt == 2 ? (nloc <= 8 ? 0 : 1) : nloc <= 8 ? 2 : nloc <= 16 ? 3 : 4;
     p.arith = k3_i8_arith(type); p.ksplit = KS8; p.kstyle = MMK_RANGES; p.kunit = nloc;   // Q8_0: fma(sumi, d1 * d0); Q5_0: fma(d0 * sumi, d1) -- K3p-int8's labels: the same arithmetic
     p.nloc = nloc; p.wmt = wmt;

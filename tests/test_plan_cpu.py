@@ -109,8 +109,10 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     # (... and, with the XCD-aware tile order, whatever K for the int8 types and Q4_1; Q4_0 keeps the K rule: its staged forms are better)
     assert plan(Q8_0, 4096, 11008, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 8192, 128).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 65).family == FAM["k3s_i8"]
     # (r5: Q4_0 at 65..128 rows runs its stage-free forms whatever K -- K3s and K3p are one tree, the family follows M: test_k3s_and_k3p_mx_are_one_tree...)
-    assert plan(Q4_0, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 8192, 28672, 96).family == FAM["k3s_mx"] and plan(Q4_0, 4096, 4096, 128).family == FAM["k3s_mx"]
-    assert plan(Q4_1, 4096, 4096, 128).family == FAM["k3s_mx"]
+    assert plan(Q4_0, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 8192, 28672, 64).family == FAM["k3s_mx"] and plan(Q4_0, 4096, 4096, 128).family == FAM["k3s_mx"]
+    # (r5: Q4_1 from 65 rows on the int8 pair -- K3s-int8 on a short matrix, K3p-int8 on a tall one; up to 64 rows its MX form)
+    assert plan(Q4_1, 4096, 4096, 128).family == FAM["k3s_i8"] and plan(Q4_1, 8192, 8192, 96).family == FAM["k3p_i8"] and plan(Q4_1, 4096, 4096, 64).family == FAM["k3s_mx"]
+    assert plan(Q4_1, 8192, 28672, 96).family == FAM["k3s_mx"] and plan(Q4_1, 4096, 11008, 128).family == FAM["k3s_mx"] and plan(Q4_1, 1024, 11008, 129).family == FAM["k3s_i8"]   # (behind K >= 11008 its MX form keeps 65..128 rows)
     assert plan(Q8_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_0, 4096, 4096, 32).family == FAM["k3s_mx"]
     # r4: Q5_0 (on its int8 operand planes) and Q5_1 (+ the min-term product: INIT writes the piece planes) run the batched-decode form too
     assert plan(Q5_0, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q5_0, 4096, 4096, 32).image_kind == 0
@@ -125,7 +127,7 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert plan(Q4_1, 4096, 4096, 1024).family == FAM["k3p_i8"] and plan(Q4_1, 4096, 4096, 1025).family == FAM["mx"]
     assert plan(Q4_0, 4096, 4096, 513).family == FAM["mx"]
     assert plan(Q8_0, 4096, 4096, 129).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 4096, 128).family != FAM["k3p_i8"]   # (from 129 rows: Q8_0 / Q5_0 / Q5_1)
-    assert plan(Q4_1, 4096, 4096, 128).family == FAM["k3s_mx"] and plan(Q4_1, 4096, 4096, 129).family == FAM["k3p_i8"]  # (r5: Q4_1 from 129 too; it was 257)
+    assert plan(Q4_1, 4096, 4096, 64).family == FAM["k3s_mx"] and plan(Q4_1, 4096, 4096, 192).family == FAM["k3p_i8"]  # (r5: Q4_1 from 129 too; it was 257 -- then from 65 with K3s-int8 beside it)
     assert plan(Q5_1, 4096, 4096, 4096).family == FAM["k3p_i8"] and plan(Q5_K, 4096, 11008, 8192).family == FAM["k3p_i8"]   # (Q5_1 / Q5_K: no upper bound)
     # r4: K > 19968 -- the eight scale tables no longer fit LDS whole: K3p refills them in slices (up to four: K <= 79872), beyond that the staged forms
     assert plan(Q8_0, 4096, 22016, 512).family == FAM["k3p_i8"] and plan(Q4_0, 4096, 28672, 512).family == FAM["k3p_mx"]
@@ -166,7 +168,7 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
     assert plan(Q6_K, 4096, 4096, 32).tile_m == 16 and plan(Q6_K, 4096, 4096, 5).tile_m == 16              # (Q6_K lives in Q4_2's form)
     # r5: K3p (both kernels) on 64-row wave tiles where a grid of 128-row tiles leaves CUs idle (<= 256 workgroups of 64 rows): the tree of the 128-row form
     for t, N in ((Q8_0, 192), (Q5_0, 129), (Q5_1, 256), (Q4_1, 300), (Q4_0, 512), (Q5_K, 256)):
-        Ms = 4096 if N <= 256 and t not in (Q4_1, Q4_0) else 2048    # (up to 256 src1 rows the int8 types' SHORT matrices run K3s, see below: 4096 rows are 192+ workgroups of K3p)
+        Ms = 4096 if N <= 256 and t != Q4_0 else 2048 if t == Q4_0 else 3072    # (short matrices run K3s up to 512 src1 rows, see below: these have 192+ workgroups of K3p)
         a, b = plan(t, Ms, 4096, N), plan(t, 32768, 4096, N)
         assert (a.tile_m, b.tile_m) == (64, 128) and a.tree_id == b.tree_id and a.family == b.family and a.family in (FAM["k3p_mx"], FAM["k3p_i8"]), (t, N)
     assert plan(Q8_0, 4096, 4096, 256).tile_m == 64 and plan(Q8_0, 4096, 4096, 257).tile_m == 128       # (256 workgroups of 64 rows fit one round, 320 do not)
@@ -196,10 +198,12 @@ def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
     """r5: the stage-free int8 families -- batched decode K3s and prompt-sized K3p -- share their summation tree (the same eight K
     ranges, statement, wave-order sum; GPU: test_k3s_and_k3p_int8_compute_the_same_bits), so between 65 and 512 src1 rows the plan picks the FAMILY by
     M: K3p once its grid of 64-row tiles has 192 workgroups, K3s below.  tree_id may not move with that choice."""
-    for t in (Q8_0, Q5_0, Q5_1, Q4_2, Q5_K, Q6_K):
+    for t in (Q8_0, Q5_0, Q5_1, Q4_1, Q4_2, Q5_K, Q6_K):
         for K in (4096, 11008, 2048 + (256 if t in (Q5_K, Q6_K) else 64)):
             for N in (65, 100, 128, 129, 200, 256, 384, 512):
                 ids, fams = set(), set()
+                if t == Q4_1 and K >= 11008 and N <= 128:
+                    continue                                   # (its MX form there)
                 for M in (512, 1024, 2048, 4096, 8192, 11008, 32000):
                     p = plan(t, M, K, N)
                     assert p.family in (FAM["k3s_i8"], FAM["k3p_i8"]), (t, M, K, N, p.family)
@@ -213,8 +217,9 @@ def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
     # ... and the two families label the same arithmetic the same way below and above it too (one K range rule: an even number of k-blocks per wave)
     assert plan(Q8_0, 4096, 11008, 32).kunit == plan(Q8_0, 4096, 11008, 512).kunit == 44
     assert plan(Q8_0, 4096, 11008, 32).tree_id == plan(Q8_0, 4096, 11008, 512).tree_id
-    # Q4_1's batched-decode form is the MX kernel's (another arithmetic): its K3p keeps 129 rows as the lower bound, no shared range
-    assert plan(Q4_1, 32000, 4096, 128).family == FAM["k3s_mx"] and plan(Q4_1, 512, 4096, 129).family == FAM["k3p_i8"]
+    # Q4_1: its MX batched-decode form up to 64 rows (another arithmetic), from 65 the int8 pair like the others
+    assert plan(Q4_1, 32000, 4096, 64).family == FAM["k3s_mx"] and plan(Q4_1, 32000, 4096, 128).family == FAM["k3p_i8"] and plan(Q4_1, 512, 4096, 129).family == FAM["k3s_i8"]
+    assert plan(Q4_1, 32000, 4096, 128).tree_id == plan(Q4_1, 512, 4096, 128).tree_id != plan(Q4_1, 512, 4096, 64).tree_id
 
 
 def test_k3s_and_k3p_mx_are_one_tree_and_the_family_follows_M():
@@ -230,4 +235,4 @@ def test_k3s_and_k3p_mx_are_one_tree_and_the_family_follows_M():
             assert len(ids) == 1 and len(fams) == 2, (K, N)
     assert plan(Q4_0, 32000, 4096, 64).family == FAM["k3s_mx"] and plan(Q4_0, 512, 4096, 513).family == FAM["mx"] and plan(Q4_0, 4096, 1024, 129).family == FAM["mx"]      # outside the range nothing moved
     assert plan(Q4_0, 4096, 11008, 32).kunit == plan(Q4_0, 4096, 11008, 512).kunit == 44 and plan(Q4_0, 4096, 11008, 32).tree_id == plan(Q4_0, 4096, 11008, 512).tree_id
-    assert plan(Q4_1, 32000, 4096, 128).family == FAM["k3s_mx"]                                                           # (Q4_1: its K3p is the int8 kernel -- another arithmetic)
+    assert plan(Q4_1, 32000, 4096, 64).family == FAM["k3s_mx"]                                                            # (Q4_1: its K3p is the int8 kernel -- another arithmetic; from 65 rows the int8 pair)

@@ -19,7 +19,7 @@ import kbench  # noqa: E402
 from ggmlsharp_amd import device  # noqa: E402
 
 TYPES = ["q4_0", "q4_1", "q5_0", "q5_1", "q8_0", "q4_2"]
-SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096)]
+SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096), (1024, 4096), (32000, 4096)]   # (r5: + a short matrix -- a grouped-query k / v projection -- and a vocabulary-sized one: the family follows M)
 NS = [1, 4, 5, 9, 16, 17, 32, 64, 65, 128, 129, 256, 257, 512, 768, 1024, 2048, 4096]
 
 
