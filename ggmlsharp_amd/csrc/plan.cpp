@@ -34,8 +34,13 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // src1 rows between which K3s-int8 and K3p-int8 both serve (one tree: the family follows M).  512: a short matrix (a grouped-query model's k / v projection, 1024 x 4096) at
 // prompt sizes is 128 workgroups of K3p -- K3p | K3s: Q8_0 1024 x 4096 x 384 / 512 13.6 | 10.7, 13.7 | 11.4, 512 x 4096 x 512 13.5 | 7.8, 1024 x 11008 x 512 31.5 | 25.3, Q5_1 1024 x 4096 x 512 15.1 | 12.4,
 // Q4_0 (the MX pair) 14.9 | 11.9, 512 x 4096 x 512 14.3 | 8.0, 1024 x 11008 x 512 33.4 | 23.2 (tools/experiments/ab_dual_512.sh)
-constexpr int64_t K3_DUAL_MIN = 65, K3_DUAL_MAX = 512;
-int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : K3_DUAL_MIN; }   // Q4_1: the first src1 row count served by the int8 pair (below: its MX batched-decode form)
+// ... and from 33 rows: a tall matrix at 33..64 rows is one column tile of K3p per 64 / 128 rows -- one round of the chip for 32000 rows where K3s re-reads a weight tile per
+// 32 columns.  K3s | K3p: Q8_0 16384 x 4096 x 64 24.1 | 19.2 us, 32000 x 4096 x 33 / 64 44.1 | 34.8, 44.4 | 35.7, 28672 x 8192 x 64 73.6 | 60.5, Q5_1 32000 x 4096 x 64 60.0 | 38.4, Q4_2 64.6 | 52.0,
+// Q4_0 32000 x 4096 x 48 / 64 38.8 | 29.9, 39.5 | 30.7, 28672 x 8192 x 64 65.9 | 51.1 (tools/experiments/ab_dual_33.sh); up to 32 rows half of K3p's column tile would be padding: K3s.
+constexpr int64_t K3_DUAL_MIN_DEFAULT = 33, K3_DUAL_MAX = 512;
+int64_t k3_dual_min() { static const int v = dev_env_int("GGML_HIP_K3_DUAL_NMIN", (int)K3_DUAL_MIN_DEFAULT); return v; }   // developer A/B switch
+#define K3_DUAL_MIN k3_dual_min()
+int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : 65; }   // Q4_1: the first src1 row count served by the int8 pair (below: its MX batched-decode form)
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
     // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
@@ -368,7 +373,7 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     // 8192 x 8192 x 192 57.3 | 42.1, 1024 x 11008 x 256 35.2 | 17.1; the price is a grid just past a whole round -- 11008 x 4096 x 192 / 256 (258 / 344 workgroups of 128 rows) 37.7 | 46.5, 42.6 | 48.4
     // (tools/experiments/ab_mx_dual_256.sh)
     static const int mxdual_nmax = dev_env_int("GGML_HIP_MX_DUAL_NMAX", (int)K3_DUAL_MAX);   // (r5: 512 -- short matrices at prompt sizes, see K3_DUAL_MAX)
-    if (mxdual > 0 && q40 && N > 64 && N <= mxdual_nmax && nbk >= 64 && var == 0) {
+    if (mxdual > 0 && q40 && N >= K3_DUAL_MIN && N <= mxdual_nmax && nbk >= 64 && var == 0) {
         if (cdiv(M, 64) * cdiv(N, 64) >= mxdual && plan_k3p_mx(p, M, Mpad, K, N)) return;
         if (plan_k3s_mx(p, type, M, Mpad, K, N)) return;
         if (plan_k3p_mx(p, M, Mpad, K, N)) return;

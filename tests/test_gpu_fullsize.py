@@ -242,7 +242,7 @@ def test_k3s_16_row_tiles_are_bitwise_the_32_row_form(dev, t, K, N):
     W.free()
 
 
-@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 64), (Q8_0, 24), (Q5_0, 64), (3, 32), (7, 48), (4, 64)])
+@pytest.mark.parametrize("t,N", [(Q4_0, 32), (Q4_0, 24), (Q8_0, 24), (Q5_0, 32), (3, 32), (3, 64), (7, 32), (4, 32)])
 def test_every_batched_decode_geometry_computes_the_same_bits(dev, t, N):
     """the batched-decode forms pick their geometry from M -- 16-row tiles (r5), one, two or four 32-row tiles per workgroup -- and the
     CPU plan test can only see that the LABELS agree.  Here every geometry really runs: a 33000-row matrix (four tiles per workgroup for Q4_0, two
@@ -400,10 +400,10 @@ def test_k3p_forms_tall_matrix_and_its_shards_are_bitwise_slices(dev, t, N):
     W.free()
 
 
-@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 128), (2048, 96), (22016, 96), (4096, 256), (11008, 200), (4096, 512)])
+@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 128), (2048, 96), (22016, 96), (4096, 256), (11008, 200), (4096, 512), (4096, 48), (11008, 33)])
 def test_k3s_and_k3p_mx_compute_the_same_bits(dev, K, N):
     """r5: Q4_0's stage-free forms on the MX cores -- K3s (pairs of k-blocks per operand set) and K3p (one k-block per trip) -- are one tree as well: the same
-    eight K ranges of an even number of k-blocks, acc += (sumi * d1) * d0 block by block, the eight sums in wave order.  Between 65 and 512 src1 rows the
+    eight K ranges of an even number of k-blocks, acc += (sumi * d1) * d0 block by block, the eight sums in wave order.  Between 33 and 512 src1 rows the
     plan picks by M; a tall matrix (K3p) and its short shards (K3s) agree BIT FOR BIT, the short form meets fp64 and the oracle sample.  K with an odd
     number of k-blocks per eighth (11008), a ragged last range (2112), the smallest K of the forms (2048), sliced scale tables on the K3p side (22016)."""
     from ggmlsharp_amd import _lib
@@ -430,17 +430,17 @@ def test_k3s_and_k3p_mx_compute_the_same_bits(dev, K, N):
 
 
 @pytest.mark.parametrize("t", [Q8_0, Q5_0, 7, 4, 3])
-@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 256), (4096, 200), (22016, 96), (4096, 512)])
+@pytest.mark.parametrize("K,N", [(4096, 128), (4096, 65), (11008, 100), (2048 + 64, 256), (4096, 200), (22016, 96), (4096, 512), (4096, 48)])
 def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):
-    """r5: between 65 and 512 src1 rows the plan picks K3s-int8 or K3p-int8 by M -- allowed because the two families are one
+    """r5: between 33 and 512 src1 rows the plan picks K3s-int8 or K3p-int8 by M -- allowed because the two families are one
     summation tree: the same eight K ranges (an even number of k-blocks per wave), a range's min-term chunks and blocks in the same order with the
     same statement, the eight sums added in wave order.  Here both really run: a tall matrix (K3p) and its short shards (K3s) agree BIT FOR BIT; the
     short form also meets fp64 and the oracle sample.  Q8_0, Q5_0, the min-term types Q5_1 and Q4_1 (from 65 rows on this pair; its MX form below) and the two-scale type Q4_2; K with an odd number of
     k-blocks per eighth (11008: 43 -> 44), a ragged last range (2112) and sliced scale tables on the K3p side (22016)."""
     from ggmlsharp_amd import _lib
     import ctypes as C
-    if t == 3 and K >= 11008 and N <= 128:
-        pytest.skip("Q4_1 behind K >= 11008 keeps its MX batched-decode form up to 128 rows")
+    if t == 3 and (N <= 64 or (K >= 11008 and N <= 128)):
+        pytest.skip("Q4_1 keeps its MX batched-decode form up to 64 rows (behind K >= 11008: up to 128)")
     M = 16384 if K <= 11008 else 12288
     pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
     assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 1024, K, N, C.byref(pb)) == 0

@@ -196,13 +196,13 @@ def test_bad_arguments_are_reported():
 
 def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
     """r5: the stage-free int8 families -- batched decode K3s and prompt-sized K3p -- share their summation tree (the same eight K
-    ranges, statement, wave-order sum; GPU: test_k3s_and_k3p_int8_compute_the_same_bits), so between 65 and 512 src1 rows the plan picks the FAMILY by
+    ranges, statement, wave-order sum; GPU: test_k3s_and_k3p_int8_compute_the_same_bits), so between 33 and 512 src1 rows the plan picks the FAMILY by
     M: K3p once its grid of 64-row tiles has 192 workgroups, K3s below.  tree_id may not move with that choice."""
     for t in (Q8_0, Q5_0, Q5_1, Q4_1, Q4_2, Q5_K, Q6_K):
         for K in (4096, 11008, 2048 + (256 if t in (Q5_K, Q6_K) else 64)):
-            for N in (65, 100, 128, 129, 200, 256, 384, 512):
+            for N in (33, 64, 65, 100, 128, 129, 200, 256, 384, 512):
                 ids, fams = set(), set()
-                if t == Q4_1 and K >= 11008 and N <= 128:
+                if t == Q4_1 and (N <= 64 or (K >= 11008 and N <= 128)):
                     continue                                   # (its MX form there)
                 for M in (512, 1024, 2048, 4096, 8192, 11008, 32000):
                     p = plan(t, M, K, N)
@@ -211,9 +211,9 @@ def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
                     assert p.family == want, (t, M, K, N)
                     ids.add(p.tree_id); fams.add(p.family)
                 assert len(ids) == 1 and len(fams) == 2, (t, K, N)
-    # outside the shared range nothing moved: up to 64 rows K3s whatever M, from 513 K3p whatever M
+    # outside the shared range nothing moved: up to 32 rows K3s whatever M, from 513 K3p whatever M
     for M in (512, 4096, 32000):
-        assert plan(Q8_0, M, 4096, 64).family == FAM["k3s_i8"] and plan(Q8_0, M, 4096, 513).family == FAM["k3p_i8"]
+        assert plan(Q8_0, M, 4096, 32).family == FAM["k3s_i8"] and plan(Q8_0, M, 4096, 513).family == FAM["k3p_i8"]
     # ... and the two families label the same arithmetic the same way below and above it too (one K range rule: an even number of k-blocks per wave)
     assert plan(Q8_0, 4096, 11008, 32).kunit == plan(Q8_0, 4096, 11008, 512).kunit == 44
     assert plan(Q8_0, 4096, 11008, 32).tree_id == plan(Q8_0, 4096, 11008, 512).tree_id
@@ -223,9 +223,9 @@ def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
 
 
 def test_k3s_and_k3p_mx_are_one_tree_and_the_family_follows_M():
-    """r5: the same for Q4_0 on the MX cores between 65 and 512 src1 rows, whatever K (the staged K-split forms that served up to 256 there are left with K < 2048)."""
+    """r5: the same for Q4_0 on the MX cores between 33 and 512 src1 rows, whatever K (the staged K-split forms that served up to 256 there are left with K < 2048)."""
     for K in (2048, 4096, 11008, 2048 + 64):
-        for N in (65, 100, 128, 129, 200, 256, 384, 512):
+        for N in (33, 64, 65, 100, 128, 129, 200, 256, 384, 512):
             ids, fams = set(), set()
             for M in (512, 2048, 4096, 8192, 11008, 32000):
                 p = plan(Q4_0, M, K, N)
@@ -233,6 +233,6 @@ def test_k3s_and_k3p_mx_are_one_tree_and_the_family_follows_M():
                 assert p.family == want, (M, K, N, p.family)
                 ids.add(p.tree_id); fams.add(p.family)
             assert len(ids) == 1 and len(fams) == 2, (K, N)
-    assert plan(Q4_0, 32000, 4096, 64).family == FAM["k3s_mx"] and plan(Q4_0, 512, 4096, 513).family == FAM["mx"] and plan(Q4_0, 4096, 1024, 129).family == FAM["mx"]      # outside the range nothing moved
+    assert plan(Q4_0, 32000, 4096, 32).family == FAM["k3s_mx"] and plan(Q4_0, 512, 4096, 513).family == FAM["mx"] and plan(Q4_0, 4096, 1024, 129).family == FAM["mx"]      # outside the range nothing moved
     assert plan(Q4_0, 4096, 11008, 32).kunit == plan(Q4_0, 4096, 11008, 512).kunit == 44 and plan(Q4_0, 4096, 11008, 32).tree_id == plan(Q4_0, 4096, 11008, 512).tree_id
     assert plan(Q4_1, 32000, 4096, 64).family == FAM["k3s_mx"]                                                            # (Q4_1: its K3p is the int8 kernel -- another arithmetic; from 65 rows the int8 pair)
