@@ -28,93 +28,46 @@ int k3p_i8_nloc(int64_t K) { int n = (int)cdiv(pad_kblocks(K / QK), KS8); return
 // a hard limit at K = 20480) -- up to four slices of 78, K <= 79872 (the 32-bit offsets of the planes end earlier for wide matrices)
 bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 
-// Q8_0 (r4: and Q5_0, Q5_1 / Q5_K, Q4_2, on int8 operand planes built at upload), 2048 <= K <= 32768, from 5 (Q5_1 / Q4_2: 9) src1 rows up to 128
-// (r4: the two-scale types 256; r5: 128 for them too) -- the bounds are the constants below: the stage-free batched-decode form on the int8 matrix cores
-// (gemm_q8s.hip) -- image 0 (Q5_1: + the min-term piece planes)
-// src1 rows between which K3s-int8 and K3p-int8 both serve (one tree: the family follows M).  512: a short matrix (a grouped-query model's k / v projection, 1024 x 4096) at
-// prompt sizes is 128 workgroups of K3p -- K3p | K3s: Q8_0 1024 x 4096 x 384 / 512 13.6 | 10.7, 13.7 | 11.4, 512 x 4096 x 512 13.5 | 7.8, 1024 x 11008 x 512 31.5 | 25.3, Q5_1 1024 x 4096 x 512 15.1 | 12.4,
-// Q4_0 (the MX pair) 14.9 | 11.9, 512 x 4096 x 512 14.3 | 8.0, 1024 x 11008 x 512 33.4 | 23.2 (tools/experiments/ab_dual_512.sh)
-// ... and from 33 rows: a tall matrix at 33..64 rows is one column tile of K3p per 64 / 128 rows -- one round of the chip for 32000 rows where K3s re-reads a weight tile per
-// 32 columns.  K3s | K3p: Q8_0 16384 x 4096 x 64 24.1 | 19.2 us, 32000 x 4096 x 33 / 64 44.1 | 34.8, 44.4 | 35.7, 28672 x 8192 x 64 73.6 | 60.5, Q5_1 32000 x 4096 x 64 60.0 | 38.4, Q4_2 64.6 | 52.0,
-// Q4_0 32000 x 4096 x 48 / 64 38.8 | 29.9, 39.5 | 30.7, 28672 x 8192 x 64 65.9 | 51.1 (tools/experiments/ab_dual_33.sh); up to 32 rows half of K3p's column tile would be padding: K3s.
+// ---- the stage-free int8 pair: K3s-int8 (gemm_q8s.hip, batched decode) and K3p-int8 (gemm_qmp.hip, prompt sizes) -- image 0 (+ the min-term piece planes) ----
+// ONE summation tree (plan_mul_mat has the argument, tests/test_gpu_fullsize.py the proof), so where both serve the family follows M.  Weights: Q8_0's own planes;
+// Q5_0 / Q5_1 / Q4_1 / Q4_2 and the k-quants on int8 operand planes built at upload.  2048 <= K <= 32768 for K3s (two rounds of table pieces per wave), <= 79872
+// for K3p (sliced scale tables: k3p_lds_ok).
+//     src1 rows     served by
+//     5 .. 32       K3s   (Q5_1, Q4_2 and the k-quants of the Q5_1 form from 9: up to 8 rows their mat-vec is as fast; Q6_K, whose mat-vec ends at 4, from 5)
+//     33 .. 512     both  -- plan_mul_mat picks by M (Q4_1 joins at 65, behind K >= 11008 at 129: below that its MX batched-decode form, another arithmetic)
+//     513 .. top    K3p   (top: Q8_0 / Q5_0 3072 -- beyond, their staged f16 forms win; Q4_1 1024; Q5_1, Q4_2 and the k-quants: none)
+// The measurements behind every bound: docs/NOTEBOOK_r4.md 10.2d (round 4's), DESIGN.md 12.2c / 12.2d and the tools/experiments/ab_*.sh scripts named there (round 5's):
+//   * 33: up to 32 rows half of K3p's 64-column tile would be padding; a tall matrix at 33..64 rows is ONE round of K3p column tiles where K3s re-reads a weight tile per
+//     32 columns (Q8_0 32000 x 4096 x 64 44.4 | 35.7 us, Q5_1 60.0 | 38.4; ab_dual_33.sh);
+//   * 512: a short matrix (a grouped-query model's k / v projection, 1024 x 4096) at prompt sizes is 128 workgroups of K3p (K3p | K3s: Q8_0 1024 x 4096 x 512 13.7 | 11.4,
+//     512 x 4096 x 512 13.5 | 7.8, 1024 x 11008 x 512 31.5 | 25.3; ab_dual_512.sh);
+//   * Q4_1 at 65 / 129: MX K3s | the pair by M -- 32000 x 4096 x 128 97.5 | 65.4, 11008 x 4096 x 128 36.1 | 31.4, 1024 x 4096 x 256 15.0 | 9.0, the price 4096 x 4096 x 128 13.7 | 15.9;
+//     behind a long K the min-term product's pieces grow with K (4096 x 11008 x 128 26.6 | 32.5), so its MX form keeps 65..128 rows there;
+//   * the two-scale types (Q4_2, Q6_K in its form) ran the staged int8 kernel above 256 rows until K3p got its two-scale form (4096 x 11008 x 512 142 | 112; ab_k3p_two_scale.sh).
 constexpr int64_t K3_DUAL_MIN_DEFAULT = 33, K3_DUAL_MAX = 512;
 int64_t k3_dual_min() { static const int v = dev_env_int("GGML_HIP_K3_DUAL_NMIN", (int)K3_DUAL_MIN_DEFAULT); return v; }   // developer A/B switch
 #define K3_DUAL_MIN k3_dual_min()
-int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : 65; }   // Q4_1: the first src1 row count served by the int8 pair (below: its MX batched-decode form)
+int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : 65; }   // Q4_1: the first src1 row count served by the int8 pair
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
-    // (Q5_1 from 9 rows: up to 8 its fused mat-vec is as fast)
-    // (Q4_2 from 9 rows, see below -- i8_only: the Q6_K extension lives in this form on its int8 planes alone; its mat-vec
-    // (gemv.hip GV_TYPE_I8X2) serves up to 4 rows, the batched-decode form takes it from 5)
-    static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch
-    // (the k-quants of the Q5_1 form: their fused mat-vec ends at 4 rows, 5..8 run INIT + the mat-vec -- measured against this form from 5, whole
-    // calls: 4096 x 4096 x 8 11.2 | 12.0 us, 4096 x 11008 x 8 22.1 | 25.1, 32000 x 4096 x 8 38.0 | 40.6: 9 stays for them too)
-    static const int k3s_nmin_kq = dev_env_int("GGML_HIP_K3S_NMIN_KQ", 9);   // developer A/B switch
-    // (Q4_2: from 9 rows -- r4; it was 17, its mat-vec's two-step form serving 9..16: mat-vec | this form at 16 rows 4096 x 4096 11.7 | 9.5 us,
-    // 4096 x 11008 27.2 | 22.7, 11008 x 4096 30.2 | 16.6, 32000 x 4096 78.5 | 35.2; from 5 rows the whole calls are mixed -- 4096 x 4096 x 8 10.5 | 12.9,
-    // 32000 x 4096 x 8 44.2 | 38.9 -- so its fused mat-vec keeps 5..8)
-    static const int k3s_nmin_2sc = dev_env_int("GGML_HIP_K3S_NMIN_2SC", GEMV_MAX_N + 1);   // developer A/B switch: Q4_2's lower bound
-    // Upper bound.  The form re-reads a weight tile once per 32 src1 rows, so beyond 64 rows it pays by M -- and the choice may not follow M.
-    // The two-scale types (Q4_2, and the Q6_K extension in its form) have only the staged int8 kernel behind it, 2 x slower than the others'
-    // forms: r4, up to 256 rows (A/B in one call, staged | this form: 4096 x 4096 x 65 / 128 / 256 42.9 | 15.2, 41.5 | 15.8, 48.5 | 29.9 us,
-    // 4096 x 11008 x 128 / 192 122 | 39.4, 124 | 73.6, 11008 x 4096 x 128 / 192 58.6 | 51.1, 97.9 | 80.4; the price: 32000 x 4096 x 128 120 | 134).
-    // The one-scale types keep 64: 4096 x 4096 x 128 19.0 | 11.6 and 4096 x 11008 x 128 43.0 | 26.7, but 11008 x 4096 x 128 32.4 | 41.9 and
-    // 32000 x 4096 x 128 69 | 114 -- their staged K-split forms are good, and a choice by M would change the summation tree.
-    // r5: K3p has a two-scale form (q8_mid_serves) and takes them from 129 rows like every other type -- this form | K3p: 4096 x 4096 x 129 / 192 / 256 27.1 | 19.9,
-    // 27.3 | 20.1, 27.4 | 20.9 us, 4096 x 11008 x 192 / 256 66.8 | 46.7, 67.4 | 50.2, 11008 x 4096 x 256 78.6 | 58.3, 32000 x 4096 x 192 166 | 136; the price:
-    // 11008 x 4096 x 129 52.6 | 56.6, 8192 x 8192 x 160 68.4 | 75.5, 2048 x 4096 x 256 14.8 | 19.9 (tools/experiments/ab_k3p_two_scale_129.sh).
-    static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 128);  // developer A/B switch: the two-scale types' upper bound (r4: 256)
-    // ... except behind a LONG K (from 11008: a down projection's shape, more columns than rows in every model family looked at), where the
-    // staged forms' K split is at its worst and M is small -- up to 128 rows there (staged | this form at 128 rows unless noted: 4096 x 11008
-    // 43.0 | 26.7, 5120 x 13824 64.7 | 57.3, Q5_1 x 96 72.7 | 36.3, 8192 x 28672 151 | 120, Q5_0 132 | 119; the price is a square or tall matrix
-    // with such a K: 11008 x 11008 78 | 93).  K = 8192 is mixed (8192 x 8192 41.6 | 38.1, 28672 x 8192 124 | 166) and stays at 64.
-    // Last, with the XCD-aware tile order (common.h k3s_tile_of: the column tiles of a row tile behind one L2) the price by M shrank -- staged | this
-    // form at 128 rows: 4096 x 4096 19.5 | 12.0 us, 8192 x 8192 42.4 | 37.5, 11008 x 4096 32.5 | 32.9, 28672 x 8192 134 | 136, Q5_1 11008 x 4096 x 96
-    // 49.1 | 35.7; still behind at 13824 x 5120 44.9 | 54.5 and 32000 x 4096 69.9 | 85.3 -- over the matrices of a decoder layer that is a gain at
-    // every model size looked at (the four attention projections and the down projection against gate / up): 128 rows whatever K.
-    static const int k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);        // developer A/B switch (0: the rule above)
-    // r5: ... and up to K3_DUAL_MAX rows wherever K3p-int8 serves too: there the two families are ONE tree and plan_mul_mat picks between them by M
+    // developer A/B switches (product builds: the defaults): the lower bounds by type group, the upper bound
+    static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5), k3s_nmin_kq = dev_env_int("GGML_HIP_K3S_NMIN_KQ", 9), k3s_nmin_2sc = dev_env_int("GGML_HIP_K3S_NMIN_2SC", GEMV_MAX_N + 1);
+    static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 0), k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);
     const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K3_DUAL_MAX;
-    // (r5: Q4_1 from K3_DUAL_MIN rows -- Q5_K's instantiation on its unsigned int8 planes and three min pieces, the arithmetic of its K3p form: up to 64 rows its MX form
-    // stays.  MX K3s | this pair by M: 32000 x 4096 x 128 97.5 | 63.7 us, 11008 x 4096 x 128 36.1 | 30.3, 1024 x 4096 x 256 (it was K3p) 15.0 | 8.8; the price 4096 x 4096 x 128 13.7 | 14.7)
-    // Behind a long K (>= 11008: a down projection, more columns than rows) the MX form keeps 65..128 rows -- the min-term product's pieces grow with K: 4096 x 11008 x 128 26.6 | 32.5.
-    if (type == GGML_TYPE_Q4_1) return !kq && N >= q41_pair_min(K) && N <= k3s_nmax && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_2) &&
-           N >= (type == GGML_TYPE_Q5_1 ? (kq ? k3s_nmin_kq : 9) : type == GGML_TYPE_Q4_2 ? (i8_only ? 5 : k3s_nmin_2sc) : k3s_nmin) && N <= (type == GGML_TYPE_Q4_2 && k3s_nmax_2sc != 128 ? k3s_nmax_2sc : k3s_nmax) && K / QK >= 64 && K / QK <= 1024 && plan_force_gemm() == 0;
+    if (K / QK < 64 || K / QK > 1024 || plan_force_gemm() != 0) return false;
+    if (type == GGML_TYPE_Q4_1) return !kq && N >= q41_pair_min(K) && N <= k3s_nmax;
+    if (type == GGML_TYPE_Q4_2) return N >= (i8_only ? 5 : k3s_nmin_2sc) && N <= (k3s_nmax_2sc > 0 ? k3s_nmax_2sc : k3s_nmax);
+    if (type == GGML_TYPE_Q5_1) return N >= (kq ? k3s_nmin_kq : 9) && N <= k3s_nmax;
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N >= k3s_nmin && N <= k3s_nmax;
 }
-// Q8_0 / Q5_0 (129..3072 rows), Q5_1 and (r5) Q4_2 / Q6_K in its form (129 rows and up) and Q4_1 (129..1024; r5: it was 257), 2048 <= K <= 79872: K3p on the int8 matrix cores (gemm_qmp.hip) -- image 0.  By type,
-// N and K alone (beyond K = 20480 the eight waves' scale tables go through LDS in slices, four at most: k3p_lds_ok -- ADVICE r3: the limit used to live in the launcher only).
-// r4: the upper bound was 512 rows.  Above it these types ran the staged f16 / int8 forms, and the stage-free form beats them well past
-// one round of the chip (A/B in one gpurun call, staged | K3p): Q8_0 4096 x 11008 x 1024 165 | 131 us, x 2048 320 | 257, 8192 x 8192 x 1024
-// 249 | 183, Q5_0 4096 x 4096 x 2048 125 | 102, Q5_1 4096 x 11008 x 2048 421 | 274; it loses from 4096 rows on (4096^3 195 | 219) and on a
-// vocabulary-sized matrix (32000 x 4096 x 2048 797 | 839: accepted, the choice may not look at M); Q4_1 (whose staged form is the MX
-// kernel) wins up to 1024 rows (4096 x 11008 x 1024 163 | 138) and loses at 2048 (112 | 126).
 bool q8_mid_serves(int type, int64_t K, int64_t N) {
-    static const int nmax = dev_env_int("GGML_HIP_K3P_NMAX", 0);   // developer A/B switch
-    // (Q5_1 -- and Q5_K, which lives as Q5_1 -- has no upper bound: its staged form pays the min term per block in the loop, and the
-    // stage-free form with the min terms as a product of their own beats it at every size looked at: 4096^3 299 | 243 us, 4096 x 11008 x 4096
-    // 734 | 548, 11008 x 4096 x 4096 932 | 614, 32000 x 4096 x 4096 2527 | 1774, 4096 x 4096 x 8192 597 | 451)
-    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 3072;   // (Q8_0 / Q5_0, 2048 -> 3072: 4096 x 11008 x 3072 439 | 392 us, 4096 x 4096 x 2560 182 | 167, x 3072 178 | 175, x 3584 186 | 200)
-    // lower bound, r4: 129 rows for Q8_0 / Q5_0 / Q5_1 (it was 257 for all).  One round of 128 x 64 tiles costs the same whatever N is, the staged
-    // K-split forms below it grow with N and with M: staged | K3p at 129 .. 256 rows -- 11008 x 4096 x 129 / 192 / 256 58.5 | 44.7, 60.0 | 47.7, 61.4 | 48.3 us,
-    // 8192 x 8192 x 192 (Q5_0) 61.0 | 44.1, Q5_1 11008 x 4096 x 192 70.6 | 52.9; 4096 x 4096 x 129 / 192 / 256 20.0 | 23.0, 22.1 | 24.1, 23.7 | 24.6 (the price),
-    // 4096 x 11008 x 192 / 256 48.9 | 51.2, 55.4 | 52.1.  Q4_1 keeps 257: its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6).
-    static const int nmin_dev = dev_env_int("GGML_HIP_K3P_NMIN", 0);   // developer A/B switch
-    // (r5: Q4_1 from 129 too -- it kept 257 because its staged forms are the MX kernel's (4096 x 4096 x 192 22.8 | 26.6 us then); with K3p's 64-row wave tiles
-    // and GPU-side timing, staged | K3p: 4096 x 4096 x 129 / 192 / 256 25.0 | 18.4, 24.8 | 18.4, 25.6 | 19.2, 4096 x 11008 x 192 59.3 | 40.4, 11008 x 4096 x 192 / 256 62.9 | 48.0,
-    // 71.3 | 52.5, 32000 x 4096 x 192 139 | 95.5, 8192 x 8192 x 160 78.0 | 51.4)
-    // r5: from K3_DUAL_MIN rows where K3s-int8 serves too (K <= 32768): the same tree, the family by M
-    const bool dual = K / QK <= 1024;
+    static const int nmax = dev_env_int("GGML_HIP_K3P_NMAX", 0), nmin_dev = dev_env_int("GGML_HIP_K3P_NMIN", 0);   // developer A/B switches
+    static const int two_min = dev_env_int("GGML_HIP_K3P_2SC_NMIN", 0), two_max = dev_env_int("GGML_HIP_K3P_2SC_NMAX", 0);   // ... for the two-scale types (NMIN 100000: the staged kernel)
+    if (K / QK < 64 || !k3p_lds_ok(k3p_i8_nloc(K)) || plan_force_gemm() != 0) return false;
+    const bool dual = K / QK <= 1024;                       // (K3s serves this K too: the shared range starts at K3_DUAL_MIN; beyond, K3p alone from 129 rows)
     const int64_t nmin = nmin_dev > 0 ? nmin_dev : !dual ? 129 : type == GGML_TYPE_Q4_1 ? q41_pair_min(K) : K3_DUAL_MIN;
-    // (r5) the two-scale types -- Q4_2, and Q6_K in its form: gemm_q8_mid_kernel<Q4_2> (two K = 16 products and two scale-accumulates per tile and k-block)
-    // instead of the staged int8 kernel's stages -- staged | K3p: 4096 x 4096 x 512 / 1024 / 2048 / 4096 55.8 | 44.2, 111 | 87.9, 187 | 176, 390 | 348 us, 4096 x 11008 x 512
-    // 142 | 112, x 2048 486 | 442, 11008 x 4096 x 512 169 | 128, 32000 x 4096 x 512 401 | 348, Q6_K 4096 x 4096 x 512 54.5 | 44.8, 4096 x 11008 x 512 138 | 110
-    // (tools/experiments/ab_k3p_two_scale.sh): no upper bound, like Q5_1.  What is left of the factor 2 to the one-scale types is the format's (twice the
-    // conversions and scale-accumulates per weight).
-    static const int two_min = dev_env_int("GGML_HIP_K3P_2SC_NMIN", 129), two_max = dev_env_int("GGML_HIP_K3P_2SC_NMAX", 0);   // developer A/B switches (NMIN 100000: the staged kernel)
-    if (type == GGML_TYPE_Q4_2)
-        return N >= (two_min != 129 ? two_min : nmin) && N <= (two_max > 0 ? two_max : INT64_MAX) && K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
-    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top &&
-           K / QK >= 64 && k3p_lds_ok(k3p_i8_nloc(K)) && plan_force_gemm() == 0;
+    if (type == GGML_TYPE_Q4_2) return N >= (two_min > 0 ? two_min : nmin) && N <= (two_max > 0 ? two_max : INT64_MAX);
+    const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 3072;
+    return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top;
 }
 
 int f16_image_kind(int type) { return type == GGML_TYPE_Q8_0 ? 2 : 1; }
