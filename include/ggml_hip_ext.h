@@ -270,8 +270,8 @@ int ggml_hip_push_columns_dev(const float *d_shard, int64_t lds, int64_t N, int6
 /* The product AND the exchange in one call (r4; SURVEY 8(e): "epilogue peer-writes straight into each peer's final [N][M] buffer"):
  * this rank's rows of W (Ggml.cs:6665-6672) against all of src1, every element stored as column col0 + m of EVERY rank's reference-layout
  * dst [N][ld_total] (Ggml.cs:6692-6697).  d_peers: HOST array of n_peers <= 16 device pointers to the buffers' BASES, this rank's own at
- * index `own`, NULL entries skipped.  Where the kernel form that serves (type, K, N) has the store-phase exchange -- the staged MX forms
- * and K3p, up to 8 destinations: ggml_hip_mul_mat_push_fused says so -- the GEMM's store phase writes to all of them (no shard pass, no
+ * index `own`, NULL entries skipped.  Where the kernel form that serves this weight at N rows has the store-phase exchange -- the staged MX
+ * forms, K3p and (r5) the batched-decode forms, up to 8 destinations: ggml_hip_mul_mat_push_fused says so -- the GEMM's store phase writes to all of them (no shard pass, no
  * second launch); otherwise the product lands in this rank's buffer and ggml_hip_push_columns_dev's kernel follows.  Same bytes either
  * way.  The caller orders consumers behind a barrier of its own. */
 int ggml_hip_mul_mat_push_dev(const ggml_hip_weight *w, const float *d_src1, int64_t N, int64_t ld1, float *const *d_peers, int n_peers,
