@@ -46,7 +46,6 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 //   * the two-scale types (Q4_2, Q6_K in its form) ran the staged int8 kernel above 256 rows until K3p got its two-scale form (4096 x 11008 x 512 142 | 112; ab_k3p_two_scale.sh).
 constexpr int64_t K3_DUAL_MIN_DEFAULT = 33, K3_DUAL_MAX = 512;
 int64_t k3_dual_min() { static const int v = dev_env_int("GGML_HIP_K3_DUAL_NMIN", (int)K3_DUAL_MIN_DEFAULT); return v; }   // developer A/B switch
-#define K3_DUAL_MIN k3_dual_min()
 int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : 65; }   // Q4_1: the first src1 row count served by the int8 pair
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // developer A/B switches (product builds: the defaults): the lower bounds by type group, the upper bound
@@ -64,7 +63,7 @@ bool q8_mid_serves(int type, int64_t K, int64_t N) {
     static const int two_min = dev_env_int("GGML_HIP_K3P_2SC_NMIN", 0), two_max = dev_env_int("GGML_HIP_K3P_2SC_NMAX", 0);   // ... for the two-scale types (NMIN 100000: the staged kernel)
     if (K / QK < 64 || !k3p_lds_ok(k3p_i8_nloc(K)) || plan_force_gemm() != 0) return false;
     const bool dual = K / QK <= 1024;                       // (K3s serves this K too: the shared range starts at K3_DUAL_MIN; beyond, K3p alone from 129 rows)
-    const int64_t nmin = nmin_dev > 0 ? nmin_dev : !dual ? 129 : type == GGML_TYPE_Q4_1 ? q41_pair_min(K) : K3_DUAL_MIN;
+    const int64_t nmin = nmin_dev > 0 ? nmin_dev : !dual ? 129 : type == GGML_TYPE_Q4_1 ? q41_pair_min(K) : k3_dual_min();
     if (type == GGML_TYPE_Q4_2) return N >= (two_min > 0 ? two_min : nmin) && N <= (two_max > 0 ? two_max : INT64_MAX);
     const int64_t top = nmax > 0 ? nmax : type == GGML_TYPE_Q4_1 ? 1024 : type == GGML_TYPE_Q5_1 ? INT64_MAX : 3072;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q5_1 || type == GGML_TYPE_Q4_1) && N >= nmin && N <= top;
@@ -326,7 +325,7 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     // 8192 x 8192 x 192 57.3 | 42.1, 1024 x 11008 x 256 35.2 | 17.1; the price is a grid just past a whole round -- 11008 x 4096 x 192 / 256 (258 / 344 workgroups of 128 rows) 37.7 | 46.5, 42.6 | 48.4
     // (tools/experiments/ab_mx_dual_256.sh)
     static const int mxdual_nmax = dev_env_int("GGML_HIP_MX_DUAL_NMAX", (int)K3_DUAL_MAX);   // (r5: 512 -- short matrices at prompt sizes, see K3_DUAL_MAX)
-    if (mxdual > 0 && q40 && N >= K3_DUAL_MIN && N <= mxdual_nmax && nbk >= 64 && var == 0) {
+    if (mxdual > 0 && q40 && N >= k3_dual_min() && N <= mxdual_nmax && nbk >= 64 && var == 0) {
         if (cdiv(M, 64) * cdiv(N, 64) >= mxdual && plan_k3p_mx(p, M, Mpad, K, N)) return;
         if (plan_k3s_mx(p, type, M, Mpad, K, N)) return;
         if (plan_k3p_mx(p, M, Mpad, K, N)) return;
