@@ -74,10 +74,10 @@ def stats(ts):
             "p90_ms": round(float(np.percentile(a, 90)), 5), "launches": int(a.size)}
 
 
-Q5_0, Q8_0 = 6, 8
+Q5_0, Q5_1, Q8_0 = 6, 7, 8
 Q5_K, Q4_K, Q6_K = 113, 112, 114                      # extension types (upstream k-quant format; absent from the reference)
-BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q8_0: 36, Q5_K: 22, Q4_K: 18, Q6_K: 26.25}   # Ggml.cs:76-82; per 32 weights -- Q5_K: 176 B per 256, Q4_K: 144, Q6_K: 210
-TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q8_0: "Q8_0", Q5_K: "Q5_K", Q4_K: "Q4_K", Q6_K: "Q6_K"}
+BLOCK_BYTES = {Q4_0: 20, Q5_0: 22, Q5_1: 24, Q8_0: 36, Q5_K: 22, Q4_K: 18, Q6_K: 26.25}   # Ggml.cs:76-82; per 32 weights -- Q5_K: 176 B per 256, Q4_K: 144, Q6_K: 210
+TYPE_NAME = {Q4_0: "Q4_0", Q5_0: "Q5_0", Q5_1: "Q5_1", Q8_0: "Q8_0", Q5_K: "Q5_K", Q4_K: "Q4_K", Q6_K: "Q6_K"}
 
 
 def make_weights_q4_0(M, K, seed, qtype=Q4_0):

@@ -338,6 +338,15 @@ def single_gpu_side_configs(device):
         "config5_total_on_one_gpu_Q4_0_32000x4096x512": dict(oc["vocab512"]["roofline"], ms_per_step=oc["vocab512"]["ms_per_step"]),
         "config5_shard_of_8_Q4_0_4000x4096x512": dict(oc["vocab512_shard_of_8"]["roofline"], ms_per_step=oc["vocab512_shard_of_8"]["ms_per_step"]),
     }
+    # r5: one summation tree for the stage-free forms -- the family follows M: a grouped-query k / v projection at prompt size (short: K3s),
+    # the output projection of a batched decode step (tall: K3p), a batch-128 decode projection (K3s), a min-term type on 16-row tiles.  Guarded one by
+    # one: nothing here feeds the line, and a side measurement must not take it down.
+    for name, (M_, K_, N_, copies_, iters_, qt_) in {"q8_0_kv_proj_prompt512": (1024, 4096, 512, 32, 80, B.Q8_0), "q8_0_lm_head_batch64": (32000, 4096, 64, 3, 40, B.Q8_0),
+                                                     "q4_0_batch128": (4096, 4096, 128, 24, 80, B.Q4_0), "q5_1_batch16": (4096, 4096, 16, 24, 100, B.Q5_1)}.items():
+        try:
+            oc[name] = side_config(device, M_, K_, N_, copies=copies_, iters=iters_, qtype=qt_)
+        except Exception as e:  # noqa: BLE001
+            oc[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
     # the drop-in path with HOST tensors (PCIe-inclusive; never `value`)
     try:
         pc = pcie_probe()
