@@ -461,6 +461,41 @@ def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):
     W.free()
 
 
+@pytest.mark.parametrize("t", [Q4_0, Q8_0, 7, 4])
+def test_k3s_and_k3p_agree_on_zero_rows_and_zero_blocks(dev, t):
+    """The two families pad their K ranges differently (K3s repeats a valid block under a zero table row, K3p reads zero planes past the end), so the
+    claim "the same bits" leans on x + 0 = x and on sums that never become -0.  Inputs that reach for the corners: src1 rows that are all zero (d = 0,
+    every term 0 * d0), weight rows that are all zero, a K with a ragged last range, negative-only data; K3p on the tall matrix, K3s on its shards: bit
+    for bit, and the all-zero rows / columns give +0.0 exactly (sign bit clear)."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    M, K, N = 16384, 2048 + 96, 96
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77 + t)
+    w = -torch.rand((M, K), generator=g, device="cuda") - 0.01          # negative-only weights
+    x = torch.randn((N, K), generator=g, device="cuda")
+    w[5::97] = 0.0
+    x[3::11] = 0.0
+    x[:, 1024:1056] = 0.0                                                # a zero k-block in every src1 row
+    rows = dev.quantize_rows(t, w)
+    pa, pb = _lib.ggml_hip_mm_plan_t(), _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pa)) == 0 and _lib.lib().ggml_hip_mm_plan(t, 1000, K, N, C.byref(pb)) == 0
+    assert pa.family in (5, 6) and pb.family in (3, 4) and pa.tree_id == pb.tree_id
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    assert torch.isfinite(full).all()
+    zero_bits = full[3::11].view(torch.int32)
+    assert int((zero_bits != 0).sum()) == 0, "an all-zero src1 row must give +0.0 exactly"
+    if t in (Q4_0, Q8_0):                                                # (the min-term types' zero rows keep their min term; Q4_2's scales are its own)
+        assert int((full[:, 5::97].view(torch.int32) != 0).sum()) == 0
+    for (r0, r1) in ((0, 1000), (4000, 4000 + 900), (M - 333, M)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        assert torch.equal(dev.mul_mat(Ws, x).view(torch.int32), full[:, r0:r1].contiguous().view(torch.int32)), (t, r0, r1)
+        Ws.free()
+    _check_fp64(dev, t, rows[:1000], x, full[:, :1000].contiguous(), K)
+    W.free()
+
+
 @pytest.mark.parametrize("t,N,K", [(Q8_0, 192, 4096), (Q5_0, 129, 4096), (7, 256, 4096), (3, 300, 2048), (Q8_0, 512, 11008), (7, 200, 22016), (Q5_0, 160, 2048 + 64),
                                    (4, 129, 4096), (4, 512, 11008), (4, 200, 22016),
                                    (Q4_0, 512, 4096), (Q4_0, 257, 2048 + 64), (Q4_0, 400, 22016)])
