@@ -16,8 +16,9 @@ enum mm_family {
     MMF_NONE = 0,
     MMF_GEMV_FUSED = 1,   // gemv.hip K2f / K2: INIT + COMPUTE in one launch, N <= 8
     MMF_GEMV_ROWS = 2,    // gemv.hip two-step form on K1's planes (Q4_2 at 9..16 rows where K < 2048; the COMPUTE-only entry for N <= 8)
-    MMF_K3S_MX = 3,       // gemm_qmx.hip K3s: stage-free batched decode, MX
-    MMF_K3S_I8 = 4,       // gemm_q8s.hip: the same on the int8 cores (Q8_0, Q5_0, Q5_1 / Q5_K, Q4_2 / Q6_K)
+    MMF_K3S_MX = 3,       // gemm_qmx.hip K3s: stage-free batched decode, MX (Q4_0, Q4_1)
+    MMF_K3S_I8 = 4,       // gemm_q8s.hip: the same on the int8 cores (Q8_0, Q5_0, Q5_1 / Q5_K / Q4_K, Q4_2 / Q6_K; r5: Q4_1 from 65 rows)
+    // (r5: 3 | 5 for Q4_0 and 4 | 6 are ONE summation tree each -- the same tree_id -- and plan_mul_mat picks between them by M where both serve)
     MMF_K3P_MX = 5,       // gemm_qmp.hip K3p: prompt-sized batches, MX (Q4_0)
     MMF_K3P_I8 = 6,       // gemm_qmp.hip K3p on the int8 cores (Q8_0, Q5_0, Q5_1, Q4_1; r5: Q4_2 and Q6_K in its form)
     MMF_MX = 7,           // gemm_qmx.hip staged forms
