@@ -46,6 +46,7 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 //   * the two-scale types (Q4_2, Q6_K in its form) ran the staged int8 kernel above 256 rows until K3p got its two-scale form (4096 x 11008 x 512 142 | 112; ab_k3p_two_scale.sh).
 constexpr int64_t K3_DUAL_MIN_DEFAULT = 33, K3_DUAL_MAX = 512;
 int64_t k3_dual_min() { static const int v = dev_env_int("GGML_HIP_K3_DUAL_NMIN", (int)K3_DUAL_MIN_DEFAULT); return v; }   // developer A/B switch
+int64_t k3_dual_wgs(int64_t K) { return K >= 11008 ? 192 : 160; }   // K3p takes over from this many workgroups of 64-row tiles (plan_mul_mat has the measurements)
 int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : 65; }   // Q4_1: the first src1 row count served by the int8 pair
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // developer A/B switches (product builds: the defaults): the lower bounds by type group, the upper bound
@@ -319,7 +320,8 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
     // 4096 x 4096 x 96 / 128 17.2 | 13.8 | 17.6, 17.2 | 13.7 | 17.5, 4096 x 11008 x 128 26.2 | 26.0 | 39.6 (K3s: 128 workgroups or fewer) -- 8192 x 4096 x 128 20.8 | 19.9 | 19.1,
     // 11008 x 4096 x 65 / 128 31.8 | 31.3 | 24.8, 31.9 | 35.3 | 25.3, 16384 x 4096 x 128 35.8 | 37.2 | 28.5, 32000 x 4096 x 96 / 128 69.1 | 57.3 | 54.9, 69.7 | 71.8 | 55.8,
     // 8192 x 8192 x 128 36.3 | 30.9 | 31.8, 11008 x 11008 x 128 71.8 | 72.0 | 53.6 (K3p: 256 and more).
-    static const int mxdual = dev_env_int("GGML_HIP_MX_DUAL_WGS", 192);     // developer A/B switch: K3p from this many 64-row workgroups (1: always, 1000000: never, 0: the r4 plan)
+    static const int mxdual_dev = dev_env_int("GGML_HIP_MX_DUAL_WGS", -1);     // developer A/B switch: K3p from this many 64-row workgroups (1: always, 1000000: never, 0: the r4 plan; -1: the rule)
+    const int64_t mxdual = mxdual_dev >= 0 ? mxdual_dev : k3_dual_wgs(K);   // (160 behind K < 11008: Q4_0 2560 x 4096 x 256 16.6 | 14.8 us, 11008 x 4096 x 64 19.8 | 19.4; 192 behind a longer K)
     // ... and up to 256 rows (the staged two-/four-way forms served 129..256): the r4 plan | the family by M -- 1024 x 4096 x 256 15.3 | 8.0, 2048 x 4096 x 192 / 256 18.0 | 12.8, 17.5 | 12.6,
     // 4096 x 4096 x 129 / 192 / 256 19.1 | 17.6, 19.1 | 17.7, 19.5 | 17.8, 8192 x 4096 x 192 31.6 | 25.2, 32000 x 4096 x 192 / 256 85.5 | 79.7, 118 | 105, 4096 x 11008 x 192 / 256 45.2 | 40.0, 46.5 | 40.4,
     // 8192 x 8192 x 192 57.3 | 42.1, 1024 x 11008 x 256 35.2 | 17.1; the price is a grid just past a whole round -- 11008 x 4096 x 192 / 256 (258 / 344 workgroups of 128 rows) 37.7 | 46.5, 42.6 | 48.4
@@ -522,11 +524,14 @@ mm_plan plan_mul_mat(int type, int ext_type, int64_t M, int64_t K, int64_t N, bo
     // r5: K3s-int8 and K3p-int8 are ONE summation tree -- the same eight K ranges (k3p_i8_nloc), a range's min-term chunks and blocks in the
     // same order with the same statement, the eight sums added in wave order: the same bits per element (tests/test_gpu_fullsize.py
     // test_k3s_and_k3p_int8_compute_the_same_bits) and the same tree_id -- so where both serve (K3_DUAL_MIN .. K3_DUAL_MAX src1 rows) the FAMILY follows M: K3p once
-    // its grid of 64-row tiles has `dual` workgroups, K3s below.  K3s | K3p, us per COMPUTE launch (tools/experiments/ab_k3s_k3p_overlap.sh): Q8_0 4096 x 4096 x 128 13.3 | 15.6,
+    // its grid of 64-row tiles has k3_dual_wgs(K) workgroups, K3s below.  K3s | K3p, us per COMPUTE launch (tools/experiments/ab_k3s_k3p_overlap.sh): Q8_0 4096 x 4096 x 128 13.3 | 15.6,
     // 4096 x 11008 x 128 27.6 | 32.4, 1024 x 4096 x 256 7.8 | 13.8, 2048 x 4096 x 256 11.8 | 15.3, 1024 x 11008 x 256 16.9 | 29.2, 2048 x 8192 x 160 17.3 | 22.9 (128 workgroups
     // or fewer: K3s) -- 8192 x 4096 x 128 20.4 | 17.9, 11008 x 4096 x 65 / 128 31.1 | 27.0, 35.2 | 27.5, 16384 x 4096 x 128 39.7 | 31.4, 32000 x 4096 x 128 75.2 | 60.0, 8192 x 8192 x 128 33.0 | 30.0,
     // Q5_1 11008 x 4096 x 128 38.3 | 30.5, Q4_2 32000 x 4096 x 128 118 | 96.5, Q4_2 4096 x 4096 x 192 27.3 | 20.1 (192 workgroups and more: K3p).
-    static const int dual = dev_env_int("GGML_HIP_K3_DUAL_WGS", 192);   // developer A/B switch: K3p from this many 64-row workgroups (0: always K3s, 1: always K3p)
+    // (160 behind K < 11008, 192 behind a longer K -- ab_dual_wgs.sh, K3s | K3p: Q8_0 11008 x 4096 x 64 (172 workgroups) 20.0 | 17.2, Q5_1 27.5 | 19.5, Q4_2 31.3 | 21.3, 10240 x 4096 x 48 (160) 19.2 | 15.9,
+    // 5120 x 4096 x 128 (160) 18.3 | 15.6, 2560 x 4096 x 256 (160) 16.4 | 13.9; but 5120 x 13824 x 96 (160) 32.5 | 41.4; at 128 workgroups K3s: 8192 x 4096 x 64 14.6 | 16.9, 4096 x 4096 x 128 13.4 | 15.7)
+    static const int dual_dev = dev_env_int("GGML_HIP_K3_DUAL_WGS", 0);   // developer A/B switch: K3p from this many 64-row workgroups (1: always K3p, 1000000: never; 0: the rule)
+    const int64_t dual = dual_dev > 0 ? dual_dev : k3_dual_wgs(K);
     const bool mid_first = small && mid && cdiv(M, 64) * cdiv(N, 64) >= dual;
     if (small && !mid_first) {                              // (r4: Q5_K weights too -- planar Q5_1 form, activations by the Q8_K rule)
         if (plan_k3s_i8(p, type, M, Mpad, K, N)) { if (ext_type != 0) p.flags &= ~MM_FLAG_EPILOGUE_FUSED; p.flags |= MM_FLAG_NEEDS_WORK; return p; }

@@ -197,7 +197,7 @@ def test_bad_arguments_are_reported():
 def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
     """r5: the stage-free int8 families -- batched decode K3s and prompt-sized K3p -- share their summation tree (the same eight K
     ranges, statement, wave-order sum; GPU: test_k3s_and_k3p_int8_compute_the_same_bits), so between 33 and 512 src1 rows the plan picks the FAMILY by
-    M: K3p once its grid of 64-row tiles has 192 workgroups, K3s below.  tree_id may not move with that choice."""
+    M: K3p once its grid of 64-row tiles has 160 workgroups (192 behind K >= 11008), K3s below.  tree_id may not move with that choice."""
     for t in (Q8_0, Q5_0, Q5_1, Q4_1, Q4_2, Q5_K, Q6_K):
         for K in (4096, 11008, 2048 + (256 if t in (Q5_K, Q6_K) else 64)):
             for N in (33, 64, 65, 100, 128, 129, 200, 256, 384, 512):
@@ -207,7 +207,7 @@ def test_k3s_and_k3p_int8_are_one_tree_and_the_family_follows_M():
                 for M in (512, 1024, 2048, 4096, 8192, 11008, 32000):
                     p = plan(t, M, K, N)
                     assert p.family in (FAM["k3s_i8"], FAM["k3p_i8"]), (t, M, K, N, p.family)
-                    want = FAM["k3p_i8"] if -(-M // 64) * -(-N // 64) >= 192 else FAM["k3s_i8"]
+                    want = FAM["k3p_i8"] if -(-M // 64) * -(-N // 64) >= (192 if K >= 11008 else 160) else FAM["k3s_i8"]
                     assert p.family == want, (t, M, K, N)
                     ids.add(p.tree_id); fams.add(p.family)
                 assert len(ids) == 1 and len(fams) == 2, (t, K, N)
@@ -229,7 +229,7 @@ def test_k3s_and_k3p_mx_are_one_tree_and_the_family_follows_M():
             ids, fams = set(), set()
             for M in (512, 2048, 4096, 8192, 11008, 32000):
                 p = plan(Q4_0, M, K, N)
-                want = FAM["k3p_mx"] if -(-M // 64) * -(-N // 64) >= 192 else FAM["k3s_mx"]
+                want = FAM["k3p_mx"] if -(-M // 64) * -(-N // 64) >= (192 if K >= 11008 else 160) else FAM["k3s_mx"]
                 assert p.family == want, (M, K, N, p.family)
                 ids.add(p.tree_id); fams.add(p.family)
             assert len(ids) == 1 and len(fams) == 2, (K, N)
