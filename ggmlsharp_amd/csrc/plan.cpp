@@ -47,7 +47,7 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 constexpr int64_t K3_DUAL_MIN_DEFAULT = 33, K3_DUAL_MAX = 512;
 int64_t k3_dual_min() { static const int v = dev_env_int("GGML_HIP_K3_DUAL_NMIN", (int)K3_DUAL_MIN_DEFAULT); return v; }   // developer A/B switch
 int64_t k3_dual_wgs(int64_t K) { return K >= 11008 ? 192 : 160; }   // K3p takes over from this many workgroups of 64-row tiles (plan_mul_mat has the measurements)
-int64_t q41_pair_min(int64_t K) { return K >= 11008 ? 129 : 65; }   // Q4_1: the first src1 row count served by the int8 pair
+int64_t q41_pair_min(int64_t K) { static const int v = dev_env_int("GGML_HIP_Q41_PAIR_MIN", 65); return K >= 11008 ? 129 : v; }   // Q4_1: the first src1 row count served by the int8 pair
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // developer A/B switches (product builds: the defaults): the lower bounds by type group, the upper bound
     static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5), k3s_nmin_kq = dev_env_int("GGML_HIP_K3S_NMIN_KQ", 9), k3s_nmin_2sc = dev_env_int("GGML_HIP_K3S_NMIN_2SC", GEMV_MAX_N + 1);
