@@ -51,6 +51,29 @@ int main(int argc, char **argv) {
                                                                        (void)hipStreamSynchronize(s[0]); (void)hipStreamSynchronize(s[2]); }));
     printf("kernels of all 512 rows alone   %7.1f us\n", median([&] { kern(s[1], 0, N); (void)hipStreamSynchronize(s[1]); }));
     printf("empty synchronize               %7.1f us\n", median([&] { (void)hipStreamSynchronize(s[1]); }));
+    // uneven chunks over three streams: a small first chunk starts the download early, a small last one shortens the drain
+    {
+        const std::vector<std::vector<int>> splits = {{128, 128, 128, 128}, {64, 128, 160, 160}, {64, 192, 192, 64}, {96, 160, 160, 96}, {32, 160, 160, 160}, {170, 171, 171}, {128, 192, 192},
+                                                      {64, 64, 128, 128, 128}, {102, 102, 102, 103, 103}, {256, 128, 128}, {192, 192, 128}, {224, 160, 128}};
+        for (const auto &sp : splits) {
+            double t = median([&] {
+                size_t r0 = 0;
+                for (size_t k = 0; k < sp.size(); ++k) {
+                    const size_t c = (size_t)sp[k];
+                    (void)hipMemcpyAsync((char *)dx + r0 * K * 4, hx + r0 * K * 4, c * K * 4, hipMemcpyHostToDevice, s[0]);
+                    (void)hipEventRecord(ev[2 * k], s[0]); (void)hipStreamWaitEvent(s[1], ev[2 * k], 0);
+                    kern(s[1], r0, c);
+                    (void)hipEventRecord(ev[2 * k + 1], s[1]); (void)hipStreamWaitEvent(s[2], ev[2 * k + 1], 0);
+                    (void)hipMemcpyAsync(hd + r0 * M * 4, (char *)dd + r0 * M * 4, c * M * 4, hipMemcpyDeviceToHost, s[2]);
+                    r0 += c;
+                }
+                (void)hipStreamSynchronize(s[2]);
+            });
+            printf("three streams, chunks of");
+            for (int c : sp) printf(" %d", c);
+            printf(" rows: %7.1f us\n", t);
+        }
+    }
     for (int nch : {1, 2, 4, 8, 16}) {
         const size_t c = N / nch;
         double t3 = median([&] {                        // today's form: three streams, two event hops per chunk
