@@ -33,6 +33,7 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 // Q5_0 / Q5_1 / Q4_1 / Q4_2 and the k-quants on int8 operand planes built at upload.  2048 <= K <= 32768 for K3s (two rounds of table pieces per wave), <= 79872
 // for K3p (sliced scale tables: k3p_lds_ok).
 //     src1 rows     served by
+//     (K from 1024: r5, k3s_kmin -- behind K < 2048 K3s serves 5 .. 64 rows and nothing else of this table applies)
 //     5 .. 32       K3s   (Q5_1, Q4_2 and the k-quants of the Q5_1 form from 9: up to 8 rows their mat-vec is as fast; Q6_K, whose mat-vec ends at 4, from 5)
 //     33 .. 512     both  -- plan_mul_mat picks by M (Q4_1 joins at 65, behind K >= 11008 at 129: below that its MX batched-decode form, another arithmetic)
 //     513 .. top    K3p   (top: Q8_0 / Q5_0 3072 -- beyond, their staged f16 forms win; Q4_1 1024; Q5_1, Q4_2 and the k-quants: none)
@@ -46,15 +47,20 @@ bool k3p_lds_ok(int nloc) { return nloc <= K3P_MAX_SLICES * K3P_SLICE_ROWS; }
 //   * the two-scale types (Q4_2, Q6_K in its form) ran the staged int8 kernel above 256 rows until K3p got its two-scale form (4096 x 11008 x 512 142 | 112; ab_k3p_two_scale.sh).
 constexpr int64_t K3_DUAL_MIN_DEFAULT = 33, K3_DUAL_MAX = 512;
 int64_t k3_dual_min() { static const int v = dev_env_int("GGML_HIP_K3_DUAL_NMIN", (int)K3_DUAL_MIN_DEFAULT); return v; }   // developer A/B switch
+// r5: the batched-decode forms from K = 1024 (32 k-blocks; it was 2048) up to 64 src1 rows -- a small model's hidden size.  Behind such a K there is no K3p (its waves want 8 k-blocks each), so
+// no partner on the same tree and no choice by M: only the range where K3s wins on short and tall matrices alike.  Staged | K3s, us per COMPUTE launch (tools/experiments/ab_k3s_kmin.sh):
+// Q4_0 1536 x 1536 x 16 / 32 / 64 6.3 | 3.9, 6.0 | 4.5, 7.5 | 5.4, 2048 x 1792 x 32 6.8 | 4.6, 4096 x 1024 x 32 5.1 | 4.6, 8960 x 1536 x 32 7.7 | 7.2, Q8_0 1536 x 1536 x 32 6.5 | 4.9;
+// the price: Q8_0 8960 x 1536 x 32 8.3 | 8.7, Q5_1 x 16 8.8 | 9.4.  Beyond 64 rows it wins on short matrices only (Q8_0 1536 x 1536 x 512 14.2 | 11.1 but 8960 x 1536 x 512 38.5 | 51.9): staged stays.
+int64_t k3s_kmin() { static const int v = dev_env_int("GGML_HIP_K3S_KMIN", 32); return v; }   // developer A/B switch: the batched-decode forms from this many k-blocks (K / 32)
 int64_t k3_dual_wgs(int64_t K) { return K >= 11008 ? 192 : 160; }   // K3p takes over from this many workgroups of 64-row tiles (plan_mul_mat has the measurements)
 int64_t q41_pair_min(int64_t K) { static const int v = dev_env_int("GGML_HIP_Q41_PAIR_MIN", 65); return K >= 11008 ? 129 : v; }   // Q4_1: the first src1 row count served by the int8 pair
 bool q8_small_serves(int type, int64_t K, int64_t N, bool i8_only = false, bool kq = false) {
     // developer A/B switches (product builds: the defaults): the lower bounds by type group, the upper bound
     static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5), k3s_nmin_kq = dev_env_int("GGML_HIP_K3S_NMIN_KQ", 9), k3s_nmin_2sc = dev_env_int("GGML_HIP_K3S_NMIN_2SC", GEMV_MAX_N + 1);
     static const int k3s_nmax_2sc = dev_env_int("GGML_HIP_K3S_NMAX_2SC", 0), k3s_nmax_dev = dev_env_int("GGML_HIP_K3S_NMAX", 0);
-    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K3_DUAL_MAX;
-    if (K / QK < 64 || K / QK > 1024 || plan_force_gemm() != 0) return false;
-    if (type == GGML_TYPE_Q4_1) return !kq && N >= q41_pair_min(K) && N <= k3s_nmax;
+    const int64_t k3s_nmax = k3s_nmax_dev > 0 ? k3s_nmax_dev : K / QK < 64 ? 64 : K3_DUAL_MAX;   // (behind K < 2048: the batched-decode range only, see k3s_kmin)
+    if (K / QK < k3s_kmin() || K / QK > 1024 || plan_force_gemm() != 0) return false;
+    if (type == GGML_TYPE_Q4_1) return K / QK >= 64 && !kq && N >= q41_pair_min(K) && N <= k3s_nmax;
     if (type == GGML_TYPE_Q4_2) return N >= (i8_only ? 5 : k3s_nmin_2sc) && N <= (k3s_nmax_2sc > 0 ? k3s_nmax_2sc : k3s_nmax);
     if (type == GGML_TYPE_Q5_1) return N >= (kq ? k3s_nmin_kq : 9) && N <= k3s_nmax;
     return (type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0) && N >= k3s_nmin && N <= k3s_nmax;
@@ -108,7 +114,7 @@ int plan_image_kind(int type, int64_t K, int64_t N) {
     // (r4, A/B of whole calls in one gpurun call, K3s from 5 | the fused mat-vec up to 8: 4096 x 4096 x 8 Q4_0 10.3 | 10.1 us, Q8_0 10.8 | 9.9 -- level --
     // 4096 x 11008 x 8 20.1 | 25.6, 11008 x 4096 x 8 15.6 | 18.4, 32000 x 4096 x 8 26.5 | 40.2: 5 stays)
     static const int k3s_nmin = dev_env_int("GGML_HIP_K3S_NMIN", 5);   // developer A/B switch: the batched-decode forms from this many rows
-    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= 64 && N >= k3s_nmin)) return 0;
+    if (N <= GEMV_MAX_N && !(force == 0 && (type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && K / QK >= k3s_kmin() && N >= k3s_nmin)) return 0;
     if (type == GGML_TYPE_Q4_2) return 0;   // served by the mat-vec and int8 kernels only (its k-block carries two scales)
     // the MX / f16 kernels address weights and the activation image through 32-bit buffer offsets
     const uint64_t nba = (uint64_t)pad_kblocks(K / QK);
@@ -342,8 +348,8 @@ void plan_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64_t N
             static const int ncmax_dev = dev_env_int("GGML_HIP_K3S_COLS", 0);   // developer A/B switch: 1 = K3s up to 32 rows only (0: the rule)
             // (with the XCD-aware tile order, staged | this form at 128 rows: Q4_1 4096 x 4096 20.2 | 12.8, 11008 x 4096 x 96 42.2 | 35.4 -- Q4_1 whatever K;
             // Q4_0 4096 x 4096 16.0 | 13.1 but 11008 x 4096 28.8 | 34.0, 32000 x 4096 62.5 | 68.6, 28672 x 8192 106 | 112: its staged forms are better, K >= 11008 stays)
-            const int ncmax = ncmax_dev > 0 ? ncmax_dev : (K >= 11008 || !q40) ? 4 : 2;
-            if (N <= 32 * ncmax && nbk >= 64 && var != 25 && var != 26 && plan_k3s_mx(p, type, M, Mpad, K, N)) return;
+            const int ncmax = ncmax_dev > 0 ? ncmax_dev : nbk < 64 ? 2 : (K >= 11008 || !q40) ? 4 : 2;   // (K < 2048: up to 64 rows, see k3s_kmin)
+            if (N <= 32 * ncmax && nbk >= k3s_kmin() && var != 25 && var != 26 && plan_k3s_mx(p, type, M, Mpad, K, N)) return;
         }
         if (N <= 32 && var != 25) {
             const int h32 = var == 13 ? 32 : var == 15 || var == 12 ? 64 : (t64 < 160 ? 32 : 64);

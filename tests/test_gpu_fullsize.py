@@ -461,6 +461,34 @@ def test_k3s_and_k3p_int8_compute_the_same_bits(dev, t, K, N):
     W.free()
 
 
+@pytest.mark.parametrize("t", [Q4_0, 3, Q8_0, Q5_0, 7, 4])
+@pytest.mark.parametrize("K,N", [(1024, 16), (1024, 64), (1280, 33), (1536, 32), (1792, 9), (2016, 24)])
+def test_batched_decode_forms_behind_a_short_K(dev, t, K, N):
+    """r5: the batched-decode forms from K = 1024 (a small model's hidden size; it was 2048) up to 64 src1 rows: four to eight k-blocks per wave, slots
+    past a wave's range repeating a valid block under a zero table row.  K with an odd number of k-blocks per eighth (1280: 5 -> 6) and a ragged last range
+    (2016: 63 k-blocks).  fp64 evaluation of the block arithmetic, the oracle sample, and row shards -- 16-row tiles, one and several 32-row tiles per
+    workgroup -- are the bitwise slices of an 18000-row matrix."""
+    from ggmlsharp_amd import _lib
+    import ctypes as C
+    if t in (7, 4) and N < 9:
+        pytest.skip("this type's mat-vec serves up to 8 rows")
+    M = 18000
+    pl = _lib.ggml_hip_mm_plan_t()
+    assert _lib.lib().ggml_hip_mm_plan(t, M, K, N, C.byref(pl)) == 0 and pl.family in (3, 4), (t, K, N, pl.family)
+    rows, x, w = _make(dev, t, M, K, N, seed=K + 7 * N + t, keep_w=True)
+    W = dev.Weight.from_device(t, rows, K)
+    full = dev.mul_mat(W, x)
+    for (r0, r1) in ((0, 3000), (3000, 3000 + 4096), (9000, 9000 + 777), (M - 100, M)):
+        Ws = dev.Weight.from_device(t, rows, K, row_begin=r0, row_end=r1)
+        part = dev.mul_mat(Ws, x)
+        assert torch.equal(part, full[:, r0:r1]), (t, K, N, r0, r1)
+        if r0 == 0:
+            _check_fp64(dev, t, rows[r0:r1], x, part, K)
+            _check_oracle_sample(t, rows[r0:r1], w[r0:r1], x, part, K, seed=K + N)
+        Ws.free()
+    W.free()
+
+
 @pytest.mark.parametrize("t", [Q4_0, Q8_0, 7, 4])
 def test_k3s_and_k3p_agree_on_zero_rows_and_zero_blocks(dev, t):
     """The two families pad their K ranges differently (K3s repeats a valid block under a zero table row, K3p reads zero planes past the end), so the

@@ -102,7 +102,13 @@ def test_baseline_configs_get_the_kernels_design_md_names():
             assert plan(t, M, K, N).family == FAM["k3p_i8"], (t, M, K, N)
         assert plan(t, 4096, 4096, 512).tree_id not in {plan(u, 4096, 4096, 512).tree_id for u in (Q8_0, Q5_0, Q5_1, Q4_1)}   # (two scale-accumulates per k-block: a tree of its own)
     assert plan(Q6_K, 4096, 4096, 512).tree_id != plan(Q4_2, 4096, 4096, 512).tree_id              # (activations by the Q8_K rule)
-    assert plan(Q6_K, 4096, 1024, 5).family == FAM["i8"] and plan(Q4_2, 4096, 1024, 512).family == FAM["i8"]   # (K < 2048: the staged int8 kernel)
+    assert plan(Q6_K, 4096, 768, 5).family == FAM["i8"] and plan(Q4_2, 4096, 1024, 512).family == FAM["i8"]   # (K < 1024, or K < 2048 beyond 64 rows: the staged int8 kernel)
+    # r5: the batched-decode forms from K = 1024 (it was 2048) up to 64 src1 rows -- no K3p behind such a K, so no shared range there
+    for t, fam in ((Q8_0, "k3s_i8"), (Q5_0, "k3s_i8"), (Q4_0, "k3s_mx"), (Q4_1, "k3s_mx"), (Q6_K, "k3s_i8")):
+        for K in (1024, 1536, 1792):                          # (multiples of 256: the k-quants' super-block)
+            assert plan(t, 4096, K, 32).family == FAM[fam] and plan(t, 32000, K, 64).family == FAM[fam], (t, K)
+            assert plan(t, 4096, K, 65).family not in (FAM["k3s_i8"], FAM["k3s_mx"], FAM["k3p_i8"], FAM["k3p_mx"]), (t, K)
+        assert plan(t, 4096, 768, 32).family not in (FAM["k3s_i8"], FAM["k3s_mx"]), t
     assert plan(Q6_K, 4096, 4096, 8).tree_id != plan(Q4_2, 4096, 4096, 32).tree_id              # (activations by the Q8_K rule: another tree)
     # r4: behind a long K (>= 11008, a down projection) the one-scale int8 types stay on the batched-decode form up to 128 rows
     assert plan(Q8_0, 4096, 11008, 128).family == FAM["k3s_i8"] and plan(Q5_1, 5120, 13824, 96).family == FAM["k3s_i8"] and plan(Q5_K, 4096, 11008, 128).family == FAM["k3s_i8"]
@@ -120,7 +126,7 @@ def test_baseline_configs_get_the_kernels_design_md_names():
     assert p.family == FAM["k3s_i8"] and p.image_kind == 64 and (p.flags & MIN_PIECES)
     assert plan(Q5_1, 4096, 4096, 8).family == FAM["gemv_fused"]                    # (up to 8 rows its fused mat-vec is as fast)
     assert plan(Q4_2, 4096, 4096, 32).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 4096, 9).family == FAM["k3s_i8"] and plan(Q4_2, 4096, 4096, 8).family == FAM["gemv_fused"]   # (r4: from 9 rows; its mat-vec keeps up to 8, and 9..16 where K < 2048)
-    assert plan(Q4_2, 4096, 1024, 16).family == FAM["gemv_rows"]
+    assert plan(Q4_2, 4096, 768, 16).family == FAM["gemv_rows"] and plan(Q4_2, 4096, 1024, 16).family == FAM["k3s_i8"]   # (r5: the batched-decode form from K = 1024)
     assert len({plan(t, 4096, 4096, 32).tree_id for t in (Q8_0, Q5_0, Q5_1, Q4_2)}) == 4   # four different arithmetics, four trees
     # r4: K3p serves Q8_0 / Q5_0 up to 3072 rows, Q4_1 up to 1024, Q5_1 / Q5_K without bound; Q4_0 (MX) up to 512
     assert plan(Q8_0, 4096, 11008, 3072).family == FAM["k3p_i8"] and plan(Q8_0, 4096, 11008, 3073).family != FAM["k3p_i8"]

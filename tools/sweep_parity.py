@@ -20,7 +20,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 120):
     t = int(rng.choice(list(TYPES)))
     M = int(rng.choice(edges))
     N = int(rng.choice([1, 2, 5, 8, 9, 12, 16, 17, 24, 31, 32, 33, 64, 65, 127, 128, 129, 200, 255, 256, 257, 300, 384, 448, 512, 513, 600, 768, 1024, 1500, 2048]))
-    K = 32 * int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 33, 64, 65, 73, 100, 129]))      # (64 k-blocks and up: the stage-free forms K3s / K3p)
+    K = 32 * int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 31, 32, 33, 40, 47, 48, 56, 63, 64, 65, 73, 100, 129]))      # (32 k-blocks and up: the batched-decode forms K3s -- r5, it was 64; 64 and up: K3p too)
     kernel = int(rng.choice([0, 1, 2, 3]))
     lib().ggml_hip_debug_force_gemm(kernel)
     g = torch.Generator(device="cuda")
