@@ -183,12 +183,15 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // Q5_1 4096 x 4096 x 9 / 16 / 32 12.8 | 8.0, 12.9 | 8.0, 12.9 | 10.2 us, 4096 x 11008 x 16 / 32 27.7 | 16.2, 27.7 | 21.4, 2048 x 8192 x 32 16.7 | 13.1, 4096 x 28672 x 16 62.5 | 34.8,
     // Q5_K 4096 x 4096 x 16 13.0 | 8.1, Q4_K x 32 13.2 | 10.4, 4096 x 11008 x 16 28.4 | 16.4 -- tools/experiments/ab_q8s_16_min.sh)
     static const int min16 = dev_env_int("GGML_HIP_Q8S_16_MIN", 1);   // developer A/B switch: 0 = the min-term types keep the 32-row form
-    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q4_2 || (type == GGML_TYPE_Q5_1 && min16)) && N <= 32) {
+    // (up to 64 rows -- it was 32: on a short matrix 33..64 rows are column groups of 16 or 32 columns, 256 workgroups at most: Q4_0 1024 x 4096 x 64 7.8 -> 5.2 us, 2048 x 4096 x 64 8.9 -> 7.2,
+    // Q8_0 9.6 -> 8.4 / 1024 rows 7.6 -> 5.5, Q5_1 9.8 -> 8.6, Q4_0 1536 x 1536 x 64 5.4 -> 4.6; 4096 rows and more keep two 32-row workgroups per weight tile.  tools/experiments/ab_tile16_n64.sh)
+    static const int n16max = dev_env_int("GGML_HIP_K3S_16_NMAX", 64);   // developer A/B switch: 16-row tiles up to this many src1 rows
+    if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q4_2 || (type == GGML_TYPE_Q5_1 && min16)) && N <= n16max) {
         // (17..32 rows on a SHORT matrix: one 16-column slice per workgroup and two workgroups per weight tile while those fit one round -- 2048 rows are 256 workgroups that way,
         // 128 with both slices in one: Q4_0 2048 x 4096 x 32 7.5 -> 5.9 us, 1024 x 4096 x 32 6.7 -> 5.2, 2048 x 8192 x 32 12.6 -> 9.9, Q8_0 2048 x 4096 x 32 8.6 -> 6.6, Q5_1 8.3 -> 6.8;
         // tools/experiments/ab_tile16_tn.sh.  Geometry, like the tile height.)
         static const int tn16_dev = dev_env_int("GGML_HIP_K3S_16_TN", 0);   // developer A/B switch: 16 / 32 = that many columns per workgroup whatever M
-        const int tn16 = N <= 16 || tn16_dev == 16 || (tn16_dev == 0 && cdiv(M, 16) * 2 <= 256) ? 16 : 32;
+        const int tn16 = N <= 16 || tn16_dev == 16 || (tn16_dev == 0 && cdiv(M, 16) * cdiv(N, 16) <= 256) ? 16 : 32;
         const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
         const int nb16 = nloc <= 8 ? 8 : 16, rows16 = (int)cdiv(nloc, nb16) * nb16;   // (the launcher's slots: gemm_q8s.hip)
         const bool fits = (int64_t)KS8 * rows16 * tn16 * 4 <= 160 * 1024;
@@ -276,12 +279,13 @@ bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // reasons): Q4_0 4096 x 4096 x 32 10.6 | 8.6 us per COMPUTE launch (32-row | 16-row tiles, replayed graphs, 32 weight copies in turn), x 16 and
     // x 5 10.6 | 7.1, 4096 x 11008 x 32 22.6 | 19.0, 2048 x 8192 x 32 19.1 | 16.5; the whole call at 16 rows 13.8 | 10.3.
     // (Q4_1 too: its min term as k = 0 / 2 of one v_mfma_f32_16x16x4_f32 per pair -- the 32-row form's two fmaf in the same order)
-    if ((type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && N <= 32) {
+    static const int n16max = dev_env_int("GGML_HIP_K3S_16_NMAX", 64);   // developer A/B switch: see plan_k3s_i8
+    if ((type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && N <= n16max) {
         // (17..32 rows on a SHORT matrix: one 16-column slice per workgroup and two workgroups per weight tile while those fit one round -- 2048 rows are 256 workgroups that way,
         // 128 with both slices in one: Q4_0 2048 x 4096 x 32 7.5 -> 5.9 us, 1024 x 4096 x 32 6.7 -> 5.2, 2048 x 8192 x 32 12.6 -> 9.9, Q8_0 2048 x 4096 x 32 8.6 -> 6.6, Q5_1 8.3 -> 6.8;
         // tools/experiments/ab_tile16_tn.sh.  Geometry, like the tile height.)
         static const int tn16_dev = dev_env_int("GGML_HIP_K3S_16_TN", 0);   // developer A/B switch: 16 / 32 = that many columns per workgroup whatever M
-        const int tn16 = N <= 16 || tn16_dev == 16 || (tn16_dev == 0 && cdiv(M, 16) * 2 <= 256) ? 16 : 32;
+        const int tn16 = N <= 16 || tn16_dev == 16 || (tn16_dev == 0 && cdiv(M, 16) * cdiv(N, 16) <= 256) ? 16 : 32;
         const int64_t wg16 = cdiv(M, 16) * cdiv(N, tn16);
         const int np16 = nloc <= 8 ? 4 : 8, rows16 = nloc > 2 * np16 ? nloc : 2 * np16;   // (the launcher's slots: gemm_qmx.hip launch_small)
         const bool fits = (int64_t)KS8 * rows16 * tn16 * 4 <= 160 * 1024;

@@ -167,6 +167,8 @@ def test_geometry_may_follow_M_and_the_sweep_can_see_it():
             a, b = plan(t, 4096, 4096, N), plan(t, 16384, 4096, N)
             assert (a.tile_m, a.tile_n, a.workgroups) == (16, tn, 256) and b.tile_m >= 32 and a.tree_id == b.tree_id and a.family == b.family, (t, N)
         assert plan(t, 4096, 4096, 33).tile_m == 32 and plan(t, 4096, 4096, 64).tile_m == 32       # (33..64 rows: two 32-row workgroups per weight tile measured faster)
+        a, b = plan(t, 2048, 4096, 64), plan(t, 1024, 4096, 64)                                       # (r5: 33..64 rows on a short matrix -- column groups of 32 / 16 columns, one round at most)
+        assert (a.tile_m, a.tile_n, a.workgroups) == (16, 32, 256) and (b.tile_m, b.tile_n, b.workgroups) == (16, 16, 256) and a.tree_id == b.tree_id == plan(t, 32000, 4096, 64).tree_id, t
         a, b = plan(t, 2048, 4096, 32), plan(t, 2049, 4096, 32)                                       # (17..32 rows on a short matrix: one 16-column slice per workgroup while two workgroups per tile fit one round)
         assert (a.tile_m, a.tile_n, a.workgroups) == (16, 16, 256) and (b.tile_m, b.tile_n) == (16, 32) and a.tree_id == b.tree_id, t
         assert plan(t, 4112, 4096, 32).tile_m == 32                                                   # (more than one round of 16-row tiles: the 32-row form)
