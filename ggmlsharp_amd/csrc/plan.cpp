@@ -185,7 +185,9 @@ bool plan_k3s_i8(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     static const int min16 = dev_env_int("GGML_HIP_Q8S_16_MIN", 1);   // developer A/B switch: 0 = the min-term types keep the 32-row form
     // (up to 64 rows -- it was 32: on a short matrix 33..64 rows are column groups of 16 or 32 columns, 256 workgroups at most: Q4_0 1024 x 4096 x 64 7.8 -> 5.2 us, 2048 x 4096 x 64 8.9 -> 7.2,
     // Q8_0 9.6 -> 8.4 / 1024 rows 7.6 -> 5.5, Q5_1 9.8 -> 8.6, Q4_0 1536 x 1536 x 64 5.4 -> 4.6; 4096 rows and more keep two 32-row workgroups per weight tile.  tools/experiments/ab_tile16_n64.sh)
-    static const int n16max = dev_env_int("GGML_HIP_K3S_16_NMAX", 64);   // developer A/B switch: 16-row tiles up to this many src1 rows
+    // ... and beyond 64 rows wherever the 16-row workgroups still fit one round (1024 rows at 128 src1 rows, 512 at 256): Q4_0 1024 x 4096 x 128 7.7 -> 6.7, 512 x 4096 x 128 7.8 -> 5.2,
+    // 1024 x 11008 x 128 16.0 -> 13.9, Q5_1 1024 x 4096 x 128 9.0 -> 7.9 (ab_tile16_n512.sh): the workgroup count decides, the row count does not
+    static const int n16max = dev_env_int("GGML_HIP_K3S_16_NMAX", 512);   // developer A/B switch: 16-row tiles up to this many src1 rows
     if ((type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q5_0 || type == GGML_TYPE_Q4_2 || (type == GGML_TYPE_Q5_1 && min16)) && N <= n16max) {
         // (17..32 rows on a SHORT matrix: one 16-column slice per workgroup and two workgroups per weight tile while those fit one round -- 2048 rows are 256 workgroups that way,
         // 128 with both slices in one: Q4_0 2048 x 4096 x 32 7.5 -> 5.9 us, 1024 x 4096 x 32 6.7 -> 5.2, 2048 x 8192 x 32 12.6 -> 9.9, Q8_0 2048 x 4096 x 32 8.6 -> 6.6, Q5_1 8.3 -> 6.8;
@@ -279,7 +281,7 @@ bool plan_k3s_mx(mm_plan &p, int type, int64_t M, int64_t Mpad, int64_t K, int64
     // reasons): Q4_0 4096 x 4096 x 32 10.6 | 8.6 us per COMPUTE launch (32-row | 16-row tiles, replayed graphs, 32 weight copies in turn), x 16 and
     // x 5 10.6 | 7.1, 4096 x 11008 x 32 22.6 | 19.0, 2048 x 8192 x 32 19.1 | 16.5; the whole call at 16 rows 13.8 | 10.3.
     // (Q4_1 too: its min term as k = 0 / 2 of one v_mfma_f32_16x16x4_f32 per pair -- the 32-row form's two fmaf in the same order)
-    static const int n16max = dev_env_int("GGML_HIP_K3S_16_NMAX", 64);   // developer A/B switch: see plan_k3s_i8
+    static const int n16max = dev_env_int("GGML_HIP_K3S_16_NMAX", 512);   // developer A/B switch: see plan_k3s_i8
     if ((type == GGML_TYPE_Q4_0 || type == GGML_TYPE_Q4_1) && N <= n16max) {
         // (17..32 rows on a SHORT matrix: one 16-column slice per workgroup and two workgroups per weight tile while those fit one round -- 2048 rows are 256 workgroups that way,
         // 128 with both slices in one: Q4_0 2048 x 4096 x 32 7.5 -> 5.9 us, 1024 x 4096 x 32 6.7 -> 5.2, 2048 x 8192 x 32 12.6 -> 9.9, Q8_0 2048 x 4096 x 32 8.6 -> 6.6, Q5_1 8.3 -> 6.8;
