@@ -527,7 +527,10 @@ hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_p
     if (nloc > 128 || p.Npad < 32 * ncol) return hipErrorNotSupported;
     int64_t t32 = 0;
     for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32 * ncol;
-    const int wmt = t32 <= 256 ? 1 : 2;
+    // r5: three / four tiles per workgroup as well -- the fewest that keep the group inside one round of the chip (gate / up of a 7B model, 2 x 11008 rows: 230 workgroups of 96
+    // rows; it was 344 of 64, a second round a third full).  A 96-row tile may overhang the padded rows: it reads the neighbouring plane there and stores nothing.
+    auto groups = [&](int t) { int64_t g = 0; for (int i = 0; i < n_w; ++i) g += (w[i]->M + 32 * t - 1) / (32 * t) * ncol; return g; };
+    const int wmt = t32 <= 256 ? 1 : t32 <= 512 ? 2 : groups(3) <= 256 ? 3 : 4;
     const uint64_t aq_bytes = (uint64_t)nbkp * 2 * (uint64_t)p.Npad * 16;
     if (aq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
     q8s_set ws = {};
@@ -537,13 +540,13 @@ hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_p
         if (i < n_w) {
             const ggml_hip_weight *x = w[i];
             const uint64_t wq_bytes = (uint64_t)nbkp * 2 * (uint64_t)x->Mpad * 16;
-            if (x->type != GGML_TYPE_Q8_0 || !x->qs || !x->d || x->nbk != w[0]->nbk || x->Mpad % (32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+            if (x->type != GGML_TYPE_Q8_0 || !x->qs || !x->d || x->nbk != w[0]->nbk || x->Mpad % (wmt == 3 ? 32 : 32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
             wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt)) * ncol;
             ws.qs[i] = x->qs; ws.d[i] = x->d; ws.dst[i] = dst[i]; ws.M[i] = (int)x->M; ws.Mpad[i] = (int)x->Mpad; ws.ldd[i] = ldd[i]; ws.w_bytes[i] = (uint32_t)wq_bytes;
         }
         ws.wg_end[i] = wgs;
     }
-    const int nb = wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;   // (table rows: whole rounds of the form's slots)
+    const int nb = wmt >= 3 ? 4 : wmt == 2 || nloc <= 8 ? 8 : 16, rows = (nloc + nb - 1) / nb * nb;   // (table rows: whole rounds of the form's slots)
     const int tab = KS * rows * 32 * 4, xch = KS * wmt * 16 * 64 * 4;
     const int lds = tab > xch ? tab : xch;
     dim3 grid((unsigned)wgs);
@@ -554,7 +557,9 @@ hipError_t launch_q8_small_multi(const ggml_hip_weight *const *w, int n_w, act_p
         const hipError_t attr = once.max_dynamic_lds((const void *)kern, 160 * 1024); \
         if (attr != hipSuccess) return attr; \
         kern<<<grid, KS * 64, lds, st>>>(ws, p.a8, p.ad, (int)N, (int)p.Npad, (int)w[0]->nbk, nloc, (uint32_t)aq_bytes, ncol); } while (0)
-    if (wmt == 2) { if (nloc <= 8) Q8M_GO(8, false, 2); else Q8M_GO(8, true, 2); }
+    if (wmt == 4) { if (nloc <= 4) Q8M_GO(4, false, 4); else Q8M_GO(4, true, 4); }
+    else if (wmt == 3) { if (nloc <= 4) Q8M_GO(4, false, 3); else Q8M_GO(4, true, 3); }
+    else if (wmt == 2) { if (nloc <= 8) Q8M_GO(8, false, 2); else Q8M_GO(8, true, 2); }
     else if (nloc <= 8) Q8M_GO(8, false, 1);
     else if (nloc <= 16) Q8M_GO(16, false, 1);
     else Q8M_GO(16, true, 1);

@@ -832,7 +832,7 @@ void gemm_qmx_small_body(const uint8_t *__restrict__ w6a, const uint8_t *__restr
         for (int r = 0; r < 16; ++r) xch[(size_t)((wave * WMT + t) * 16 + r) * 64] = acc[t][r];
     __syncthreads();
     K3S_STAMP(4);
-    static_assert((16 * WMT) % KS == 0 && 16 % (16 * WMT / KS) == 0, "rows per wave");
+    static_assert((16 * WMT) % KS == 0, "rows per wave");   // (r5: three tiles per workgroup too -- six result rows per wave, spanning two tiles)
     constexpr int RW = 16 * WMT / KS;
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
@@ -1191,7 +1191,11 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
     if (p.Npad < 32 * ncol) return hipErrorNotSupported;
     int64_t t32 = 0;
     for (int i = 0; i < n_w; ++i) t32 += (w[i]->M + 31) / 32 * ncol;
-    const int wmt = t32 <= 256 ? 1 : t32 <= 512 || TYPE == GGML_TYPE_Q4_1 ? 2 : 4;
+    // r5: THREE tiles per workgroup where that is the fewest that keeps the group inside one round of the chip (gate / up of a 7B model: 2 x 11008 rows are 230 workgroups of 96 rows,
+    // 172 of 128): geometry on the form's tree, like the other tile counts.  A 96-row tile may overhang the padded rows: it reads the neighbouring plane's bytes there (inside the
+    // buffer, or zeros past it) and stores nothing.
+    auto groups = [&](int t) { int64_t g = 0; for (int i = 0; i < n_w; ++i) g += (w[i]->M + 32 * t - 1) / (32 * t) * ncol; return g; };
+    const int wmt = t32 <= 256 ? 1 : t32 <= 512 || TYPE == GGML_TYPE_Q4_1 ? 2 : groups(3) <= 256 ? 3 : 4;
     mxs_set ws = {};
     ws.n = n_w;
     int wgs = 0;
@@ -1199,7 +1203,7 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
         if (i < n_w) {
             const ggml_hip_weight *x = w[i];
             const uint64_t wq_bytes = (nba + K_LOOKAHEAD) * (uint64_t)x->Mpad * 16, wd_bytes = (nba + K_LOOKAHEAD) * (uint64_t)x->Mpad * 4;
-            if (!x->q6a || !x->q6b || x->nbk != w[0]->nbk || x->Mpad % (32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
+            if (!x->q6a || !x->q6b || x->nbk != w[0]->nbk || x->Mpad % (wmt == 3 ? 32 : 32 * wmt) != 0 || wq_bytes > 0xFFFFFFFFull) return hipErrorNotSupported;
             wgs += (int)((x->M + 32 * wmt - 1) / (32 * wmt)) * ncol;
             ws.a[i] = x->q6a; ws.b[i] = x->q6b; ws.d[i] = x->d; ws.m[i] = x->m; ws.dst[i] = dst[i];
             ws.M[i] = (int)x->M; ws.Mpad[i] = (int)x->Mpad; ws.ldd[i] = (int)ldd[i]; ws.wa_bytes[i] = (uint32_t)wq_bytes; ws.wd_bytes[i] = (uint32_t)wd_bytes;
@@ -1218,6 +1222,7 @@ hipError_t launch_small_multi(const ggml_hip_weight *const *w, int n_w, act_plan
         kern<<<grid, KS * 64, lds, st>>>(ws, (const uint8_t *)p.a8, p.ad, (const float *)p.as, (int)N, (int)p.Npad, nbkp, nloc, (uint32_t)a_bytes, \
                                       (uint32_t)ad_bytes, ncol); } while (0)
     if (wmt == 4) { if constexpr (TYPE == GGML_TYPE_Q4_0) K3M_GO(2, true, 4); }
+    else if (wmt == 3) { if constexpr (TYPE == GGML_TYPE_Q4_0) K3M_GO(2, true, 3); }
     else if (wmt == 2) { if (nloc <= 8) K3M_GO(4, false, 2); else if constexpr (TYPE == GGML_TYPE_Q4_1) K3M_GO(3, true, 2); else K3M_GO(4, true, 2); }
     else if (nloc <= 8) K3M_GO(4, false, 1);
     else if (nloc <= 16) K3M_GO(8, false, 1);

@@ -239,12 +239,13 @@ def test_multi_weight_device_form_is_bitwise_the_single_calls(dev, t):
 @pytest.mark.parametrize("t", [O.Q4_0, O.Q4_1, O.Q8_0])
 def test_multi_weight_batch_form_is_bitwise_the_single_calls(dev, t):
     """ggml_hip_mul_mat_multi_work_dev: 1..4 matrices behind ONE quantization of src1 for a batch of any size -- one launch where
-    gemm_qmx.hip has the form (9..32 rows, Q4_0 / Q4_1, K >= 2048: one / two / four tiles per workgroup by the tiles of all the
+    gemm_qmx.hip / gemm_q8s.hip have the form (5..64 rows, Q4_0 / Q4_1 / Q8_0, K >= 2048: one / two / three / four tiles per workgroup by the tiles of all the
     matrices together), else one COMPUTE after the other.  Every dst equals the single-matrix call's, bit for bit."""
     from ggmlsharp_amd._lib import lib, check
     L = lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for (Ms, K, N) in (((96, 130), 2048, 12), ((4096, 4096, 4096), 2048, 32), ((300, 8200, 40), 2048 + 64, 9), ((8192, 8192 + 300), 2048, 20),
+    # (r5: three tiles per workgroup where that keeps the group inside one round -- gate / up of a 7B model, ragged rows that overhang the last 96-row tile -- and four beyond)
+    for (Ms, K, N) in (((11008, 11008), 4096, 16), ((8192 + 40, 9000 + 7), 2048, 24), ((12000, 12000, 9000), 2048, 32), ((96, 130), 2048, 12), ((4096, 4096, 4096), 2048, 32), ((300, 8200, 40), 2048 + 64, 9), ((8192, 8192 + 300), 2048, 20),
                        ((64, 200), 512, 20), ((130, 70, 33), 2048, 3), ((100, 60), 2048, 7), ((128, 96), 4096 + 128, 70), ((77,), 2048, 16), ((4096, 300, 4096), 2048, 50), ((8192 + 40, 200), 2048 + 64, 64)):
         Ws = [dev.Weight.from_host(t, O.quantize_row(t, _rand((M, K))), K) for M in Ms]
         x = torch.from_numpy(_rand((N, K), 2.0)).cuda()
